@@ -1,0 +1,77 @@
+"""ctypes binding of libchromegcn_hip.so -- the C ABI in include/chromegcn.h.
+
+There is NO fallback: if the library is missing or a call fails, this raises.  torch is imported
+first so that the HIP runtime already mapped by torch (soname libamdhip64.so.7) is the one the
+library binds to; streams and device pointers are then interchangeable."""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede CDLL: shares torch's HIP runtime)
+
+from . import _build
+
+_c_int = ctypes.c_int
+_c_vp = ctypes.c_void_p
+_c_sz = ctypes.c_size_t
+
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "cgcn_abi_version": (_c_int, []),
+    "cgcn_strerror": (ctypes.c_char_p, [_c_int]),
+    "cgcn_spmm": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp]),
+    "cgcn_layer_fwd": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 13),
+    "cgcn_layer_bwd_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
+    "cgcn_layer_bwd": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 18 + [_c_int, _c_vp, _c_sz]),
+}
+ABI_VERSION = 1
+_lib = None
+
+
+class ChromeGCNLibraryError(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def load(build_if_missing=True):
+    """Load (once) and return the ctypes handle.  Raises ChromeGCNLibraryError if unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if build_if_missing and _build.is_stale() and _build.hipcc_path() is not None:
+        _build.build_library()
+    if not os.path.exists(path):
+        raise ChromeGCNLibraryError(
+            "chromegcn_amd: %s is missing and could not be built (run __graft_entry__.build()). "
+            "There is no CPU/torch fallback for the HIP path." % path)
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ChromeGCNLibraryError("chromegcn_amd: symbol %s missing from %s" % (name, path)) from e
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.cgcn_abi_version()
+    if got != ABI_VERSION:
+        raise ChromeGCNLibraryError("chromegcn_amd: ABI version %d != expected %d; rebuild" % (got, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().cgcn_strerror(rc).decode()
+        raise RuntimeError("chromegcn_amd: %s failed: %s (code %d)" % (what, msg, rc))
+
+
+def ptr(t):
+    """device pointer of a tensor (or None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream

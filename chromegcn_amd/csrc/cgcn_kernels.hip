@@ -1,0 +1,648 @@
+// chromegcn_amd/csrc/cgcn_kernels.hip
+//
+// gfx950 (MI355X, CDNA4) kernels for ChromeGCN's gated graph-convolution layer and the
+// C ABI declared in include/chromegcn.h.  Written for wave64 / MFMA / 160 KiB LDS; there is
+// no other target.
+//
+// Kernel inventory (DESIGN.md has the roofline for each):
+//   k_spmm<S,D>          unfused aggregation  Y = diag(rs) Ahat X                (HBM/L2 gather)
+//   k_layer_fwd<S,D>     gather -> LDS tile -> fp32 MFMA (x W) -> bias/tanh/gate/mix epilogue
+//   k_bwd_rowlocal<D>    per-row gate/tanh derivative, dUs, and H^T dU on fp32 MFMA (persistent)
+//   k_reduce_partials    deterministic second stage of the column / dW sums
+//   k_bwd_gather<S,D>    gather of dUs over Ahat^T -> LDS tile -> fp32 MFMA (x W^T) -> dX epilogue
+//
+// Reference semantics: models/SubLayers.py:42-52, models/ChromeModels.py:34-46 (forward);
+// SURVEY.md Appendix A (backward).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "chromegcn.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define WAVE 64
+#define TILE_NODES 16   // nodes per workgroup tile in the gather kernels
+#define BWD_TILE_ROWS 32  // rows per MFMA K-step group in k_bwd_rowlocal
+#define BWD_MAX_PARTIALS 256
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+  return v;
+}
+
+__device__ __forceinline__ int rl_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ float rl_f(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Geometry of one node's payload (S strands x D features) over a 64-lane wave of float4 loads.
+//   PAY = S*D floats.  PAY >= 256: NV = PAY/256 float4 per lane per neighbour.
+//   PAY == 128: the two half-waves take alternate neighbours (HALF) and are summed at the end.
+template <int S, int D>
+struct Geo {
+  static constexpr int PAY = S * D;
+  static constexpr bool HALF = (PAY == 128);
+  static constexpr int NV = HALF ? 1 : PAY / 256;
+  static_assert(PAY == 128 || PAY == 256 || PAY == 512, "unsupported payload");
+  // strand / column of float4 slot v on this lane
+  __device__ static __forceinline__ int strand(int v, int lane) { return HALF ? 0 : ((v * 64 + lane) * 4) / D; }
+  __device__ static __forceinline__ int column(int v, int lane) { return HALF ? (lane & 31) * 4 : ((v * 64 + lane) * 4) % D; }
+};
+
+// Sum val[k] * X[s, col[k], :] over k in [k0, k1) for one output node; the whole wave cooperates.
+// lane_off[v]: this lane's byte offset (strand * n_cols * D + column) * 4 into X.
+// Loads are issued 8 neighbours deep before the first add so a wave keeps 8 KiB in flight.
+template <int S, int D, bool HAS_VAL>
+__device__ __forceinline__ void gather_node(const int* __restrict__ col, const float* __restrict__ val,
+                                            int k0, int k1, const char* __restrict__ Xb,
+                                            const unsigned (&lane_off)[Geo<S, D>::NV], f32x4 (&acc)[Geo<S, D>::NV],
+                                            int lane) {
+  using G = Geo<S, D>;
+  constexpr int NV = G::NV;
+  constexpr unsigned ROWB = D * 4;  // bytes per (strand,node) row
+#pragma unroll
+  for (int v = 0; v < NV; ++v) acc[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int kb = k0; kb < k1; kb += WAVE) {
+    const int cnt = min(WAVE, k1 - kb);
+    int myc = 0;
+    float myv = 0.f;
+    if (lane < cnt) {
+      myc = col[kb + lane];
+      if (HAS_VAL) myv = val[kb + lane];
+    }
+    if (!G::HALF) {
+      int j = 0;
+      for (; j + 8 <= cnt; j += 8) {
+        f32x4 t[8][NV];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const char* rowp = Xb + (size_t)(unsigned)rl_i(myc, j + u) * ROWB;
+#pragma unroll
+          for (int v = 0; v < NV; ++v) t[u][v] = *(const f32x4*)(rowp + lane_off[v]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float w = HAS_VAL ? rl_f(myv, j + u) : 1.f;
+#pragma unroll
+          for (int v = 0; v < NV; ++v) acc[v] = HAS_VAL ? acc[v] + w * t[u][v] : acc[v] + t[u][v];
+        }
+      }
+      for (; j < cnt; ++j) {
+        const char* rowp = Xb + (size_t)(unsigned)rl_i(myc, j) * ROWB;
+        const float w = HAS_VAL ? rl_f(myv, j) : 1.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const f32x4 t = *(const f32x4*)(rowp + lane_off[v]);
+          acc[v] = HAS_VAL ? acc[v] + w * t : acc[v] + t;
+        }
+      }
+    } else {
+      // two neighbours per pass: lanes 0-31 take j, lanes 32-63 take j+1
+      const int sub = lane >> 5;
+      int j = 0;
+      for (; j + 16 <= cnt; j += 16) {
+        f32x4 t[8];
+        float w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int ca = rl_i(myc, j + 2 * u), cb = rl_i(myc, j + 2 * u + 1);
+          const unsigned c = sub ? (unsigned)cb : (unsigned)ca;
+          t[u] = *(const f32x4*)(Xb + (size_t)c * ROWB + lane_off[0]);
+          if (HAS_VAL) {
+            const float wa = rl_f(myv, j + 2 * u), wb = rl_f(myv, j + 2 * u + 1);
+            w[u] = sub ? wb : wa;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[0] = HAS_VAL ? acc[0] + w[u] * t[u] : acc[0] + t[u];
+      }
+      for (; j < cnt; j += 2) {
+        const int ca = rl_i(myc, j);
+        const int cb = rl_i(myc, min(j + 1, cnt - 1));
+        const bool ok = (j + sub) < cnt;
+        const unsigned c = sub ? (unsigned)cb : (unsigned)ca;
+        float w = 1.f;
+        if (HAS_VAL) {
+          const float wa = rl_f(myv, j), wb = rl_f(myv, min(j + 1, cnt - 1));
+          w = sub ? wb : wa;
+        }
+        if (ok) {
+          const f32x4 t = *(const f32x4*)(Xb + (size_t)c * ROWB + lane_off[0]);
+          acc[0] = HAS_VAL ? acc[0] + w * t : acc[0] + t;
+        }
+      }
+    }
+  }
+  if (G::HALF) {
+    // fold the odd-neighbour half onto the even one; afterwards both halves hold the row sum
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[0][e] += __shfl_xor(acc[0][e], 32, WAVE);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_spmm: one wave per output node, grid-stride over nodes.
+// ------------------------------------------------------------------------------------------
+template <int S, int D, bool HAS_VAL>
+__global__ __launch_bounds__(256) void k_spmm(int n_rows, int n_cols, const int* __restrict__ rowptr,
+                                              const int* __restrict__ col, const float* __restrict__ val,
+                                              const float* __restrict__ rs, const float* __restrict__ X,
+                                              float* __restrict__ Y) {
+  using G = Geo<S, D>;
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  unsigned lane_off[G::NV];
+#pragma unroll
+  for (int v = 0; v < G::NV; ++v)
+    lane_off[v] = ((unsigned)G::strand(v, lane) * (unsigned)n_cols * D + G::column(v, lane)) * 4u;
+  for (int i = wave; i < n_rows; i += nwaves) {
+    const int k0 = rowptr[i], k1 = rowptr[i + 1];
+    f32x4 acc[G::NV];
+    gather_node<S, D, HAS_VAL>(col, val, k0, k1, (const char*)X, lane_off, acc, lane);
+    const float sc = rs ? rs[i] : 1.f;
+    if (!G::HALF || lane < 32) {
+#pragma unroll
+      for (int v = 0; v < G::NV; ++v) {
+        float* dst = Y + ((size_t)G::strand(v, lane) * n_rows + i) * D + G::column(v, lane);
+        *(f32x4*)dst = acc[v] * sc;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Shared MFMA stage of the two gather kernels:
+//   out[m][j] = sum_k T[m][k] * B(k, j)   for the S*TILE_NODES rows staged in LDS.
+// TRANS_W == false: B(k,j) = W[k][j]   (forward,  U = H W)
+// TRANS_W == true : B(k,j) = W[j][k]   (backward, dS W^T)
+// Wave w owns output columns [32w, 32w+32) as two 16-wide blocks; v_mfma_f32_16x16x4_f32:
+//   A lane l: A[row l&15][k l>>4];  B lane l: B[k l>>4][col l&15];  C: col l&15, row 4*(l>>4)+reg.
+// ------------------------------------------------------------------------------------------
+template <int MB, int D, int LD, bool TRANS_W>
+__device__ __forceinline__ void tile_mfma(const float* __restrict__ T, const float* __restrict__ W, int wave, int lane,
+                                          f32x4 (&acc)[MB][2]) {
+  const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) acc[mb][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int j0 = wave * 32 + r;
+#pragma unroll 8
+  for (int kk = 0; kk < D / 4; ++kk) {
+    const int k = 4 * kk + q;
+    float b[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) b[cb] = TRANS_W ? W[(size_t)(j0 + 16 * cb) * D + k] : W[(size_t)k * D + j0 + 16 * cb];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const float a = T[(mb * 16 + r) * LD + k];
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) acc[mb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[cb], acc[mb][cb], 0, 0, 0);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_layer_fwd: one workgroup = TILE_NODES nodes x S strands.
+// ------------------------------------------------------------------------------------------
+template <int S, int D, bool HAS_VAL>
+__global__ __launch_bounds__(D * 2) void k_layer_fwd(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                     const float* __restrict__ val, const float* __restrict__ rs,
+                                                     const float* __restrict__ X, const float* __restrict__ W,
+                                                     const float* __restrict__ bias, const float* __restrict__ wg,
+                                                     const float* __restrict__ cg, float* __restrict__ Xn,
+                                                     float* __restrict__ Zout, float* __restrict__ Hout,
+                                                     float* __restrict__ gate) {
+  using G = Geo<S, D>;
+  constexpr int R = TILE_NODES;
+  constexpr int NW = D / 32;         // waves per workgroup (each owns 32 output columns)
+  constexpr int ROWS = S * R;        // MFMA rows in the tile
+  constexpr int MB = ROWS / 16;
+  constexpr int LD = D + 4;          // LDS row stride (floats); keeps float4 alignment
+  constexpr int EPL = D / 64;        // floats per lane in the row-wise epilogue
+  __shared__ __attribute__((aligned(16))) float T[ROWS * LD];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int node0 = blockIdx.x * R;
+
+  unsigned lane_off[G::NV];
+#pragma unroll
+  for (int v = 0; v < G::NV; ++v) lane_off[v] = ((unsigned)G::strand(v, lane) * (unsigned)n * D + G::column(v, lane)) * 4u;
+
+  // ---- phase 1: aggregate rows of H = diag(rs) Ahat X into LDS (and to Hout when training)
+  for (int rr = wave; rr < R; rr += NW) {
+    const int i = node0 + rr;
+    f32x4 acc[G::NV];
+    if (i < n) {
+      const int k0 = rowptr[i], k1 = rowptr[i + 1];
+      gather_node<S, D, HAS_VAL>(col, val, k0, k1, (const char*)X, lane_off, acc, lane);
+      const float sc = rs ? rs[i] : 1.f;
+#pragma unroll
+      for (int v = 0; v < G::NV; ++v) acc[v] *= sc;
+    } else {
+#pragma unroll
+      for (int v = 0; v < G::NV; ++v) acc[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    if (!G::HALF || lane < 32) {
+#pragma unroll
+      for (int v = 0; v < G::NV; ++v) {
+        const int s = G::strand(v, lane), c = G::column(v, lane);
+        *(f32x4*)&T[(s * R + rr) * LD + c] = acc[v];
+        if (Hout && i < n) *(f32x4*)&Hout[((size_t)s * n + i) * D + c] = acc[v];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: U = H W on the matrix cores
+  f32x4 acc[MB][2];
+  tile_mfma<MB, D, LD, false>(T, W, wave, lane, acc);
+  __syncthreads();  // every wave is done reading T as the A operand
+
+  // ---- phase 3a: Z = tanh(U + b) back into the tile
+  {
+    const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int j = wave * 32 + cb * 16 + r;
+      const float bj = bias[j];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) T[(mb * 16 + q * 4 + e) * LD + j] = tanhf(acc[mb][cb][e] + bj);
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 3b: row-wise gate + residual mix, coalesced stores
+  float wgl[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) wgl[e] = wg[lane * EPL + e];
+  const float c0 = cg[0];
+  for (int m = wave; m < ROWS; m += NW) {
+    const int s = m / R, rr = m % R;
+    const int i = node0 + rr;
+    if (i >= n) continue;  // wave-uniform
+    float z[EPL], x[EPL];
+    float dot = 0.f;
+    const size_t g_off = ((size_t)s * n + i) * D + lane * EPL;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      z[e] = T[m * LD + lane * EPL + e];
+      x[e] = X[g_off + e];
+      dot += z[e] * wgl[e];
+    }
+    dot = wave_sum(dot);
+    const float g = sigmoidf_(dot + c0);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      Xn[g_off + e] = (1.f - g) * x[e] + g * z[e];
+      if (Zout) Zout[g_off + e] = z[e];
+    }
+    if (lane == 0) gate[(size_t)s * n + i] = g;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_bwd_rowlocal: everything in the layer backward that is local to a (strand,node) row, plus
+// dW = H^T dU on MFMA.  Persistent: each workgroup walks row tiles and keeps its D x D slice of
+// dW in accumulators, then writes one partial.  Rows are the flattened [S*n] axis.
+//   partial layout per workgroup: [D*D dW][D db][D dwg][1 dcg][3 pad]
+// ------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(D * 2) void k_bwd_rowlocal(int M, int n, const float* __restrict__ dXn,
+                                                        const float* __restrict__ Z, const float* __restrict__ X,
+                                                        const float* __restrict__ gate, const float* __restrict__ dgate,
+                                                        const float* __restrict__ H, const float* __restrict__ wg,
+                                                        const float* __restrict__ rs, float* __restrict__ dUs,
+                                                        float* __restrict__ part) {
+  constexpr int NW = D / 32;
+  constexpr int TR = BWD_TILE_ROWS;
+  constexpr int LD = D + 16;  // stride = 16 (mod 32): conflict-free transposed ds_read_b32
+  constexpr int EPL = D / 64;
+  constexpr int JB = D / 16;
+  constexpr int PSTRIDE = D * D + 2 * D + 4;
+  __shared__ __attribute__((aligned(16))) float Ht[TR * LD];
+  __shared__ __attribute__((aligned(16))) float Ut[TR * LD];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, q = lane >> 4;
+
+  float wgl[EPL], db_acc[EPL], dwg_acc[EPL];
+  float dcg_acc = 0.f;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    wgl[e] = wg[lane * EPL + e];
+    db_acc[e] = 0.f;
+    dwg_acc[e] = 0.f;
+  }
+  f32x4 acc[2][JB];
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb) acc[ib][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int ntiles = (M + TR - 1) / TR;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // ---- row pass
+    for (int t = wave; t < TR; t += NW) {
+      const int m = tile * TR + t;
+      float du[EPL], h[EPL];
+      if (m < M) {
+        const size_t off = (size_t)m * D + lane * EPL;
+        float gup[EPL], z[EPL];
+        float dg = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+          gup[e] = dXn[off + e];
+          z[e] = Z[off + e];
+          const float x = X[off + e];
+          h[e] = H[off + e];
+          dg += gup[e] * (z[e] - x);
+        }
+        dg = wave_sum(dg);
+        if (dgate) dg += dgate[m];
+        const float g = gate[m];
+        const float gamma = g * (1.f - g) * dg;
+        const int node = m % n;
+        const float sc = rs ? rs[node] : 1.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+          const float dz = g * gup[e] + gamma * wgl[e];
+          du[e] = dz * (1.f - z[e] * z[e]);
+          db_acc[e] += du[e];
+          dwg_acc[e] += gamma * z[e];
+          dUs[off + e] = du[e] * sc;
+        }
+        dcg_acc += gamma;
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) du[e] = h[e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        Ht[t * LD + lane * EPL + e] = h[e];
+        Ut[t * LD + lane * EPL + e] = du[e];
+      }
+    }
+    __syncthreads();
+    // ---- dW += Ht^T Ut  (K = TR rows)
+#pragma unroll
+    for (int kk = 0; kk < TR / 4; ++kk) {
+      const int k = 4 * kk + q;
+      float a[2];
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib) a[ib] = Ht[k * LD + (2 * wave + ib) * 16 + r];
+#pragma unroll
+      for (int jb = 0; jb < JB; ++jb) {
+        const float b = Ut[k * LD + jb * 16 + r];
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) acc[ib][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ib], b, acc[ib][jb], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- write this workgroup's partial
+  float* P = part + (size_t)blockIdx.x * PSTRIDE;
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = (2 * wave + ib) * 16 + q * 4 + e;
+        const int j = jb * 16 + r;
+        P[i * D + j] = acc[ib][jb][e];
+      }
+  // column sums: combine the NW waves through LDS in a fixed order
+  float* red = Ht;  // [NW][2*D + 1]
+  constexpr int RS = 2 * D + 1;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    red[wave * RS + lane * EPL + e] = db_acc[e];
+    red[wave * RS + D + lane * EPL + e] = dwg_acc[e];
+  }
+  if (lane == 0) red[wave * RS + 2 * D] = dcg_acc;
+  __syncthreads();
+  for (int c = threadIdx.x; c < RS; c += blockDim.x) {
+    float s = 0.f;
+    for (int w = 0; w < NW; ++w) s += red[w * RS + c];
+    P[D * D + c] = s;
+  }
+}
+
+// Second stage: out[e] (+)= sum_p part[p][e], fixed order => deterministic.
+__global__ __launch_bounds__(256) void k_reduce_partials(int P, int D, const float* __restrict__ part,
+                                                         float* __restrict__ dW, float* __restrict__ db,
+                                                         float* __restrict__ dwg, float* __restrict__ dcg,
+                                                         int accumulate) {
+  const int PSTRIDE = D * D + 2 * D + 4;
+  const int total = D * D + 2 * D + 1;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  float s = 0.f;
+  for (int p = 0; p < P; ++p) s += part[(size_t)p * PSTRIDE + e];
+  float* dst;
+  if (e < D * D) dst = dW + e;
+  else if (e < D * D + D) dst = db + (e - D * D);
+  else if (e < D * D + 2 * D) dst = dwg + (e - D * D - D);
+  else dst = dcg;
+  *dst = accumulate ? (*dst + s) : s;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_bwd_gather: dX = (1-g) dXn + (Ahat^T dUs) W^T, same skeleton as the forward.
+// ------------------------------------------------------------------------------------------
+template <int S, int D, bool HAS_VAL>
+__global__ __launch_bounds__(D * 2) void k_bwd_gather(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                      const float* __restrict__ val, const float* __restrict__ dUs,
+                                                      const float* __restrict__ W, const float* __restrict__ dXn,
+                                                      const float* __restrict__ gate, float* __restrict__ dX) {
+  using G = Geo<S, D>;
+  constexpr int R = TILE_NODES;
+  constexpr int NW = D / 32;
+  constexpr int ROWS = S * R;
+  constexpr int MB = ROWS / 16;
+  constexpr int LD = D + 4;
+  constexpr int EPL = D / 64;
+  __shared__ __attribute__((aligned(16))) float T[ROWS * LD];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int node0 = blockIdx.x * R;
+
+  unsigned lane_off[G::NV];
+#pragma unroll
+  for (int v = 0; v < G::NV; ++v) lane_off[v] = ((unsigned)G::strand(v, lane) * (unsigned)n * D + G::column(v, lane)) * 4u;
+
+  for (int rr = wave; rr < R; rr += NW) {
+    const int i = node0 + rr;
+    f32x4 acc[G::NV];
+    if (i < n) {
+      gather_node<S, D, HAS_VAL>(col, val, rowptr[i], rowptr[i + 1], (const char*)dUs, lane_off, acc, lane);
+    } else {
+#pragma unroll
+      for (int v = 0; v < G::NV; ++v) acc[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    if (!G::HALF || lane < 32) {
+#pragma unroll
+      for (int v = 0; v < G::NV; ++v) *(f32x4*)&T[(G::strand(v, lane) * R + rr) * LD + G::column(v, lane)] = acc[v];
+    }
+  }
+  __syncthreads();
+
+  f32x4 acc[MB][2];
+  tile_mfma<MB, D, LD, true>(T, W, wave, lane, acc);
+  __syncthreads();
+  {
+    const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int j = wave * 32 + cb * 16 + r;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) T[(mb * 16 + q * 4 + e) * LD + j] = acc[mb][cb][e];
+    }
+  }
+  __syncthreads();
+
+  for (int m = wave; m < ROWS; m += NW) {
+    const int s = m / R, rr = m % R;
+    const int i = node0 + rr;
+    if (i >= n) continue;
+    const float g = gate[(size_t)s * n + i];
+    const size_t g_off = ((size_t)s * n + i) * D + lane * EPL;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) dX[g_off + e] = (1.f - g) * dXn[g_off + e] + T[m * LD + lane * EPL + e];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+static inline bool misaligned16(const void* p) { return ((uintptr_t)p & 15u) != 0; }
+
+static int check_shape(int n, int S, int d) {
+  if (n < 0) return CGCN_ERR_BAD_ARG;
+  if (!(S == 1 || S == 2) || !(d == 128 || d == 256)) return CGCN_ERR_UNSUPPORTED;
+  if ((double)n * (double)S * (double)d * 4.0 >= 4294967296.0) return CGCN_ERR_UNSUPPORTED;  // 32-bit byte offsets
+  return CGCN_OK;
+}
+
+static int launch_status() { return hipGetLastError() == hipSuccess ? CGCN_OK : CGCN_ERR_LAUNCH; }
+
+#define DISPATCH_SDV(S_, d_, hasval_, CALL)                                      \
+  do {                                                                           \
+    if ((S_) == 1 && (d_) == 128) { if (hasval_) { CALL(1, 128, true); } else { CALL(1, 128, false); } } \
+    else if ((S_) == 2 && (d_) == 128) { if (hasval_) { CALL(2, 128, true); } else { CALL(2, 128, false); } } \
+    else if ((S_) == 1 && (d_) == 256) { if (hasval_) { CALL(1, 256, true); } else { CALL(1, 256, false); } } \
+    else { if (hasval_) { CALL(2, 256, true); } else { CALL(2, 256, false); } }  \
+  } while (0)
+
+extern "C" {
+
+int cgcn_abi_version(void) { return CGCN_ABI_VERSION; }
+
+const char* cgcn_strerror(int code) {
+  switch (code) {
+    case CGCN_OK: return "ok";
+    case CGCN_ERR_BAD_ARG: return "bad argument (null pointer, negative size or misaligned buffer)";
+    case CGCN_ERR_UNSUPPORTED: return "unsupported shape (need S in {1,2}, d in {128,256}, S*n*d*4 < 4 GiB)";
+    case CGCN_ERR_LAUNCH: return "HIP kernel launch failed";
+    case CGCN_ERR_WORKSPACE: return "workspace too small";
+    default: return "unknown chromegcn error";
+  }
+}
+
+int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d, const int32_t* rowptr, const int32_t* col,
+              const float* val, const float* row_scale, const float* X, float* Y) {
+  int rc = check_shape(n_rows > n_cols ? n_rows : n_cols, S, d);
+  if (rc) return rc;
+  if (n_rows == 0) return CGCN_OK;
+  if (!rowptr || !col || !X || !Y || X == Y) return CGCN_ERR_BAD_ARG;
+  if (misaligned16(X) || misaligned16(Y)) return CGCN_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = (n_rows + 3) / 4 < 4096 ? (n_rows + 3) / 4 : 4096;
+#define CALL(S_, D_, V_) \
+  hipLaunchKernelGGL((k_spmm<S_, D_, V_>), dim3(blocks), dim3(256), 0, st, n_rows, n_cols, rowptr, col, val, row_scale, X, Y)
+  DISPATCH_SDV(S, d, val != nullptr, CALL);
+#undef CALL
+  return launch_status();
+}
+
+int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* rowptr, const int32_t* col, const float* val,
+                   const float* row_scale, const float* X, const float* W, const float* b, const float* wg,
+                   const float* cg, float* Xn, float* Z, float* H, float* gate) {
+  int rc = check_shape(n, S, d);
+  if (rc) return rc;
+  if (n == 0) return CGCN_OK;
+  if (!rowptr || !col || !X || !W || !b || !wg || !cg || !Xn || !gate || X == Xn) return CGCN_ERR_BAD_ARG;
+  if (misaligned16(X) || misaligned16(Xn) || (Z && misaligned16(Z)) || (H && misaligned16(H))) return CGCN_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = (n + TILE_NODES - 1) / TILE_NODES;
+#define CALL(S_, D_, V_)                                                                                        \
+  hipLaunchKernelGGL((k_layer_fwd<S_, D_, V_>), dim3(blocks), dim3(D_ * 2), 0, st, n, rowptr, col, val, row_scale, X, W, \
+                     b, wg, cg, Xn, Z, H, gate)
+  DISPATCH_SDV(S, d, val != nullptr, CALL);
+#undef CALL
+  return launch_status();
+}
+
+static int bwd_partials(int n, int S) {
+  const int M = n * S;
+  const int ntiles = (M + BWD_TILE_ROWS - 1) / BWD_TILE_ROWS;
+  int P = ntiles < BWD_MAX_PARTIALS ? ntiles : BWD_MAX_PARTIALS;
+  return P < 1 ? 1 : P;
+}
+
+size_t cgcn_layer_bwd_workspace_bytes(int n, int S, int d) {
+  if (check_shape(n, S, d) != CGCN_OK) return 0;
+  return (size_t)bwd_partials(n, S) * ((size_t)d * d + 2 * d + 4) * sizeof(float);
+}
+
+int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* rowptr_t, const int32_t* col_t,
+                   const float* val_t, const float* row_scale, const float* X, const float* Z, const float* H,
+                   const float* gate, const float* W, const float* wg, const float* dXn, const float* dgate, float* dX,
+                   float* dUs, float* dW, float* db, float* dwg, float* dcg, int accumulate, void* workspace,
+                   size_t workspace_bytes) {
+  int rc = check_shape(n, S, d);
+  if (rc) return rc;
+  if (!rowptr_t || !col_t || !X || !Z || !H || !gate || !W || !wg || !dXn || !dX || !dUs || !dW || !db || !dwg || !dcg)
+    return CGCN_ERR_BAD_ARG;
+  if (dX == dXn || misaligned16(dUs) || misaligned16(dX) || misaligned16(dXn)) return CGCN_ERR_BAD_ARG;
+  if (!workspace || workspace_bytes < cgcn_layer_bwd_workspace_bytes(n, S, d)) return CGCN_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int P = bwd_partials(n, S);
+  float* part = (float*)workspace;
+  const int M = n * S;
+  if (d == 128)
+    hipLaunchKernelGGL((k_bwd_rowlocal<128>), dim3(P), dim3(256), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dUs, part);
+  else
+    hipLaunchKernelGGL((k_bwd_rowlocal<256>), dim3(P), dim3(512), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dUs, part);
+  if ((rc = launch_status())) return rc;
+  const int total = d * d + 2 * d + 1;
+  hipLaunchKernelGGL(k_reduce_partials, dim3((total + 255) / 256), dim3(256), 0, st, P, d, part, dW, db, dwg, dcg, accumulate);
+  if ((rc = launch_status())) return rc;
+  if (n == 0) return CGCN_OK;
+  const int blocks = (n + TILE_NODES - 1) / TILE_NODES;
+#define CALL(S_, D_, V_)                                                                                       \
+  hipLaunchKernelGGL((k_bwd_gather<S_, D_, V_>), dim3(blocks), dim3(D_ * 2), 0, st, n, rowptr_t, col_t, val_t, dUs, W, \
+                     dXn, gate, dX)
+  DISPATCH_SDV(S, d, val_t != nullptr, CALL);
+#undef CALL
+  return launch_status();
+}
+
+}  // extern "C"

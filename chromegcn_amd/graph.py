@@ -1,0 +1,213 @@
+"""Graph side of the hot path: the adjacency normaliser (host logic) and the device CSR handle the
+HIP kernels consume.
+
+Mirrors the reference's `process_graph(adj_type, split_adj_dict, x_size, chrom)`
+(utils/util_methods.py:146-180) but emits what the kernels want -- int32 CSR of A-hat, optional
+per-edge values, fp32 1/deg row scale -- instead of a torch COO tensor, and caches it per
+chromosome (the reference rebuilds it every chromosome every epoch, finetune.py:36)."""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, Optional
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+BAND_RADIUS = 7  # utils/util_methods.py:147
+
+
+# ----------------------------------------------------------------------------------------------
+# host-side normaliser (numpy / scipy only)
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class HostCSR:
+    """A = diag(row_scale) * Ahat, Ahat given by (rowptr, col, val); val None means all ones."""
+    n: int
+    rowptr: np.ndarray            # int32 [n+1]
+    col: np.ndarray               # int32 [nnz]
+    val: Optional[np.ndarray]     # float32 [nnz] or None
+    row_scale: Optional[np.ndarray]  # float32 [n] or None
+    symmetric: bool               # Ahat == Ahat^T (structure and values)
+
+    @property
+    def nnz(self) -> int:
+        return int(self.col.shape[0])
+
+    def ahat(self) -> sp.csr_matrix:
+        data = np.ones(self.nnz, np.float32) if self.val is None else self.val
+        return sp.csr_matrix((data, self.col, self.rowptr), shape=(self.n, self.n))
+
+    def to_scipy(self) -> sp.csr_matrix:
+        """the normalised adjacency as float32 scipy CSR (what process_graph returns, as a matrix)."""
+        a = self.ahat().astype(np.float64)
+        if self.row_scale is not None:
+            a = sp.diags(self.row_scale.astype(np.float64)).dot(a)
+        return sp.csr_matrix(a, dtype=np.float32)
+
+
+def _band(n: int, radius: int = BAND_RADIUS) -> sp.csr_matrix:
+    """ones on the +-radius off-diagonals (create_constant_graph, utils/util_methods.py:137-144).
+    Offsets beyond the matrix are clipped; the reference raises for n < radius."""
+    offs = [k for k in range(-radius, radius + 1) if k != 0 and abs(k) < n]
+    if not offs:
+        return sp.csr_matrix((n, n), dtype=np.float64)
+    return sp.diags([np.ones(n - abs(k)) for k in offs], offs, shape=(n, n), format="csr", dtype=np.float64)
+
+
+def _is_symmetric(a: sp.csr_matrix) -> bool:
+    d = a - a.T
+    return d.nnz == 0 or not np.any(d.data)
+
+
+def normalize_graph(adj_type: str, hic: Optional[sp.spmatrix], n: int) -> HostCSR:
+    """The four branches of process_graph (utils/util_methods.py:148-174) followed by the row
+    normalisation of `normalize` (:99-106), kept factored as (Ahat, 1/rowsum)."""
+    eye = sp.identity(n, dtype=np.float64, format="csr")
+    if adj_type in ("hic", "both"):
+        if hic is None:
+            raise ValueError("adj_type %r needs a Hi-C matrix" % adj_type)
+        hic = sp.csr_matrix(hic, dtype=np.float64)
+        if hic.shape != (n, n):
+            raise ValueError("graph is %s but the chromosome has %d windows" % (hic.shape, n))
+    if adj_type == "hic":
+        a = sp.csr_matrix(hic + eye)
+        a.sum_duplicates()
+        a.data = (a.data > 0).astype(np.float64)  # :164-165 binarise; entries <= 0 drop out
+        a.eliminate_zeros()
+        implicit = True
+    elif adj_type == "constant":
+        a = sp.csr_matrix(_band(n) + eye)
+        implicit = True
+    elif adj_type == "both":
+        a = sp.csr_matrix(hic + _band(n) + eye)  # :168-171, values stay 1/2/3
+        a.sum_duplicates()
+        a.eliminate_zeros()
+        implicit = bool(np.all(a.data == 1.0))
+    elif adj_type == "none":
+        a = eye
+        implicit = True
+    else:
+        raise ValueError("unsupported adj_type %r (reference: UnboundLocalError)" % (adj_type,))
+    a.sort_indices()
+    rowsum = np.asarray(a.sum(1)).ravel()
+    with np.errstate(divide="ignore"):
+        r_inv = 1.0 / rowsum
+    r_inv[np.isinf(r_inv)] = 0.0  # :103
+    if a.nnz >= 2 ** 31 or n >= 2 ** 31:
+        raise ValueError("graph too large for int32 CSR")
+    return HostCSR(n=n, rowptr=a.indptr.astype(np.int32), col=a.indices.astype(np.int32),
+                   val=None if implicit else a.data.astype(np.float32),
+                   row_scale=r_inv.astype(np.float32), symmetric=_is_symmetric(a))
+
+
+def host_csr_from_matrix(a: sp.spmatrix) -> HostCSR:
+    """Wrap an already-normalised adjacency (e.g. the COO tensor the reference's own process_graph
+    produced): values are carried explicitly, no row scale, transpose built if needed."""
+    a = sp.csr_matrix(a, dtype=np.float32)
+    a.sum_duplicates()
+    a.sort_indices()
+    n = a.shape[0]
+    return HostCSR(n=n, rowptr=a.indptr.astype(np.int32), col=a.indices.astype(np.int32),
+                   val=a.data.astype(np.float32), row_scale=None, symmetric=_is_symmetric(a))
+
+
+# ----------------------------------------------------------------------------------------------
+# device handle
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class ChromGraph:
+    """Device-resident CSR of one chromosome's adjacency, plus the CSR of Ahat^T for the backward
+    (the same arrays when Ahat is symmetric, which Hi-C graphs are by construction,
+    data/7create_graph_new.py:115-116)."""
+    n: int
+    nnz: int
+    rowptr: torch.Tensor
+    col: torch.Tensor
+    val: Optional[torch.Tensor]
+    row_scale: Optional[torch.Tensor]
+    rowptr_t: torch.Tensor
+    col_t: torch.Tensor
+    val_t: Optional[torch.Tensor]
+    symmetric: bool
+    host: Optional[HostCSR] = field(default=None, repr=False)
+
+    @property
+    def device(self):
+        return self.rowptr.device
+
+    @property
+    def shape(self):
+        return (self.n, self.n)
+
+    def size(self, dim=None):
+        return self.shape if dim is None else self.shape[dim]
+
+
+def upload(h: HostCSR, device) -> ChromGraph:
+    dev = torch.device(device)
+
+    def up(a, dt):
+        return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=dt)
+
+    rowptr, col, val = up(h.rowptr, torch.int32), up(h.col, torch.int32), up(h.val, torch.float32)
+    rs = up(h.row_scale, torch.float32)
+    if h.symmetric:
+        rowptr_t, col_t, val_t = rowptr, col, val
+    else:
+        at = sp.csr_matrix(h.ahat().T)
+        at.sort_indices()
+        rowptr_t, col_t = up(at.indptr.astype(np.int32), torch.int32), up(at.indices.astype(np.int32), torch.int32)
+        val_t = None if h.val is None else up(at.data.astype(np.float32), torch.float32)
+    return ChromGraph(n=h.n, nnz=h.nnz, rowptr=rowptr, col=col, val=val, row_scale=rs,
+                      rowptr_t=rowptr_t, col_t=col_t, val_t=val_t, symmetric=h.symmetric, host=h)
+
+
+def process_graph(adj_type: str, split_adj_dict_chrom: Optional[Dict[str, sp.spmatrix]], x_size: int, chrom: str,
+                  device="cuda") -> ChromGraph:
+    """Drop-in for the reference's process_graph (utils/util_methods.py:146): same arguments, but the
+    result is the device CSR handle (ChromeGCN.forward accepts it wherever it accepts `adj`)."""
+    hic = None
+    if adj_type in ("hic", "both"):
+        hic = split_adj_dict_chrom[chrom]
+    return upload(normalize_graph(adj_type, hic, x_size), device)
+
+
+# ----------------------------------------------------------------------------------------------
+# torch sparse tensors from reference-style callers
+# ----------------------------------------------------------------------------------------------
+_coo_cache: Dict[tuple, ChromGraph] = {}
+_COO_CACHE_MAX = 64
+
+
+def graph_from_torch_sparse(adj: torch.Tensor, device=None) -> ChromGraph:
+    """Accept the torch sparse COO adjacency a reference caller passes (finetune.py:36 builds it with
+    the reference's process_graph).  Converted once per distinct tensor and cached."""
+    if adj.layout != torch.sparse_coo:
+        raise TypeError("expected a torch sparse COO tensor or a ChromGraph")
+    idx, vals = adj._indices(), adj._values()
+    key = (idx.data_ptr(), vals.data_ptr(), int(vals.shape[0]), tuple(adj.shape), str(adj.device), idx._version, vals._version)
+    g = _coo_cache.get(key)
+    if g is not None:
+        return g
+    dev = adj.device if device is None else torch.device(device)
+    i = idx.detach().cpu().numpy()
+    v = vals.detach().cpu().numpy().astype(np.float32)
+    if adj.shape[0] != adj.shape[1]:
+        raise ValueError("adjacency must be square")
+    m = sp.coo_matrix((v, (i[0], i[1])), shape=tuple(adj.shape)).tocsr()
+    g = upload(host_csr_from_matrix(m), dev)
+    if len(_coo_cache) >= _COO_CACHE_MAX:
+        _coo_cache.pop(next(iter(_coo_cache)))
+    _coo_cache[key] = g
+    return g
+
+
+def as_graph(adj, device) -> ChromGraph:
+    if isinstance(adj, ChromGraph):
+        if adj.device != torch.device(device) and str(adj.device) != str(device):
+            raise RuntimeError("graph is on %s but features are on %s" % (adj.device, device))
+        return adj
+    if isinstance(adj, torch.Tensor) and adj.layout == torch.sparse_coo:
+        return graph_from_torch_sparse(adj, device)
+    raise TypeError("adj must be a ChromGraph or a torch sparse COO tensor, got %r" % type(adj))

@@ -1,0 +1,128 @@
+"""Host-side mirror of the reference's module surface for the hot path:
+
+    GraphConvolution(in_features, out_features, bias=True, init='xavier').forward(input, adj, deg)
+        -- models/SubLayers.py:7-52
+    ChromeGCN(nfeat, nhid, nclass, dropout, gate, layers).forward(x_in, adj, deg, src_dict=None,
+        return_gate=False) -> (x_in, out, (g, g2), None)
+        -- models/ChromeModels.py:21-52
+
+Same constructor arguments, forward signatures, return tuples and state_dict keys, so reference
+checkpoints load and reference callers (finetune.py:41-42) run unchanged.  The math runs in the
+HIP kernels behind include/chromegcn.h; there is no CPU path."""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .graph import as_graph
+
+
+class GraphConvolution(nn.Module):
+    """output = adj @ (input @ weight) + bias   (models/SubLayers.py:42-52).  `deg` is accepted and
+    ignored, as in the reference.  adj: ChromGraph, torch sparse COO, or None (-> input @ weight + bias)."""
+
+    def __init__(self, in_features, out_features, bias=True, init="xavier"):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.weight = nn.Parameter(torch.empty(in_features, out_features))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_features))
+        else:
+            self.register_parameter("bias", None)
+        if init == "uniform":  # SubLayers.py:26-30 (the reference forgets to import math here)
+            stdv = 1.0 / math.sqrt(self.weight.size(1))
+            nn.init.uniform_(self.weight, -stdv, stdv)
+            if self.bias is not None:
+                nn.init.uniform_(self.bias, -stdv, stdv)
+        elif init == "xavier":  # SubLayers.py:32-35
+            nn.init.xavier_normal_(self.weight, gain=0.02)
+            if self.bias is not None:
+                nn.init.zeros_(self.bias)
+        elif init == "kaiming":  # SubLayers.py:37-40
+            nn.init.kaiming_normal_(self.weight, a=0, mode="fan_in")
+            if self.bias is not None:
+                nn.init.zeros_(self.bias)
+        else:
+            raise NotImplementedError
+
+    def forward(self, input, adj, deg=None):
+        ops._require_cuda(input, "input")
+        support = torch.mm(input, self.weight)
+        if adj is not None:
+            g = as_graph(adj, input.device)
+            output = ops.spmm(support.unsqueeze(0), g).squeeze(0)
+        else:
+            output = support
+        return output + self.bias if self.bias is not None else output
+
+    def __repr__(self):
+        return "%s (%d -> %d)" % (self.__class__.__name__, self.in_features, self.out_features)
+
+
+class ChromeGCN(nn.Module):
+    """Gated GCN over one chromosome (models/ChromeModels.py:21-52).
+
+    `layers`: the reference builds a second layer only when layers == 2 and silently a 1-layer model
+    for every other value (:25); here layers = L builds L gated layers (GC1/W1 ... GCL/WL, extending
+    the reference's naming), unless reference_layer_rule=True.  `gate` is accepted and ignored
+    exactly as in the reference (:22-31)."""
+
+    def __init__(self, nfeat, nhid, nclass, dropout, gate=True, layers=2, reference_layer_rule=False):
+        super().__init__()
+        if nfeat != nhid:
+            raise ValueError("ChromeGCN needs nfeat == nhid (the gated residual adds x and z)")
+        if reference_layer_rule:
+            layers = 2 if layers == 2 else 1
+        if layers < 1:
+            raise ValueError("layers must be >= 1")
+        self.n_layers = int(layers)
+        for k in range(1, self.n_layers + 1):
+            setattr(self, "GC%d" % k, GraphConvolution(nfeat, nhid, bias=True, init="xavier"))
+            setattr(self, "W%d" % k, nn.Linear(nfeat, 1))
+        self.dropout = dropout
+        self.batch_norm = nn.BatchNorm1d(nfeat)
+        self.out = nn.Linear(nfeat, nclass)
+
+    # -- the gated stack on a [S, n, d] block -------------------------------------------------
+    def _gated_stack(self, x, graph):
+        gates = []
+        for k in range(1, self.n_layers + 1):
+            if k > 1:
+                x = F.dropout(x, self.dropout, training=self.training)  # ChromeModels.py:42
+            gc = getattr(self, "GC%d" % k)
+            wk = getattr(self, "W%d" % k)
+            x, g = ops.gated_layer(x, gc.weight, gc.bias, wk.weight, wk.bias, graph)
+            gates.append(g)
+        return x, gates
+
+    def _head(self, x):
+        """relu -> BatchNorm1d over the node axis -> dropout -> Linear (ChromeModels.py:48-51).
+        x: [S, n, d]; strands go through BatchNorm one after the other, as the reference's two
+        forward calls do (running statistics are updated forward strand first)."""
+        x = F.relu(x)
+        x = torch.stack([self.batch_norm(x[s]) for s in range(x.shape[0])], 0)
+        x = F.dropout(x, self.dropout, training=self.training)
+        return self.out(x)
+
+    def forward(self, x_in, adj, deg=None, src_dict=None, return_gate=False):
+        ops._require_cuda(x_in, "x_in")
+        graph = as_graph(adj, x_in.device)
+        x, gates = self._gated_stack(x_in.unsqueeze(0), graph)
+        out = self._head(x).squeeze(0)
+        gs = [g.view(-1, 1) for g in gates]  # [n,1] like sigmoid(Linear(d,1)(z))
+        if len(gs) > 2:
+            return x_in, out, tuple(gs), None
+        return x_in, out, (gs[0], gs[1] if len(gs) > 1 else None), None  # ChromeModels.py:52
+
+    def forward_strands(self, x_fr, adj):
+        """Both strands of finetune.py:41-42 in one pass over the graph.
+        x_fr: [2, n, d] (forward strand, reverse-complement strand).  Returns (logits [2,n,C], gates)."""
+        ops._require_cuda(x_fr, "x_fr")
+        graph = as_graph(adj, x_fr.device)
+        x, gates = self._gated_stack(x_fr, graph)
+        return self._head(x), gates

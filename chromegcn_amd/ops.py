@@ -1,0 +1,124 @@
+"""torch.autograd bindings of the C ABI (include/chromegcn.h).  Plumbing only: every tensor
+allocation is torch's caching allocator, every launch goes to torch's current HIP stream, so
+all of it can be captured into a HIP graph.  No fallbacks: CPU tensors raise."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .graph import ChromGraph
+
+SUPPORTED_D = (128, 256)
+
+
+def _require_cuda(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(
+            "chromegcn_amd: %s is on %s; the gated-GCN path only exists as HIP kernels "
+            "(no CPU fallback) -- move the model and inputs to the GPU" % (name, t.device))
+    if t.dtype != torch.float32:
+        raise RuntimeError("chromegcn_amd: %s must be float32, got %s" % (name, t.dtype))
+
+
+def _check_feat(x: torch.Tensor, g: ChromGraph, name="x"):
+    _require_cuda(x, name)
+    if x.dim() != 3 or x.shape[0] not in (1, 2) or x.shape[2] not in SUPPORTED_D:
+        raise RuntimeError("chromegcn_amd: %s must be [S in {1,2}, n, d in {128,256}], got %s" % (name, tuple(x.shape)))
+    if x.shape[1] != g.n:
+        raise RuntimeError("chromegcn_amd: %s has %d nodes but the graph has %d" % (name, x.shape[1], g.n))
+
+
+class SpmmFn(torch.autograd.Function):
+    """Y = diag(row_scale) Ahat X  (torch.spmm of models/SubLayers.py:46)."""
+
+    @staticmethod
+    def forward(ctx, x, graph: ChromGraph):
+        _check_feat(x, graph)
+        x = x.contiguous()
+        S, n, d = x.shape
+        y = torch.empty_like(x)
+        lib = _lib.load()
+        _lib.check(lib.cgcn_spmm(_lib.stream_ptr(), n, n, S, d, _lib.ptr(graph.rowptr), _lib.ptr(graph.col),
+                                 _lib.ptr(graph.val), _lib.ptr(graph.row_scale), x.data_ptr(), y.data_ptr()), "cgcn_spmm")
+        ctx.graph = graph
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        g = ctx.graph
+        dy = dy.contiguous()
+        S, n, d = dy.shape
+        # A^T dY = Ahat^T (diag(row_scale) dY)
+        if g.row_scale is not None:
+            dy = dy * g.row_scale.view(1, n, 1)
+        dx = torch.empty_like(dy)
+        lib = _lib.load()
+        _lib.check(lib.cgcn_spmm(_lib.stream_ptr(), n, n, S, d, _lib.ptr(g.rowptr_t), _lib.ptr(g.col_t),
+                                 _lib.ptr(g.val_t), None, dy.data_ptr(), dx.data_ptr()), "cgcn_spmm(T)")
+        return dx, None
+
+
+def spmm(x, graph):
+    return SpmmFn.apply(x, graph)
+
+
+class GatedLayerFn(torch.autograd.Function):
+    """One gated GCN layer (models/ChromeModels.py:37-40), fused; see cgcn_layer_fwd / cgcn_layer_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gate_w, gate_b, graph: ChromGraph):
+        _check_feat(x, graph)
+        for t, nm in ((weight, "weight"), (bias, "bias"), (gate_w, "gate weight"), (gate_b, "gate bias")):
+            _require_cuda(t, nm)
+        x = x.contiguous()
+        S, n, d = x.shape
+        if tuple(weight.shape) != (d, d):
+            raise RuntimeError("chromegcn_amd: fused layer needs a square [d,d] weight, got %s" % (tuple(weight.shape),))
+        weight = weight.contiguous()
+        bias = bias.contiguous()
+        wg = gate_w.contiguous().view(-1)
+        cg = gate_b.contiguous().view(-1)
+        need_bwd = any(ctx.needs_input_grad[:5])
+        xn = torch.empty_like(x)
+        gate = torch.empty((S, n), device=x.device, dtype=torch.float32)
+        z = torch.empty_like(x) if need_bwd else None
+        h = torch.empty_like(x) if need_bwd else None
+        lib = _lib.load()
+        _lib.check(lib.cgcn_layer_fwd(_lib.stream_ptr(), n, S, d, _lib.ptr(graph.rowptr), _lib.ptr(graph.col),
+                                      _lib.ptr(graph.val), _lib.ptr(graph.row_scale), x.data_ptr(), weight.data_ptr(),
+                                      bias.data_ptr(), wg.data_ptr(), cg.data_ptr(), xn.data_ptr(), _lib.ptr(z),
+                                      _lib.ptr(h), gate.data_ptr()), "cgcn_layer_fwd")
+        if need_bwd:
+            ctx.save_for_backward(x, z, h, gate, weight, wg)
+        ctx.graph = graph
+        ctx.gate_w_shape = gate_w.shape
+        ctx.gate_b_shape = gate_b.shape
+        return xn, gate
+
+    @staticmethod
+    def backward(ctx, dxn, dgate):
+        x, z, h, gate, weight, wg = ctx.saved_tensors
+        g = ctx.graph
+        S, n, d = x.shape
+        dxn = torch.zeros_like(x) if dxn is None else dxn.contiguous()
+        dgate = None if dgate is None else dgate.contiguous()
+        dx = torch.empty_like(x)
+        dus = torch.empty_like(x)
+        dw = torch.empty_like(weight)
+        db = torch.empty(d, device=x.device, dtype=torch.float32)
+        dwg = torch.empty(d, device=x.device, dtype=torch.float32)
+        dcg = torch.empty(1, device=x.device, dtype=torch.float32)
+        lib = _lib.load()
+        ws_bytes = lib.cgcn_layer_bwd_workspace_bytes(n, S, d)
+        ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8)
+        _lib.check(lib.cgcn_layer_bwd(_lib.stream_ptr(), n, S, d, _lib.ptr(g.rowptr_t), _lib.ptr(g.col_t),
+                                      _lib.ptr(g.val_t), _lib.ptr(g.row_scale), x.data_ptr(), z.data_ptr(),
+                                      h.data_ptr(), gate.data_ptr(), weight.data_ptr(), wg.data_ptr(),
+                                      dxn.data_ptr(), _lib.ptr(dgate), dx.data_ptr(), dus.data_ptr(), dw.data_ptr(),
+                                      db.data_ptr(), dwg.data_ptr(), dcg.data_ptr(), 0, ws.data_ptr(), ws_bytes),
+                   "cgcn_layer_bwd")
+        return dx, dw, db, dwg.view(ctx.gate_w_shape), dcg.view(ctx.gate_b_shape), None
+
+
+def gated_layer(x, weight, bias, gate_w, gate_b, graph):
+    return GatedLayerFn.apply(x, weight, bias, gate_w, gate_b, graph)

@@ -1,0 +1,110 @@
+/*
+ * chromegcn.h -- C ABI of libchromegcn_hip.so: the MI355X (gfx950) implementation of
+ * ChromeGCN's per-chromosome gated graph-convolution hot path.
+ *
+ * The reference (QData/ChromeGCN) has no FFI of its own: its boundary for this path is
+ * the Python nn.Module surface.  Each entry point below names the
+ * reference code it replaces (file:line relative to the reference repository root); the
+ * Python host side in chromegcn_amd/ binds them with ctypes (INTEGRATION.md shows the
+ * stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer unless marked "host".  No torch types.
+ *   - All work is enqueued on `stream` (a hipStream_t passed as void*); nothing here
+ *     synchronises, allocates or frees device memory, or keeps a pointer after return.
+ *     All entry points are therefore legal inside HIP-graph stream capture.
+ *   - Return value: CGCN_OK (0) or a negative CGCN_ERR_* code; cgcn_strerror() names it.
+ *   - Dense matrices are row-major fp32.  Node features are laid out [S, n, d]:
+ *     S strands (S = 1: one call of ChromeGCN.forward; S = 2: the forward and the
+ *     reverse-complement strand of finetune.py:41-42 sharing one pass over the graph),
+ *     n nodes (windows of one chromosome), d features.  d must be 128 or 256.
+ *   - A graph is a CSR triple: rowptr[n+1], col[nnz] (int32, columns sorted or not),
+ *     val[nnz] fp32 or NULL meaning "all ones", plus an optional per-row scale
+ *     row_scale[n] (NULL = 1).  The row-normalised adjacency of process_graph
+ *     (utils/util_methods.py:146-180) is A = diag(row_scale) * Ahat with
+ *     row_scale = 1/deg; 'hic', 'constant' and 'none' graphs have val == NULL,
+ *     'both' graphs carry val in {1,2,3}.
+ *   - The backward needs Ahat^T; (rowptr_t, col_t, val_t) is its CSR.  Hi-C graphs are
+ *     symmetric (data/7create_graph_new.py:115-116) so callers pass the same arrays.
+ */
+#ifndef CHROMEGCN_H
+#define CHROMEGCN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CGCN_OK 0
+#define CGCN_ERR_BAD_ARG (-1)     /* null pointer, negative size, misaligned buffer      */
+#define CGCN_ERR_UNSUPPORTED (-2) /* d not in {128,256}, S not in {1,2}, size overflow   */
+#define CGCN_ERR_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after a launch      */
+#define CGCN_ERR_WORKSPACE (-4)   /* workspace too small (see cgcn_*_workspace_bytes)    */
+
+#define CGCN_ABI_VERSION 1
+
+typedef void *cgcn_stream_t; /* hipStream_t */
+
+/* ABI version of the loaded library (compare with CGCN_ABI_VERSION). */
+int cgcn_abi_version(void);
+
+/* Static string for an error code.  Never NULL. */
+const char *cgcn_strerror(int code);
+
+/*
+ * Y[s,i,:] = row_scale[i] * sum_{k in row i} val[k] * X[s, col[k], :]
+ * Unfused sparse aggregation.  Replaces torch.spmm(adj, support), models/SubLayers.py:46.
+ * X, Y: [S, n_cols, d] and [S, n_rows, d]; X and Y must not alias.
+ */
+int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d,
+              const int32_t *rowptr, const int32_t *col, const float *val, const float *row_scale,
+              const float *X, float *Y);
+
+/*
+ * One gated graph-convolution layer, forward, fused in one launch:
+ *     H  = diag(row_scale) Ahat X          (aggregation)
+ *     U  = H W + b                          (models/SubLayers.py:43-50; the reference
+ *                                            computes A (X W) + b -- same value up to fp32
+ *                                            re-association)
+ *     Z  = tanh(U)                          (models/ChromeModels.py:38 / :44)
+ *     g  = sigmoid(Z . wg + cg)             (models/ChromeModels.py:39 / :45, nn.Linear(d,1))
+ *     Xn = (1 - g) X + g Z                  (models/ChromeModels.py:40 / :46)
+ * X, Xn, Z, H: [S,n,d].  gate: [S,n].  W: [d,d] stored in x out (GraphConvolution.weight).
+ * b, wg: [d].  cg: [1] (device).  Z and H may be NULL for inference (they are what the
+ * backward needs).  Xn must not alias X.
+ */
+int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d,
+                   const int32_t *rowptr, const int32_t *col, const float *val, const float *row_scale,
+                   const float *X, const float *W, const float *b, const float *wg, const float *cg,
+                   float *Xn, float *Z, float *H, float *gate);
+
+/* Bytes of scratch cgcn_layer_bwd needs for (n, S, d).  0 on unsupported shapes. */
+size_t cgcn_layer_bwd_workspace_bytes(int n, int S, int d);
+
+/*
+ * Backward of cgcn_layer_fwd (what autograd derives for models/ChromeModels.py:37-40 /
+ * :43-46; math in SURVEY.md Appendix A).  Given dXn = dL/dXn [S,n,d] and optionally
+ * dgate = dL/dgate [S,n] (NULL = 0):
+ *     gamma = g (1-g) (sum_k dXn (Z - X) + dgate)
+ *     dU    = (g dXn + gamma wg^T) (1 - Z^2)
+ *     db = sum_rows dU,  dwg = sum_rows gamma Z,  dcg = sum gamma,  dW = H^T dU
+ *     dX    = (1-g) dXn + (Ahat^T (diag(row_scale) dU)) W^T
+ * dX: [S,n,d], must not alias dXn.  dW [d,d], db [d], dwg [d], dcg [1] are overwritten
+ * when accumulate == 0 and added to when accumulate != 0.  dUs is a [S,n,d] scratch output
+ * (holds diag(row_scale) dU on return).  Sums over rows are two-stage and deterministic
+ * (no float atomics): results are bit-reproducible run to run.
+ */
+int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d,
+                   const int32_t *rowptr_t, const int32_t *col_t, const float *val_t, const float *row_scale,
+                   const float *X, const float *Z, const float *H, const float *gate,
+                   const float *W, const float *wg,
+                   const float *dXn, const float *dgate,
+                   float *dX, float *dUs, float *dW, float *db, float *dwg, float *dcg,
+                   int accumulate, void *workspace, size_t workspace_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHROMEGCN_H */

@@ -1,0 +1,258 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the oracle and against the golden
+vectors recorded from the reference.  fp32, atol = rtol = 1e-4 (the north-star tolerance) unless a
+tighter bound is stated.  Eval mode or dropout = 0 (device RNG streams differ)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+import torch.nn.functional as F
+
+import chromegcn_amd as C
+from chromegcn_amd import graph as G
+from chromegcn_amd import ops
+from oracle import chromegcn_oracle as O
+from helpers import csr_from, state_from
+
+pytestmark = pytest.mark.gpu
+TOL = dict(atol=1e-4, rtol=1e-4)
+DEV = "cuda"
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def graph_cases():
+    """(name, HostCSR) -- covers implicit/explicit values, empty rows, a dense row, rows longer
+    than one and two 64-entry index chunks, n not a multiple of the 16-node tile, n = 1."""
+    out = []
+    a = O.random_symmetric_graph(257, 1500, 1)
+    out.append(("hic257", G.normalize_graph("hic", a, 257)))
+    out.append(("both97", G.normalize_graph("both", O.random_symmetric_graph(97, 300, 2), 97)))
+    out.append(("const61", G.normalize_graph("constant", None, 61)))
+    out.append(("none33", G.normalize_graph("none", None, 33)))
+    out.append(("one", G.normalize_graph("hic", sp.csr_matrix((1, 1)), 1)))
+    m = np.zeros((300, 300)); m[5, :] = 1; m[:, 5] = 1; m[5, 5] = 0
+    rng = np.random.RandomState(3)
+    i, j = rng.randint(0, 300, 4000), rng.randint(0, 300, 4000)
+    m[i, j] = 1; m[j, i] = 1; np.fill_diagonal(m, 0)
+    m[77, :] = 0; m[:, 77] = 0; m[77, 77] = -1  # empty row after +I
+    out.append(("dense300", G.normalize_graph("hic", sp.csr_matrix(m), 300)))
+    # an asymmetric, arbitrary-valued operator (what a torch-COO caller may hand in)
+    r = sp.random(90, 90, 0.08, format="csr", random_state=4, dtype=np.float32)
+    out.append(("asym90", G.host_csr_from_matrix(r)))
+    return out
+
+
+@pytest.mark.parametrize("S,d", [(1, 128), (2, 128), (1, 256), (2, 256)])
+def test_spmm_matches_oracle(S, d):
+    for name, h in graph_cases():
+        g = G.upload(h, DEV)
+        rng = np.random.RandomState(10)
+        x = rng.randn(S, h.n, d).astype(np.float32)
+        xt = dev(x).requires_grad_(True)
+        y = ops.spmm(xt, g)
+        a = h.to_scipy().astype(np.float64)
+        want = np.stack([a @ x[s].astype(np.float64) for s in range(S)])
+        np.testing.assert_allclose(y.detach().cpu().numpy(), want, err_msg=name, **TOL)
+        dy = rng.randn(S, h.n, d).astype(np.float32)
+        y.backward(dev(dy))
+        want_dx = np.stack([a.T @ dy[s].astype(np.float64) for s in range(S)])
+        np.testing.assert_allclose(xt.grad.cpu().numpy(), want_dx, err_msg=name, **TOL)
+
+
+def _layer_params(d, seed):
+    rng = np.random.RandomState(seed)
+    return ((rng.randn(d, d) / np.sqrt(d) * 1.5).astype(np.float32), (rng.randn(d) * 0.2).astype(np.float32),
+            (rng.randn(d) / np.sqrt(d) * 2).astype(np.float32), np.float32(rng.randn() * 0.3))
+
+
+@pytest.mark.parametrize("S,d", [(1, 128), (2, 128), (1, 256), (2, 256)])
+def test_gated_layer_forward_backward_matches_oracle(S, d):
+    for name, h in graph_cases():
+        g = G.upload(h, DEV)
+        rng = np.random.RandomState(20)
+        W, b, wg, cg = _layer_params(d, 21)
+        x = rng.randn(S, h.n, d).astype(np.float32)
+        gup = (rng.randn(S, h.n, d) * 0.1).astype(np.float32)
+        ggate = (rng.randn(S, h.n) * 0.1).astype(np.float32)
+        t = {k: dev(v).requires_grad_(True) for k, v in dict(x=x, W=W, b=b, wg=wg.reshape(1, d), cg=np.array([cg])).items()}
+        xn, gate = ops.gated_layer(t["x"], t["W"], t["b"], t["wg"], t["cg"], g)
+        (xn * dev(gup)).sum().add((gate * dev(ggate)).sum()).backward()
+        a = h.to_scipy()
+        acc = {k: 0.0 for k in ["dW", "db", "dwg", "dcg"]}
+        for s in range(S):
+            f = O.layer_forward_np(a, x[s], W, b, wg, float(cg))
+            np.testing.assert_allclose(xn[s].detach().cpu().numpy(), f["Xn"], err_msg=name, **TOL)
+            np.testing.assert_allclose(gate[s].detach().cpu().numpy(), f["g"], err_msg=name, **TOL)
+            bw = O.layer_backward_np(a, x[s], W, wg, f["Z"], f["g"], gup[s], ggate[s])
+            np.testing.assert_allclose(t["x"].grad[s].cpu().numpy(), bw["dX"], err_msg=name + " dX", **TOL)
+            for k in acc:
+                acc[k] = acc[k] + bw[k]
+        np.testing.assert_allclose(t["W"].grad.cpu().numpy(), acc["dW"], err_msg=name + " dW", **TOL)
+        np.testing.assert_allclose(t["b"].grad.cpu().numpy(), acc["db"], err_msg=name + " db", **TOL)
+        np.testing.assert_allclose(t["wg"].grad.cpu().numpy().ravel(), acc["dwg"], err_msg=name + " dwg", **TOL)
+        np.testing.assert_allclose(t["cg"].grad.cpu().numpy().ravel()[0], acc["dcg"], err_msg=name + " dcg", **TOL)
+
+
+def test_gated_layer_against_reference_golden(golden):
+    """G2: values recorded from the reference's own GraphConvolution + gate math."""
+    z = golden("g2_gated_layer.npz")
+    for name in z["cases"]:
+        adj_type = name.split("_")[-1]
+        a_in = csr_from(z, name + "_in"); n = a_in.shape[0]
+        g = C.process_graph(adj_type, {"c": a_in}, n, "c", device=DEV)
+        t = {k: dev(z[name + "_" + k]).requires_grad_(True) for k in ["X", "W", "b", "wg", "cg"]}
+        xn, gate = ops.gated_layer(t["X"].unsqueeze(0), t["W"], t["b"], t["wg"], t["cg"], g)
+        np.testing.assert_allclose(xn[0].detach().cpu().numpy(), z[name + "_Xn"], err_msg=name, **TOL)
+        np.testing.assert_allclose(gate[0].detach().cpu().numpy(), z[name + "_g"].ravel(), err_msg=name, **TOL)
+        xn.backward(dev(z[name + "_Gup"]).unsqueeze(0))
+        for k, gk in [("X", "dX"), ("W", "dW"), ("b", "db"), ("wg", "dwg"), ("cg", "dcg")]:
+            np.testing.assert_allclose(t[k].grad.cpu().numpy(), z[name + "_" + gk], err_msg=name + gk, **TOL)
+
+
+def test_layer_results_are_bit_reproducible():
+    h = G.normalize_graph("hic", O.random_symmetric_graph(500, 4000, 5), 500)
+    g = G.upload(h, DEV)
+    W, b, wg, cg = _layer_params(128, 6)
+    x = dev(np.random.RandomState(7).randn(2, 500, 128).astype(np.float32))
+    outs = []
+    for _ in range(3):
+        t = [dev(v).requires_grad_(True) for v in (W, b, wg.reshape(1, -1), np.array([cg]))]
+        xx = x.clone().requires_grad_(True)
+        xn, gate = ops.gated_layer(xx, *t, g)
+        xn.sum().backward()
+        outs.append([xn.detach().clone(), xx.grad.clone()] + [p.grad.clone() for p in t])
+    for o in outs[1:]:
+        for a, b_ in zip(outs[0], o):
+            assert torch.equal(a, b_)
+
+
+def _load_model(name, z, L_override=None):
+    _, d, L = name.split("_")
+    d = int(d[1:]); L = int(L[1:])
+    init = state_from(z, name + "_init")
+    m = C.ChromeGCN(d, d, init["out.weight"].shape[0], 0.0, True, L)
+    m.load_state_dict(init)  # reference state_dict keys load as-is
+    return m.to(DEV), d, L
+
+
+def test_model_eval_forward_against_reference_golden(golden):
+    z = golden("g3_model.npz")
+    for name in z["cases"]:
+        m, d, L = _load_model(name, z)
+        a_in = csr_from(z, name + "_in"); n = a_in.shape[0]
+        g = C.process_graph("hic", {"c": a_in}, n, "c", device=DEV)
+        m.eval()
+        with torch.no_grad():
+            x_in, lf, gates, none = m(dev(z[name + "_xf"]), g, None)
+            _, lr, _, _ = m(dev(z[name + "_xr"]), g, None)
+            both, _ = m.forward_strands(torch.stack([dev(z[name + "_xf"]), dev(z[name + "_xr"])]), g)
+        assert none is None and x_in.shape == (n, d)
+        np.testing.assert_allclose(lf.cpu().numpy(), z[name + "_eval_logits_f"], **TOL)
+        np.testing.assert_allclose(lr.cpu().numpy(), z[name + "_eval_logits_r"], **TOL)
+        np.testing.assert_allclose(both[0].cpu().numpy(), z[name + "_eval_logits_f"], **TOL)
+        np.testing.assert_allclose(both[1].cpu().numpy(), z[name + "_eval_logits_r"], **TOL)
+        assert gates[0].shape == (n, 1)
+        np.testing.assert_allclose(gates[0].cpu().numpy(), z[name + "_eval_g1"], **TOL)
+        if L == 2:
+            np.testing.assert_allclose(gates[1].cpu().numpy(), z[name + "_eval_g2"], **TOL)
+        else:
+            assert gates[1] is None
+
+
+@pytest.mark.parametrize("batched", [False, True])
+def test_model_train_steps_against_reference_golden(golden, batched):
+    """loss, every gradient (incl. d/dx_in, finetune.py:33-34), parameters and BatchNorm running
+    statistics after one and two SGD steps (lr .25, momentum .9, wd 1e-6)."""
+    z = golden("g3_model.npz")
+    for name in z["cases"]:
+        m, d, L = _load_model(name, z)
+        a_in = csr_from(z, name + "_in"); n = a_in.shape[0]
+        # reference-style caller: a torch sparse COO adjacency
+        adj = O.process_graph("hic", {"c": a_in}, n, "c").to(DEV) if not batched else \
+            C.process_graph("hic", {"c": a_in}, n, "c", device=DEV)
+        tgt = dev(z[name + "_tgt"])
+        opt = torch.optim.SGD(m.parameters(), lr=0.25, weight_decay=1e-6, momentum=0.9)
+        m.train()
+        xf = dev(z[name + "_xf"]).requires_grad_(True); xr = dev(z[name + "_xr"]).requires_grad_(True)
+
+        def step():
+            opt.zero_grad()
+            if batched:
+                p, _ = m.forward_strands(torch.stack([xf, xr]), adj)
+                pf, pr = p[0], p[1]
+            else:
+                _, pf, _, _ = m(xf, adj, None)
+                _, pr, _, _ = m(xr, adj, None)
+            loss = F.binary_cross_entropy_with_logits((pf + pr) / 2, tgt)
+            loss.backward()
+            return loss
+
+        loss = step()
+        assert abs(loss.item() - float(z[name + "_train_loss"])) < 1e-4
+        np.testing.assert_allclose(xf.grad.cpu().numpy(), z[name + "_train_dxf"], atol=1e-6, rtol=1e-3)
+        np.testing.assert_allclose(xr.grad.cpu().numpy(), z[name + "_train_dxr"], atol=1e-6, rtol=1e-3)
+        for k, p in m.named_parameters():
+            ref = z["%s_grad_%s" % (name, k)]
+            np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=1e-4 * max(1.0, float(np.abs(ref).max())), rtol=1e-4, err_msg=k)
+        opt.step()
+        post = state_from(z, name + "_post")
+        for k, v in m.state_dict().items():
+            np.testing.assert_allclose(v.cpu().numpy(), post[k].numpy(), err_msg=k, **TOL)
+        xf.grad = None; xr.grad = None
+        loss2 = step(); opt.step()
+        assert abs(loss2.item() - float(z[name + "_train_loss2"])) < 1e-4
+        post2 = state_from(z, name + "_post2")
+        for k, v in m.state_dict().items():
+            tol = dict(atol=1e-5, rtol=1e-5) if "running" in k else TOL
+            np.testing.assert_allclose(v.cpu().numpy(), post2[k].numpy(), err_msg=k, **tol)
+
+
+def test_deeper_wider_model_against_oracle():
+    """config 4 shape family: d = 256, 4 layers -- beyond the reference (its ctor caps at 2 layers);
+    oracle = the restatement rule 'repeat ChromeModels.py:42-46'."""
+    n, d, L, c = 300, 256, 4, 11
+    a = O.random_symmetric_graph(n, 2000, 9)
+    orc = O.GatedGCNOracle(d, c, 0.0, L)
+    g_ = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for k, p in orc.named_parameters():
+            if "GC" in k and "weight" in k:
+                p.copy_(torch.randn(p.shape, generator=g_) / np.sqrt(d) * 1.5)
+            elif p.dim() == 1:
+                p.copy_(torch.randn(p.shape, generator=g_) * 0.2)
+    m = C.ChromeGCN(d, d, c, 0.0, True, L)
+    m.load_state_dict(orc.state_dict()); m.to(DEV)
+    x = torch.randn(2, n, d, generator=g_)
+    tgt = (torch.rand(n, c, generator=g_) < 0.1).float()
+    adj_cpu = O.process_graph("hic", {"c": a}, n, "c")
+    g = C.process_graph("hic", {"c": a}, n, "c", device=DEV)
+    orc.train(); m.train()
+    xo = x.clone().requires_grad_(True)
+    lo = F.binary_cross_entropy_with_logits((orc(xo[0], adj_cpu)[1] + orc(xo[1], adj_cpu)[1]) / 2, tgt)
+    lo.backward()
+    xg = x.to(DEV).requires_grad_(True)
+    p, gates = m.forward_strands(xg, g)
+    lg = F.binary_cross_entropy_with_logits((p[0] + p[1]) / 2, tgt.to(DEV))
+    lg.backward()
+    assert len(gates) == 4 and abs(lo.item() - lg.item()) < 1e-4
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xo.grad.numpy(), atol=1e-6, rtol=1e-3)
+    po = dict(orc.named_parameters())
+    for k, pp in m.named_parameters():
+        ref = po[k].grad.numpy()
+        np.testing.assert_allclose(pp.grad.cpu().numpy(), ref, atol=1e-4 * max(1.0, float(np.abs(ref).max())), rtol=1e-4, err_msg=k)
+
+
+def test_cpu_inputs_fail_loudly():
+    m = C.ChromeGCN(128, 128, 5, 0.0, True, 2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.randn(4, 128), None)
+
+
+def test_bad_shapes_are_rejected():
+    g = C.process_graph("none", None, 8, "c", device=DEV)
+    with pytest.raises(RuntimeError):
+        ops.spmm(torch.randn(1, 8, 100, device=DEV), g)
+    with pytest.raises(RuntimeError):
+        ops.spmm(torch.randn(1, 9, 128, device=DEV), g)

@@ -1,0 +1,67 @@
+"""Host logic (no GPU): the product's own graph normaliser against the golden vectors recorded
+from the reference's process_graph and against the oracle."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from chromegcn_amd import graph as G
+from oracle import chromegcn_oracle as O
+from helpers import coo_to_csr, csr_from
+
+
+def test_normalize_graph_matches_reference_golden(golden):
+    z = golden("g1_process_graph.npz")
+    for name in z["cases"]:
+        a_in = csr_from(z, "%s_in" % name)
+        n = a_in.shape[0]
+        for adj_type in ["hic", "constant", "both", "none"]:
+            key = "%s_%s" % (name, adj_type)
+            if key + "_row" not in z.files:
+                continue
+            h = G.normalize_graph(adj_type, a_in, n)
+            assert h.rowptr.dtype == np.int32 and h.col.dtype == np.int32
+            ref = coo_to_csr(z, key, n)
+            got = h.to_scipy()
+            # same sparsity pattern wherever the reference stores a non-zero
+            ref.eliminate_zeros()
+            assert (got != 0).astype(int).sum() == (ref != 0).astype(int).sum()
+            np.testing.assert_allclose(got.toarray(), ref.toarray(), rtol=2e-7, atol=0)
+            # implicit-value graphs really are uniform per row
+            if h.val is None:
+                deg = np.diff(h.rowptr)
+                np.testing.assert_array_equal(h.row_scale[deg > 0], (1.0 / deg[deg > 0]).astype(np.float32))
+            assert h.symmetric
+
+
+def test_both_graph_carries_values():
+    a = O.random_symmetric_graph(40, 60, 3)
+    h = G.normalize_graph("both", a, 40)
+    assert h.val is not None and set(np.unique(h.val)).issubset({1.0, 2.0, 3.0})
+    np.testing.assert_allclose(h.to_scipy().toarray(), O.normalized_adjacency("both", a, 40).toarray(), rtol=2e-7)
+
+
+def test_small_n_and_bad_args():
+    h = G.normalize_graph("constant", None, 3)
+    np.testing.assert_allclose(h.to_scipy().toarray(), np.full((3, 3), 1 / 3, np.float32), rtol=1e-7)
+    h1 = G.normalize_graph("hic", sp.csr_matrix((1, 1)), 1)
+    assert h1.nnz == 1 and h1.row_scale[0] == 1.0
+    with pytest.raises(ValueError):
+        G.normalize_graph("random", None, 4)
+    with pytest.raises(ValueError):
+        G.normalize_graph("hic", sp.csr_matrix((3, 3)), 4)
+
+
+def test_negative_diagonal_gives_empty_row():
+    # hic_ii = -1 cancels the added identity: the reference keeps a zero there and the row
+    # normaliser maps 1/0 -> 0 (utils/util_methods.py:103)
+    a = sp.csr_matrix(np.array([[-1.0, 0, 0], [0, 0, 1.0], [0, 1.0, 0]]))
+    h = G.normalize_graph("hic", a, 3)
+    assert h.rowptr[1] - h.rowptr[0] == 0 and h.row_scale[0] == 0.0
+    np.testing.assert_allclose(h.to_scipy().toarray(), O.normalized_adjacency("hic", a, 3).toarray())
+
+
+def test_asymmetric_matrix_detected():
+    m = sp.csr_matrix(np.array([[0.5, 0.5, 0], [0, 1.0, 0], [0.2, 0.3, 0.5]], dtype=np.float32))
+    h = G.host_csr_from_matrix(m)
+    assert not h.symmetric and h.row_scale is None
+    np.testing.assert_array_equal(h.to_scipy().toarray(), m.toarray())
