@@ -1,0 +1,355 @@
+"""GCN-stage loop: the build's counterpart of the reference's finetune.py / runner.py.
+
+`finetune(...)` keeps the reference signature and return value (finetune.py:9, :67) so runner.py-style
+callers work unchanged.  Underneath, `GCNStage` does what the MI355X wants instead of what the
+reference does per chromosome per epoch:
+
+  reference (finetune.py:20-53)                      here
+  -------------------------------------------------  ------------------------------------------------
+  pickle.load of all graphs every call (:21-23)      graphs normalised + uploaded once, cached on device
+  process_graph on the CPU every chromosome (:36)    (ChromGraph), features/targets cached on device
+  H2D of features / COO adjacency (:30-36)
+  two forward calls, forward + reverse strand        one strand-batched pass ([2,n,d]) over the graph
+  (:41-42)
+  ~60 small launches + loss.item() sync (:51)        whole step captured once per chromosome into a HIP
+                                                     graph and replayed; losses stay on device until the
+                                                     split ends
+  single GPU                                         one process per GPU, chromosomes sharded across ranks,
+                                                     one all-reduce of the flat gradient buffer per step
+                                                     group (RCCL over xGMI)
+Semantics at world_size 1 are exactly the reference's: one SGD step per chromosome, in dict order."""
+from __future__ import annotations
+
+import os
+import pickle
+import time
+from typing import Dict, Iterable, List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from . import graph as G
+from .dist import ShardPlan, plan_shards
+
+
+class _Chrom:
+    __slots__ = ("name", "n", "graph", "x", "target", "cost")
+
+    def __init__(self, name, n, graph, x, target, cost):
+        self.name, self.n, self.graph, self.x, self.target, self.cost = name, n, graph, x, target, cost
+
+
+class GCNStage:
+    """Device-resident state + step engine of the GCN stage for one split-independent model.
+
+    model      : ChromeGCN-like module with forward_strands(x_fr [2,n,d], graph) -> (logits [2,n,C], gates)
+    optimizer  : torch optimizer over model.parameters() (utils/util_methods.py:14-19 builds SGD/Adam)
+    hip_graphs : capture each chromosome's step into a HIP graph (needs a GPU)
+    input_grad : also produce d loss / d features, as finetune.py:33-34 asks autograd to
+    group      : torch.distributed process group (None = single process)"""
+
+    def __init__(self, model, optimizer=None, adj_type: str = "hic", device="cuda", hip_graphs: bool = True,
+                 input_grad: bool = True, group=None):
+        self.model = model
+        self.optimizer = optimizer
+        self.adj_type = adj_type
+        self.device = torch.device(device)
+        self.hip_graphs = bool(hip_graphs) and self.device.type == "cuda"
+        self.input_grad = input_grad
+        self.group = group
+        if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(group)
+            self.rank = torch.distributed.get_rank(group)
+        else:
+            self.world, self.rank = 1, 0
+        self.chroms: Dict[str, _Chrom] = {}
+        self._graphs: Dict[tuple, dict] = {}
+        self._pool = None
+        self._flat_grad: Optional[torch.Tensor] = None
+        self._captured_lr = None
+
+    # ------------------------------------------------------------------ data
+    def add_chromosome(self, name: str, feats: Dict[str, torch.Tensor], hic=None):
+        """feats: {'forward': [n,d], 'backward': [n,d], 'target': [n,C]} (utils/util_methods.py:183-199);
+        hic: scipy matrix for 'hic'/'both' graphs (data/7create_graph_new.py:118)."""
+        n = feats["forward"].shape[0]
+        h = G.normalize_graph(self.adj_type, hic, n)
+        g = G.upload(h, self.device)
+        x = torch.stack([feats["forward"], feats["backward"]]).to(self.device, torch.float32).contiguous()
+        t = feats["target"].to(self.device, torch.float32).contiguous()
+        d = x.shape[2]
+        cost = float(h.nnz) * d + 3.0 * n * d * d / 16.0
+        self.chroms[name] = _Chrom(name, n, g, x, t, cost)
+        self._graphs = {k: v for k, v in self._graphs.items() if k[0] != name}
+
+    def load(self, chrom_feature_dict, split_adj_dict=None, only: Optional[Iterable[str]] = None):
+        for name in chrom_feature_dict:
+            if only is not None and name not in only:
+                continue
+            if name in self.chroms and self.chroms[name].n == chrom_feature_dict[name]["forward"].shape[0]:
+                continue
+            hic = None if split_adj_dict is None else split_adj_dict.get(name)
+            self.add_chromosome(name, chrom_feature_dict[name], hic)
+
+    # ------------------------------------------------------------------ gradients as one flat buffer
+    def _params(self):
+        return [p for p in self.model.parameters() if p.requires_grad]
+
+    def _ensure_flat_grad(self):
+        ps = self._params()
+        total = sum(p.numel() for p in ps)
+        ok = self._flat_grad is not None and self._flat_grad.numel() == total and self._flat_grad.device == ps[0].device
+        if ok:
+            off = 0
+            for p in ps:
+                if p.grad is None or p.grad.data_ptr() != self._flat_grad.data_ptr() + 4 * off:
+                    ok = False
+                    break
+                off += p.numel()
+        if ok:
+            return
+        self._flat_grad = torch.zeros(total, device=ps[0].device, dtype=torch.float32)
+        off = 0
+        for p in ps:
+            p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self._graphs.clear()
+
+    # ------------------------------------------------------------------ one chromosome, eager
+    def _forward_loss(self, c: _Chrom, x):
+        logits, _ = self.model.forward_strands(x, c.graph)
+        pred = (logits[0] + logits[1]) / 2                                # finetune.py:43
+        loss = F.binary_cross_entropy_with_logits(pred, c.target)          # finetune.py:45
+        return loss, torch.sigmoid(pred).detach()                          # finetune.py:52
+
+    def _fwd_bwd(self, c: _Chrom):
+        x = c.x.detach().requires_grad_(True) if self.input_grad else c.x  # finetune.py:33-34
+        self._flat_grad.zero_()                                            # finetune.py:39
+        loss, probs = self._forward_loss(c, x)
+        loss.backward()                                                    # finetune.py:48
+        return loss.detach(), probs, (x.grad if self.input_grad else None)
+
+    def _eval(self, c: _Chrom):
+        with torch.no_grad():
+            loss, probs = self._forward_loss(c, c.x)
+        return loss, probs
+
+    # ------------------------------------------------------------------ HIP-graph capture
+    def _snapshot(self):
+        st = {"model": {k: v.clone() for k, v in self.model.state_dict().items()}}
+        if self.optimizer is not None:
+            st["opt"] = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in s.items()}
+                         for s in (self.optimizer.state.get(p, {}) for p in self._params())]
+        return st
+
+    def _restore(self, st):
+        with torch.no_grad():
+            for k, v in self.model.state_dict().items():
+                v.copy_(st["model"][k])
+            if self.optimizer is not None:
+                for p, saved in zip(self._params(), st["opt"]):
+                    cur = self.optimizer.state.get(p, {})
+                    for k, v in cur.items():
+                        if torch.is_tensor(v):
+                            if k in saved and torch.is_tensor(saved[k]):
+                                v.copy_(saved[k])
+                            else:
+                                v.zero_()  # state created during warm-up (e.g. momentum_buffer): 0 == "not yet stepped"
+
+    def _lr_signature(self):
+        return None if self.optimizer is None else tuple(g.get("lr") for g in self.optimizer.param_groups)
+
+    def _capture(self, c: _Chrom, kind: str):
+        """kind: 'train' (zero_grad+fwd+bwd+step), 'fwdbwd' (no optimizer step: multi-rank), 'eval'."""
+        was_training = self.model.training
+        self.model.train(kind != "eval")
+        snap = self._snapshot()
+
+        def body():
+            if kind == "eval":
+                loss, probs = self._eval(c)
+                return loss, probs, None
+            loss, probs, dx = self._fwd_bwd(c)
+            if kind == "train":
+                self.optimizer.step()                                     # finetune.py:49
+            return loss, probs, dx
+
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(2):  # warm-up: allocator pools, rocBLAS/MIOpen handles, lazy optimizer state
+                body()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        self._restore(snap)
+        graph = torch.cuda.CUDAGraph()
+        if self._pool is None:
+            self._pool = torch.cuda.graph_pool_handle()
+        with torch.cuda.graph(graph, pool=self._pool):
+            loss, probs, dx = body()
+        self._restore(snap)  # capture launches nothing, but keep state bit-identical regardless
+        self.model.train(was_training)
+        return {"graph": graph, "loss": loss, "probs": probs, "dx": dx}
+
+    def _replay(self, c: _Chrom, kind: str):
+        if self._captured_lr != self._lr_signature():
+            self._graphs.clear()  # the learning rate is baked into the captured optimizer kernels
+            self._captured_lr = self._lr_signature()
+        key = (c.name, kind)
+        ent = self._graphs.get(key)
+        if ent is None:
+            ent = self._graphs[key] = self._capture(c, kind)
+        ent["graph"].replay()
+        return ent["loss"], ent["probs"], ent["dx"]
+
+    # ------------------------------------------------------------------ public steps
+    def train_step(self, name: str):
+        """One reference train step on one chromosome (finetune.py:38-49).  Returns device tensors
+        (loss [], probs [n,C], dx [2,n,d] or None); valid until the next step."""
+        c = self.chroms[name]
+        self.model.train()
+        self._ensure_flat_grad()
+        if self.world > 1:
+            raise RuntimeError("use train_group() when running on more than one rank")
+        if self.hip_graphs:
+            return self._replay(c, "train")
+        loss, probs, dx = self._fwd_bwd(c)
+        self.optimizer.step()
+        return loss, probs, dx
+
+    def eval_step(self, name: str):
+        c = self.chroms[name]
+        self.model.eval()
+        if self.hip_graphs:
+            loss, probs, _ = self._replay(c, "eval")
+            return loss, probs
+        return self._eval(c)
+
+    def train_group(self, name: Optional[str], group_size: int):
+        """Multi-rank step group: every rank runs fwd+bwd on its own chromosome (or none), gradients are
+        summed across ranks in ONE all-reduce of the flat buffer and divided by the number of chromosomes
+        in the group, then every rank takes the same optimizer step."""
+        self.model.train()
+        self._ensure_flat_grad()
+        out = (None, None, None)
+        if name is not None:
+            c = self.chroms[name]
+            out = self._replay(c, "fwdbwd") if self.hip_graphs else self._fwd_bwd(c)
+        else:
+            self._flat_grad.zero_()
+        if self.world > 1:
+            torch.distributed.all_reduce(self._flat_grad, op=torch.distributed.ReduceOp.SUM, group=self.group)
+        if group_size > 1:
+            self._flat_grad.div_(group_size)
+        self.optimizer.step()
+        return out
+
+    def sync_running_stats(self):
+        """BatchNorm running statistics see different chromosomes on different ranks; average them so
+        every rank evaluates with the same model (deliberate deviation)."""
+        if self.world <= 1:
+            return
+        bufs = [b for k, b in self.model.named_buffers() if b.dtype.is_floating_point]
+        if not bufs:
+            return
+        flat = torch.cat([b.reshape(-1) for b in bufs])
+        torch.distributed.all_reduce(flat, group=self.group)
+        flat.div_(self.world)
+        off = 0
+        for b in bufs:
+            b.copy_(flat[off:off + b.numel()].view_as(b))
+            off += b.numel()
+
+    # ------------------------------------------------------------------ a whole split
+    def run_split(self, split: str, names: Optional[Sequence[str]] = None):
+        """(all_preds, all_targets, total_loss) with finetune.py:67's meaning: sigmoid probabilities and
+        targets concatenated in chromosome order (CPU tensors), total_loss = sum of per-chromosome
+        mean BCE.  Multi-rank: every rank returns the full concatenation."""
+        names = list(self.chroms) if names is None else list(names)
+        train = split == "train"
+        C = next(iter(self.chroms.values())).target.shape[1] if self.chroms else 0
+        if self.world == 1:
+            losses, probs = [], []
+            for nm in names:
+                loss, p, _ = self.train_step(nm) if train else (*self.eval_step(nm), None)
+                losses.append(loss.clone())
+                probs.append(p.clone())
+            total = float(torch.stack(losses).sum().item()) if losses else 0.0
+            preds = torch.cat(probs, 0).cpu() if probs else torch.empty(0, C)
+        else:
+            plan = plan_shards({nm: self.chroms[nm].cost for nm in names}, self.world) if train else \
+                plan_shards({nm: self.chroms[nm].cost for nm in names}, self.world)
+            mine: Dict[str, torch.Tensor] = {}
+            loss_sum = torch.zeros((), device=self.device)
+            for group in plan.rounds:
+                nm = group[self.rank] if self.rank < len(group) else None
+                k = sum(1 for g in group if g is not None)
+                if train:
+                    loss, p, _ = self.train_group(nm, k)
+                elif nm is not None:
+                    loss, p = self.eval_step(nm)
+                else:
+                    loss = p = None
+                if nm is not None:
+                    mine[nm] = p.clone()
+                    loss_sum += loss
+            if train:
+                self.sync_running_stats()
+            torch.distributed.all_reduce(loss_sum, group=self.group)
+            total = float(loss_sum.item())
+            preds = _gather_predictions(mine, names, {nm: self.chroms[nm].n for nm in names}, C, plan, self)
+        targets = torch.cat([self.chroms[nm].target for nm in names], 0).cpu() if names else torch.empty(0, C)
+        return preds, targets, total
+
+
+def _gather_predictions(mine, names, sizes, C, plan: ShardPlan, stage: GCNStage):
+    """No data-path collective is needed for predictions: each rank broadcasts the rows it produced."""
+    owner = plan.owner
+    parts = []
+    for nm in names:
+        buf = mine[nm] if owner[nm] == stage.rank else torch.empty(sizes[nm], C, device=stage.device)
+        torch.distributed.broadcast(buf, src=owner[nm], group=stage.group)
+        parts.append(buf.cpu())
+    return torch.cat(parts, 0) if parts else torch.empty(0, C)
+
+
+# ---------------------------------------------------------------------------------------------
+# reference-signature entry points
+# ---------------------------------------------------------------------------------------------
+_GRAPH_FILES: Dict[str, dict] = {}
+
+
+def _load_graph_file(opt, split):
+    """finetune.py:20-23 -- but unpickled once per file, not once per call."""
+    path = os.path.join(opt.graph_root, split + "_graphs_" + opt.hicsize + "_" + opt.hicnorm + "norm.pkl")
+    if path not in _GRAPH_FILES:
+        with open(path, "rb") as f:
+            _GRAPH_FILES[path] = pickle.load(f)
+    return _GRAPH_FILES[path]
+
+
+def finetune(WindowModel, ChromeModel, chrom_feature_dict, crit, optimizer, epoch, data_dict, opt, split,
+             split_adj_dict=None):
+    """Same arguments and return value as the reference's finetune (finetune.py:9,67).  WindowModel, crit,
+    epoch and data_dict are accepted and unused, as in the reference.  Extra keyword split_adj_dict lets a
+    caller hand the {chrom: scipy matrix} dict in directly instead of via opt.graph_root."""
+    adj_type = getattr(opt, "adj_type", "hic")
+    if split_adj_dict is None and adj_type in ("hic", "both"):
+        split_adj_dict = _load_graph_file(opt, split)
+    stages = ChromeModel.__dict__.setdefault("_cgcn_stages", {})
+    key = (split, id(optimizer), adj_type)
+    stage = stages.get(key)
+    if stage is None:
+        dev = next(ChromeModel.parameters()).device
+        stage = stages[key] = GCNStage(ChromeModel, optimizer, adj_type=adj_type, device=dev,
+                                       hip_graphs=getattr(opt, "hip_graphs", True))
+    stage.load(chrom_feature_dict, split_adj_dict)
+    return stage.run_split(split, list(chrom_feature_dict))
+
+
+def run_epoch(WindowModel, ChromeModel, split_data, crit, optimizer, epoch, data_dict, opt, split, **kw):
+    """runner.py:10-23: times the stage; elapsed is in minutes like the reference."""
+    start = time.time()
+    pred, targ, loss = finetune(WindowModel, ChromeModel, split_data, crit, optimizer, epoch, data_dict, opt, split, **kw)
+    elapsed = (time.time() - start) / 60
+    return pred, targ, loss, elapsed
