@@ -96,8 +96,7 @@ def cpu_baseline(args, n, pairs, seed, steps):
     same workload: a bounded sample of `steps` train steps."""
     from oracle import chromegcn_oracle as O  # cpu_baseline leg: the oracle is the thing timed here, nowhere else
     from chromegcn_amd import synth
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     feats = synth.chrom_features(n, args.d, synth.N_LABELS, 1000 + seed)
     hic = synth.contact_graph(n, pairs, seed, args.hic_like)
     torch.manual_seed(0)
@@ -105,14 +104,33 @@ def cpu_baseline(args, n, pairs, seed, steps):
     opt = O.make_sgd(model, 0.25)
     data = {"c": feats}
     cache = {}
-    O.finetune_epoch(model, data, {"c": hic}, opt, "train", "hic", adj_cache=cache)  # warm-up (+ builds adj)
+
+    def one(cached=True):
+        t0 = time.perf_counter()
+        O.finetune_epoch(model, data, {"c": hic}, opt, "train", "hic", adj_cache=cache if cached else None)
+        return time.perf_counter() - t0
+
+    # torch's CPU spmm does not scale to every core of a big host (256 threads measured 20x slower than
+    # 8-32): pick the thread count that is fastest on this box, so the baseline is the CPU's best case.
+    best = None
+    for th in sorted({t for t in (4, 8, 16, 32, 64, ncpu) if t <= ncpu}):
+        torch.set_num_threads(th)
+        one()  # warm-up at this thread count (the first call also builds the cached adjacency)
+        dt = min(one(), one())
+        if best is None or dt < best[1]:
+            best = (th, dt)
+        if dt > 4.0 * best[1] or dt > 8.0:
+            break
+    cores = best[0]
+    torch.set_num_threads(cores)
+    one()
     t0 = time.perf_counter()
     for _ in range(steps):
-        O.finetune_epoch(model, data, {"c": hic}, opt, "train", "hic", adj_cache=cache)
+        one()
     t_cached = (time.perf_counter() - t0) / steps
     t0 = time.perf_counter()
     for _ in range(max(1, steps // 4)):
-        O.finetune_epoch(model, data, {"c": hic}, opt, "train", "hic")  # reference behaviour: process_graph every step
+        one(cached=False)  # reference behaviour: process_graph every chromosome every epoch (finetune.py:36)
     t_full = (time.perf_counter() - t0) / max(1, steps // 4)
     cpu_model = platform.processor() or ""
     try:
@@ -126,7 +144,7 @@ def cpu_baseline(args, n, pairs, seed, steps):
     return {"value": n / t_cached, "unit": "windows/s", "cores": cores, "kind": "port",
             "sample": "%d train steps (f+r fwd, BCE, bwd, SGD) on the same %d-window chromosome, adjacency cached; "
                       "oracle = torch-CPU restatement of the reference ops" % (steps, n),
-            "s_per_step": t_cached, "with_process_graph_windows_per_s": n / t_full,
+            "s_per_step": t_cached, "with_process_graph_windows_per_s": n / t_full, "host_cpus": ncpu,
             "cpu_model": cpu_model, "torch": torch.__version__}
 
 

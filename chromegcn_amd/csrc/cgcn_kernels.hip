@@ -442,23 +442,43 @@ __global__ __launch_bounds__(D * 2) void k_bwd_rowlocal(int M, int n, const floa
   }
 }
 
-// Second stage: out[e] (+)= sum_p part[p][e], fixed order => deterministic.
+// Second stage: out[e] (+)= sum_p part[p][e].  64 elements x 4 partial-slices per workgroup: every
+// thread sums P/4 partials with 16 loads in flight, the 4 slices are combined through LDS in a fixed
+// order => deterministic, and latency is ~P/64 dependent round trips instead of P.
 __global__ __launch_bounds__(256) void k_reduce_partials(int P, int D, const float* __restrict__ part,
                                                          float* __restrict__ dW, float* __restrict__ db,
                                                          float* __restrict__ dwg, float* __restrict__ dcg,
                                                          int accumulate) {
   const int PSTRIDE = D * D + 2 * D + 4;
   const int total = D * D + 2 * D + 1;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= total) return;
+  __shared__ float red[4][64];
+  const int el = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + el;
   float s = 0.f;
-  for (int p = 0; p < P; ++p) s += part[(size_t)p * PSTRIDE + e];
-  float* dst;
-  if (e < D * D) dst = dW + e;
-  else if (e < D * D + D) dst = db + (e - D * D);
-  else if (e < D * D + 2 * D) dst = dwg + (e - D * D - D);
-  else dst = dcg;
-  *dst = accumulate ? (*dst + s) : s;
+  if (e < total) {
+    const int per = (P + 3) / 4;
+    const int p0 = slice * per, p1 = min(P, p0 + per);
+    int p = p0;
+    for (; p + 16 <= p1; p += 16) {
+      float t[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) t[u] = part[(size_t)(p + u) * PSTRIDE + e];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += t[u];
+    }
+    for (; p < p1; ++p) s += part[(size_t)p * PSTRIDE + e];
+  }
+  red[slice][el] = s;
+  __syncthreads();
+  if (slice == 0 && e < total) {
+    s = ((red[0][el] + red[1][el]) + red[2][el]) + red[3][el];
+    float* dst;
+    if (e < D * D) dst = dW + e;
+    else if (e < D * D + D) dst = db + (e - D * D);
+    else if (e < D * D + 2 * D) dst = dwg + (e - D * D - D);
+    else dst = dcg;
+    *dst = accumulate ? (*dst + s) : s;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -633,7 +653,7 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
     hipLaunchKernelGGL((k_bwd_rowlocal<256>), dim3(P), dim3(512), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dUs, part);
   if ((rc = launch_status())) return rc;
   const int total = d * d + 2 * d + 1;
-  hipLaunchKernelGGL(k_reduce_partials, dim3((total + 255) / 256), dim3(256), 0, st, P, d, part, dW, db, dwg, dcg, accumulate);
+  hipLaunchKernelGGL(k_reduce_partials, dim3((total + 63) / 64), dim3(256), 0, st, P, d, part, dW, db, dwg, dcg, accumulate);
   if ((rc = launch_status())) return rc;
   if (n == 0) return CGCN_OK;
   const int blocks = (n + TILE_NODES - 1) / TILE_NODES;

@@ -67,6 +67,7 @@ class GCNStage:
         self._pool = None
         self._flat_grad: Optional[torch.Tensor] = None
         self._captured_lr = None
+        self._int_synced: Dict[str, torch.Tensor] = {}
 
     # ------------------------------------------------------------------ data
     def add_chromosome(self, name: str, feats: Dict[str, torch.Tensor], hic=None):
@@ -250,15 +251,24 @@ class GCNStage:
         if self.world <= 1:
             return
         bufs = [b for k, b in self.model.named_buffers() if b.dtype.is_floating_point]
-        if not bufs:
-            return
-        flat = torch.cat([b.reshape(-1) for b in bufs])
-        torch.distributed.all_reduce(flat, group=self.group)
-        flat.div_(self.world)
-        off = 0
-        for b in bufs:
-            b.copy_(flat[off:off + b.numel()].view_as(b))
-            off += b.numel()
+        if bufs:
+            flat = torch.cat([b.reshape(-1) for b in bufs])
+            torch.distributed.all_reduce(flat, group=self.group)
+            flat.div_(self.world)
+            off = 0
+            for b in bufs:
+                b.copy_(flat[off:off + b.numel()].view_as(b))
+                off += b.numel()
+        # integer counters (num_batches_tracked): every rank ends with the total number of BatchNorm
+        # calls made by all ranks, which is what one sequential process would have counted
+        for k, b in self.model.named_buffers():
+            if not b.dtype.is_floating_point:
+                prev = self._int_synced.get(k)
+                prev = torch.zeros_like(b) if prev is None else prev
+                delta = (b - prev).clone()
+                torch.distributed.all_reduce(delta, group=self.group)
+                b.copy_(prev + delta)
+                self._int_synced[k] = b.clone()
 
     # ------------------------------------------------------------------ a whole split
     def run_split(self, split: str, names: Optional[Sequence[str]] = None):

@@ -1,0 +1,70 @@
+"""The stage loop on the GPU against G4 (recorded from the reference's model + process_graph driven
+in finetune.py's order): per-epoch predictions, loss totals, final parameters -- eagerly and through
+the captured HIP graphs (which must leave the training state bit-identical to never having warmed up)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import chromegcn_amd as C
+from chromegcn_amd.finetune import finetune, run_epoch, GCNStage
+from helpers import csr_from, state_from
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _load(z):
+    chroms = [str(c) for c in z["chroms"]]
+    feats, graphs = {}, {}
+    for c in chroms:
+        graphs[c] = csr_from(z, c + "_in")
+        feats[c] = {"forward": torch.from_numpy(z[c + "_xf"]), "backward": torch.from_numpy(z[c + "_xr"]),
+                    "target": torch.from_numpy(z[c + "_tgt"])}
+    return chroms, feats, graphs
+
+
+@pytest.mark.parametrize("hip_graphs", [False, True])
+def test_finetune_loop_matches_reference_golden(golden, hip_graphs):
+    z = golden("g4_finetune_loop.npz")
+    chroms, feats, graphs = _load(z)
+    init = state_from(z, "init")
+    m = C.ChromeGCN(128, 128, init["out.weight"].shape[0], 0.0, True, 2)
+    m.load_state_dict(init)
+    m.to(DEV)
+    optim = torch.optim.SGD(m.parameters(), lr=0.25, weight_decay=1e-6, momentum=0.9)
+    opt = types.SimpleNamespace(adj_type="hic", hip_graphs=hip_graphs)
+    ref_tr = z["train_losses"]
+    for e in range(2):
+        preds, targets, total = finetune(None, m, feats, None, optim, e + 1, None, opt, "train", split_adj_dict=graphs)
+        assert preds.device.type == "cpu" and preds.shape == targets.shape
+        np.testing.assert_allclose(preds.numpy(), z["train_preds_e%d" % e], atol=1e-4, rtol=1e-4)
+        assert abs(total - ref_tr[3 * e:3 * e + 3].sum()) < 2e-4
+        np.testing.assert_array_equal(targets.numpy(), np.concatenate([z[c + "_tgt"] for c in chroms]))
+    preds, targets, total, elapsed = run_epoch(None, m, feats, None, optim, 3, None, opt, "valid", split_adj_dict=graphs)
+    np.testing.assert_allclose(preds.numpy(), z["eval_preds"], atol=1e-4, rtol=1e-4)
+    assert abs(total - z["eval_losses"].sum()) < 2e-4 and elapsed >= 0
+    final = state_from(z, "final")
+    for k, v in m.state_dict().items():
+        np.testing.assert_allclose(v.cpu().numpy(), final[k].numpy(), atol=1e-4, rtol=1e-4, err_msg=k)
+
+
+def test_captured_step_equals_eager_step_bitwise(golden):
+    z = golden("g4_finetune_loop.npz")
+    chroms, feats, graphs = _load(z)
+    init = state_from(z, "init")
+    outs = []
+    for hip_graphs in (False, True):
+        m = C.ChromeGCN(128, 128, init["out.weight"].shape[0], 0.0, True, 2)
+        m.load_state_dict(init); m.to(DEV)
+        optim = torch.optim.SGD(m.parameters(), lr=0.25, weight_decay=1e-6, momentum=0.9)
+        st = GCNStage(m, optim, "hic", DEV, hip_graphs=hip_graphs)
+        st.load(feats, graphs)
+        for _ in range(2):
+            for c in chroms:
+                loss, probs, dx = st.train_step(c)
+        outs.append(({k: v.clone() for k, v in m.state_dict().items()}, loss.clone(), dx.clone()))
+    for k in outs[0][0]:
+        assert torch.equal(outs[0][0][k], outs[1][0][k]), k
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
