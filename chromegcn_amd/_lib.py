@@ -13,6 +13,7 @@ from . import _build
 _c_int = ctypes.c_int
 _c_vp = ctypes.c_void_p
 _c_sz = ctypes.c_size_t
+_c_float = ctypes.c_float
 
 _SIGNATURES = {
     # name: (restype, argtypes)
@@ -22,6 +23,10 @@ _SIGNATURES = {
     "cgcn_layer_fwd": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 13),
     "cgcn_layer_bwd_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
     "cgcn_layer_bwd": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 18 + [_c_int, _c_vp, _c_sz]),
+    "cgcn_head_workspace_bytes": (_c_sz, [_c_int] * 4),
+    "cgcn_head_fwd": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp] * 6 + [_c_float, _c_float, _c_int] + [_c_vp] * 3
+                      + [_c_float] + [_c_vp] * 8 + [_c_sz]),
+    "cgcn_head_bwd": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp] * 8 + [_c_float] + [_c_vp] * 6 + [_c_int, _c_vp, _c_sz]),
 }
 ABI_VERSION = 1
 _lib = None

@@ -1,0 +1,59 @@
+// chromegcn_amd/csrc/cgcn_common.hpp -- helpers shared by the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "chromegcn.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define WAVE 64
+#define TILE_NODES 16   // nodes per workgroup tile in the gather kernels
+#define BWD_TILE_ROWS 32  // rows per MFMA K-step group in k_bwd_rowlocal
+#define BWD_MAX_PARTIALS 256
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+  return v;
+}
+
+__device__ __forceinline__ int rl_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ float rl_f(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+
+// Counter-based dropout RNG: a mask bit is a pure function of (seed, step counter, stream id, element
+// index), so the backward regenerates the forward's mask instead of storing it.  rng_state lives in
+// device memory ([0] = seed, [1] = step counter) so that a captured HIP graph sees a fresh counter on
+// every replay.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t dropout_key(const unsigned long long* rng_state, uint32_t stream_id) {
+  const unsigned long long seed = rng_state[0], ctr = rng_state[1];
+  uint32_t k = mix32((uint32_t)seed ^ 0x9E3779B9u);
+  k = mix32(k ^ (uint32_t)(seed >> 32));
+  k = mix32(k + (uint32_t)ctr * 0x85EBCA6Bu);
+  k = mix32(k ^ (uint32_t)(ctr >> 32) ^ (stream_id * 0xC2B2AE35u));
+  return k;
+}
+__device__ __forceinline__ bool dropout_keep(uint32_t key, uint32_t elem, uint32_t thresh) {
+  return mix32(elem * 0x9E3779B1u + key) >= thresh;
+}
+static inline uint32_t dropout_threshold(float p) {
+  double t = (double)p * 4294967296.0;
+  if (t <= 0.0) return 0u;
+  if (t >= 4294967295.0) return 4294967295u;
+  return (uint32_t)t;
+}
+
+static inline bool misaligned16(const void* p) { return ((uintptr_t)p & 15u) != 0; }
+static inline int launch_status() { return hipGetLastError() == hipSuccess ? CGCN_OK : CGCN_ERR_LAUNCH; }

@@ -1,0 +1,619 @@
+// chromegcn_amd/csrc/cgcn_head.hip
+//
+// Fused classifier head of ChromeGCN for the GCN-stage train/eval step (gfx950 only):
+//     relu -> BatchNorm1d over the node axis -> dropout -> Linear(d, C)      models/ChromeModels.py:48-51
+//     pred = mean over strands of the logits                                 finetune.py:43
+//     loss = binary_cross_entropy_with_logits(pred, target) (mean)           finetune.py:45
+//     probs = sigmoid(pred)                                                  finetune.py:52
+// and its backward.  Because Linear is affine, mean_s(Linear(y_s)) = Linear(mean_s y_s): the strands are
+// averaged BEFORE the d x C contraction, which halves the MFMA work and the dW_out reduction.
+//
+// Kernels:
+//   k_head_colstats<D>     per-strand column mean / M2 of relu(X) (Welford per thread, Chan combine)
+//   k_head_bn_finalize     combine partials -> batch mean / invstd, running-stat update (strand 0 then 1,
+//                          like the reference's two forward calls), num_batches_tracked += S
+//   k_head_fwd<D>          16-node tile: ym = mean_s dropout(BN(relu(x_s))) -> LDS -> fp32 MFMA x W_out^T
+//                          -> sigmoid / BCE / d(loss)/d(pred) epilogue
+//   k_sum_scale            deterministic sum of the per-workgroup loss partials
+//   k_head_bwd<D,CBMAX>    persistent, 32-node tiles: dym = dpred W_out (MFMA), dW_out += dpred^T ym (MFMA,
+//                          accumulated in registers), column sums for db_out and the BatchNorm backward
+//   k_head_bwd_finalize    deterministic second stage: dW_out, db_out, d(bn weight), d(bn bias), BN constants
+//   k_head_bn_bwd_apply<D> dX = bn_w invstd (dy - mean(dy) - xhat mean(dy xhat)) [x > 0]
+#include "cgcn_common.hpp"
+
+#define HEAD_STAT_BLOCKS 128
+#define HEAD_TILE 16
+#define HEADB_TILE 32
+#define HEAD_MAX_PARTIALS 256
+#define HEAD_STREAM_ID 0x4845u  // dropout stream of the head ("HE")
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm statistics
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void chan_combine(float& nA, float& meanA, float& m2A, float nB, float meanB, float m2B) {
+  const float nAB = nA + nB;
+  if (nAB > 0.f) {
+    const float delta = meanB - meanA;
+    meanA += delta * (nB / nAB);
+    m2A += m2B + delta * delta * (nA * nB / nAB);
+    nA = nAB;
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_head_colstats(int n, int S, int rows_per_blk, const float* __restrict__ X,
+                                                       float* __restrict__ part) {
+  constexpr int RL = 256 / D;  // row lanes per column
+  __shared__ float sm[3][256];
+  const int c = threadIdx.x % D, rl = threadIdx.x / D;
+  const int r0 = blockIdx.x * rows_per_blk, r1 = min(n, r0 + rows_per_blk);
+  for (int s = 0; s < S; ++s) {
+    float mean = 0.f, m2 = 0.f, k = 0.f;
+    for (int i = r0 + rl; i < r1; i += RL) {
+      const float x = fmaxf(X[((size_t)s * n + i) * D + c], 0.f);
+      k += 1.f;
+      const float delta = x - mean;
+      mean += delta / k;
+      m2 += delta * (x - mean);
+    }
+    if (RL > 1) {
+      if (rl > 0) { sm[0][threadIdx.x] = k; sm[1][threadIdx.x] = mean; sm[2][threadIdx.x] = m2; }
+      __syncthreads();
+      if (rl == 0) {
+        for (int o = 1; o < RL; ++o) chan_combine(k, mean, m2, sm[0][o * D + c], sm[1][o * D + c], sm[2][o * D + c]);
+      }
+      __syncthreads();
+    }
+    if (rl == 0) {
+      float* p = part + (((size_t)blockIdx.x * S + s) * D + c) * 2;
+      p[0] = mean;
+      p[1] = m2;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_head_bn_finalize(int n, int S, int D, int nblk, int rows_per_blk,
+                                                          const float* __restrict__ part, float momentum, float eps,
+                                                          float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                          long long* __restrict__ nbt, float* __restrict__ save_mean,
+                                                          float* __restrict__ save_invstd,
+                                                          unsigned long long* __restrict__ rng_state,
+                                                          unsigned long long* __restrict__ rng_saved) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) nbt[0] += S;
+  if (c == 0 && rng_state) {  // snapshot the dropout counter for this step's fwd+bwd, then advance it
+    rng_saved[0] = rng_state[0];
+    rng_saved[1] = rng_state[1];
+    rng_state[1] += 1ull;
+  }
+  if (c >= D) return;
+  float rm = run_mean ? run_mean[c] : 0.f, rv = run_var ? run_var[c] : 1.f;
+  for (int s = 0; s < S; ++s) {
+    float cnt = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll 8
+    for (int b = 0; b < nblk; ++b) {
+      const float* p = part + (((size_t)b * S + s) * D + c) * 2;
+      const float nb = (float)max(0, min(n, (b + 1) * rows_per_blk) - b * rows_per_blk);
+      chan_combine(cnt, mean, m2, nb, p[0], p[1]);
+    }
+    const float var_b = m2 / (float)n;
+    save_mean[s * D + c] = mean;
+    save_invstd[s * D + c] = rsqrtf(var_b + eps);
+    // sequential update: the reference calls the model on the forward strand, then the reverse one
+    rm = (1.f - momentum) * rm + momentum * mean;
+    rv = (1.f - momentum) * rv + momentum * (m2 / (float)(n - 1));
+  }
+  if (run_mean) run_mean[c] = rm;
+  if (run_var) run_var[c] = rv;
+}
+
+// ------------------------------------------------------------------------------------------
+// ym row of one node: mean over strands of dropout(BN(relu(x_s))).  Lane owns EPL consecutive columns.
+// ------------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ void head_row(int n, int S, int i, int lane, const float* __restrict__ X,
+                                         const float* __restrict__ bn_w, const float* __restrict__ bn_b,
+                                         const float* __restrict__ mean, const float* __restrict__ vr, int use_running,
+                                         float eps, float keep_scale, uint32_t thresh, uint32_t key,
+                                         float (&ym)[D / 64]) {
+  constexpr int EPL = D / 64;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) ym[e] = 0.f;
+  for (int s = 0; s < S; ++s) {
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      const int c = lane * EPL + e;
+      const uint32_t el = (uint32_t)(((size_t)s * n + i) * D + c);
+      const float x = X[el];
+      const float mu = use_running ? mean[c] : mean[s * D + c];
+      const float is = use_running ? rsqrtf(vr[c] + eps) : vr[s * D + c];
+      float y = (fmaxf(x, 0.f) - mu) * is * bn_w[c] + bn_b[c];
+      if (thresh) y = dropout_keep(key, el, thresh) ? y * keep_scale : 0.f;
+      ym[e] += y;
+    }
+  }
+  const float invS = 1.f / (float)S;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) ym[e] *= invS;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_head_fwd
+// MFMA K index is permuted so that both operands are 16-byte reads: lane (q = l>>4) owns the K range
+// [q*D/4, (q+1)*D/4); step (t,u) uses k = q*D/4 + 4t + u for A (LDS) and B (W_out row) alike.
+// ------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void k_head_fwd(int n, int S, int C, const float* __restrict__ X,
+                                                  const float* __restrict__ bn_w, const float* __restrict__ bn_b,
+                                                  const float* __restrict__ mean, const float* __restrict__ vr,
+                                                  int use_running, float eps, const float* __restrict__ Wout,
+                                                  const float* __restrict__ bout, const float* __restrict__ target,
+                                                  float keep_scale, uint32_t thresh,
+                                                  const unsigned long long* __restrict__ rng_state, float inv_count,
+                                                  float* __restrict__ probs, float* __restrict__ dpred,
+                                                  float* __restrict__ loss_part) {
+  constexpr int R = HEAD_TILE, LD = D + 4, EPL = D / 64, NW = 4, KQ = D / 4;
+  __shared__ __attribute__((aligned(16))) float Y[R * LD];
+  __shared__ float lsum[NW];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int node0 = blockIdx.x * R;
+  const uint32_t key = thresh ? dropout_key(rng_state, HEAD_STREAM_ID) : 0u;
+
+  for (int rr = wave; rr < R; rr += NW) {
+    const int i = node0 + rr;
+    float ym[EPL];
+    if (i < n) {
+      head_row<D>(n, S, i, lane, X, bn_w, bn_b, mean, vr, use_running, eps, keep_scale, thresh, key, ym);
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) ym[e] = 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) Y[rr * LD + lane * EPL + e] = ym[e];
+  }
+  __syncthreads();
+
+  const int r = lane & 15, q = lane >> 4;
+  float lacc = 0.f;
+  for (int c0 = 0; c0 < C; c0 += 256) {
+    const int CB = min(16, (C - c0 + 15) / 16);
+    f32x4 acc[4];
+#pragma unroll
+    for (int cbi = 0; cbi < 4; ++cbi) acc[cbi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int t = 0; t < KQ / 4; ++t) {
+      const f32x4 a = *(const f32x4*)&Y[r * LD + q * KQ + 4 * t];
+#pragma unroll
+      for (int cbi = 0; cbi < 4; ++cbi) {
+        const int cb = wave + 4 * cbi;
+        if (cb < CB) {
+          const int j = c0 + cb * 16 + r;
+          f32x4 b = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (j < C) b = *(const f32x4*)&Wout[(size_t)j * D + q * KQ + 4 * t];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[cbi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc[cbi], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int cbi = 0; cbi < 4; ++cbi) {
+      const int cb = wave + 4 * cbi;
+      const int j = c0 + cb * 16 + r;
+      if (cb < CB && j < C) {
+        const float bj = bout[j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = node0 + q * 4 + e;
+          if (i < n) {
+            const float pred = acc[cbi][e] + bj;
+            const float tg = target[(size_t)i * C + j];
+            const float p = sigmoidf_(pred);
+            lacc += fmaxf(pred, 0.f) - pred * tg + log1pf(expf(-fabsf(pred)));
+            probs[(size_t)i * C + j] = p;
+            if (dpred) dpred[(size_t)i * C + j] = (p - tg) * inv_count;
+          }
+        }
+      }
+    }
+  }
+  lacc = wave_sum(lacc);
+  if (lane == 0) lsum[wave] = lacc;
+  __syncthreads();
+  if (threadIdx.x == 0) loss_part[blockIdx.x] = ((lsum[0] + lsum[1]) + lsum[2]) + lsum[3];
+}
+
+// out[0] = scale * sum(part[0..m)), one workgroup, fixed-order tree => deterministic
+__global__ __launch_bounds__(256) void k_sum_scale(int m, const float* __restrict__ part, float scale, float* __restrict__ out) {
+  __shared__ float sm[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < m; i += 256) s += part[i];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = sm[0] * scale;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_head_bwd: persistent over 32-node tiles.
+//   partial layout per workgroup: [CP*D dW_out][CP db_out][S*D sum dy][S*D sum dy*xhat]
+// ------------------------------------------------------------------------------------------
+template <int D, int CBMAX>
+__global__ __launch_bounds__(256) void k_head_bwd(int n, int S, int C, const float* __restrict__ X,
+                                                  const float* __restrict__ bn_w, const float* __restrict__ bn_b,
+                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                  const float* __restrict__ Wout, const float* __restrict__ dpred,
+                                                  const float* __restrict__ dloss, float keep_scale, uint32_t thresh,
+                                                  const unsigned long long* __restrict__ rng_state,
+                                                  float* __restrict__ dym, float* __restrict__ part) {
+  constexpr int TR = HEADB_TILE, NW = 4, EPL = D / 64;
+  constexpr int CP = CBMAX * 16;
+  constexpr int LDP = CP + ((CP & 16) ? 2 : 18);  // = 18 (mod 32): row reads and transposed reads both (nearly) conflict-free
+  constexpr int LDY = D + 16;                      // = 16 (mod 32): conflict-free transposed reads
+  constexpr int JBW = D / 64;                      // 16-wide column blocks of D owned by one wave
+  constexpr int PS = CP * D + CP + 2 * 2 * D;      // partial stride (S <= 2)
+  __shared__ __attribute__((aligned(16))) float Pt[TR * LDP];
+  __shared__ __attribute__((aligned(16))) float Yt[TR * LDY];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const uint32_t key = thresh ? dropout_key(rng_state, HEAD_STREAM_ID) : 0u;
+  const float gl = dloss ? dloss[0] : 1.f;
+  const int CB = (C + 15) / 16;
+
+  f32x4 accW[CBMAX][JBW];
+#pragma unroll
+  for (int ib = 0; ib < CBMAX; ++ib)
+#pragma unroll
+    for (int jb = 0; jb < JBW; ++jb) accW[ib][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float dbo = 0.f;                       // thread j < CP: column sum of dpred
+  float sdy[2][EPL], sdyx[2][EPL];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) sdy[s][e] = sdyx[s][e] = 0.f;
+
+  const int ntiles = (n + TR - 1) / TR;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int node0 = tile * TR;
+    // ---- stage dpred tile (scaled by the upstream d loss) and recompute ym tile
+    for (int idx = threadIdx.x; idx < TR * CP; idx += 256) {
+      const int row = idx / CP, j = idx % CP;
+      const int i = node0 + row;
+      Pt[row * LDP + j] = (i < n && j < C) ? dpred[(size_t)i * C + j] * gl : 0.f;
+    }
+    for (int t = wave; t < TR; t += NW) {
+      const int i = node0 + t;
+      float ym[EPL];
+      if (i < n) {
+        head_row<D>(n, S, i, lane, X, bn_w, bn_b, mean, invstd, 0, 0.f, keep_scale, thresh, key, ym);
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) ym[e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) Yt[t * LDY + lane * EPL + e] = ym[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < CP) {
+      float sacc = 0.f;
+#pragma unroll 8
+      for (int row = 0; row < TR; ++row) sacc += Pt[row * LDP + threadIdx.x];
+      dbo += sacc;
+    }
+    // ---- dW_out += Pt^T Yt   (K = TR rows)
+#pragma unroll
+    for (int kk = 0; kk < TR / 4; ++kk) {
+      const int k = 4 * kk + q;
+      float b[JBW];
+#pragma unroll
+      for (int jb = 0; jb < JBW; ++jb) b[jb] = Yt[k * LDY + (wave * JBW + jb) * 16 + r];
+#pragma unroll
+      for (int ib = 0; ib < CBMAX; ++ib) {
+        if (ib < CB) {
+          const float a = Pt[k * LDP + ib * 16 + r];
+#pragma unroll
+          for (int jb = 0; jb < JBW; ++jb) accW[ib][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[jb], accW[ib][jb], 0, 0, 0);
+        }
+      }
+    }
+    // ---- dym tile = Pt W_out   (M = TR rows, K = labels, N = D); wave owns columns [32w, 32w+32) (D=128)
+    f32x4 accY[2][JBW];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int jb = 0; jb < JBW; ++jb) accY[mb][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kk = 0; kk < CB * 4; ++kk) {
+      const int k = 4 * kk + q;  // label index
+      float b[JBW];
+#pragma unroll
+      for (int jb = 0; jb < JBW; ++jb) b[jb] = (k < C) ? Wout[(size_t)k * D + (wave * JBW + jb) * 16 + r] : 0.f;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        const float a = Pt[(mb * 16 + r) * LDP + k];
+#pragma unroll
+        for (int jb = 0; jb < JBW; ++jb) accY[mb][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[jb], accY[mb][jb], 0, 0, 0);
+      }
+    }
+    __syncthreads();  // all reads of Yt / Pt done
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int jb = 0; jb < JBW; ++jb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Yt[(mb * 16 + q * 4 + e) * LDY + (wave * JBW + jb) * 16 + r] = accY[mb][jb][e];
+    __syncthreads();
+    // ---- row pass: write dym, accumulate the BatchNorm-backward column sums
+    for (int t = wave; t < TR; t += NW) {
+      const int i = node0 + t;
+      if (i >= n) continue;
+      const float invS = 1.f / (float)S;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        const int c = lane * EPL + e;
+        const float g = Yt[t * LDY + c];
+        dym[(size_t)i * D + c] = g;
+        for (int s = 0; s < S; ++s) {
+          const uint32_t el = (uint32_t)(((size_t)s * n + i) * D + c);
+          float dy = g * invS;
+          if (thresh) dy = dropout_keep(key, el, thresh) ? dy * keep_scale : 0.f;
+          const float xh = (fmaxf(X[el], 0.f) - mean[s * D + c]) * invstd[s * D + c];
+          sdy[s][e] += dy;
+          sdyx[s][e] += dy * xh;
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- partials
+  float* P = part + (size_t)blockIdx.x * PS;
+#pragma unroll
+  for (int ib = 0; ib < CBMAX; ++ib)
+#pragma unroll
+    for (int jb = 0; jb < JBW; ++jb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) P[(ib * 16 + q * 4 + e) * D + (wave * JBW + jb) * 16 + r] = accW[ib][jb][e];
+  if (threadIdx.x < CP) P[CP * D + threadIdx.x] = dbo;
+  float* red = Yt;  // [NW][4*D]
+  constexpr int RS = 4 * D;
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      red[wave * RS + s * D + lane * EPL + e] = sdy[s][e];
+      red[wave * RS + 2 * D + s * D + lane * EPL + e] = sdyx[s][e];
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < RS; c += 256) {
+    float s = 0.f;
+    for (int w = 0; w < NW; ++w) s += red[w * RS + c];
+    P[CP * D + CP + c] = s;
+  }
+}
+
+// second stage.  Elements: [CP*D dW_out][CP db_out][D columns of the BatchNorm sums]
+__global__ __launch_bounds__(256) void k_head_bwd_finalize(int P, int n, int S, int D, int C, int CP,
+                                                           const float* __restrict__ part, float* __restrict__ dWout,
+                                                           float* __restrict__ dbout, float* __restrict__ dbn_w,
+                                                           float* __restrict__ dbn_b, float* __restrict__ bnc,
+                                                           int accumulate) {
+  const int PS = CP * D + CP + 4 * D;
+  const int total = CP * D + CP + D;
+  __shared__ float red[4][4][64];
+  const int el = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + el;
+  const bool stats = e >= CP * D + CP;
+  const int nq = stats ? 4 : 1;  // a stats element reduces (sdy_0, sdy_1, sdyx_0, sdyx_1) of one column
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (e < total) {
+    const int per = (P + 3) / 4;
+    const int p0 = slice * per, p1 = min(P, p0 + per);
+    const int base = stats ? (CP * D + CP + (e - CP * D - CP)) : e;
+    for (int qd = 0; qd < nq; ++qd) {
+      float a = 0.f;
+      int p = p0;
+      for (; p + 8 <= p1; p += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = part[(size_t)(p + u) * PS + base + qd * D];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += t[u];
+      }
+      for (; p < p1; ++p) a += part[(size_t)p * PS + base + qd * D];
+      s[qd] = a;
+    }
+  }
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) red[slice][qd][el] = s[qd];
+  __syncthreads();
+  if (slice != 0 || e >= total) return;
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) s[qd] = ((red[0][qd][el] + red[1][qd][el]) + red[2][qd][el]) + red[3][qd][el];
+  if (e < CP * D) {
+    const int i = e / D;
+    if (i < C) dWout[e] = accumulate ? dWout[e] + s[0] : s[0];
+  } else if (e < CP * D + CP) {
+    const int j = e - CP * D;
+    if (j < C) dbout[j] = accumulate ? dbout[j] + s[0] : s[0];
+  } else {
+    const int c = e - CP * D - CP;
+    // s[0], s[1] = sum dy (strand 0, 1); s[2], s[3] = sum dy*xhat (strand 0, 1); strand 1 is zero when S == 1
+    const float db_ = s[0] + s[1], dg_ = s[2] + s[3];
+    dbn_b[c] = accumulate ? dbn_b[c] + db_ : db_;
+    dbn_w[c] = accumulate ? dbn_w[c] + dg_ : dg_;
+    const float invn = 1.f / (float)n;
+    for (int st = 0; st < S; ++st) {
+      bnc[(st * 2 + 0) * D + c] = s[st] * invn;
+      bnc[(st * 2 + 1) * D + c] = s[2 + st] * invn;
+    }
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_head_bn_bwd_apply(int n, int S, const float* __restrict__ X,
+                                                           const float* __restrict__ bn_w, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ dym,
+                                                           const float* __restrict__ bnc, float keep_scale, uint32_t thresh,
+                                                           const unsigned long long* __restrict__ rng_state,
+                                                           float* __restrict__ dX) {
+  const uint32_t key = thresh ? dropout_key(rng_state, HEAD_STREAM_ID) : 0u;
+  const size_t total4 = (size_t)S * n * D / 4;
+  const float invS = 1.f / (float)S;
+  for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < total4; v += (size_t)gridDim.x * blockDim.x) {
+    const size_t el0 = v * 4;
+    const int c0 = (int)(el0 % D);
+    const size_t row = el0 / D;       // s*n + i
+    const int s = (int)(row / n);
+    const int i = (int)(row % n);
+    const f32x4 x = *(const f32x4*)&X[el0];
+    const f32x4 g = *(const f32x4*)&dym[(size_t)i * D + c0];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = c0 + e;
+      float dy = g[e] * invS;
+      if (thresh) dy = dropout_keep(key, (uint32_t)(el0 + e), thresh) ? dy * keep_scale : 0.f;
+      const float is = invstd[s * D + c];
+      const float xh = (fmaxf(x[e], 0.f) - mean[s * D + c]) * is;
+      const float dr = bn_w[c] * is * (dy - bnc[(s * 2 + 0) * D + c] - xh * bnc[(s * 2 + 1) * D + c]);
+      o[e] = x[e] > 0.f ? dr : 0.f;
+    }
+    *(f32x4*)&dX[el0] = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+static int head_check(int n, int S, int d, int C) {
+  if (n < 0 || C < 1) return CGCN_ERR_BAD_ARG;
+  if (!(S == 1 || S == 2) || !(d == 128 || d == 256) || C > 256) return CGCN_ERR_UNSUPPORTED;
+  if ((double)n * S * d * 4.0 >= 4294967296.0 || (double)n * C * 4.0 >= 4294967296.0) return CGCN_ERR_UNSUPPORTED;
+  return CGCN_OK;
+}
+static inline int head_cp(int C) { return C <= 128 ? 128 : 256; }
+static inline int head_stat_blocks(int n, int* rows_per_blk) {
+  int rpb = (n + HEAD_STAT_BLOCKS - 1) / HEAD_STAT_BLOCKS;
+  if (rpb < 32) rpb = 32;
+  *rows_per_blk = rpb;
+  int nb = (n + rpb - 1) / rpb;
+  return nb < 1 ? 1 : nb;
+}
+static inline int head_bwd_partials(int n) {
+  int t = (n + HEADB_TILE - 1) / HEADB_TILE;
+  if (t > HEAD_MAX_PARTIALS) t = HEAD_MAX_PARTIALS;
+  return t < 1 ? 1 : t;
+}
+// workspace regions (floats), in this order
+static inline size_t ws_stats(int S, int d) { return (size_t)HEAD_STAT_BLOCKS * S * d * 2; }
+static inline size_t ws_loss(int n) { return (size_t)((n + HEAD_TILE - 1) / HEAD_TILE + 4); }
+static inline size_t ws_dym(int n, int d) { return (size_t)n * d + 4; }
+static inline size_t ws_bnc(int d) { return (size_t)2 * 2 * d; }
+static inline size_t ws_part(int n, int d, int C) { return (size_t)head_bwd_partials(n) * ((size_t)head_cp(C) * d + head_cp(C) + 4 * d); }
+static inline size_t align4(size_t x) { return (x + 3) & ~(size_t)3; }
+
+extern "C" {
+
+size_t cgcn_head_workspace_bytes(int n, int S, int d, int C) {
+  if (head_check(n, S, d, C) != CGCN_OK) return 0;
+  return 4 * (align4(ws_stats(S, d)) + align4(ws_loss(n)) + align4(ws_dym(n, d)) + align4(ws_bnc(d)) + align4(ws_part(n, d, C)));
+}
+
+int cgcn_head_fwd(cgcn_stream_t stream, int n, int S, int d, int C, const float* X, const float* bn_w,
+                  const float* bn_b, float* run_mean, float* run_var, long long* num_batches_tracked, float momentum,
+                  float eps, int training, const float* Wout, const float* bout, const float* target, float dropout_p,
+                  unsigned long long* rng_state, unsigned long long* rng_saved, float* probs, float* loss, float* dpred,
+                  float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes) {
+  int rc = head_check(n, S, d, C);
+  if (rc) return rc;
+  if (!X || !bn_w || !bn_b || !Wout || !bout || !target || !probs || !loss || !workspace) return CGCN_ERR_BAD_ARG;
+  if (!run_mean || !run_var) return CGCN_ERR_BAD_ARG;
+  if (training && (!save_mean || !save_invstd || n < 2)) return CGCN_ERR_BAD_ARG;  // BatchNorm needs > 1 value per channel
+  const bool drop = training && dropout_p > 0.f;
+  if (drop && (!rng_state || !rng_saved || dropout_p >= 1.f)) return CGCN_ERR_BAD_ARG;
+  if (workspace_bytes < cgcn_head_workspace_bytes(n, S, d, C)) return CGCN_ERR_WORKSPACE;
+  if (misaligned16(Wout) || misaligned16(workspace)) return CGCN_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  float* w_stats = (float*)workspace;
+  float* w_loss = w_stats + align4(ws_stats(S, d));
+  if (n == 0) {
+    hipLaunchKernelGGL(k_sum_scale, dim3(1), dim3(256), 0, st, 0, w_loss, 0.f, loss);
+    return launch_status();
+  }
+  if (training) {
+    int rpb;
+    const int nblk = head_stat_blocks(n, &rpb);
+    if (d == 128) hipLaunchKernelGGL((k_head_colstats<128>), dim3(nblk), dim3(256), 0, st, n, S, rpb, X, w_stats);
+    else hipLaunchKernelGGL((k_head_colstats<256>), dim3(nblk), dim3(256), 0, st, n, S, rpb, X, w_stats);
+    if ((rc = launch_status())) return rc;
+    hipLaunchKernelGGL(k_head_bn_finalize, dim3((d + 255) / 256), dim3(256), 0, st, n, S, d, nblk, rpb, w_stats, momentum, eps,
+                       run_mean, run_var, num_batches_tracked, save_mean, save_invstd, drop ? rng_state : nullptr, rng_saved);
+    if ((rc = launch_status())) return rc;
+  }
+  const int blocks = (n + HEAD_TILE - 1) / HEAD_TILE;
+  const float keep_scale = drop ? 1.f / (1.f - dropout_p) : 1.f;
+  const uint32_t thresh = drop ? dropout_threshold(dropout_p) : 0u;
+  const float inv_count = 1.f / ((float)n * (float)C);
+  const float* mean = training ? save_mean : run_mean;
+  const float* vr = training ? save_invstd : run_var;
+#define HF(D_)                                                                                                        \
+  hipLaunchKernelGGL((k_head_fwd<D_>), dim3(blocks), dim3(256), 0, st, n, S, C, X, bn_w, bn_b, mean, vr, training ? 0 : 1, \
+                     eps, Wout, bout, target, keep_scale, thresh, rng_saved, inv_count, probs, training ? dpred : nullptr, w_loss)
+  if (d == 128) HF(128); else HF(256);
+#undef HF
+  if ((rc = launch_status())) return rc;
+  hipLaunchKernelGGL(k_sum_scale, dim3(1), dim3(256), 0, st, blocks, w_loss, inv_count, loss);
+  return launch_status();
+}
+
+int cgcn_head_bwd(cgcn_stream_t stream, int n, int S, int d, int C, const float* X, const float* bn_w,
+                  const float* bn_b, const float* save_mean, const float* save_invstd, const float* Wout,
+                  const float* dpred, const float* dloss, float dropout_p, const unsigned long long* rng_state,
+                  float* dX, float* dWout, float* dbout, float* dbn_w, float* dbn_b, int accumulate, void* workspace,
+                  size_t workspace_bytes) {
+  int rc = head_check(n, S, d, C);
+  if (rc) return rc;
+  if (!X || !bn_w || !bn_b || !save_mean || !save_invstd || !Wout || !dpred || !dX || !dWout || !dbout || !dbn_w || !dbn_b || !workspace)
+    return CGCN_ERR_BAD_ARG;
+  const bool drop = dropout_p > 0.f;
+  if (drop && (!rng_state || dropout_p >= 1.f)) return CGCN_ERR_BAD_ARG;
+  if (workspace_bytes < cgcn_head_workspace_bytes(n, S, d, C)) return CGCN_ERR_WORKSPACE;
+  if (misaligned16(X) || misaligned16(dX) || misaligned16(workspace) || n < 1) return CGCN_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  float* w = (float*)workspace;
+  float* w_dym = w + align4(ws_stats(S, d)) + align4(ws_loss(n));
+  float* w_bnc = w_dym + align4(ws_dym(n, d));
+  float* w_part = w_bnc + align4(ws_bnc(d));
+  const int P = head_bwd_partials(n);
+  const int CP = head_cp(C);
+  const float keep_scale = drop ? 1.f / (1.f - dropout_p) : 1.f;
+  const uint32_t thresh = drop ? dropout_threshold(dropout_p) : 0u;
+#define HB(D_, CB_)                                                                                                   \
+  hipLaunchKernelGGL((k_head_bwd<D_, CB_>), dim3(P), dim3(256), 0, st, n, S, C, X, bn_w, bn_b, save_mean, save_invstd, Wout, \
+                     dpred, dloss, keep_scale, thresh, rng_state, w_dym, w_part)
+  if (d == 128) { if (CP == 128) HB(128, 8); else HB(128, 16); }
+  else { if (CP == 128) HB(256, 8); else HB(256, 16); }
+#undef HB
+  if ((rc = launch_status())) return rc;
+  const int total = CP * d + CP + d;
+  hipLaunchKernelGGL(k_head_bwd_finalize, dim3((total + 63) / 64), dim3(256), 0, st, P, n, S, d, C, CP, w_part, dWout, dbout,
+                     dbn_w, dbn_b, w_bnc, accumulate);
+  if ((rc = launch_status())) return rc;
+  const size_t total4 = (size_t)S * n * d / 4;
+  int blocks = (int)((total4 + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (d == 128)
+    hipLaunchKernelGGL((k_head_bn_bwd_apply<128>), dim3(blocks), dim3(256), 0, st, n, S, X, bn_w, save_mean, save_invstd, w_dym,
+                       w_bnc, keep_scale, thresh, rng_state, dX);
+  else
+    hipLaunchKernelGGL((k_head_bn_bwd_apply<256>), dim3(blocks), dim3(256), 0, st, n, S, X, bn_w, save_mean, save_invstd, w_dym,
+                       w_bnc, keep_scale, thresh, rng_state, dX);
+  return launch_status();
+}
+
+}  // extern "C"

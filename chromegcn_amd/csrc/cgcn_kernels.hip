@@ -13,33 +13,7 @@
 //
 // Reference semantics: models/SubLayers.py:42-52, models/ChromeModels.py:34-46 (forward);
 // SURVEY.md Appendix A (backward).
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-
-#include "chromegcn.h"
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#define WAVE 64
-#define TILE_NODES 16   // nodes per workgroup tile in the gather kernels
-#define BWD_TILE_ROWS 32  // rows per MFMA K-step group in k_bwd_rowlocal
-#define BWD_MAX_PARTIALS 256
-
-// ------------------------------------------------------------------------------------------
-// small helpers
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
-  return v;
-}
-
-__device__ __forceinline__ int rl_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
-__device__ __forceinline__ float rl_f(float v, int lane) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
-
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+#include "cgcn_common.hpp"
 
 // Geometry of one node's payload (S strands x D features) over a 64-lane wave of float4 loads.
 //   PAY = S*D floats.  PAY >= 256: NV = PAY/256 float4 per lane per neighbour.
@@ -552,7 +526,6 @@ __global__ __launch_bounds__(D * 2) void k_bwd_gather(int n, const int* __restri
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
-static inline bool misaligned16(const void* p) { return ((uintptr_t)p & 15u) != 0; }
 
 static int check_shape(int n, int S, int d) {
   if (n < 0) return CGCN_ERR_BAD_ARG;
@@ -561,7 +534,6 @@ static int check_shape(int n, int S, int d) {
   return CGCN_OK;
 }
 
-static int launch_status() { return hipGetLastError() == hipSuccess ? CGCN_OK : CGCN_ERR_LAUNCH; }
 
 #define DISPATCH_SDV(S_, d_, hasval_, CALL)                                      \
   do {                                                                           \

@@ -49,8 +49,9 @@ class GCNStage:
     group      : torch.distributed process group (None = single process)"""
 
     def __init__(self, model, optimizer=None, adj_type: str = "hic", device="cuda", hip_graphs: bool = True,
-                 input_grad: bool = True, group=None):
+                 input_grad: bool = True, group=None, fused_head: bool = True):
         self.model = model
+        self.fused_head = fused_head
         self.optimizer = optimizer
         self.adj_type = adj_type
         self.device = torch.device(device)
@@ -118,6 +119,9 @@ class GCNStage:
 
     # ------------------------------------------------------------------ one chromosome, eager
     def _forward_loss(self, c: _Chrom, x):
+        if self.fused_head and hasattr(self.model, "forward_loss"):
+            loss, probs, _ = self.model.forward_loss(x, c.graph, c.target)  # fused head + loss kernels
+            return loss, probs
         logits, _ = self.model.forward_strands(x, c.graph)
         pred = (logits[0] + logits[1]) / 2                                # finetune.py:43
         loss = F.binary_cross_entropy_with_logits(pred, c.target)          # finetune.py:45

@@ -87,6 +87,15 @@ class ChromeGCN(nn.Module):
         self.dropout = dropout
         self.batch_norm = nn.BatchNorm1d(nfeat)
         self.out = nn.Linear(nfeat, nclass)
+        # {seed, step counter} of the counter-based dropout RNG used by the fused kernels; lives on the
+        # device so captured HIP graphs draw fresh masks on every replay.  Not part of the state_dict
+        # (the reference has no such key).
+        self.register_buffer("_rng_state", torch.tensor([0x5DEECE66D, 0], dtype=torch.int64), persistent=False)
+
+    def seed_dropout(self, seed: int):
+        """reseed the fused-kernel dropout stream (torch.manual_seed does not reach it)"""
+        self._rng_state[0] = int(seed) & 0x7FFFFFFFFFFFFFFF
+        self._rng_state[1] = 0
 
     # -- the gated stack on a [S, n, d] block -------------------------------------------------
     def _gated_stack(self, x, graph):
@@ -126,3 +135,13 @@ class ChromeGCN(nn.Module):
         graph = as_graph(adj, x_fr.device)
         x, gates = self._gated_stack(x_fr, graph)
         return self._head(x), gates
+
+    def forward_loss(self, x_fr, adj, target):
+        """The whole per-chromosome forward of the GCN stage (finetune.py:41-45,52) in fused kernels:
+        gated stack on both strands, then ReLU/BatchNorm/dropout/Linear/strand-mean/BCE.
+        Returns (loss [], probs [n,C] = sigmoid(pred), gates)."""
+        ops._require_cuda(x_fr, "x_fr")
+        graph = as_graph(adj, x_fr.device)
+        x, gates = self._gated_stack(x_fr, graph)
+        loss, probs = ops.head_loss(x, self.batch_norm, self.out, target, self.training, self.dropout, self._rng_state)
+        return loss, probs, gates

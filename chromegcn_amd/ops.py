@@ -122,3 +122,76 @@ class GatedLayerFn(torch.autograd.Function):
 
 def gated_layer(x, weight, bias, gate_w, gate_b, graph):
     return GatedLayerFn.apply(x, weight, bias, gate_w, gate_b, graph)
+
+
+class HeadLossFn(torch.autograd.Function):
+    """relu -> BatchNorm1d -> dropout -> Linear, mean over strands, BCE-with-logits, sigmoid -- fused
+    (models/ChromeModels.py:48-51 + finetune.py:43,45,52); see cgcn_head_fwd / cgcn_head_bwd.
+    Returns (loss [], probs [n,C]).  Running statistics / num_batches_tracked are updated in place when
+    training, exactly as two successive ChromeGCN.forward calls would."""
+
+    @staticmethod
+    def forward(ctx, x, bn_w, bn_b, w_out, b_out, target, run_mean, run_var, nbt, momentum, eps, training,
+                dropout_p, rng_state):
+        _require_cuda(x, "x")
+        for t, nm in ((bn_w, "bn weight"), (bn_b, "bn bias"), (w_out, "out.weight"), (b_out, "out.bias"), (target, "target")):
+            _require_cuda(t, nm)
+        if momentum is None:
+            raise RuntimeError("chromegcn_amd: BatchNorm momentum=None (cumulative average) is not supported by the fused head")
+        x = x.contiguous()
+        S, n, d = x.shape
+        C = w_out.shape[0]
+        target = target.contiguous()
+        if tuple(target.shape) != (n, C):
+            raise RuntimeError("chromegcn_amd: target must be [n, C] = [%d, %d], got %s" % (n, C, tuple(target.shape)))
+        bn_w, bn_b, w_out, b_out = bn_w.contiguous(), bn_b.contiguous(), w_out.contiguous(), b_out.contiguous()
+        lib = _lib.load()
+        ws_bytes = lib.cgcn_head_workspace_bytes(n, S, d, C)
+        if ws_bytes == 0:
+            raise RuntimeError("chromegcn_amd: fused head does not support S=%d n=%d d=%d C=%d" % (S, n, d, C))
+        ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8)
+        need_bwd = training and any(ctx.needs_input_grad[:5])
+        probs = torch.empty((n, C), device=x.device, dtype=torch.float32)
+        loss = torch.empty(1, device=x.device, dtype=torch.float32)
+        dpred = torch.empty((n, C), device=x.device, dtype=torch.float32) if need_bwd else None
+        save_mean = torch.empty((S, d), device=x.device, dtype=torch.float32) if training else None
+        save_invstd = torch.empty((S, d), device=x.device, dtype=torch.float32) if training else None
+        drop = bool(training) and dropout_p > 0
+        rng_saved = torch.empty(2, device=x.device, dtype=torch.int64) if drop else None
+        _lib.check(lib.cgcn_head_fwd(_lib.stream_ptr(), n, S, d, C, x.data_ptr(), bn_w.data_ptr(), bn_b.data_ptr(),
+                                     run_mean.data_ptr(), run_var.data_ptr(), _lib.ptr(nbt), float(momentum), float(eps),
+                                     1 if training else 0, w_out.data_ptr(), b_out.data_ptr(), target.data_ptr(),
+                                     float(dropout_p), _lib.ptr(rng_state) if drop else None, _lib.ptr(rng_saved),
+                                     probs.data_ptr(), loss.data_ptr(), _lib.ptr(dpred), _lib.ptr(save_mean),
+                                     _lib.ptr(save_invstd), ws.data_ptr(), ws_bytes), "cgcn_head_fwd")
+        if need_bwd:
+            ctx.save_for_backward(x, bn_w, bn_b, w_out, dpred, save_mean, save_invstd, rng_saved)
+            ctx.dropout_p = float(dropout_p) if drop else 0.0
+        ctx.mark_non_differentiable(probs)
+        return loss.view(()), probs
+
+    @staticmethod
+    def backward(ctx, dloss, _dprobs):
+        x, bn_w, bn_b, w_out, dpred, save_mean, save_invstd, rng_saved = ctx.saved_tensors
+        S, n, d = x.shape
+        C = w_out.shape[0]
+        lib = _lib.load()
+        ws_bytes = lib.cgcn_head_workspace_bytes(n, S, d, C)
+        ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8)
+        dx = torch.empty_like(x)
+        dw_out = torch.empty_like(w_out)
+        db_out = torch.empty(C, device=x.device, dtype=torch.float32)
+        dbn_w = torch.empty(d, device=x.device, dtype=torch.float32)
+        dbn_b = torch.empty(d, device=x.device, dtype=torch.float32)
+        dloss = dloss.contiguous().view(1)
+        _lib.check(lib.cgcn_head_bwd(_lib.stream_ptr(), n, S, d, C, x.data_ptr(), bn_w.data_ptr(), bn_b.data_ptr(),
+                                     save_mean.data_ptr(), save_invstd.data_ptr(), w_out.data_ptr(), dpred.data_ptr(),
+                                     dloss.data_ptr(), ctx.dropout_p, _lib.ptr(rng_saved), dx.data_ptr(),
+                                     dw_out.data_ptr(), db_out.data_ptr(), dbn_w.data_ptr(), dbn_b.data_ptr(), 0,
+                                     ws.data_ptr(), ws_bytes), "cgcn_head_bwd")
+        return (dx, dbn_w, dbn_b, dw_out, db_out) + (None,) * 9
+
+
+def head_loss(x, bn: torch.nn.BatchNorm1d, out: torch.nn.Linear, target, training, dropout_p, rng_state):
+    return HeadLossFn.apply(x, bn.weight, bn.bias, out.weight, out.bias, target, bn.running_mean, bn.running_var,
+                            bn.num_batches_tracked, bn.momentum, bn.eps, bool(training), float(dropout_p), rng_state)

@@ -104,6 +104,43 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d,
                    float *dX, float *dUs, float *dW, float *db, float *dwg, float *dcg,
                    int accumulate, void *workspace, size_t workspace_bytes);
 
+/* Bytes of scratch cgcn_head_fwd / cgcn_head_bwd need for (n, S, d, C).  0 on unsupported shapes. */
+size_t cgcn_head_workspace_bytes(int n, int S, int d, int C);
+
+/*
+ * Classifier head + loss of the GCN-stage step, fused (models/ChromeModels.py:48-51 applied to each
+ * strand, then finetune.py:43,45,52):
+ *     y_s   = dropout(BatchNorm1d(relu(X_s)))     batch statistics over the n nodes when training
+ *     pred  = mean_s (y_s W_out^T + b_out)        computed as (mean_s y_s) W_out^T + b_out
+ *     loss  = mean over n*C of BCE-with-logits(pred, target);   probs = sigmoid(pred)
+ * X: [S,n,d].  bn_w, bn_b, run_mean, run_var: [d]; num_batches_tracked: int64[1] or NULL.  W_out: [C,d],
+ * b_out: [C], target: [n,C] (0/1 floats).  C <= 256.
+ * training != 0: batch statistics, running statistics updated once per strand in strand order (what two
+ *   successive ChromeGCN.forward calls do), num_batches_tracked += S, dropout with probability dropout_p
+ *   driven by rng_state = {seed, step counter} (uint64[2], device): the counter is copied to rng_saved
+ *   (uint64[2], device, needed by cgcn_head_bwd) and then advanced.  Outputs dpred = d loss / d pred
+ *   [n,C] (may be NULL), save_mean / save_invstd [S,d].
+ * training == 0: running statistics, no dropout; dpred, save_*, rng_* unused.
+ * probs: [n,C]; loss: [1].
+ */
+int cgcn_head_fwd(cgcn_stream_t stream, int n, int S, int d, int C, const float *X, const float *bn_w,
+                  const float *bn_b, float *run_mean, float *run_var, long long *num_batches_tracked,
+                  float momentum, float eps, int training, const float *W_out, const float *b_out,
+                  const float *target, float dropout_p, unsigned long long *rng_state,
+                  unsigned long long *rng_saved, float *probs, float *loss, float *dpred, float *save_mean,
+                  float *save_invstd, void *workspace, size_t workspace_bytes);
+
+/*
+ * Backward of cgcn_head_fwd (training mode).  dloss: [1] upstream gradient of the loss or NULL (= 1).
+ * Outputs dX [S,n,d] and, overwritten (accumulate == 0) or added to (accumulate != 0): dW_out [C,d],
+ * db_out [C], dbn_w [d], dbn_b [d].  rng_saved: the value cgcn_head_fwd stored.  Deterministic.
+ */
+int cgcn_head_bwd(cgcn_stream_t stream, int n, int S, int d, int C, const float *X, const float *bn_w,
+                  const float *bn_b, const float *save_mean, const float *save_invstd, const float *W_out,
+                  const float *dpred, const float *dloss, float dropout_p, const unsigned long long *rng_saved,
+                  float *dX, float *dW_out, float *db_out, float *dbn_w, float *dbn_b, int accumulate,
+                  void *workspace, size_t workspace_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,123 @@
+"""Fused head (relu -> BatchNorm1d -> dropout -> Linear -> strand mean -> BCE) against a float64 torch
+restatement of models/ChromeModels.py:48-51 + finetune.py:43,45,52.  (The reference-recorded vectors
+reach this code through tests/test_gpu_loop.py and the model tests, which run the whole step.)"""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from chromegcn_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def ref_head(x64, bn, out, target64, training):
+    """float64 CPU: per-strand BatchNorm (sequential running-stat updates), mean of logits, BCE"""
+    logits = []
+    for s in range(x64.shape[0]):
+        y = bn(F.relu(x64[s]))
+        logits.append(out(y))
+    pred = sum(logits) / len(logits)
+    loss = F.binary_cross_entropy_with_logits(pred, target64)
+    return loss, torch.sigmoid(pred)
+
+
+def make(S, n, d, C, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(S, n, d, generator=g) * 1.3 + 0.2
+    tgt = (torch.rand(n, C, generator=g) < 0.2).float()
+    bn = nn.BatchNorm1d(d); out = nn.Linear(d, C)
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.2 * torch.randn(d, generator=g)); bn.bias.copy_(0.1 * torch.randn(d, generator=g))
+        bn.running_mean.copy_(0.1 * torch.randn(d, generator=g)); bn.running_var.copy_(1 + 0.3 * torch.rand(d, generator=g))
+        out.weight.copy_(torch.randn(C, d, generator=g) / np.sqrt(d) * 2)
+    return x, tgt, bn, out
+
+
+@pytest.mark.parametrize("S,n,d,C", [(2, 333, 128, 103), (1, 37, 128, 19), (2, 2, 128, 7), (2, 150, 256, 200),
+                                     (1, 70, 256, 130), (2, 4100, 128, 103)])
+def test_head_train_matches_float64(S, n, d, C):
+    x, tgt, bn, out = make(S, n, d, C, 7)
+    import copy
+    bn64, out64 = copy.deepcopy(bn).double(), copy.deepcopy(out).double()
+    bn64.train()
+    x64 = x.double().requires_grad_(True)
+    loss64, probs64 = ref_head(x64, bn64, out64, tgt.double(), True)
+    (loss64 * 1.7).backward()
+
+    bn, out = bn.to(DEV), out.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    rng = torch.tensor([1, 0], dtype=torch.int64, device=DEV)
+    loss, probs = ops.head_loss(xg, bn, out, tgt.to(DEV), True, 0.0, rng)
+    (loss * 1.7).backward()
+    assert abs(loss.item() - loss64.item()) < 1e-5
+    np.testing.assert_allclose(probs.cpu().numpy(), probs64.detach().numpy(), atol=1e-5, rtol=1e-4)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), x64.grad.numpy(), atol=2e-6, rtol=2e-3)
+    for a, b in [(bn.weight, bn64.weight), (bn.bias, bn64.bias), (out.weight, out64.weight), (out.bias, out64.bias)]:
+        ref = b.grad.numpy()
+        np.testing.assert_allclose(a.grad.cpu().numpy(), ref, atol=1e-5 * max(1.0, np.abs(ref).max()), rtol=1e-4)
+    np.testing.assert_allclose(bn.running_mean.cpu().numpy(), bn64.running_mean.numpy(), atol=1e-6, rtol=1e-5)
+    np.testing.assert_allclose(bn.running_var.cpu().numpy(), bn64.running_var.numpy(), atol=1e-6, rtol=1e-5)
+    assert int(bn.num_batches_tracked.item()) == S == int(bn64.num_batches_tracked.item())
+
+
+@pytest.mark.parametrize("S,n,d,C", [(2, 333, 128, 103), (1, 1, 128, 5), (2, 90, 256, 257 - 1)])
+def test_head_eval_matches_float64(S, n, d, C):
+    x, tgt, bn, out = make(S, n, d, C, 8)
+    import copy
+    bn64, out64 = copy.deepcopy(bn).double().eval(), copy.deepcopy(out).double()
+    with torch.no_grad():
+        loss64, probs64 = ref_head(x.double(), bn64, out64, tgt.double(), False)
+    bn, out = bn.to(DEV).eval(), out.to(DEV)
+    with torch.no_grad():
+        loss, probs = ops.head_loss(x.to(DEV), bn, out, tgt.to(DEV), False, 0.2, None)
+    assert abs(loss.item() - loss64.item()) < 1e-5
+    np.testing.assert_allclose(probs.cpu().numpy(), probs64.numpy(), atol=1e-5, rtol=1e-4)
+    assert int(bn.num_batches_tracked.item()) == 0
+
+
+def test_head_dropout_mask_is_consistent_between_forward_and_backward():
+    """With the step counter pinned, the mask is a fixed function, so the analytic gradient must match a
+    central finite difference of the (masked) loss along a random direction."""
+    S, n, d, C, p = 2, 61, 128, 11, 0.3
+    x, tgt, bn, out = make(S, n, d, C, 9)
+    bn, out, tgt = bn.to(DEV), out.to(DEV), tgt.to(DEV)
+    rng = torch.tensor([1234, 0], dtype=torch.int64, device=DEV)
+
+    def f(xx):
+        rng[1] = 5  # same mask every call
+        return ops.head_loss(xx, bn, out, tgt, True, p, rng)
+
+    xg = x.to(DEV).requires_grad_(True)
+    loss, probs = f(xg)
+    loss.backward()
+    assert int(rng[1].item()) == 6  # the forward advanced the counter
+    v = torch.randn(x.shape, generator=torch.Generator().manual_seed(1)).to(DEV)
+    eps = 2e-2
+    with torch.no_grad():
+        lp, _ = f(xg + eps * v)
+        lm, _ = f(xg - eps * v)
+    num = (lp.double() - lm.double()).item() / (2 * eps)
+    ana = (xg.grad.double() * v.double()).sum().item()
+    assert abs(num - ana) < 2e-2 * max(abs(ana), 1e-3), (num, ana)
+    # the mask really drops about p of the activations and differs between steps
+    rng[1] = 5
+    l5, _ = ops.head_loss(xg.detach(), bn, out, tgt, True, p, rng)
+    l6, _ = ops.head_loss(xg.detach(), bn, out, tgt, True, p, rng)  # counter now 6
+    assert l5.item() == loss.item() and l6.item() != l5.item()
+
+
+def test_head_dropout_keep_rate():
+    # bn_w = 0, bn_b = 1 -> y = 1 before dropout; W_out = ones/d, so pred = kept fraction / (1-p) per node
+    S, n, d, C, p = 2, 500, 128, 3, 0.25
+    bn = nn.BatchNorm1d(d).to(DEV); out = nn.Linear(d, C).to(DEV)
+    with torch.no_grad():
+        bn.weight.zero_(); bn.bias.fill_(1.0); out.weight.fill_(1.0 / d); out.bias.zero_()
+    x = torch.randn(S, n, d, device=DEV)
+    rng = torch.tensor([99, 0], dtype=torch.int64, device=DEV)
+    _, probs = ops.head_loss(x, bn, out, torch.zeros(n, C, device=DEV), True, p, rng)
+    pred = torch.logit(probs[:, 0].double())
+    keep = (pred * (1 - p)).mean().item()
+    assert abs(keep - (1 - p)) < 0.01, keep
