@@ -14,21 +14,23 @@ _c_int = ctypes.c_int
 _c_vp = ctypes.c_void_p
 _c_sz = ctypes.c_size_t
 _c_float = ctypes.c_float
+_c_uint = ctypes.c_uint
 
 _SIGNATURES = {
     # name: (restype, argtypes)
     "cgcn_abi_version": (_c_int, []),
     "cgcn_strerror": (ctypes.c_char_p, [_c_int]),
     "cgcn_spmm": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp]),
-    "cgcn_layer_fwd": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 13),
+    "cgcn_layer_fwd": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 13 + [_c_float, _c_vp, _c_uint]),
     "cgcn_layer_bwd_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
-    "cgcn_layer_bwd": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 18 + [_c_int, _c_vp, _c_sz]),
+    "cgcn_layer_bwd": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 18 + [_c_int, _c_float, _c_vp, _c_uint, _c_vp, _c_sz]),
     "cgcn_head_workspace_bytes": (_c_sz, [_c_int] * 4),
     "cgcn_head_fwd": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp] * 6 + [_c_float, _c_float, _c_int] + [_c_vp] * 3
-                      + [_c_float] + [_c_vp] * 8 + [_c_sz]),
+                      + [_c_float] + [_c_vp] * 7 + [_c_sz]),
     "cgcn_head_bwd": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp] * 8 + [_c_float] + [_c_vp] * 6 + [_c_int, _c_vp, _c_sz]),
+    "cgcn_sgd_step": (_c_int, [_c_vp, ctypes.c_longlong, _c_vp, _c_vp, _c_vp, _c_float, _c_float, _c_float, _c_int, _c_vp]),
 }
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 
 

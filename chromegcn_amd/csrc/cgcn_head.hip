@@ -72,39 +72,59 @@ __global__ __launch_bounds__(256) void k_head_colstats(int n, int S, int rows_pe
   }
 }
 
+// 16 columns x 16 partial-slices per workgroup: each thread Chan-combines nblk/16 partials (independent
+// loads), the 16 slices are merged through LDS in a fixed order, then one thread per column finishes
+// both strands (the running-stat update is sequential in the strand index).
 __global__ __launch_bounds__(256) void k_head_bn_finalize(int n, int S, int D, int nblk, int rows_per_blk,
                                                           const float* __restrict__ part, float momentum, float eps,
                                                           float* __restrict__ run_mean, float* __restrict__ run_var,
                                                           long long* __restrict__ nbt, float* __restrict__ save_mean,
-                                                          float* __restrict__ save_invstd,
-                                                          unsigned long long* __restrict__ rng_state,
-                                                          unsigned long long* __restrict__ rng_saved) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && nbt) nbt[0] += S;
-  if (c == 0 && rng_state) {  // snapshot the dropout counter for this step's fwd+bwd, then advance it
-    rng_saved[0] = rng_state[0];
-    rng_saved[1] = rng_state[1];
-    rng_state[1] += 1ull;
-  }
-  if (c >= D) return;
-  float rm = run_mean ? run_mean[c] : 0.f, rv = run_var ? run_var[c] : 1.f;
+                                                          float* __restrict__ save_invstd) {
+  __shared__ float sm[2][3][16][17];
+  const int cl = threadIdx.x & 15, slice = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += S;
+  const int per = (nblk + 15) / 16;
+  const int b0 = slice * per, b1 = min(nblk, b0 + per);
   for (int s = 0; s < S; ++s) {
     float cnt = 0.f, mean = 0.f, m2 = 0.f;
-#pragma unroll 8
-    for (int b = 0; b < nblk; ++b) {
-      const float* p = part + (((size_t)b * S + s) * D + c) * 2;
-      const float nb = (float)max(0, min(n, (b + 1) * rows_per_blk) - b * rows_per_blk);
-      chan_combine(cnt, mean, m2, nb, p[0], p[1]);
+    if (c < D) {
+      for (int b = b0; b < b1; b += 8) {
+        float pm[8], p2[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int bb = min(b + u, b1 - 1);
+          const float* p = part + (((size_t)bb * S + s) * D + c) * 2;
+          pm[u] = p[0];
+          p2[u] = p[1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (b + u < b1) {
+            const float nb = (float)max(0, min(n, (b + u + 1) * rows_per_blk) - (b + u) * rows_per_blk);
+            chan_combine(cnt, mean, m2, nb, pm[u], p2[u]);
+          }
+        }
+      }
     }
-    const float var_b = m2 / (float)n;
+    sm[s][0][slice][cl] = cnt;
+    sm[s][1][slice][cl] = mean;
+    sm[s][2][slice][cl] = m2;
+  }
+  __syncthreads();
+  if (slice != 0 || c >= D) return;
+  float rm = run_mean[c], rv = run_var[c];
+  for (int s = 0; s < S; ++s) {
+    float cnt = 0.f, mean = 0.f, m2 = 0.f;
+    for (int o = 0; o < 16; ++o) chan_combine(cnt, mean, m2, sm[s][0][o][cl], sm[s][1][o][cl], sm[s][2][o][cl]);
     save_mean[s * D + c] = mean;
-    save_invstd[s * D + c] = rsqrtf(var_b + eps);
+    save_invstd[s * D + c] = rsqrtf(m2 / (float)n + eps);
     // sequential update: the reference calls the model on the forward strand, then the reverse one
     rm = (1.f - momentum) * rm + momentum * mean;
     rv = (1.f - momentum) * rv + momentum * (m2 / (float)(n - 1));
   }
-  if (run_mean) run_mean[c] = rm;
-  if (run_var) run_var[c] = rv;
+  run_mean[c] = rm;
+  run_var[c] = rv;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -527,15 +547,15 @@ size_t cgcn_head_workspace_bytes(int n, int S, int d, int C) {
 int cgcn_head_fwd(cgcn_stream_t stream, int n, int S, int d, int C, const float* X, const float* bn_w,
                   const float* bn_b, float* run_mean, float* run_var, long long* num_batches_tracked, float momentum,
                   float eps, int training, const float* Wout, const float* bout, const float* target, float dropout_p,
-                  unsigned long long* rng_state, unsigned long long* rng_saved, float* probs, float* loss, float* dpred,
-                  float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes) {
+                  const unsigned long long* rng_state, float* probs, float* loss, float* dpred, float* save_mean,
+                  float* save_invstd, void* workspace, size_t workspace_bytes) {
   int rc = head_check(n, S, d, C);
   if (rc) return rc;
   if (!X || !bn_w || !bn_b || !Wout || !bout || !target || !probs || !loss || !workspace) return CGCN_ERR_BAD_ARG;
   if (!run_mean || !run_var) return CGCN_ERR_BAD_ARG;
   if (training && (!save_mean || !save_invstd || n < 2)) return CGCN_ERR_BAD_ARG;  // BatchNorm needs > 1 value per channel
   const bool drop = training && dropout_p > 0.f;
-  if (drop && (!rng_state || !rng_saved || dropout_p >= 1.f)) return CGCN_ERR_BAD_ARG;
+  if (drop && (!rng_state || dropout_p >= 1.f)) return CGCN_ERR_BAD_ARG;
   if (workspace_bytes < cgcn_head_workspace_bytes(n, S, d, C)) return CGCN_ERR_WORKSPACE;
   if (misaligned16(Wout) || misaligned16(workspace)) return CGCN_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
@@ -551,8 +571,8 @@ int cgcn_head_fwd(cgcn_stream_t stream, int n, int S, int d, int C, const float*
     if (d == 128) hipLaunchKernelGGL((k_head_colstats<128>), dim3(nblk), dim3(256), 0, st, n, S, rpb, X, w_stats);
     else hipLaunchKernelGGL((k_head_colstats<256>), dim3(nblk), dim3(256), 0, st, n, S, rpb, X, w_stats);
     if ((rc = launch_status())) return rc;
-    hipLaunchKernelGGL(k_head_bn_finalize, dim3((d + 255) / 256), dim3(256), 0, st, n, S, d, nblk, rpb, w_stats, momentum, eps,
-                       run_mean, run_var, num_batches_tracked, save_mean, save_invstd, drop ? rng_state : nullptr, rng_saved);
+    hipLaunchKernelGGL(k_head_bn_finalize, dim3((d + 15) / 16), dim3(256), 0, st, n, S, d, nblk, rpb, w_stats, momentum, eps,
+                       run_mean, run_var, num_batches_tracked, save_mean, save_invstd);
     if ((rc = launch_status())) return rc;
   }
   const int blocks = (n + HEAD_TILE - 1) / HEAD_TILE;
@@ -563,7 +583,7 @@ int cgcn_head_fwd(cgcn_stream_t stream, int n, int S, int d, int C, const float*
   const float* vr = training ? save_invstd : run_var;
 #define HF(D_)                                                                                                        \
   hipLaunchKernelGGL((k_head_fwd<D_>), dim3(blocks), dim3(256), 0, st, n, S, C, X, bn_w, bn_b, mean, vr, training ? 0 : 1, \
-                     eps, Wout, bout, target, keep_scale, thresh, rng_saved, inv_count, probs, training ? dpred : nullptr, w_loss)
+                     eps, Wout, bout, target, keep_scale, thresh, rng_state, inv_count, probs, training ? dpred : nullptr, w_loss)
   if (d == 128) HF(128); else HF(256);
 #undef HF
   if ((rc = launch_status())) return rc;

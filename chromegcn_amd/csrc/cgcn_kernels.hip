@@ -153,66 +153,136 @@ __global__ __launch_bounds__(256) void k_spmm(int n_rows, int n_cols, const int*
 }
 
 // ------------------------------------------------------------------------------------------
-// Shared MFMA stage of the two gather kernels:
-//   out[m][j] = sum_k T[m][k] * B(k, j)   for the S*TILE_NODES rows staged in LDS.
-// TRANS_W == false: B(k,j) = W[k][j]   (forward,  U = H W)
-// TRANS_W == true : B(k,j) = W[j][k]   (backward, dS W^T)
-// Wave w owns output columns [32w, 32w+32) as two 16-wide blocks; v_mfma_f32_16x16x4_f32:
-//   A lane l: A[row l&15][k l>>4];  B lane l: B[k l>>4][col l&15];  C: col l&15, row 4*(l>>4)+reg.
+// Shared pieces of the two gather kernels (k_layer_fwd, k_bwd_gather).
+//
+// Tile: TN = 16*MB/S nodes x S strands = 16*MB MFMA rows, staged in LDS as T[row][D+4].
+// MFMA: v_mfma_f32_16x16x4_f32.  A lane l: A[row l&15][k-slot l>>4]; B lane l: B[k-slot l>>4][col l&15];
+// C: col l&15, row 4*(l>>4)+reg.  The K index is permuted so that operand reads are 16 bytes wide:
+// k-slot q (= l>>4) owns k in [q*D/4, (q+1)*D/4); step kk uses k = q*D/4 + kk for A and B alike.
+// Wave w owns output columns [32w, 32w+32) as two 16-wide blocks.
+//   TRANS_W == false: B(k,j) = W[k][j]   (forward,  U = H W)
+//   TRANS_W == true : B(k,j) = W[j][k]   (backward, dS W^T)
+// For D = 128 a wave's whole B operand (2 x 32 floats per lane) is fetched into registers BEFORE the
+// gather phase, so its L2 latency hides behind the gather; for D = 256 it is read in the K loop.
 // ------------------------------------------------------------------------------------------
-template <int MB, int D, int LD, bool TRANS_W>
-__device__ __forceinline__ void tile_mfma(const float* __restrict__ T, const float* __restrict__ W, int wave, int lane,
-                                          f32x4 (&acc)[MB][2]) {
+__device__ __forceinline__ int xcd_contiguous(int b, int nblk) {
+  // Workgroups are dealt round-robin over the 8 XCDs; give each XCD (each private L2) a contiguous
+  // range of tiles so that near-diagonal Hi-C neighbourhoods stay L2-resident.  Bijective for any nblk.
+  const int q = nblk >> 3, r = nblk & 7, xcd = b & 7, idx = b >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <int D, bool TRANS_W>
+__device__ __forceinline__ void load_wfrag(const float* __restrict__ W, int wave, int lane, float (&bw)[2][D / 4]) {
+  constexpr int KQ = D / 4;
+  const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const int j = wave * 32 + cb * 16 + r;
+    if (TRANS_W) {
+#pragma unroll
+      for (int t = 0; t < KQ / 4; ++t) {
+        const f32x4 v = *(const f32x4*)&W[(size_t)j * D + q * KQ + 4 * t];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bw[cb][4 * t + u] = v[u];
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < KQ; ++kk) bw[cb][kk] = W[(size_t)(q * KQ + kk) * D + j];
+    }
+  }
+}
+
+template <int MB, int D, int LD, bool TRANS_W, bool PRELOADED>
+__device__ __forceinline__ void tile_mfma(const float* __restrict__ T, const float* __restrict__ W,
+                                          const float (&bw)[2][D / 4], int wave, int lane, f32x4 (&acc)[MB][2]) {
+  constexpr int KQ = D / 4;
   const int r = lane & 15, q = lane >> 4;
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) acc[mb][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int j0 = wave * 32 + r;
-#pragma unroll 8
-  for (int kk = 0; kk < D / 4; ++kk) {
-    const int k = 4 * kk + q;
-    float b[2];
+  if (PRELOADED) {
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) b[cb] = TRANS_W ? W[(size_t)(j0 + 16 * cb) * D + k] : W[(size_t)k * D + j0 + 16 * cb];
+    for (int t = 0; t < KQ / 4; ++t) {
+      f32x4 a[MB];
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      const float a = T[(mb * 16 + r) * LD + k];
+      for (int mb = 0; mb < MB; ++mb) a[mb] = *(const f32x4*)&T[(mb * 16 + r) * LD + q * KQ + 4 * t];
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) acc[mb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[cb], acc[mb][cb], 0, 0, 0);
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+            acc[mb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb][u], bw[cb][4 * t + u], acc[mb][cb], 0, 0, 0);
+    }
+  } else {
+    const int j0 = wave * 32 + r;
+#pragma unroll 2
+    for (int t = 0; t < KQ / 4; ++t) {
+      f32x4 a[MB];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) a[mb] = *(const f32x4*)&T[(mb * 16 + r) * LD + q * KQ + 4 * t];
+      f32x4 b[2];
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        if (TRANS_W) {
+          b[cb] = *(const f32x4*)&W[(size_t)(j0 + 16 * cb) * D + q * KQ + 4 * t];
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) b[cb][u] = W[(size_t)(q * KQ + 4 * t + u) * D + j0 + 16 * cb];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+            acc[mb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb][u], b[cb][u], acc[mb][cb], 0, 0, 0);
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------
-// k_layer_fwd: one workgroup = TILE_NODES nodes x S strands.
+// k_layer_fwd: one workgroup = TN nodes x S strands.
+//   phase 0  W fragments -> registers (D = 128)
+//   phase 1  each wave gathers whole rows of H = diag(rs) Ahat X into the LDS tile (+ Hout)
+//   phase 2  U = H W on the matrix cores; the residual rows of X are prefetched meanwhile
+//   phase 3  Z = tanh(U + b) -> LDS -> row-wise gate (wave reduction), mix, optional dropout, stores
 // ------------------------------------------------------------------------------------------
-template <int S, int D, bool HAS_VAL>
+template <int S, int D, int MB, bool HAS_VAL>
 __global__ __launch_bounds__(D * 2) void k_layer_fwd(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
                                                      const float* __restrict__ val, const float* __restrict__ rs,
                                                      const float* __restrict__ X, const float* __restrict__ W,
                                                      const float* __restrict__ bias, const float* __restrict__ wg,
                                                      const float* __restrict__ cg, float* __restrict__ Xn,
                                                      float* __restrict__ Zout, float* __restrict__ Hout,
-                                                     float* __restrict__ gate) {
+                                                     float* __restrict__ gate, float keep_scale, uint32_t thresh,
+                                                     const unsigned long long* __restrict__ rng_state,
+                                                     uint32_t stream_id) {
   using G = Geo<S, D>;
-  constexpr int R = TILE_NODES;
+  constexpr int ROWS = 16 * MB;      // MFMA rows in the tile
+  constexpr int R = ROWS / S;        // nodes in the tile
   constexpr int NW = D / 32;         // waves per workgroup (each owns 32 output columns)
-  constexpr int ROWS = S * R;        // MFMA rows in the tile
-  constexpr int MB = ROWS / 16;
-  constexpr int LD = D + 4;          // LDS row stride (floats); keeps float4 alignment
+  constexpr int LD = D + 4;          // LDS row stride (floats); keeps 16-byte alignment
   constexpr int EPL = D / 64;        // floats per lane in the row-wise epilogue
+  constexpr int RPW = (ROWS + NW - 1) / NW;  // epilogue rows per wave
+  constexpr bool PRE = (D == 128);
   __shared__ __attribute__((aligned(16))) float T[ROWS * LD];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int node0 = blockIdx.x * R;
+  const int node0 = xcd_contiguous(blockIdx.x, gridDim.x) * R;
+
+  float bw[2][D / 4];
+  if (PRE) load_wfrag<D, false>(W, wave, lane, bw);
 
   unsigned lane_off[G::NV];
 #pragma unroll
   for (int v = 0; v < G::NV; ++v) lane_off[v] = ((unsigned)G::strand(v, lane) * (unsigned)n * D + G::column(v, lane)) * 4u;
 
-  // ---- phase 1: aggregate rows of H = diag(rs) Ahat X into LDS (and to Hout when training)
+  // ---- phase 1
   for (int rr = wave; rr < R; rr += NW) {
     const int i = node0 + rr;
     f32x4 acc[G::NV];
@@ -235,11 +305,21 @@ __global__ __launch_bounds__(D * 2) void k_layer_fwd(int n, const int* __restric
       }
     }
   }
+  // prefetch the residual rows this wave will mix in phase 3 (latency hides behind the MFMA phase)
+  float xres[RPW][EPL];
+#pragma unroll
+  for (int t = 0; t < RPW; ++t) {
+    const int m = wave + t * NW;
+    const int i = node0 + (m % R);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e)
+      xres[t][e] = (m < ROWS && i < n) ? X[((size_t)(m / R) * n + i) * D + lane * EPL + e] : 0.f;
+  }
   __syncthreads();
 
-  // ---- phase 2: U = H W on the matrix cores
+  // ---- phase 2
   f32x4 acc[MB][2];
-  tile_mfma<MB, D, LD, false>(T, W, wave, lane, acc);
+  tile_mfma<MB, D, LD, false, PRE>(T, W, bw, wave, lane, acc);
   __syncthreads();  // every wave is done reading T as the A operand
 
   // ---- phase 3a: Z = tanh(U + b) back into the tile
@@ -255,31 +335,35 @@ __global__ __launch_bounds__(D * 2) void k_layer_fwd(int n, const int* __restric
         for (int e = 0; e < 4; ++e) T[(mb * 16 + q * 4 + e) * LD + j] = tanhf(acc[mb][cb][e] + bj);
     }
   }
-  __syncthreads();
-
-  // ---- phase 3b: row-wise gate + residual mix, coalesced stores
   float wgl[EPL];
 #pragma unroll
   for (int e = 0; e < EPL; ++e) wgl[e] = wg[lane * EPL + e];
   const float c0 = cg[0];
-  for (int m = wave; m < ROWS; m += NW) {
+  const uint32_t key = thresh ? dropout_key(rng_state, stream_id) : 0u;
+  __syncthreads();
+
+  // ---- phase 3b: row-wise gate + residual mix, coalesced stores
+#pragma unroll
+  for (int t = 0; t < RPW; ++t) {
+    const int m = wave + t * NW;
     const int s = m / R, rr = m % R;
     const int i = node0 + rr;
-    if (i >= n) continue;  // wave-uniform
-    float z[EPL], x[EPL];
+    if (m >= ROWS || i >= n) continue;  // wave-uniform
+    float z[EPL];
     float dot = 0.f;
     const size_t g_off = ((size_t)s * n + i) * D + lane * EPL;
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
       z[e] = T[m * LD + lane * EPL + e];
-      x[e] = X[g_off + e];
       dot += z[e] * wgl[e];
     }
     dot = wave_sum(dot);
     const float g = sigmoidf_(dot + c0);
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
-      Xn[g_off + e] = (1.f - g) * x[e] + g * z[e];
+      float xo = (1.f - g) * xres[t][e] + g * z[e];
+      if (thresh) xo = dropout_keep(key, (uint32_t)(g_off + e), thresh) ? xo * keep_scale : 0.f;
+      Xn[g_off + e] = xo;
       if (Zout) Zout[g_off + e] = z[e];
     }
     if (lane == 0) gate[(size_t)s * n + i] = g;
@@ -456,25 +540,33 @@ __global__ __launch_bounds__(256) void k_reduce_partials(int P, int D, const flo
 }
 
 // ------------------------------------------------------------------------------------------
-// k_bwd_gather: dX = (1-g) dXn + (Ahat^T dUs) W^T, same skeleton as the forward.
+// k_bwd_gather: dX = mask * ((1-g) dXn + (Ahat^T dUs) W^T), same skeleton as the forward.
+// mask: the dropout the PREVIOUS layer applied to this layer's input (stream_id of that layer).
 // ------------------------------------------------------------------------------------------
-template <int S, int D, bool HAS_VAL>
+template <int S, int D, int MB, bool HAS_VAL>
 __global__ __launch_bounds__(D * 2) void k_bwd_gather(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
                                                       const float* __restrict__ val, const float* __restrict__ dUs,
                                                       const float* __restrict__ W, const float* __restrict__ dXn,
-                                                      const float* __restrict__ gate, float* __restrict__ dX) {
+                                                      const float* __restrict__ gate, float* __restrict__ dX,
+                                                      float keep_scale, uint32_t thresh,
+                                                      const unsigned long long* __restrict__ rng_state,
+                                                      uint32_t stream_id) {
   using G = Geo<S, D>;
-  constexpr int R = TILE_NODES;
+  constexpr int ROWS = 16 * MB;
+  constexpr int R = ROWS / S;
   constexpr int NW = D / 32;
-  constexpr int ROWS = S * R;
-  constexpr int MB = ROWS / 16;
   constexpr int LD = D + 4;
   constexpr int EPL = D / 64;
+  constexpr int RPW = (ROWS + NW - 1) / NW;
+  constexpr bool PRE = (D == 128);
   __shared__ __attribute__((aligned(16))) float T[ROWS * LD];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int node0 = blockIdx.x * R;
+  const int node0 = xcd_contiguous(blockIdx.x, gridDim.x) * R;
+
+  float bw[2][D / 4];
+  if (PRE) load_wfrag<D, true>(W, wave, lane, bw);
 
   unsigned lane_off[G::NV];
 #pragma unroll
@@ -494,10 +586,22 @@ __global__ __launch_bounds__(D * 2) void k_bwd_gather(int n, const int* __restri
       for (int v = 0; v < G::NV; ++v) *(f32x4*)&T[(G::strand(v, lane) * R + rr) * LD + G::column(v, lane)] = acc[v];
     }
   }
+  // prefetch (1-g) dXn for the rows this wave finishes
+  float res[RPW][EPL];
+#pragma unroll
+  for (int t = 0; t < RPW; ++t) {
+    const int m = wave + t * NW;
+    const int i = node0 + (m % R);
+    const bool ok = m < ROWS && i < n;
+    const size_t row = (size_t)(m / R) * n + i;
+    const float og = ok ? 1.f - gate[row] : 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) res[t][e] = ok ? og * dXn[row * D + lane * EPL + e] : 0.f;
+  }
   __syncthreads();
 
   f32x4 acc[MB][2];
-  tile_mfma<MB, D, LD, true>(T, W, wave, lane, acc);
+  tile_mfma<MB, D, LD, true, PRE>(T, W, bw, wave, lane, acc);
   __syncthreads();
   {
     const int r = lane & 15, q = lane >> 4;
@@ -510,17 +614,46 @@ __global__ __launch_bounds__(D * 2) void k_bwd_gather(int n, const int* __restri
         for (int e = 0; e < 4; ++e) T[(mb * 16 + q * 4 + e) * LD + j] = acc[mb][cb][e];
     }
   }
+  const uint32_t key = thresh ? dropout_key(rng_state, stream_id) : 0u;
   __syncthreads();
 
-  for (int m = wave; m < ROWS; m += NW) {
+#pragma unroll
+  for (int t = 0; t < RPW; ++t) {
+    const int m = wave + t * NW;
     const int s = m / R, rr = m % R;
     const int i = node0 + rr;
-    if (i >= n) continue;
-    const float g = gate[(size_t)s * n + i];
+    if (m >= ROWS || i >= n) continue;
     const size_t g_off = ((size_t)s * n + i) * D + lane * EPL;
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) dX[g_off + e] = (1.f - g) * dXn[g_off + e] + T[m * LD + lane * EPL + e];
+    for (int e = 0; e < EPL; ++e) {
+      float o = res[t][e] + T[m * LD + lane * EPL + e];
+      if (thresh) o = dropout_keep(key, (uint32_t)(g_off + e), thresh) ? o * keep_scale : 0.f;
+      dX[g_off + e] = o;
+    }
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_sgd: torch.optim.SGD semantics on one flat buffer (utils/util_methods.py:14-19 builds
+// SGD(lr, momentum=0.9, weight_decay=1e-6)):  d = g + wd p;  m = mu m + d;  p -= lr (nesterov ? d + mu m : m).
+// A zero-initialised m reproduces torch's first step (m = d).  Also advances the dropout step counter:
+// this is the last kernel of a train step.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sgd(int count, float* __restrict__ p, const float* __restrict__ g,
+                                             float* __restrict__ m, float lr, float mu, float wd, int nesterov,
+                                             unsigned long long* __restrict__ rng_state) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && rng_state) rng_state[1] += 1ull;
+  if (i >= count) return;
+  const float pi = p[i];
+  float d = g[i] + wd * pi;
+  float upd = d;
+  if (m) {
+    const float b = mu * m[i] + d;
+    m[i] = b;
+    upd = nesterov ? d + mu * b : b;
+  }
+  p[i] = pi - lr * upd;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -542,6 +675,23 @@ static int check_shape(int n, int S, int d) {
     else if ((S_) == 1 && (d_) == 256) { if (hasval_) { CALL(1, 256, true); } else { CALL(1, 256, false); } } \
     else { if (hasval_) { CALL(2, 256, true); } else { CALL(2, 256, false); } }  \
   } while (0)
+
+// Tile height of the gather kernels: 32 MFMA rows (MB = 2) when that still gives >= 4 workgroups per CU,
+// otherwise 16 rows (MB = 1) so small chromosomes fill the 256 CUs.
+static inline int pick_mb(int n, int S) {
+  const int tn2 = 32 / S;
+  return ((n + tn2 - 1) / tn2 >= 1024) ? 2 : 1;
+}
+
+static int dropout_args(float p, const unsigned long long* rng_state, float* keep_scale, uint32_t* thresh) {
+  *keep_scale = 1.f;
+  *thresh = 0u;
+  if (p <= 0.f) return CGCN_OK;
+  if (!rng_state || p >= 1.f) return CGCN_ERR_BAD_ARG;
+  *keep_scale = 1.f / (1.f - p);
+  *thresh = dropout_threshold(p);
+  return CGCN_OK;
+}
 
 extern "C" {
 
@@ -576,17 +726,30 @@ int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d, const 
 
 int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* rowptr, const int32_t* col, const float* val,
                    const float* row_scale, const float* X, const float* W, const float* b, const float* wg,
-                   const float* cg, float* Xn, float* Z, float* H, float* gate) {
+                   const float* cg, float* Xn, float* Z, float* H, float* gate, float dropout_p,
+                   const unsigned long long* rng_state, unsigned int stream_id) {
   int rc = check_shape(n, S, d);
   if (rc) return rc;
   if (n == 0) return CGCN_OK;
   if (!rowptr || !col || !X || !W || !b || !wg || !cg || !Xn || !gate || X == Xn) return CGCN_ERR_BAD_ARG;
-  if (misaligned16(X) || misaligned16(Xn) || (Z && misaligned16(Z)) || (H && misaligned16(H))) return CGCN_ERR_BAD_ARG;
+  if (misaligned16(X) || misaligned16(Xn) || misaligned16(W) || (Z && misaligned16(Z)) || (H && misaligned16(H)))
+    return CGCN_ERR_BAD_ARG;
+  float ks;
+  uint32_t th;
+  if ((rc = dropout_args(dropout_p, rng_state, &ks, &th))) return rc;
   hipStream_t st = (hipStream_t)stream;
-  const int blocks = (n + TILE_NODES - 1) / TILE_NODES;
-#define CALL(S_, D_, V_)                                                                                        \
-  hipLaunchKernelGGL((k_layer_fwd<S_, D_, V_>), dim3(blocks), dim3(D_ * 2), 0, st, n, rowptr, col, val, row_scale, X, W, \
-                     b, wg, cg, Xn, Z, H, gate)
+  const int mb = pick_mb(n, S);
+  const int tn = 16 * mb / S;
+  const int blocks = (n + tn - 1) / tn;
+#define CALL(S_, D_, V_)                                                                                            \
+  do {                                                                                                              \
+    if (mb == 2)                                                                                                    \
+      hipLaunchKernelGGL((k_layer_fwd<S_, D_, 2, V_>), dim3(blocks), dim3(D_ * 2), 0, st, n, rowptr, col, val, row_scale, \
+                         X, W, b, wg, cg, Xn, Z, H, gate, ks, th, rng_state, stream_id);                            \
+    else                                                                                                            \
+      hipLaunchKernelGGL((k_layer_fwd<S_, D_, 1, V_>), dim3(blocks), dim3(D_ * 2), 0, st, n, rowptr, col, val, row_scale, \
+                         X, W, b, wg, cg, Xn, Z, H, gate, ks, th, rng_state, stream_id);                            \
+  } while (0)
   DISPATCH_SDV(S, d, val != nullptr, CALL);
 #undef CALL
   return launch_status();
@@ -607,14 +770,18 @@ size_t cgcn_layer_bwd_workspace_bytes(int n, int S, int d) {
 int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* rowptr_t, const int32_t* col_t,
                    const float* val_t, const float* row_scale, const float* X, const float* Z, const float* H,
                    const float* gate, const float* W, const float* wg, const float* dXn, const float* dgate, float* dX,
-                   float* dUs, float* dW, float* db, float* dwg, float* dcg, int accumulate, void* workspace,
+                   float* dUs, float* dW, float* db, float* dwg, float* dcg, int accumulate, float in_dropout_p,
+                   const unsigned long long* rng_state, unsigned int in_stream_id, void* workspace,
                    size_t workspace_bytes) {
   int rc = check_shape(n, S, d);
   if (rc) return rc;
   if (!rowptr_t || !col_t || !X || !Z || !H || !gate || !W || !wg || !dXn || !dX || !dUs || !dW || !db || !dwg || !dcg)
     return CGCN_ERR_BAD_ARG;
-  if (dX == dXn || misaligned16(dUs) || misaligned16(dX) || misaligned16(dXn)) return CGCN_ERR_BAD_ARG;
+  if (dX == dXn || misaligned16(dUs) || misaligned16(dX) || misaligned16(dXn) || misaligned16(W)) return CGCN_ERR_BAD_ARG;
   if (!workspace || workspace_bytes < cgcn_layer_bwd_workspace_bytes(n, S, d)) return CGCN_ERR_WORKSPACE;
+  float ks;
+  uint32_t th;
+  if ((rc = dropout_args(in_dropout_p, rng_state, &ks, &th))) return rc;
   hipStream_t st = (hipStream_t)stream;
   const int P = bwd_partials(n, S);
   float* part = (float*)workspace;
@@ -628,12 +795,33 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   hipLaunchKernelGGL(k_reduce_partials, dim3((total + 63) / 64), dim3(256), 0, st, P, d, part, dW, db, dwg, dcg, accumulate);
   if ((rc = launch_status())) return rc;
   if (n == 0) return CGCN_OK;
-  const int blocks = (n + TILE_NODES - 1) / TILE_NODES;
-#define CALL(S_, D_, V_)                                                                                       \
-  hipLaunchKernelGGL((k_bwd_gather<S_, D_, V_>), dim3(blocks), dim3(D_ * 2), 0, st, n, rowptr_t, col_t, val_t, dUs, W, \
-                     dXn, gate, dX)
+  const int mb = pick_mb(n, S);
+  const int tn = 16 * mb / S;
+  const int blocks = (n + tn - 1) / tn;
+#define CALL(S_, D_, V_)                                                                                             \
+  do {                                                                                                               \
+    if (mb == 2)                                                                                                     \
+      hipLaunchKernelGGL((k_bwd_gather<S_, D_, 2, V_>), dim3(blocks), dim3(D_ * 2), 0, st, n, rowptr_t, col_t, val_t, dUs, \
+                         W, dXn, gate, dX, ks, th, rng_state, in_stream_id);                                         \
+    else                                                                                                             \
+      hipLaunchKernelGGL((k_bwd_gather<S_, D_, 1, V_>), dim3(blocks), dim3(D_ * 2), 0, st, n, rowptr_t, col_t, val_t, dUs, \
+                         W, dXn, gate, dX, ks, th, rng_state, in_stream_id);                                         \
+  } while (0)
   DISPATCH_SDV(S, d, val_t != nullptr, CALL);
 #undef CALL
+  return launch_status();
+}
+
+int cgcn_sgd_step(cgcn_stream_t stream, long long count, float* param, const float* grad, float* momentum_buf, float lr,
+                  float momentum, float weight_decay, int nesterov, unsigned long long* rng_state) {
+  if (count < 0 || count > 2147483647LL) return CGCN_ERR_UNSUPPORTED;
+  if (count > 0 && (!param || !grad)) return CGCN_ERR_BAD_ARG;
+  if (momentum != 0.f && !momentum_buf) return CGCN_ERR_BAD_ARG;
+  if (nesterov && momentum == 0.f) return CGCN_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = count > 0 ? (int)((count + 255) / 256) : 1;
+  hipLaunchKernelGGL(k_sgd, dim3(blocks), dim3(256), 0, st, (int)count, param, grad, momentum != 0.f ? momentum_buf : nullptr,
+                     lr, momentum, weight_decay, nesterov, rng_state);
   return launch_status();
 }
 

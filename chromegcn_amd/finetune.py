@@ -67,6 +67,9 @@ class GCNStage:
         self._graphs: Dict[tuple, dict] = {}
         self._pool = None
         self._flat_grad: Optional[torch.Tensor] = None
+        self._flat_param: Optional[torch.Tensor] = None
+        self._flat_mom: Optional[torch.Tensor] = None
+        self._fused_sgd = False
         self._captured_lr = None
         self._int_synced: Dict[str, torch.Tensor] = {}
 
@@ -93,29 +96,82 @@ class GCNStage:
             hic = None if split_adj_dict is None else split_adj_dict.get(name)
             self.add_chromosome(name, chrom_feature_dict[name], hic)
 
-    # ------------------------------------------------------------------ gradients as one flat buffer
+    # ------------------------------------------------------------------ flat parameter / gradient / momentum arenas
     def _params(self):
         return [p for p in self.model.parameters() if p.requires_grad]
 
-    def _ensure_flat_grad(self):
-        ps = self._params()
-        total = sum(p.numel() for p in ps)
-        ok = self._flat_grad is not None and self._flat_grad.numel() == total and self._flat_grad.device == ps[0].device
-        if ok:
-            off = 0
-            for p in ps:
-                if p.grad is None or p.grad.data_ptr() != self._flat_grad.data_ptr() + 4 * off:
-                    ok = False
-                    break
-                off += p.numel()
-        if ok:
-            return
-        self._flat_grad = torch.zeros(total, device=ps[0].device, dtype=torch.float32)
+    def _fused_sgd_eligible(self, ps):
+        o = self.optimizer
+        if o is None or type(o) is not torch.optim.SGD or len(o.param_groups) != 1 or self.device.type != "cuda":
+            return False
+        g = o.param_groups[0]
+        same = len(g["params"]) == len(ps) and all(a is b for a, b in zip(g["params"], ps))
+        return bool(same and g.get("dampening", 0) == 0 and not g.get("maximize", False))
+
+    def _views_ok(self, ps, flat, attr):
+        if flat is None or flat.numel() != sum(p.numel() for p in ps) or flat.device != ps[0].device:
+            return False
         off = 0
         for p in ps:
-            p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
+            t = p.data if attr == "data" else p.grad
+            if t is None or t.data_ptr() != flat.data_ptr() + 4 * off or not t.is_contiguous():
+                return False
             off += p.numel()
+        return True
+
+    def _ensure_flat_grad(self):
+        """Make every parameter, its .grad and (plain SGD) its momentum buffer a view into one flat fp32
+        buffer each: one all-reduce for the gradients, one launch for the optimizer step, and gradient
+        'sinks' the backward kernels write into directly (no per-parameter autograd accumulate kernels)."""
+        ps = self._params()
+        total = sum(p.numel() for p in ps)
+        dev = ps[0].device
+        ok = self._views_ok(ps, self._flat_param, "data") and self._views_ok(ps, self._flat_grad, "grad")
+        if ok and self._fused_sgd == self._fused_sgd_eligible(ps):
+            return
+        with torch.no_grad():
+            flat_p = torch.empty(total, device=dev, dtype=torch.float32)
+            off = 0
+            for p in ps:
+                flat_p[off:off + p.numel()].copy_(p.data.reshape(-1))
+                p.data = flat_p[off:off + p.numel()].view(p.shape)
+                off += p.numel()
+            self._flat_param = flat_p
+            self._flat_grad = torch.zeros(total, device=dev, dtype=torch.float32)
+            off = 0
+            for p in ps:
+                p.grad = self._flat_grad[off:off + p.numel()].view(p.shape)
+                off += p.numel()
+            self._fused_sgd = self._fused_sgd_eligible(ps)
+            self._flat_mom = None
+            if self._fused_sgd and self.optimizer.param_groups[0].get("momentum", 0) != 0:
+                self._flat_mom = torch.zeros(total, device=dev, dtype=torch.float32)
+                off = 0
+                for p in ps:
+                    st = self.optimizer.state[p]
+                    view = self._flat_mom[off:off + p.numel()].view(p.shape)
+                    if torch.is_tensor(st.get("momentum_buffer")):
+                        view.copy_(st["momentum_buffer"])
+                    st["momentum_buffer"] = view  # torch's own step() would keep using (and updating) this view
+                    off += p.numel()
+        managed = dev.type == "cuda" and hasattr(self.model, "_rng_state")
+        self.model._rng_managed = managed
+        self.model._grad_sink = dev.type == "cuda" and hasattr(self.model, "forward_loss") and self.fused_head
         self._graphs.clear()
+
+    def _optimizer_step(self):
+        """finetune.py:49.  Plain torch SGD runs as one fused launch over the flat buffers (which also
+        advances the dropout counter); anything else goes through optimizer.step()."""
+        rng = self.model._rng_state if getattr(self.model, "_rng_managed", False) else None
+        if self._fused_sgd:
+            from . import ops
+            g = self.optimizer.param_groups[0]
+            ops.sgd_step(self._flat_param, self._flat_grad, self._flat_mom, g["lr"], g.get("momentum", 0),
+                         g.get("weight_decay", 0), g.get("nesterov", False), rng)
+        else:
+            self.optimizer.step()
+            if rng is not None:
+                rng[1] += 1
 
     # ------------------------------------------------------------------ one chromosome, eager
     def _forward_loss(self, c: _Chrom, x):
@@ -129,7 +185,8 @@ class GCNStage:
 
     def _fwd_bwd(self, c: _Chrom):
         x = c.x.detach().requires_grad_(True) if self.input_grad else c.x  # finetune.py:33-34
-        self._flat_grad.zero_()                                            # finetune.py:39
+        if not getattr(self.model, "_grad_sink", False):
+            self._flat_grad.zero_()                                        # finetune.py:39 (sinks overwrite instead)
         loss, probs = self._forward_loss(c, x)
         loss.backward()                                                    # finetune.py:48
         return loss.detach(), probs, (x.grad if self.input_grad else None)
@@ -162,7 +219,9 @@ class GCNStage:
                                 v.zero_()  # state created during warm-up (e.g. momentum_buffer): 0 == "not yet stepped"
 
     def _lr_signature(self):
-        return None if self.optimizer is None else tuple(g.get("lr") for g in self.optimizer.param_groups)
+        if self.optimizer is None:
+            return None
+        return tuple((g.get("lr"), g.get("momentum"), g.get("weight_decay"), g.get("nesterov")) for g in self.optimizer.param_groups)
 
     def _capture(self, c: _Chrom, kind: str):
         """kind: 'train' (zero_grad+fwd+bwd+step), 'fwdbwd' (no optimizer step: multi-rank), 'eval'."""
@@ -176,7 +235,7 @@ class GCNStage:
                 return loss, probs, None
             loss, probs, dx = self._fwd_bwd(c)
             if kind == "train":
-                self.optimizer.step()                                     # finetune.py:49
+                self._optimizer_step()                                    # finetune.py:49
             return loss, probs, dx
 
         side = torch.cuda.Stream(device=self.device)
@@ -219,7 +278,7 @@ class GCNStage:
         if self.hip_graphs:
             return self._replay(c, "train")
         loss, probs, dx = self._fwd_bwd(c)
-        self.optimizer.step()
+        self._optimizer_step()
         return loss, probs, dx
 
     def eval_step(self, name: str):
@@ -246,7 +305,7 @@ class GCNStage:
             torch.distributed.all_reduce(self._flat_grad, op=torch.distributed.ReduceOp.SUM, group=self.group)
         if group_size > 1:
             self._flat_grad.div_(group_size)
-        self.optimizer.step()
+        self._optimizer_step()
         return out
 
     def sync_running_stats(self):

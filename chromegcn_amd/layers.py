@@ -97,15 +97,39 @@ class ChromeGCN(nn.Module):
         self._rng_state[0] = int(seed) & 0x7FFFFFFFFFFFFFFF
         self._rng_state[1] = 0
 
+    # -- dropout RNG bookkeeping ---------------------------------------------------------------
+    def _step_rng(self):
+        """rng_state tensor for this forward.  Stand-alone use: a snapshot is taken and the live counter is
+        advanced, so every forward draws fresh masks and its backward still sees the counter it used.  Under
+        GCNStage (`_rng_managed`), the live tensor is used and the engine advances it once per step."""
+        if not (self.training and self.dropout > 0):
+            return None
+        if getattr(self, "_rng_managed", False):
+            return self._rng_state
+        snap = self._rng_state.clone()
+        self._rng_state[1] += 1
+        return snap
+
+    def _sink(self, *params):
+        """gradient sinks (engine use): the .grad views the backward kernels write straight into"""
+        if not getattr(self, "_grad_sink", False):
+            return None
+        grads = tuple(p.grad for p in params)
+        return None if any(g is None for g in grads) else grads
+
     # -- the gated stack on a [S, n, d] block -------------------------------------------------
-    def _gated_stack(self, x, graph):
+    def _gated_stack(self, x, graph, rng):
         gates = []
-        for k in range(1, self.n_layers + 1):
-            if k > 1:
-                x = F.dropout(x, self.dropout, training=self.training)  # ChromeModels.py:42
+        L = self.n_layers
+        p = float(self.dropout) if (self.training and rng is not None) else 0.0
+        for k in range(1, L + 1):
             gc = getattr(self, "GC%d" % k)
             wk = getattr(self, "W%d" % k)
-            x, g = ops.gated_layer(x, gc.weight, gc.bias, wk.weight, wk.bias, graph)
+            # F.dropout between layers (ChromeModels.py:42) runs inside the kernels: layer k drops its own
+            # output (k < L) and un-drops the gradient of its input (k > 1)
+            x, g = ops.gated_layer(x, gc.weight, gc.bias, wk.weight, wk.bias, graph,
+                                   dropout_out=p if k < L else 0.0, dropout_in=p if k > 1 else 0.0,
+                                   rng_state=rng, layer_id=k, grad_sink=self._sink(gc.weight, gc.bias, wk.weight, wk.bias))
             gates.append(g)
         return x, gates
 
@@ -121,7 +145,7 @@ class ChromeGCN(nn.Module):
     def forward(self, x_in, adj, deg=None, src_dict=None, return_gate=False):
         ops._require_cuda(x_in, "x_in")
         graph = as_graph(adj, x_in.device)
-        x, gates = self._gated_stack(x_in.unsqueeze(0), graph)
+        x, gates = self._gated_stack(x_in.unsqueeze(0), graph, self._step_rng())
         out = self._head(x).squeeze(0)
         gs = [g.view(-1, 1) for g in gates]  # [n,1] like sigmoid(Linear(d,1)(z))
         if len(gs) > 2:
@@ -133,7 +157,7 @@ class ChromeGCN(nn.Module):
         x_fr: [2, n, d] (forward strand, reverse-complement strand).  Returns (logits [2,n,C], gates)."""
         ops._require_cuda(x_fr, "x_fr")
         graph = as_graph(adj, x_fr.device)
-        x, gates = self._gated_stack(x_fr, graph)
+        x, gates = self._gated_stack(x_fr, graph, self._step_rng())
         return self._head(x), gates
 
     def forward_loss(self, x_fr, adj, target):
@@ -142,6 +166,9 @@ class ChromeGCN(nn.Module):
         Returns (loss [], probs [n,C] = sigmoid(pred), gates)."""
         ops._require_cuda(x_fr, "x_fr")
         graph = as_graph(adj, x_fr.device)
-        x, gates = self._gated_stack(x_fr, graph)
-        loss, probs = ops.head_loss(x, self.batch_norm, self.out, target, self.training, self.dropout, self._rng_state)
+        rng = self._step_rng()
+        x, gates = self._gated_stack(x_fr, graph, rng)
+        bn, out = self.batch_norm, self.out
+        loss, probs = ops.head_loss(x, bn, out, target, self.training, self.dropout if rng is not None else 0.0, rng,
+                                    grad_sink=self._sink(bn.weight, bn.bias, out.weight, out.bias))
         return loss, probs, gates

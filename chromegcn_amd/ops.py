@@ -62,11 +62,24 @@ def spmm(x, graph):
     return SpmmFn.apply(x, graph)
 
 
+def _sink_ok(sink, shapes):
+    return sink is not None and all(t is not None and tuple(t.shape) == tuple(sh) and t.is_contiguous()
+                                    for t, sh in zip(sink, shapes))
+
+
 class GatedLayerFn(torch.autograd.Function):
-    """One gated GCN layer (models/ChromeModels.py:37-40), fused; see cgcn_layer_fwd / cgcn_layer_bwd."""
+    """One gated GCN layer (models/ChromeModels.py:37-40), fused; see cgcn_layer_fwd / cgcn_layer_bwd.
+
+    dropout_out / dropout_in implement the F.dropout between layers (models/ChromeModels.py:42) inside the
+    kernels: this layer's output is dropped with stream id `layer_id`; its input was dropped by the previous
+    layer (stream id layer_id - 1), which the backward undoes on dX.  rng_state: uint64[2] device tensor
+    {seed, step counter}, constant over one step.
+    grad_sink (engine use): tensors (dW, db, dgate_w, dgate_b) the backward writes the parameter gradients
+    INTO (overwrite); autograd then receives None for them, which skips its per-parameter accumulate kernels."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gate_w, gate_b, graph: ChromGraph):
+    def forward(ctx, x, weight, bias, gate_w, gate_b, graph: ChromGraph, dropout_out, dropout_in, rng_state,
+                layer_id, grad_sink):
         _check_feat(x, graph)
         for t, nm in ((weight, "weight"), (bias, "bias"), (gate_w, "gate weight"), (gate_b, "gate bias")):
             _require_cuda(t, nm)
@@ -83,31 +96,41 @@ class GatedLayerFn(torch.autograd.Function):
         gate = torch.empty((S, n), device=x.device, dtype=torch.float32)
         z = torch.empty_like(x) if need_bwd else None
         h = torch.empty_like(x) if need_bwd else None
+        if (dropout_out > 0 or dropout_in > 0) and rng_state is None:
+            raise RuntimeError("chromegcn_amd: fused dropout needs the model's rng_state tensor")
         lib = _lib.load()
         _lib.check(lib.cgcn_layer_fwd(_lib.stream_ptr(), n, S, d, _lib.ptr(graph.rowptr), _lib.ptr(graph.col),
                                       _lib.ptr(graph.val), _lib.ptr(graph.row_scale), x.data_ptr(), weight.data_ptr(),
                                       bias.data_ptr(), wg.data_ptr(), cg.data_ptr(), xn.data_ptr(), _lib.ptr(z),
-                                      _lib.ptr(h), gate.data_ptr()), "cgcn_layer_fwd")
+                                      _lib.ptr(h), gate.data_ptr(), float(dropout_out),
+                                      _lib.ptr(rng_state) if dropout_out > 0 else None, int(layer_id)),
+                   "cgcn_layer_fwd")
         if need_bwd:
-            ctx.save_for_backward(x, z, h, gate, weight, wg)
+            ctx.save_for_backward(x, z, h, gate, weight, wg, rng_state if dropout_in > 0 else None)
         ctx.graph = graph
         ctx.gate_w_shape = gate_w.shape
         ctx.gate_b_shape = gate_b.shape
+        ctx.dropout_in = float(dropout_in)
+        ctx.layer_id = int(layer_id)
+        ctx.sink = grad_sink if _sink_ok(grad_sink, ((d, d), (d,), gate_w.shape, gate_b.shape)) else None
         return xn, gate
 
     @staticmethod
     def backward(ctx, dxn, dgate):
-        x, z, h, gate, weight, wg = ctx.saved_tensors
+        x, z, h, gate, weight, wg, rng_state = ctx.saved_tensors
         g = ctx.graph
         S, n, d = x.shape
         dxn = torch.zeros_like(x) if dxn is None else dxn.contiguous()
         dgate = None if dgate is None else dgate.contiguous()
         dx = torch.empty_like(x)
         dus = torch.empty_like(x)
-        dw = torch.empty_like(weight)
-        db = torch.empty(d, device=x.device, dtype=torch.float32)
-        dwg = torch.empty(d, device=x.device, dtype=torch.float32)
-        dcg = torch.empty(1, device=x.device, dtype=torch.float32)
+        if ctx.sink is not None:
+            dw, db, dwg, dcg = ctx.sink
+        else:
+            dw = torch.empty_like(weight)
+            db = torch.empty(d, device=x.device, dtype=torch.float32)
+            dwg = torch.empty(d, device=x.device, dtype=torch.float32)
+            dcg = torch.empty(1, device=x.device, dtype=torch.float32)
         lib = _lib.load()
         ws_bytes = lib.cgcn_layer_bwd_workspace_bytes(n, S, d)
         ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8)
@@ -115,24 +138,29 @@ class GatedLayerFn(torch.autograd.Function):
                                       _lib.ptr(g.val_t), _lib.ptr(g.row_scale), x.data_ptr(), z.data_ptr(),
                                       h.data_ptr(), gate.data_ptr(), weight.data_ptr(), wg.data_ptr(),
                                       dxn.data_ptr(), _lib.ptr(dgate), dx.data_ptr(), dus.data_ptr(), dw.data_ptr(),
-                                      db.data_ptr(), dwg.data_ptr(), dcg.data_ptr(), 0, ws.data_ptr(), ws_bytes),
+                                      db.data_ptr(), dwg.data_ptr(), dcg.data_ptr(), 0, ctx.dropout_in,
+                                      _lib.ptr(rng_state), max(ctx.layer_id - 1, 0), ws.data_ptr(), ws_bytes),
                    "cgcn_layer_bwd")
-        return dx, dw, db, dwg.view(ctx.gate_w_shape), dcg.view(ctx.gate_b_shape), None
+        if ctx.sink is not None:
+            return (dx, None, None, None, None) + (None,) * 6
+        return (dx, dw, db, dwg.view(ctx.gate_w_shape), dcg.view(ctx.gate_b_shape)) + (None,) * 6
 
 
-def gated_layer(x, weight, bias, gate_w, gate_b, graph):
-    return GatedLayerFn.apply(x, weight, bias, gate_w, gate_b, graph)
+def gated_layer(x, weight, bias, gate_w, gate_b, graph, dropout_out=0.0, dropout_in=0.0, rng_state=None,
+                layer_id=0, grad_sink=None):
+    return GatedLayerFn.apply(x, weight, bias, gate_w, gate_b, graph, float(dropout_out), float(dropout_in),
+                              rng_state, int(layer_id), grad_sink)
 
 
 class HeadLossFn(torch.autograd.Function):
     """relu -> BatchNorm1d -> dropout -> Linear, mean over strands, BCE-with-logits, sigmoid -- fused
     (models/ChromeModels.py:48-51 + finetune.py:43,45,52); see cgcn_head_fwd / cgcn_head_bwd.
     Returns (loss [], probs [n,C]).  Running statistics / num_batches_tracked are updated in place when
-    training, exactly as two successive ChromeGCN.forward calls would."""
+    training, exactly as two successive ChromeGCN.forward calls would.  grad_sink: (dbn_w, dbn_b, dW_out, db_out)."""
 
     @staticmethod
     def forward(ctx, x, bn_w, bn_b, w_out, b_out, target, run_mean, run_var, nbt, momentum, eps, training,
-                dropout_p, rng_state):
+                dropout_p, rng_state, grad_sink):
         _require_cuda(x, "x")
         for t, nm in ((bn_w, "bn weight"), (bn_b, "bn bias"), (w_out, "out.weight"), (b_out, "out.bias"), (target, "target")):
             _require_cuda(t, nm)
@@ -157,41 +185,57 @@ class HeadLossFn(torch.autograd.Function):
         save_mean = torch.empty((S, d), device=x.device, dtype=torch.float32) if training else None
         save_invstd = torch.empty((S, d), device=x.device, dtype=torch.float32) if training else None
         drop = bool(training) and dropout_p > 0
-        rng_saved = torch.empty(2, device=x.device, dtype=torch.int64) if drop else None
+        if drop and rng_state is None:
+            raise RuntimeError("chromegcn_amd: fused dropout needs the model's rng_state tensor")
         _lib.check(lib.cgcn_head_fwd(_lib.stream_ptr(), n, S, d, C, x.data_ptr(), bn_w.data_ptr(), bn_b.data_ptr(),
                                      run_mean.data_ptr(), run_var.data_ptr(), _lib.ptr(nbt), float(momentum), float(eps),
                                      1 if training else 0, w_out.data_ptr(), b_out.data_ptr(), target.data_ptr(),
-                                     float(dropout_p), _lib.ptr(rng_state) if drop else None, _lib.ptr(rng_saved),
+                                     float(dropout_p), _lib.ptr(rng_state) if drop else None,
                                      probs.data_ptr(), loss.data_ptr(), _lib.ptr(dpred), _lib.ptr(save_mean),
                                      _lib.ptr(save_invstd), ws.data_ptr(), ws_bytes), "cgcn_head_fwd")
         if need_bwd:
-            ctx.save_for_backward(x, bn_w, bn_b, w_out, dpred, save_mean, save_invstd, rng_saved)
+            ctx.save_for_backward(x, bn_w, bn_b, w_out, dpred, save_mean, save_invstd, rng_state if drop else None)
             ctx.dropout_p = float(dropout_p) if drop else 0.0
+            ctx.sink = grad_sink if _sink_ok(grad_sink, ((d,), (d,), (C, d), (C,))) else None
         ctx.mark_non_differentiable(probs)
         return loss.view(()), probs
 
     @staticmethod
     def backward(ctx, dloss, _dprobs):
-        x, bn_w, bn_b, w_out, dpred, save_mean, save_invstd, rng_saved = ctx.saved_tensors
+        x, bn_w, bn_b, w_out, dpred, save_mean, save_invstd, rng_state = ctx.saved_tensors
         S, n, d = x.shape
         C = w_out.shape[0]
         lib = _lib.load()
         ws_bytes = lib.cgcn_head_workspace_bytes(n, S, d, C)
         ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8)
         dx = torch.empty_like(x)
-        dw_out = torch.empty_like(w_out)
-        db_out = torch.empty(C, device=x.device, dtype=torch.float32)
-        dbn_w = torch.empty(d, device=x.device, dtype=torch.float32)
-        dbn_b = torch.empty(d, device=x.device, dtype=torch.float32)
+        if ctx.sink is not None:
+            dbn_w, dbn_b, dw_out, db_out = ctx.sink
+        else:
+            dw_out = torch.empty_like(w_out)
+            db_out = torch.empty(C, device=x.device, dtype=torch.float32)
+            dbn_w = torch.empty(d, device=x.device, dtype=torch.float32)
+            dbn_b = torch.empty(d, device=x.device, dtype=torch.float32)
         dloss = dloss.contiguous().view(1)
         _lib.check(lib.cgcn_head_bwd(_lib.stream_ptr(), n, S, d, C, x.data_ptr(), bn_w.data_ptr(), bn_b.data_ptr(),
                                      save_mean.data_ptr(), save_invstd.data_ptr(), w_out.data_ptr(), dpred.data_ptr(),
-                                     dloss.data_ptr(), ctx.dropout_p, _lib.ptr(rng_saved), dx.data_ptr(),
+                                     dloss.data_ptr(), ctx.dropout_p, _lib.ptr(rng_state), dx.data_ptr(),
                                      dw_out.data_ptr(), db_out.data_ptr(), dbn_w.data_ptr(), dbn_b.data_ptr(), 0,
                                      ws.data_ptr(), ws_bytes), "cgcn_head_bwd")
-        return (dx, dbn_w, dbn_b, dw_out, db_out) + (None,) * 9
+        if ctx.sink is not None:
+            return (dx,) + (None,) * 14
+        return (dx, dbn_w, dbn_b, dw_out, db_out) + (None,) * 10
 
 
-def head_loss(x, bn: torch.nn.BatchNorm1d, out: torch.nn.Linear, target, training, dropout_p, rng_state):
+def head_loss(x, bn: torch.nn.BatchNorm1d, out: torch.nn.Linear, target, training, dropout_p, rng_state, grad_sink=None):
     return HeadLossFn.apply(x, bn.weight, bn.bias, out.weight, out.bias, target, bn.running_mean, bn.running_var,
-                            bn.num_batches_tracked, bn.momentum, bn.eps, bool(training), float(dropout_p), rng_state)
+                            bn.num_batches_tracked, bn.momentum, bn.eps, bool(training), float(dropout_p), rng_state,
+                            grad_sink)
+
+
+def sgd_step(flat_param, flat_grad, flat_mom, lr, momentum, weight_decay, nesterov, rng_state=None):
+    """torch.optim.SGD step on flat buffers in one launch (cgcn_sgd_step); also advances the dropout counter."""
+    lib = _lib.load()
+    _lib.check(lib.cgcn_sgd_step(_lib.stream_ptr(), flat_param.numel(), flat_param.data_ptr(), flat_grad.data_ptr(),
+                                 _lib.ptr(flat_mom), float(lr), float(momentum), float(weight_decay),
+                                 1 if nesterov else 0, _lib.ptr(rng_state)), "cgcn_sgd_step")

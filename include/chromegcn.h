@@ -26,6 +26,10 @@
  *     'both' graphs carry val in {1,2,3}.
  *   - The backward needs Ahat^T; (rowptr_t, col_t, val_t) is its CSR.  Hi-C graphs are
  *     symmetric (data/7create_graph_new.py:115-116) so callers pass the same arrays.
+ *   - Dropout (F.dropout of models/ChromeModels.py:42,50) is counter based: a mask bit is a pure
+ *     function of rng_state = {seed, step counter} (uint64[2] in DEVICE memory), a stream id and
+ *     the element index, so the backward regenerates the forward's mask.  Every kernel of one
+ *     train step must see the same counter; cgcn_sgd_step (the last kernel of a step) advances it.
  */
 #ifndef CHROMEGCN_H
 #define CHROMEGCN_H
@@ -43,7 +47,7 @@ extern "C" {
 #define CGCN_ERR_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after a launch      */
 #define CGCN_ERR_WORKSPACE (-4)   /* workspace too small (see cgcn_*_workspace_bytes)    */
 
-#define CGCN_ABI_VERSION 1
+#define CGCN_ABI_VERSION 2
 
 typedef void *cgcn_stream_t; /* hipStream_t */
 
@@ -74,11 +78,14 @@ int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d,
  * X, Xn, Z, H: [S,n,d].  gate: [S,n].  W: [d,d] stored in x out (GraphConvolution.weight).
  * b, wg: [d].  cg: [1] (device).  Z and H may be NULL for inference (they are what the
  * backward needs).  Xn must not alias X.
+ * dropout_p > 0 additionally applies the inter-layer dropout of models/ChromeModels.py:42 to Xn
+ * (Xn <- mask * Xn / (1-p), mask from (rng_state, stream_id)); pass 0 / NULL / 0 for none.
  */
 int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d,
                    const int32_t *rowptr, const int32_t *col, const float *val, const float *row_scale,
                    const float *X, const float *W, const float *b, const float *wg, const float *cg,
-                   float *Xn, float *Z, float *H, float *gate);
+                   float *Xn, float *Z, float *H, float *gate,
+                   float dropout_p, const unsigned long long *rng_state, unsigned int stream_id);
 
 /* Bytes of scratch cgcn_layer_bwd needs for (n, S, d).  0 on unsupported shapes. */
 size_t cgcn_layer_bwd_workspace_bytes(int n, int S, int d);
@@ -95,6 +102,8 @@ size_t cgcn_layer_bwd_workspace_bytes(int n, int S, int d);
  * when accumulate == 0 and added to when accumulate != 0.  dUs is a [S,n,d] scratch output
  * (holds diag(row_scale) dU on return).  Sums over rows are two-stage and deterministic
  * (no float atomics): results are bit-reproducible run to run.
+ * in_dropout_p > 0: X was produced by a layer that applied dropout (in_stream_id = that layer's
+ * stream_id); dX is then the gradient w.r.t. the pre-dropout tensor (mask / (1-p) applied).
  */
 int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d,
                    const int32_t *rowptr_t, const int32_t *col_t, const float *val_t, const float *row_scale,
@@ -102,7 +111,8 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d,
                    const float *W, const float *wg,
                    const float *dXn, const float *dgate,
                    float *dX, float *dUs, float *dW, float *db, float *dwg, float *dcg,
-                   int accumulate, void *workspace, size_t workspace_bytes);
+                   int accumulate, float in_dropout_p, const unsigned long long *rng_state,
+                   unsigned int in_stream_id, void *workspace, size_t workspace_bytes);
 
 /* Bytes of scratch cgcn_head_fwd / cgcn_head_bwd need for (n, S, d, C).  0 on unsupported shapes. */
 size_t cgcn_head_workspace_bytes(int n, int S, int d, int C);
@@ -117,29 +127,39 @@ size_t cgcn_head_workspace_bytes(int n, int S, int d, int C);
  * b_out: [C], target: [n,C] (0/1 floats).  C <= 256.
  * training != 0: batch statistics, running statistics updated once per strand in strand order (what two
  *   successive ChromeGCN.forward calls do), num_batches_tracked += S, dropout with probability dropout_p
- *   driven by rng_state = {seed, step counter} (uint64[2], device): the counter is copied to rng_saved
- *   (uint64[2], device, needed by cgcn_head_bwd) and then advanced.  Outputs dpred = d loss / d pred
- *   [n,C] (may be NULL), save_mean / save_invstd [S,d].
- * training == 0: running statistics, no dropout; dpred, save_*, rng_* unused.
+ *   driven by rng_state (see Conventions; the head uses its own fixed stream id).  Outputs
+ *   dpred = d loss / d pred [n,C] (may be NULL), save_mean / save_invstd [S,d].
+ * training == 0: running statistics, no dropout; dpred, save_*, rng_state unused.
  * probs: [n,C]; loss: [1].
  */
 int cgcn_head_fwd(cgcn_stream_t stream, int n, int S, int d, int C, const float *X, const float *bn_w,
                   const float *bn_b, float *run_mean, float *run_var, long long *num_batches_tracked,
                   float momentum, float eps, int training, const float *W_out, const float *b_out,
-                  const float *target, float dropout_p, unsigned long long *rng_state,
-                  unsigned long long *rng_saved, float *probs, float *loss, float *dpred, float *save_mean,
-                  float *save_invstd, void *workspace, size_t workspace_bytes);
+                  const float *target, float dropout_p, const unsigned long long *rng_state,
+                  float *probs, float *loss, float *dpred, float *save_mean, float *save_invstd,
+                  void *workspace, size_t workspace_bytes);
 
 /*
  * Backward of cgcn_head_fwd (training mode).  dloss: [1] upstream gradient of the loss or NULL (= 1).
  * Outputs dX [S,n,d] and, overwritten (accumulate == 0) or added to (accumulate != 0): dW_out [C,d],
- * db_out [C], dbn_w [d], dbn_b [d].  rng_saved: the value cgcn_head_fwd stored.  Deterministic.
+ * db_out [C], dbn_w [d], dbn_b [d].  rng_state: same contents as in the forward.  Deterministic.
  */
 int cgcn_head_bwd(cgcn_stream_t stream, int n, int S, int d, int C, const float *X, const float *bn_w,
                   const float *bn_b, const float *save_mean, const float *save_invstd, const float *W_out,
-                  const float *dpred, const float *dloss, float dropout_p, const unsigned long long *rng_saved,
+                  const float *dpred, const float *dloss, float dropout_p, const unsigned long long *rng_state,
                   float *dX, float *dW_out, float *db_out, float *dbn_w, float *dbn_b, int accumulate,
                   void *workspace, size_t workspace_bytes);
+
+/*
+ * torch.optim.SGD step on one flat fp32 buffer (utils/util_methods.py:14-19 builds
+ * SGD(lr, momentum=0.9, weight_decay=1e-6); dampening 0):
+ *     d = grad + weight_decay * param;  buf = momentum * buf + d;
+ *     param -= lr * (nesterov ? d + momentum * buf : buf)
+ * momentum_buf zero-initialised reproduces torch's first step (buf = d); may be NULL when momentum == 0.
+ * rng_state (may be NULL): its step counter is advanced by one -- this is the last kernel of a train step.
+ */
+int cgcn_sgd_step(cgcn_stream_t stream, long long count, float *param, const float *grad, float *momentum_buf,
+                  float lr, float momentum, float weight_decay, int nesterov, unsigned long long *rng_state);
 
 #ifdef __cplusplus
 }
