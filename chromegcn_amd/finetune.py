@@ -108,15 +108,24 @@ class GCNStage:
         same = len(g["params"]) == len(ps) and all(a is b for a, b in zip(g["params"], ps))
         return bool(same and g.get("dampening", 0) == 0 and not g.get("maximize", False))
 
-    def _views_ok(self, ps, flat, attr):
-        if flat is None or flat.numel() != sum(p.numel() for p in ps) or flat.device != ps[0].device:
-            return False
-        off = 0
+    @staticmethod
+    def _offsets(ps):
+        """element offset of each parameter in the flat arenas; every parameter starts 16-byte aligned
+        (the kernels read weights with 16-byte loads), padding elements stay zero forever"""
+        offs, off = [], 0
         for p in ps:
+            offs.append(off)
+            off += (p.numel() + 3) & ~3
+        return offs, off
+
+    def _views_ok(self, ps, flat, attr):
+        offs, total = self._offsets(ps)
+        if flat is None or flat.numel() != total or flat.device != ps[0].device:
+            return False
+        for p, off in zip(ps, offs):
             t = p.data if attr == "data" else p.grad
             if t is None or t.data_ptr() != flat.data_ptr() + 4 * off or not t.is_contiguous():
                 return False
-            off += p.numel()
         return True
 
     def _ensure_flat_grad(self):
@@ -124,36 +133,30 @@ class GCNStage:
         buffer each: one all-reduce for the gradients, one launch for the optimizer step, and gradient
         'sinks' the backward kernels write into directly (no per-parameter autograd accumulate kernels)."""
         ps = self._params()
-        total = sum(p.numel() for p in ps)
+        offs, total = self._offsets(ps)
         dev = ps[0].device
         ok = self._views_ok(ps, self._flat_param, "data") and self._views_ok(ps, self._flat_grad, "grad")
         if ok and self._fused_sgd == self._fused_sgd_eligible(ps):
             return
         with torch.no_grad():
-            flat_p = torch.empty(total, device=dev, dtype=torch.float32)
-            off = 0
-            for p in ps:
+            flat_p = torch.zeros(total, device=dev, dtype=torch.float32)
+            for p, off in zip(ps, offs):
                 flat_p[off:off + p.numel()].copy_(p.data.reshape(-1))
                 p.data = flat_p[off:off + p.numel()].view(p.shape)
-                off += p.numel()
             self._flat_param = flat_p
             self._flat_grad = torch.zeros(total, device=dev, dtype=torch.float32)
-            off = 0
-            for p in ps:
+            for p, off in zip(ps, offs):
                 p.grad = self._flat_grad[off:off + p.numel()].view(p.shape)
-                off += p.numel()
             self._fused_sgd = self._fused_sgd_eligible(ps)
             self._flat_mom = None
             if self._fused_sgd and self.optimizer.param_groups[0].get("momentum", 0) != 0:
                 self._flat_mom = torch.zeros(total, device=dev, dtype=torch.float32)
-                off = 0
-                for p in ps:
+                for p, off in zip(ps, offs):
                     st = self.optimizer.state[p]
                     view = self._flat_mom[off:off + p.numel()].view(p.shape)
                     if torch.is_tensor(st.get("momentum_buffer")):
                         view.copy_(st["momentum_buffer"])
                     st["momentum_buffer"] = view  # torch's own step() would keep using (and updating) this view
-                    off += p.numel()
         managed = dev.type == "cuda" and hasattr(self.model, "_rng_state")
         self.model._rng_managed = managed
         self.model._grad_sink = dev.type == "cuda" and hasattr(self.model, "forward_loss") and self.fused_head
