@@ -31,18 +31,62 @@ struct Geo {
 
 // Sum val[k] * X[s, col[k], :] over k in [k0, k1) for one output node; the whole wave cooperates.
 // lane_off[v]: this lane's byte offset (strand * n_cols * D + column) * 4 into X.
-// Loads are issued 8 neighbours deep before the first add so a wave keeps 8 KiB in flight.
+// Neighbour rows are fetched in batches of GU wave-loads, double buffered: while one batch is being
+// added the next is already in flight, so a wave keeps 8-16 KiB outstanding; the ragged tail of a row
+// is a predicated batch, never a serial load-wait-add chain.  Column indices of up to 64 neighbours are
+// read with one coalesced load and broadcast to the scalar unit with v_readlane.
+#define GU 8
+template <int S, int D, bool HAS_VAL>
+struct Gather {
+  using G = Geo<S, D>;
+  static constexpr int NV = G::NV;
+  static constexpr int NPL = G::HALF ? 2 : 1;   // neighbours per wave-load
+  static constexpr unsigned ROWB = D * 4;       // bytes per (strand,node) row
+
+  // issue the loads of batch `b` (slots b*GU .. b*GU+GU-1) of a chunk of `cnt` neighbours
+  static __device__ __forceinline__ void issue(f32x4 (&t)[GU][NV], float (&w)[GU], int b, int cnt, int myc, float myv,
+                                               const char* __restrict__ Xb, const unsigned (&lane_off)[NV], int lane) {
+#pragma unroll
+    for (int u = 0; u < GU; ++u) {
+      const int slot = b * GU + u;
+      if (slot * NPL < cnt) {  // wave-uniform
+        if (!G::HALF) {
+          const char* rowp = Xb + (size_t)(unsigned)rl_i(myc, slot) * ROWB;
+#pragma unroll
+          for (int v = 0; v < NV; ++v) t[u][v] = *(const f32x4*)(rowp + lane_off[v]);
+          if (HAS_VAL) w[u] = rl_f(myv, slot);
+        } else {
+          const int sub = lane >> 5;
+          const int i0 = 2 * slot, i1 = min(2 * slot + 1, cnt - 1);
+          const unsigned c = sub ? (unsigned)rl_i(myc, i1) : (unsigned)rl_i(myc, i0);
+          if (HAS_VAL) { const float wa = rl_f(myv, i0), wb = rl_f(myv, i1); w[u] = sub ? wb : wa; }
+          if (2 * slot + sub < cnt) t[u][0] = *(const f32x4*)(Xb + (size_t)c * ROWB + lane_off[0]);
+          else { t[u][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; if (HAS_VAL) w[u] = 0.f; }
+        }
+      }
+    }
+  }
+  static __device__ __forceinline__ void consume(const f32x4 (&t)[GU][NV], const float (&w)[GU], int b, int cnt,
+                                                 f32x4 (&acc)[NV]) {
+#pragma unroll
+    for (int u = 0; u < GU; ++u) {
+      if ((b * GU + u) * NPL < cnt) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] = HAS_VAL ? acc[v] + w[u] * t[u][v] : acc[v] + t[u][v];
+      }
+    }
+  }
+};
+
 template <int S, int D, bool HAS_VAL>
 __device__ __forceinline__ void gather_node(const int* __restrict__ col, const float* __restrict__ val,
                                             int k0, int k1, const char* __restrict__ Xb,
                                             const unsigned (&lane_off)[Geo<S, D>::NV], f32x4 (&acc)[Geo<S, D>::NV],
                                             int lane) {
-  using G = Geo<S, D>;
-  constexpr int NV = G::NV;
-  constexpr unsigned ROWB = D * 4;  // bytes per (strand,node) row
+  using GA = Gather<S, D, HAS_VAL>;
+  constexpr int NV = GA::NV;
 #pragma unroll
   for (int v = 0; v < NV; ++v) acc[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
   for (int kb = k0; kb < k1; kb += WAVE) {
     const int cnt = min(WAVE, k1 - kb);
     int myc = 0;
@@ -51,70 +95,18 @@ __device__ __forceinline__ void gather_node(const int* __restrict__ col, const f
       myc = col[kb + lane];
       if (HAS_VAL) myv = val[kb + lane];
     }
-    if (!G::HALF) {
-      int j = 0;
-      for (; j + 8 <= cnt; j += 8) {
-        f32x4 t[8][NV];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const char* rowp = Xb + (size_t)(unsigned)rl_i(myc, j + u) * ROWB;
-#pragma unroll
-          for (int v = 0; v < NV; ++v) t[u][v] = *(const f32x4*)(rowp + lane_off[v]);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const float w = HAS_VAL ? rl_f(myv, j + u) : 1.f;
-#pragma unroll
-          for (int v = 0; v < NV; ++v) acc[v] = HAS_VAL ? acc[v] + w * t[u][v] : acc[v] + t[u][v];
-        }
-      }
-      for (; j < cnt; ++j) {
-        const char* rowp = Xb + (size_t)(unsigned)rl_i(myc, j) * ROWB;
-        const float w = HAS_VAL ? rl_f(myv, j) : 1.f;
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-          const f32x4 t = *(const f32x4*)(rowp + lane_off[v]);
-          acc[v] = HAS_VAL ? acc[v] + w * t : acc[v] + t;
-        }
-      }
-    } else {
-      // two neighbours per pass: lanes 0-31 take j, lanes 32-63 take j+1
-      const int sub = lane >> 5;
-      int j = 0;
-      for (; j + 16 <= cnt; j += 16) {
-        f32x4 t[8];
-        float w[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int ca = rl_i(myc, j + 2 * u), cb = rl_i(myc, j + 2 * u + 1);
-          const unsigned c = sub ? (unsigned)cb : (unsigned)ca;
-          t[u] = *(const f32x4*)(Xb + (size_t)c * ROWB + lane_off[0]);
-          if (HAS_VAL) {
-            const float wa = rl_f(myv, j + 2 * u), wb = rl_f(myv, j + 2 * u + 1);
-            w[u] = sub ? wb : wa;
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc[0] = HAS_VAL ? acc[0] + w[u] * t[u] : acc[0] + t[u];
-      }
-      for (; j < cnt; j += 2) {
-        const int ca = rl_i(myc, j);
-        const int cb = rl_i(myc, min(j + 1, cnt - 1));
-        const bool ok = (j + sub) < cnt;
-        const unsigned c = sub ? (unsigned)cb : (unsigned)ca;
-        float w = 1.f;
-        if (HAS_VAL) {
-          const float wa = rl_f(myv, j), wb = rl_f(myv, min(j + 1, cnt - 1));
-          w = sub ? wb : wa;
-        }
-        if (ok) {
-          const f32x4 t = *(const f32x4*)(Xb + (size_t)c * ROWB + lane_off[0]);
-          acc[0] = HAS_VAL ? acc[0] + w * t : acc[0] + t;
-        }
-      }
+    const int nbat = (cnt + GU * GA::NPL - 1) / (GU * GA::NPL);
+    f32x4 ta[GU][NV], tb[GU][NV];
+    float wa[GU], wb[GU];
+    GA::issue(ta, wa, 0, cnt, myc, myv, Xb, lane_off, lane);
+    for (int b = 0; b < nbat; b += 2) {
+      if (b + 1 < nbat) GA::issue(tb, wb, b + 1, cnt, myc, myv, Xb, lane_off, lane);
+      GA::consume(ta, wa, b, cnt, acc);
+      if (b + 2 < nbat) GA::issue(ta, wa, b + 2, cnt, myc, myv, Xb, lane_off, lane);
+      if (b + 1 < nbat) GA::consume(tb, wb, b + 1, cnt, acc);
     }
   }
-  if (G::HALF) {
+  if (Geo<S, D>::HALF) {
     // fold the odd-neighbour half onto the even one; afterwards both halves hold the row sum
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[0][e] += __shfl_xor(acc[0][e], 32, WAVE);
@@ -172,13 +164,13 @@ __device__ __forceinline__ int xcd_contiguous(int b, int nblk) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int D, bool TRANS_W>
-__device__ __forceinline__ void load_wfrag(const float* __restrict__ W, int wave, int lane, float (&bw)[2][D / 4]) {
+template <int D, int CBW, bool TRANS_W>
+__device__ __forceinline__ void load_wfrag(const float* __restrict__ W, int wave, int lane, float (&bw)[CBW][D / 4]) {
   constexpr int KQ = D / 4;
   const int r = lane & 15, q = lane >> 4;
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb) {
-    const int j = wave * 32 + cb * 16 + r;
+  for (int cb = 0; cb < CBW; ++cb) {
+    const int j = wave * (16 * CBW) + cb * 16 + r;
     if (TRANS_W) {
 #pragma unroll
       for (int t = 0; t < KQ / 4; ++t) {
@@ -193,15 +185,15 @@ __device__ __forceinline__ void load_wfrag(const float* __restrict__ W, int wave
   }
 }
 
-template <int MB, int D, int LD, bool TRANS_W, bool PRELOADED>
+template <int MB, int D, int CBW, int LD, bool TRANS_W, bool PRELOADED>
 __device__ __forceinline__ void tile_mfma(const float* __restrict__ T, const float* __restrict__ W,
-                                          const float (&bw)[2][D / 4], int wave, int lane, f32x4 (&acc)[MB][2]) {
+                                          const float (&bw)[CBW][D / 4], int wave, int lane, f32x4 (&acc)[MB][CBW]) {
   constexpr int KQ = D / 4;
   const int r = lane & 15, q = lane >> 4;
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) acc[mb][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int cb = 0; cb < CBW; ++cb) acc[mb][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
   if (PRELOADED) {
 #pragma unroll
     for (int t = 0; t < KQ / 4; ++t) {
@@ -213,19 +205,19 @@ __device__ __forceinline__ void tile_mfma(const float* __restrict__ T, const flo
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-          for (int cb = 0; cb < 2; ++cb)
+          for (int cb = 0; cb < CBW; ++cb)
             acc[mb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb][u], bw[cb][4 * t + u], acc[mb][cb], 0, 0, 0);
     }
   } else {
-    const int j0 = wave * 32 + r;
+    const int j0 = wave * (16 * CBW) + r;
 #pragma unroll 2
     for (int t = 0; t < KQ / 4; ++t) {
       f32x4 a[MB];
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) a[mb] = *(const f32x4*)&T[(mb * 16 + r) * LD + q * KQ + 4 * t];
-      f32x4 b[2];
+      f32x4 b[CBW];
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
+      for (int cb = 0; cb < CBW; ++cb) {
         if (TRANS_W) {
           b[cb] = *(const f32x4*)&W[(size_t)(j0 + 16 * cb) * D + q * KQ + 4 * t];
         } else {
@@ -238,7 +230,7 @@ __device__ __forceinline__ void tile_mfma(const float* __restrict__ T, const flo
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-          for (int cb = 0; cb < 2; ++cb)
+          for (int cb = 0; cb < CBW; ++cb)
             acc[mb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb][u], b[cb][u], acc[mb][cb], 0, 0, 0);
     }
   }
@@ -252,7 +244,7 @@ __device__ __forceinline__ void tile_mfma(const float* __restrict__ T, const flo
 //   phase 3  Z = tanh(U + b) -> LDS -> row-wise gate (wave reduction), mix, optional dropout, stores
 // ------------------------------------------------------------------------------------------
 template <int S, int D, int MB, bool HAS_VAL>
-__global__ __launch_bounds__(D * 2) void k_layer_fwd(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
+__global__ __launch_bounds__(512) void k_layer_fwd(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
                                                      const float* __restrict__ val, const float* __restrict__ rs,
                                                      const float* __restrict__ X, const float* __restrict__ W,
                                                      const float* __restrict__ bias, const float* __restrict__ wg,
@@ -264,7 +256,8 @@ __global__ __launch_bounds__(D * 2) void k_layer_fwd(int n, const int* __restric
   using G = Geo<S, D>;
   constexpr int ROWS = 16 * MB;      // MFMA rows in the tile
   constexpr int R = ROWS / S;        // nodes in the tile
-  constexpr int NW = D / 32;         // waves per workgroup (each owns 32 output columns)
+  constexpr int CBW = D / 128;       // 16-wide output column blocks per wave
+  constexpr int NW = D / (16 * CBW); // 8 waves per workgroup
   constexpr int LD = D + 4;          // LDS row stride (floats); keeps 16-byte alignment
   constexpr int EPL = D / 64;        // floats per lane in the row-wise epilogue
   constexpr int RPW = (ROWS + NW - 1) / NW;  // epilogue rows per wave
@@ -275,8 +268,8 @@ __global__ __launch_bounds__(D * 2) void k_layer_fwd(int n, const int* __restric
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int node0 = xcd_contiguous(blockIdx.x, gridDim.x) * R;
 
-  float bw[2][D / 4];
-  if (PRE) load_wfrag<D, false>(W, wave, lane, bw);
+  float bw[CBW][D / 4];
+  if (PRE) load_wfrag<D, CBW, false>(W, wave, lane, bw);
 
   unsigned lane_off[G::NV];
 #pragma unroll
@@ -318,16 +311,16 @@ __global__ __launch_bounds__(D * 2) void k_layer_fwd(int n, const int* __restric
   __syncthreads();
 
   // ---- phase 2
-  f32x4 acc[MB][2];
-  tile_mfma<MB, D, LD, false, PRE>(T, W, bw, wave, lane, acc);
+  f32x4 acc[MB][CBW];
+  tile_mfma<MB, D, CBW, LD, false, PRE>(T, W, bw, wave, lane, acc);
   __syncthreads();  // every wave is done reading T as the A operand
 
   // ---- phase 3a: Z = tanh(U + b) back into the tile
   {
     const int r = lane & 15, q = lane >> 4;
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-      const int j = wave * 32 + cb * 16 + r;
+    for (int cb = 0; cb < CBW; ++cb) {
+      const int j = wave * (16 * CBW) + cb * 16 + r;
       const float bj = bias[j];
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
@@ -544,7 +537,7 @@ __global__ __launch_bounds__(256) void k_reduce_partials(int P, int D, const flo
 // mask: the dropout the PREVIOUS layer applied to this layer's input (stream_id of that layer).
 // ------------------------------------------------------------------------------------------
 template <int S, int D, int MB, bool HAS_VAL>
-__global__ __launch_bounds__(D * 2) void k_bwd_gather(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
+__global__ __launch_bounds__(512) void k_bwd_gather(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
                                                       const float* __restrict__ val, const float* __restrict__ dUs,
                                                       const float* __restrict__ W, const float* __restrict__ dXn,
                                                       const float* __restrict__ gate, float* __restrict__ dX,
@@ -554,7 +547,8 @@ __global__ __launch_bounds__(D * 2) void k_bwd_gather(int n, const int* __restri
   using G = Geo<S, D>;
   constexpr int ROWS = 16 * MB;
   constexpr int R = ROWS / S;
-  constexpr int NW = D / 32;
+  constexpr int CBW = D / 128;
+  constexpr int NW = D / (16 * CBW);
   constexpr int LD = D + 4;
   constexpr int EPL = D / 64;
   constexpr int RPW = (ROWS + NW - 1) / NW;
@@ -565,8 +559,8 @@ __global__ __launch_bounds__(D * 2) void k_bwd_gather(int n, const int* __restri
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int node0 = xcd_contiguous(blockIdx.x, gridDim.x) * R;
 
-  float bw[2][D / 4];
-  if (PRE) load_wfrag<D, true>(W, wave, lane, bw);
+  float bw[CBW][D / 4];
+  if (PRE) load_wfrag<D, CBW, true>(W, wave, lane, bw);
 
   unsigned lane_off[G::NV];
 #pragma unroll
@@ -600,14 +594,14 @@ __global__ __launch_bounds__(D * 2) void k_bwd_gather(int n, const int* __restri
   }
   __syncthreads();
 
-  f32x4 acc[MB][2];
-  tile_mfma<MB, D, LD, true, PRE>(T, W, bw, wave, lane, acc);
+  f32x4 acc[MB][CBW];
+  tile_mfma<MB, D, CBW, LD, true, PRE>(T, W, bw, wave, lane, acc);
   __syncthreads();
   {
     const int r = lane & 15, q = lane >> 4;
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-      const int j = wave * 32 + cb * 16 + r;
+    for (int cb = 0; cb < CBW; ++cb) {
+      const int j = wave * (16 * CBW) + cb * 16 + r;
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -744,10 +738,10 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
 #define CALL(S_, D_, V_)                                                                                            \
   do {                                                                                                              \
     if (mb == 2)                                                                                                    \
-      hipLaunchKernelGGL((k_layer_fwd<S_, D_, 2, V_>), dim3(blocks), dim3(D_ * 2), 0, st, n, rowptr, col, val, row_scale, \
+      hipLaunchKernelGGL((k_layer_fwd<S_, D_, 2, V_>), dim3(blocks), dim3(512), 0, st, n, rowptr, col, val, row_scale, \
                          X, W, b, wg, cg, Xn, Z, H, gate, ks, th, rng_state, stream_id);                            \
     else                                                                                                            \
-      hipLaunchKernelGGL((k_layer_fwd<S_, D_, 1, V_>), dim3(blocks), dim3(D_ * 2), 0, st, n, rowptr, col, val, row_scale, \
+      hipLaunchKernelGGL((k_layer_fwd<S_, D_, 1, V_>), dim3(blocks), dim3(512), 0, st, n, rowptr, col, val, row_scale, \
                          X, W, b, wg, cg, Xn, Z, H, gate, ks, th, rng_state, stream_id);                            \
   } while (0)
   DISPATCH_SDV(S, d, val != nullptr, CALL);
@@ -801,10 +795,10 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
 #define CALL(S_, D_, V_)                                                                                             \
   do {                                                                                                               \
     if (mb == 2)                                                                                                     \
-      hipLaunchKernelGGL((k_bwd_gather<S_, D_, 2, V_>), dim3(blocks), dim3(D_ * 2), 0, st, n, rowptr_t, col_t, val_t, dUs, \
+      hipLaunchKernelGGL((k_bwd_gather<S_, D_, 2, V_>), dim3(blocks), dim3(512), 0, st, n, rowptr_t, col_t, val_t, dUs, \
                          W, dXn, gate, dX, ks, th, rng_state, in_stream_id);                                         \
     else                                                                                                             \
-      hipLaunchKernelGGL((k_bwd_gather<S_, D_, 1, V_>), dim3(blocks), dim3(D_ * 2), 0, st, n, rowptr_t, col_t, val_t, dUs, \
+      hipLaunchKernelGGL((k_bwd_gather<S_, D_, 1, V_>), dim3(blocks), dim3(512), 0, st, n, rowptr_t, col_t, val_t, dUs, \
                          W, dXn, gate, dX, ks, th, rng_state, in_stream_id);                                         \
   } while (0)
   DISPATCH_SDV(S, d, val_t != nullptr, CALL);
