@@ -25,19 +25,20 @@ def is_stale():
     return any(os.path.getmtime(f) > t for f in SRC + HDR if os.path.exists(f))
 
 
-def build_library(force=False, verbose=False):
-    if not force and not is_stale():
+def build_library(force=False, verbose=False, out=None):
+    if out is None and not force and not is_stale():
         return LIB
     hipcc = hipcc_path()
     if hipcc is None:
         raise RuntimeError("chromegcn_amd: hipcc not found; cannot build libchromegcn_hip.so")
+    extra = os.environ.get("CGCN_EXTRA_FLAGS", "").split()  # tuning experiments only (tools/)
     cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-           "-I" + os.path.join(ROOT, "include")] + SRC + ["-o", LIB + ".tmp"]
+           "-I" + os.path.join(ROOT, "include")] + extra + SRC + ["-o", (out or LIB) + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    os.replace((out or LIB) + ".tmp", out or LIB)
+    return out or LIB
 
 
 if __name__ == "__main__":

@@ -23,14 +23,15 @@ _SIGNATURES = {
     "cgcn_spmm": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp]),
     "cgcn_layer_fwd": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 13 + [_c_float, _c_vp, _c_uint]),
     "cgcn_layer_bwd_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
-    "cgcn_layer_bwd": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 18 + [_c_int, _c_float, _c_vp, _c_uint, _c_vp, _c_sz]),
+    "cgcn_layer_bwd": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 18 + [_c_int, _c_float, _c_vp, _c_uint, _c_vp, _c_vp, _c_sz]),
     "cgcn_head_workspace_bytes": (_c_sz, [_c_int] * 4),
+    "cgcn_head_workspace_layout": (_c_int, [_c_int] * 4 + [ctypes.POINTER(_c_sz), ctypes.POINTER(_c_sz)]),
     "cgcn_head_fwd": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp] * 6 + [_c_float, _c_float, _c_int] + [_c_vp] * 3
                       + [_c_float] + [_c_vp] * 7 + [_c_sz]),
     "cgcn_head_bwd": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp] * 8 + [_c_float] + [_c_vp] * 6 + [_c_int, _c_vp, _c_sz]),
     "cgcn_sgd_step": (_c_int, [_c_vp, ctypes.c_longlong, _c_vp, _c_vp, _c_vp, _c_float, _c_float, _c_float, _c_int, _c_vp]),
 }
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 
 
@@ -47,8 +48,8 @@ def load(build_if_missing=True):
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB
-    if build_if_missing and _build.is_stale() and _build.hipcc_path() is not None:
+    path = os.environ.get("CHROMEGCN_LIB") or _build.LIB  # override: tuning experiments load a variant build
+    if path == _build.LIB and build_if_missing and _build.is_stale() and _build.hipcc_path() is not None:
         _build.build_library()
     if not os.path.exists(path):
         raise ChromeGCNLibraryError(
@@ -73,6 +74,12 @@ def check(rc, what):
     if rc != 0:
         msg = load().cgcn_strerror(rc).decode()
         raise RuntimeError("chromegcn_amd: %s failed: %s (code %d)" % (what, msg, rc))
+
+
+class HeadGrad(ctypes.Structure):
+    """mirror of cgcn_head_grad (include/chromegcn.h)"""
+    _fields_ = [("dym", _c_vp), ("bnc", _c_vp), ("save_mean", _c_vp), ("save_invstd", _c_vp), ("bn_w", _c_vp),
+                ("dropout_p", _c_float), ("rng_state", _c_vp)]
 
 
 def ptr(t):

@@ -55,5 +55,22 @@ static inline uint32_t dropout_threshold(float p) {
   return (uint32_t)t;
 }
 
+#define HEAD_STREAM_ID 0x4845u  // dropout stream of the classifier head ("HE")
+
+// Optional prologue of k_bwd_rowlocal for the LAST gated layer: instead of reading dL/dXn it is
+// recomputed per row from the head's backward state (BatchNorm backward + ReLU + dropout mask), which
+// removes one launch and one write+read of an [S,n,d] tensor.  dym == nullptr disables it.
+struct HeadApply {
+  const float* dym;      // [n][d]   d loss / d (mean over strands of the dropped BatchNorm output)
+  const float* bnc;      // [S][2][d] per-strand mean(dy), mean(dy * xhat)
+  const float* mean;     // [S][d]   batch mean of relu(Xn)
+  const float* invstd;   // [S][d]
+  const float* bn_w;     // [d]
+  const unsigned long long* rng_state;
+  float keep_scale;
+  uint32_t thresh;
+  int S;
+};
+
 static inline bool misaligned16(const void* p) { return ((uintptr_t)p & 15u) != 0; }
 static inline int launch_status() { return hipGetLastError() == hipSuccess ? CGCN_OK : CGCN_ERR_LAUNCH; }

@@ -25,7 +25,6 @@
 #define HEAD_TILE 16
 #define HEADB_TILE 32
 #define HEAD_MAX_PARTIALS 256
-#define HEAD_STREAM_ID 0x4845u  // dropout stream of the head ("HE")
 
 // ------------------------------------------------------------------------------------------
 // BatchNorm statistics
@@ -539,6 +538,15 @@ static inline size_t align4(size_t x) { return (x + 3) & ~(size_t)3; }
 
 extern "C" {
 
+int cgcn_head_workspace_layout(int n, int S, int d, int C, size_t* dym_offset, size_t* bnc_offset) {
+  int rc = head_check(n, S, d, C);
+  if (rc) return rc;
+  if (!dym_offset || !bnc_offset) return CGCN_ERR_BAD_ARG;
+  *dym_offset = 4 * (align4(ws_stats(S, d)) + align4(ws_loss(n)));
+  *bnc_offset = *dym_offset + 4 * align4(ws_dym(n, d));
+  return CGCN_OK;
+}
+
 size_t cgcn_head_workspace_bytes(int n, int S, int d, int C) {
   if (head_check(n, S, d, C) != CGCN_OK) return 0;
   return 4 * (align4(ws_stats(S, d)) + align4(ws_loss(n)) + align4(ws_dym(n, d)) + align4(ws_bnc(d)) + align4(ws_part(n, d, C)));
@@ -598,12 +606,12 @@ int cgcn_head_bwd(cgcn_stream_t stream, int n, int S, int d, int C, const float*
                   size_t workspace_bytes) {
   int rc = head_check(n, S, d, C);
   if (rc) return rc;
-  if (!X || !bn_w || !bn_b || !save_mean || !save_invstd || !Wout || !dpred || !dX || !dWout || !dbout || !dbn_w || !dbn_b || !workspace)
+  if (!X || !bn_w || !bn_b || !save_mean || !save_invstd || !Wout || !dpred || !dWout || !dbout || !dbn_w || !dbn_b || !workspace)
     return CGCN_ERR_BAD_ARG;
   const bool drop = dropout_p > 0.f;
   if (drop && (!rng_state || dropout_p >= 1.f)) return CGCN_ERR_BAD_ARG;
   if (workspace_bytes < cgcn_head_workspace_bytes(n, S, d, C)) return CGCN_ERR_WORKSPACE;
-  if (misaligned16(X) || misaligned16(dX) || misaligned16(workspace) || n < 1) return CGCN_ERR_BAD_ARG;
+  if (misaligned16(X) || (dX && misaligned16(dX)) || misaligned16(workspace) || n < 1) return CGCN_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   float* w = (float*)workspace;
   float* w_dym = w + align4(ws_stats(S, d)) + align4(ws_loss(n));
@@ -624,6 +632,7 @@ int cgcn_head_bwd(cgcn_stream_t stream, int n, int S, int d, int C, const float*
   hipLaunchKernelGGL(k_head_bwd_finalize, dim3((total + 63) / 64), dim3(256), 0, st, P, n, S, d, C, CP, w_part, dWout, dbout,
                      dbn_w, dbn_b, w_bnc, accumulate);
   if ((rc = launch_status())) return rc;
+  if (!dX) return CGCN_OK;  // deferred: cgcn_layer_bwd (head mode) applies the BatchNorm backward itself
   const size_t total4 = (size_t)S * n * d / 4;
   int blocks = (int)((total4 + 255) / 256);
   if (blocks > 2048) blocks = 2048;

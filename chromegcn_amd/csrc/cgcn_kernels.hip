@@ -31,11 +31,20 @@ struct Geo {
 
 // Sum val[k] * X[s, col[k], :] over k in [k0, k1) for one output node; the whole wave cooperates.
 // lane_off[v]: this lane's byte offset (strand * n_cols * D + column) * 4 into X.
-// Neighbour rows are fetched in batches of GU wave-loads, double buffered: while one batch is being
-// added the next is already in flight, so a wave keeps 8-16 KiB outstanding; the ragged tail of a row
-// is a predicated batch, never a serial load-wait-add chain.  Column indices of up to 64 neighbours are
-// read with one coalesced load and broadcast to the scalar unit with v_readlane.
+// Column indices of up to 64 neighbours are read with one coalesced load and broadcast to the scalar
+// unit with v_readlane.  Neighbour rows are fetched GU wave-loads at a time, all issued before the first
+// add.  The code is branch-free inside a 64-neighbour chunk: a ragged tail re-reads the row's last valid
+// neighbour (an L1 hit) and adds a selected zero, so it never degenerates into a serial
+// load-wait-add chain.  GATHER_DB = 1 additionally double-buffers the batches.
+#ifndef GU
 #define GU 8
+#endif
+#ifndef CBW128
+#define CBW128 1   // column blocks per wave at D = 128: 1 -> 8-wave workgroups, 2 -> 4-wave
+#endif
+#ifndef GATHER_DB
+#define GATHER_DB 0
+#endif
 template <int S, int D, bool HAS_VAL>
 struct Gather {
   using G = Geo<S, D>;
@@ -43,36 +52,39 @@ struct Gather {
   static constexpr int NPL = G::HALF ? 2 : 1;   // neighbours per wave-load
   static constexpr unsigned ROWB = D * 4;       // bytes per (strand,node) row
 
-  // issue the loads of batch `b` (slots b*GU .. b*GU+GU-1) of a chunk of `cnt` neighbours
+  // issue the GU wave-loads of batch b (neighbour slots b*GU .. b*GU+GU-1, clamped to the chunk)
   static __device__ __forceinline__ void issue(f32x4 (&t)[GU][NV], float (&w)[GU], int b, int cnt, int myc, float myv,
                                                const char* __restrict__ Xb, const unsigned (&lane_off)[NV], int lane) {
+    const int last = cnt - 1;
 #pragma unroll
     for (int u = 0; u < GU; ++u) {
       const int slot = b * GU + u;
-      if (slot * NPL < cnt) {  // wave-uniform
-        if (!G::HALF) {
-          const char* rowp = Xb + (size_t)(unsigned)rl_i(myc, slot) * ROWB;
+      if (!G::HALF) {
+        const int idx = min(slot, last);
+        const char* rowp = Xb + (size_t)(unsigned)rl_i(myc, idx) * ROWB;
 #pragma unroll
-          for (int v = 0; v < NV; ++v) t[u][v] = *(const f32x4*)(rowp + lane_off[v]);
-          if (HAS_VAL) w[u] = rl_f(myv, slot);
-        } else {
-          const int sub = lane >> 5;
-          const int i0 = 2 * slot, i1 = min(2 * slot + 1, cnt - 1);
-          const unsigned c = sub ? (unsigned)rl_i(myc, i1) : (unsigned)rl_i(myc, i0);
-          if (HAS_VAL) { const float wa = rl_f(myv, i0), wb = rl_f(myv, i1); w[u] = sub ? wb : wa; }
-          if (2 * slot + sub < cnt) t[u][0] = *(const f32x4*)(Xb + (size_t)c * ROWB + lane_off[0]);
-          else { t[u][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; if (HAS_VAL) w[u] = 0.f; }
-        }
+        for (int v = 0; v < NV; ++v) t[u][v] = *(const f32x4*)(rowp + lane_off[v]);
+        if (HAS_VAL) w[u] = rl_f(myv, idx);
+      } else {
+        const int sub = lane >> 5;
+        const int i0 = min(2 * slot, last), i1 = min(2 * slot + 1, last);
+        const unsigned c = sub ? (unsigned)rl_i(myc, i1) : (unsigned)rl_i(myc, i0);
+        if (HAS_VAL) { const float wa = rl_f(myv, i0), wb = rl_f(myv, i1); w[u] = sub ? wb : wa; }
+        t[u][0] = *(const f32x4*)(Xb + (size_t)c * ROWB + lane_off[0]);
       }
     }
   }
   static __device__ __forceinline__ void consume(const f32x4 (&t)[GU][NV], const float (&w)[GU], int b, int cnt,
-                                                 f32x4 (&acc)[NV]) {
+                                                 f32x4 (&acc)[NV], int lane) {
+    const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < GU; ++u) {
-      if ((b * GU + u) * NPL < cnt) {
+      const int slot = b * GU + u;
+      const bool ok = G::HALF ? (2 * slot + (lane >> 5) < cnt) : (slot < cnt);
 #pragma unroll
-        for (int v = 0; v < NV; ++v) acc[v] = HAS_VAL ? acc[v] + w[u] * t[u][v] : acc[v] + t[u][v];
+      for (int v = 0; v < NV; ++v) {
+        const f32x4 x = HAS_VAL ? w[u] * t[u][v] : t[u][v];
+        acc[v] += ok ? x : zero;
       }
     }
   }
@@ -96,15 +108,24 @@ __device__ __forceinline__ void gather_node(const int* __restrict__ col, const f
       if (HAS_VAL) myv = val[kb + lane];
     }
     const int nbat = (cnt + GU * GA::NPL - 1) / (GU * GA::NPL);
+#if GATHER_DB
     f32x4 ta[GU][NV], tb[GU][NV];
     float wa[GU], wb[GU];
     GA::issue(ta, wa, 0, cnt, myc, myv, Xb, lane_off, lane);
     for (int b = 0; b < nbat; b += 2) {
-      if (b + 1 < nbat) GA::issue(tb, wb, b + 1, cnt, myc, myv, Xb, lane_off, lane);
-      GA::consume(ta, wa, b, cnt, acc);
-      if (b + 2 < nbat) GA::issue(ta, wa, b + 2, cnt, myc, myv, Xb, lane_off, lane);
-      if (b + 1 < nbat) GA::consume(tb, wb, b + 1, cnt, acc);
+      GA::issue(tb, wb, b + 1, cnt, myc, myv, Xb, lane_off, lane);   // past the end: clamped re-reads, adds zero
+      GA::consume(ta, wa, b, cnt, acc, lane);
+      GA::issue(ta, wa, b + 2, cnt, myc, myv, Xb, lane_off, lane);
+      GA::consume(tb, wb, b + 1, cnt, acc, lane);
     }
+#else
+    for (int b = 0; b < nbat; ++b) {
+      f32x4 t[GU][NV];
+      float w[GU];
+      GA::issue(t, w, b, cnt, myc, myv, Xb, lane_off, lane);
+      GA::consume(t, w, b, cnt, acc, lane);
+    }
+#endif
   }
   if (Geo<S, D>::HALF) {
     // fold the odd-neighbour half onto the even one; afterwards both halves hold the row sum
@@ -244,7 +265,7 @@ __device__ __forceinline__ void tile_mfma(const float* __restrict__ T, const flo
 //   phase 3  Z = tanh(U + b) -> LDS -> row-wise gate (wave reduction), mix, optional dropout, stores
 // ------------------------------------------------------------------------------------------
 template <int S, int D, int MB, bool HAS_VAL>
-__global__ __launch_bounds__(512) void k_layer_fwd(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
+__global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) void k_layer_fwd(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
                                                      const float* __restrict__ val, const float* __restrict__ rs,
                                                      const float* __restrict__ X, const float* __restrict__ W,
                                                      const float* __restrict__ bias, const float* __restrict__ wg,
@@ -256,7 +277,7 @@ __global__ __launch_bounds__(512) void k_layer_fwd(int n, const int* __restrict_
   using G = Geo<S, D>;
   constexpr int ROWS = 16 * MB;      // MFMA rows in the tile
   constexpr int R = ROWS / S;        // nodes in the tile
-  constexpr int CBW = D / 128;       // 16-wide output column blocks per wave
+  constexpr int CBW = (D == 128) ? CBW128 : 2;  // 16-wide output column blocks per wave
   constexpr int NW = D / (16 * CBW); // 8 waves per workgroup
   constexpr int LD = D + 4;          // LDS row stride (floats); keeps 16-byte alignment
   constexpr int EPL = D / 64;        // floats per lane in the row-wise epilogue
@@ -370,17 +391,20 @@ __global__ __launch_bounds__(512) void k_layer_fwd(int n, const int* __restrict_
 //   partial layout per workgroup: [D*D dW][D db][D dwg][1 dcg][3 pad]
 // ------------------------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(D * 2) void k_bwd_rowlocal(int M, int n, const float* __restrict__ dXn,
-                                                        const float* __restrict__ Z, const float* __restrict__ X,
-                                                        const float* __restrict__ gate, const float* __restrict__ dgate,
-                                                        const float* __restrict__ H, const float* __restrict__ wg,
-                                                        const float* __restrict__ rs, float* __restrict__ dUs,
-                                                        float* __restrict__ part) {
-  constexpr int NW = D / 32;
+__global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float* __restrict__ dXn,
+                                                      const float* __restrict__ Z, const float* __restrict__ X,
+                                                      const float* __restrict__ gate, const float* __restrict__ dgate,
+                                                      const float* __restrict__ H, const float* __restrict__ wg,
+                                                      const float* __restrict__ rs, float* __restrict__ dUs,
+                                                      float* __restrict__ part, HeadApply hp,
+                                                      float* __restrict__ dxn_store) {
+  constexpr int NW = 8;
+  constexpr int IBW = D / 128;        // 16-row blocks of dW owned by one wave (i index)
   constexpr int TR = BWD_TILE_ROWS;
-  constexpr int LD = D + 16;  // stride = 16 (mod 32): conflict-free transposed ds_read_b32
+  constexpr int LD = D + 16;          // stride = 16 (mod 32): conflict-free transposed ds_read_b32
   constexpr int EPL = D / 64;
   constexpr int JB = D / 16;
+  constexpr int RPW = TR / NW;        // rows per wave per tile (4)
   constexpr int PSTRIDE = D * D + 2 * D + 4;
   __shared__ __attribute__((aligned(16))) float Ht[TR * LD];
   __shared__ __attribute__((aligned(16))) float Ut[TR * LD];
@@ -397,53 +421,81 @@ __global__ __launch_bounds__(D * 2) void k_bwd_rowlocal(int M, int n, const floa
     db_acc[e] = 0.f;
     dwg_acc[e] = 0.f;
   }
-  f32x4 acc[2][JB];
+  f32x4 acc[IBW][JB];
 #pragma unroll
-  for (int ib = 0; ib < 2; ++ib)
+  for (int ib = 0; ib < IBW; ++ib)
 #pragma unroll
     for (int jb = 0; jb < JB; ++jb) acc[ib][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const uint32_t hkey = (hp.dym && hp.thresh) ? dropout_key(hp.rng_state, HEAD_STREAM_ID) : 0u;
 
   const int ntiles = (M + TR - 1) / TR;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    // ---- row pass
-    for (int t = wave; t < TR; t += NW) {
-      const int m = tile * TR + t;
-      float du[EPL], h[EPL];
+    // ---- row pass: all loads of the wave's RPW rows are issued before the first use
+    float gup[RPW][EPL], z[RPW][EPL], x[RPW][EPL], h[RPW][EPL], gt[RPW], dgt[RPW];
+#pragma unroll
+    for (int t = 0; t < RPW; ++t) {
+      const int m = tile * TR + wave + t * NW;
+      const bool ok = m < M;
+      const size_t off = (size_t)m * D + lane * EPL;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        z[t][e] = ok ? Z[off + e] : 0.f;
+        x[t][e] = ok ? X[off + e] : 0.f;
+        h[t][e] = ok ? H[off + e] : 0.f;
+        if (hp.dym) gup[t][e] = ok ? hp.dym[(size_t)(m % n) * D + lane * EPL + e] : 0.f;
+        else gup[t][e] = ok ? dXn[off + e] : 0.f;
+      }
+      gt[t] = ok ? gate[m] : 0.f;
+      dgt[t] = (ok && dgate) ? dgate[m] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < RPW; ++t) {
+      const int trow = wave + t * NW;
+      const int m = tile * TR + trow;
+      float du[EPL];
       if (m < M) {
         const size_t off = (size_t)m * D + lane * EPL;
-        float gup[EPL], z[EPL];
+        const float g = gt[t];
+        if (hp.dym) {
+          // dL/dXn of the last layer from the head's backward state (see HeadApply)
+          const int s = m / n;
+          const float invS = 1.f / (float)hp.S;
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) {
+            const int c = lane * EPL + e;
+            const float xn = (1.f - g) * x[t][e] + g * z[t][e];
+            float dy = gup[t][e] * invS;
+            if (hp.thresh) dy = dropout_keep(hkey, (uint32_t)(off + e), hp.thresh) ? dy * hp.keep_scale : 0.f;
+            const float is = hp.invstd[s * D + c];
+            const float xh = (fmaxf(xn, 0.f) - hp.mean[s * D + c]) * is;
+            const float dr = hp.bn_w[c] * is * (dy - hp.bnc[(s * 2 + 0) * D + c] - xh * hp.bnc[(s * 2 + 1) * D + c]);
+            gup[t][e] = xn > 0.f ? dr : 0.f;
+            dxn_store[off + e] = gup[t][e];  // k_bwd_gather reads it back as dL/dXn for the (1-g) dXn term
+          }
+        }
         float dg = 0.f;
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-          gup[e] = dXn[off + e];
-          z[e] = Z[off + e];
-          const float x = X[off + e];
-          h[e] = H[off + e];
-          dg += gup[e] * (z[e] - x);
-        }
-        dg = wave_sum(dg);
-        if (dgate) dg += dgate[m];
-        const float g = gate[m];
+        for (int e = 0; e < EPL; ++e) dg += gup[t][e] * (z[t][e] - x[t][e]);
+        dg = wave_sum(dg) + dgt[t];
         const float gamma = g * (1.f - g) * dg;
-        const int node = m % n;
-        const float sc = rs ? rs[node] : 1.f;
+        const float sc = rs ? rs[m % n] : 1.f;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
-          const float dz = g * gup[e] + gamma * wgl[e];
-          du[e] = dz * (1.f - z[e] * z[e]);
+          const float dz = g * gup[t][e] + gamma * wgl[e];
+          du[e] = dz * (1.f - z[t][e] * z[t][e]);
           db_acc[e] += du[e];
-          dwg_acc[e] += gamma * z[e];
+          dwg_acc[e] += gamma * z[t][e];
           dUs[off + e] = du[e] * sc;
         }
         dcg_acc += gamma;
       } else {
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) du[e] = h[e] = 0.f;
+        for (int e = 0; e < EPL; ++e) du[e] = 0.f;
       }
 #pragma unroll
       for (int e = 0; e < EPL; ++e) {
-        Ht[t * LD + lane * EPL + e] = h[e];
-        Ut[t * LD + lane * EPL + e] = du[e];
+        Ht[trow * LD + lane * EPL + e] = h[t][e];
+        Ut[trow * LD + lane * EPL + e] = du[e];
       }
     }
     __syncthreads();
@@ -451,14 +503,14 @@ __global__ __launch_bounds__(D * 2) void k_bwd_rowlocal(int M, int n, const floa
 #pragma unroll
     for (int kk = 0; kk < TR / 4; ++kk) {
       const int k = 4 * kk + q;
-      float a[2];
+      float a[IBW];
 #pragma unroll
-      for (int ib = 0; ib < 2; ++ib) a[ib] = Ht[k * LD + (2 * wave + ib) * 16 + r];
+      for (int ib = 0; ib < IBW; ++ib) a[ib] = Ht[k * LD + (IBW * wave + ib) * 16 + r];
 #pragma unroll
       for (int jb = 0; jb < JB; ++jb) {
         const float b = Ut[k * LD + jb * 16 + r];
 #pragma unroll
-        for (int ib = 0; ib < 2; ++ib) acc[ib][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ib], b, acc[ib][jb], 0, 0, 0);
+        for (int ib = 0; ib < IBW; ++ib) acc[ib][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ib], b, acc[ib][jb], 0, 0, 0);
       }
     }
     __syncthreads();
@@ -467,12 +519,12 @@ __global__ __launch_bounds__(D * 2) void k_bwd_rowlocal(int M, int n, const floa
   // ---- write this workgroup's partial
   float* P = part + (size_t)blockIdx.x * PSTRIDE;
 #pragma unroll
-  for (int ib = 0; ib < 2; ++ib)
+  for (int ib = 0; ib < IBW; ++ib)
 #pragma unroll
     for (int jb = 0; jb < JB; ++jb)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int i = (2 * wave + ib) * 16 + q * 4 + e;
+        const int i = (IBW * wave + ib) * 16 + q * 4 + e;
         const int j = jb * 16 + r;
         P[i * D + j] = acc[ib][jb][e];
       }
@@ -537,17 +589,17 @@ __global__ __launch_bounds__(256) void k_reduce_partials(int P, int D, const flo
 // mask: the dropout the PREVIOUS layer applied to this layer's input (stream_id of that layer).
 // ------------------------------------------------------------------------------------------
 template <int S, int D, int MB, bool HAS_VAL>
-__global__ __launch_bounds__(512) void k_bwd_gather(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
+__global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) void k_bwd_gather(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
                                                       const float* __restrict__ val, const float* __restrict__ dUs,
-                                                      const float* __restrict__ W, const float* __restrict__ dXn,
-                                                      const float* __restrict__ gate, float* __restrict__ dX,
+                                                      const float* __restrict__ W, const float* dXn,
+                                                      const float* __restrict__ gate, float* dX,
                                                       float keep_scale, uint32_t thresh,
                                                       const unsigned long long* __restrict__ rng_state,
                                                       uint32_t stream_id) {
   using G = Geo<S, D>;
   constexpr int ROWS = 16 * MB;
   constexpr int R = ROWS / S;
-  constexpr int CBW = D / 128;
+  constexpr int CBW = (D == 128) ? CBW128 : 2;
   constexpr int NW = D / (16 * CBW);
   constexpr int LD = D + 4;
   constexpr int EPL = D / 64;
@@ -738,10 +790,10 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
 #define CALL(S_, D_, V_)                                                                                            \
   do {                                                                                                              \
     if (mb == 2)                                                                                                    \
-      hipLaunchKernelGGL((k_layer_fwd<S_, D_, 2, V_>), dim3(blocks), dim3(512), 0, st, n, rowptr, col, val, row_scale, \
+      hipLaunchKernelGGL((k_layer_fwd<S_, D_, 2, V_>), dim3(blocks), dim3((D_ == 128 && CBW128 == 2) ? 256 : 512), 0, st, n, rowptr, col, val, row_scale, \
                          X, W, b, wg, cg, Xn, Z, H, gate, ks, th, rng_state, stream_id);                            \
     else                                                                                                            \
-      hipLaunchKernelGGL((k_layer_fwd<S_, D_, 1, V_>), dim3(blocks), dim3(512), 0, st, n, rowptr, col, val, row_scale, \
+      hipLaunchKernelGGL((k_layer_fwd<S_, D_, 1, V_>), dim3(blocks), dim3((D_ == 128 && CBW128 == 2) ? 256 : 512), 0, st, n, rowptr, col, val, row_scale, \
                          X, W, b, wg, cg, Xn, Z, H, gate, ks, th, rng_state, stream_id);                            \
   } while (0)
   DISPATCH_SDV(S, d, val != nullptr, CALL);
@@ -765,13 +817,22 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
                    const float* val_t, const float* row_scale, const float* X, const float* Z, const float* H,
                    const float* gate, const float* W, const float* wg, const float* dXn, const float* dgate, float* dX,
                    float* dUs, float* dW, float* db, float* dwg, float* dcg, int accumulate, float in_dropout_p,
-                   const unsigned long long* rng_state, unsigned int in_stream_id, void* workspace,
-                   size_t workspace_bytes) {
+                   const unsigned long long* rng_state, unsigned int in_stream_id, const cgcn_head_grad* head,
+                   void* workspace, size_t workspace_bytes) {
   int rc = check_shape(n, S, d);
   if (rc) return rc;
-  if (!rowptr_t || !col_t || !X || !Z || !H || !gate || !W || !wg || !dXn || !dX || !dUs || !dW || !db || !dwg || !dcg)
+  if (!rowptr_t || !col_t || !X || !Z || !H || !gate || !W || !wg || !dX || !dUs || !dW || !db || !dwg || !dcg)
     return CGCN_ERR_BAD_ARG;
-  if (dX == dXn || misaligned16(dUs) || misaligned16(dX) || misaligned16(dXn) || misaligned16(W)) return CGCN_ERR_BAD_ARG;
+  if ((dXn == nullptr) == (head == nullptr)) return CGCN_ERR_BAD_ARG;  // exactly one source of dL/dXn
+  if (dX == dXn || misaligned16(dUs) || misaligned16(dX) || misaligned16(W)) return CGCN_ERR_BAD_ARG;
+  HeadApply hp = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1.f, 0u, S};
+  if (head) {
+    if (!head->dym || !head->bnc || !head->save_mean || !head->save_invstd || !head->bn_w) return CGCN_ERR_BAD_ARG;
+    float hks;
+    uint32_t hth;
+    if ((rc = dropout_args(head->dropout_p, head->rng_state, &hks, &hth))) return rc;
+    hp = HeadApply{head->dym, head->bnc, head->save_mean, head->save_invstd, head->bn_w, head->rng_state, hks, hth, S};
+  }
   if (!workspace || workspace_bytes < cgcn_layer_bwd_workspace_bytes(n, S, d)) return CGCN_ERR_WORKSPACE;
   float ks;
   uint32_t th;
@@ -781,9 +842,9 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   float* part = (float*)workspace;
   const int M = n * S;
   if (d == 128)
-    hipLaunchKernelGGL((k_bwd_rowlocal<128>), dim3(P), dim3(256), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dUs, part);
+    hipLaunchKernelGGL((k_bwd_rowlocal<128>), dim3(P), dim3(512), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dUs, part, hp, dX);
   else
-    hipLaunchKernelGGL((k_bwd_rowlocal<256>), dim3(P), dim3(512), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dUs, part);
+    hipLaunchKernelGGL((k_bwd_rowlocal<256>), dim3(P), dim3(512), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dUs, part, hp, dX);
   if ((rc = launch_status())) return rc;
   const int total = d * d + 2 * d + 1;
   hipLaunchKernelGGL(k_reduce_partials, dim3((total + 63) / 64), dim3(256), 0, st, P, d, part, dW, db, dwg, dcg, accumulate);
@@ -792,13 +853,14 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   const int mb = pick_mb(n, S);
   const int tn = 16 * mb / S;
   const int blocks = (n + tn - 1) / tn;
+  if (head) dXn = dX;  // k_bwd_rowlocal left dL/dXn there; each thread reads its elements before overwriting them
 #define CALL(S_, D_, V_)                                                                                             \
   do {                                                                                                               \
     if (mb == 2)                                                                                                     \
-      hipLaunchKernelGGL((k_bwd_gather<S_, D_, 2, V_>), dim3(blocks), dim3(512), 0, st, n, rowptr_t, col_t, val_t, dUs, \
+      hipLaunchKernelGGL((k_bwd_gather<S_, D_, 2, V_>), dim3(blocks), dim3((D_ == 128 && CBW128 == 2) ? 256 : 512), 0, st, n, rowptr_t, col_t, val_t, dUs, \
                          W, dXn, gate, dX, ks, th, rng_state, in_stream_id);                                         \
     else                                                                                                             \
-      hipLaunchKernelGGL((k_bwd_gather<S_, D_, 1, V_>), dim3(blocks), dim3(512), 0, st, n, rowptr_t, col_t, val_t, dUs, \
+      hipLaunchKernelGGL((k_bwd_gather<S_, D_, 1, V_>), dim3(blocks), dim3((D_ == 128 && CBW128 == 2) ? 256 : 512), 0, st, n, rowptr_t, col_t, val_t, dUs, \
                          W, dXn, gate, dX, ks, th, rng_state, in_stream_id);                                         \
   } while (0)
   DISPATCH_SDV(S, d, val_t != nullptr, CALL);

@@ -118,11 +118,11 @@ class ChromeGCN(nn.Module):
         return None if any(g is None for g in grads) else grads
 
     # -- the gated stack on a [S, n, d] block -------------------------------------------------
-    def _gated_stack(self, x, graph, rng):
+    def _gated_stack(self, x, graph, rng, upto=None):
         gates = []
         L = self.n_layers
         p = float(self.dropout) if (self.training and rng is not None) else 0.0
-        for k in range(1, L + 1):
+        for k in range(1, (L if upto is None else upto) + 1):
             gc = getattr(self, "GC%d" % k)
             wk = getattr(self, "W%d" % k)
             # F.dropout between layers (ChromeModels.py:42) runs inside the kernels: layer k drops its own
@@ -162,13 +162,18 @@ class ChromeGCN(nn.Module):
 
     def forward_loss(self, x_fr, adj, target):
         """The whole per-chromosome forward of the GCN stage (finetune.py:41-45,52) in fused kernels:
-        gated stack on both strands, then ReLU/BatchNorm/dropout/Linear/strand-mean/BCE.
+        gated stack on both strands, then ReLU/BatchNorm/dropout/Linear/strand-mean/BCE.  The last gated
+        layer and the head form one autograd node (ops.LastLayerHeadLossFn).
         Returns (loss [], probs [n,C] = sigmoid(pred), gates)."""
         ops._require_cuda(x_fr, "x_fr")
         graph = as_graph(adj, x_fr.device)
         rng = self._step_rng()
-        x, gates = self._gated_stack(x_fr, graph, rng)
-        bn, out = self.batch_norm, self.out
-        loss, probs = ops.head_loss(x, bn, out, target, self.training, self.dropout if rng is not None else 0.0, rng,
-                                    grad_sink=self._sink(bn.weight, bn.bias, out.weight, out.bias))
-        return loss, probs, gates
+        L = self.n_layers
+        x, gates = self._gated_stack(x_fr, graph, rng, upto=L - 1)
+        p = float(self.dropout) if (self.training and rng is not None) else 0.0
+        gc, wk, bn, out = getattr(self, "GC%d" % L), getattr(self, "W%d" % L), self.batch_norm, self.out
+        loss, probs, g = ops.last_layer_head_loss(
+            x, gc, wk, bn, out, graph, target, self.training, p, p if L > 1 else 0.0, rng, L,
+            layer_sink=self._sink(gc.weight, gc.bias, wk.weight, wk.bias),
+            head_sink=self._sink(bn.weight, bn.bias, out.weight, out.bias))
+        return loss, probs, gates + [g]

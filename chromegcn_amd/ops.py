@@ -113,6 +113,7 @@ class GatedLayerFn(torch.autograd.Function):
         ctx.dropout_in = float(dropout_in)
         ctx.layer_id = int(layer_id)
         ctx.sink = grad_sink if _sink_ok(grad_sink, ((d, d), (d,), gate_w.shape, gate_b.shape)) else None
+        ctx.set_materialize_grads(False)  # an unused gate output must not cost a zero-fill + an extra read
         return xn, gate
 
     @staticmethod
@@ -120,6 +121,8 @@ class GatedLayerFn(torch.autograd.Function):
         x, z, h, gate, weight, wg, rng_state = ctx.saved_tensors
         g = ctx.graph
         S, n, d = x.shape
+        if dxn is None and dgate is None:
+            return (None,) * 11
         dxn = torch.zeros_like(x) if dxn is None else dxn.contiguous()
         dgate = None if dgate is None else dgate.contiguous()
         dx = torch.empty_like(x)
@@ -139,7 +142,7 @@ class GatedLayerFn(torch.autograd.Function):
                                       h.data_ptr(), gate.data_ptr(), weight.data_ptr(), wg.data_ptr(),
                                       dxn.data_ptr(), _lib.ptr(dgate), dx.data_ptr(), dus.data_ptr(), dw.data_ptr(),
                                       db.data_ptr(), dwg.data_ptr(), dcg.data_ptr(), 0, ctx.dropout_in,
-                                      _lib.ptr(rng_state), max(ctx.layer_id - 1, 0), ws.data_ptr(), ws_bytes),
+                                      _lib.ptr(rng_state), max(ctx.layer_id - 1, 0), None, ws.data_ptr(), ws_bytes),
                    "cgcn_layer_bwd")
         if ctx.sink is not None:
             return (dx, None, None, None, None) + (None,) * 6
@@ -225,6 +228,125 @@ class HeadLossFn(torch.autograd.Function):
         if ctx.sink is not None:
             return (dx,) + (None,) * 14
         return (dx, dbn_w, dbn_b, dw_out, db_out) + (None,) * 10
+
+
+class LastLayerHeadLossFn(torch.autograd.Function):
+    """Last gated layer + classifier head + loss as ONE autograd node (engine path).  Forward = cgcn_layer_fwd
+    then cgcn_head_fwd.  Backward = cgcn_head_bwd in deferred mode, then cgcn_layer_bwd in head mode: the
+    gradient w.r.t. the layer's output never exists in memory as a tensor of its own (include/chromegcn.h,
+    cgcn_head_grad).  Inputs/semantics as GatedLayerFn + HeadLossFn; returns (loss [], probs [n,C], gate [S,n])."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gate_w, gate_b, bn_w, bn_b, w_out, b_out, graph, target, run_mean, run_var, nbt,
+                momentum, eps, training, dropout_p, dropout_in, rng_state, layer_id, layer_sink, head_sink):
+        _check_feat(x, graph)
+        for t, nm in ((weight, "weight"), (bias, "bias"), (gate_w, "gate weight"), (gate_b, "gate bias"),
+                      (bn_w, "bn weight"), (bn_b, "bn bias"), (w_out, "out.weight"), (b_out, "out.bias"), (target, "target")):
+            _require_cuda(t, nm)
+        if momentum is None:
+            raise RuntimeError("chromegcn_amd: BatchNorm momentum=None (cumulative average) is not supported by the fused head")
+        x = x.contiguous()
+        S, n, d = x.shape
+        C = w_out.shape[0]
+        target = target.contiguous()
+        if tuple(weight.shape) != (d, d) or tuple(target.shape) != (n, C):
+            raise RuntimeError("chromegcn_amd: bad shapes for the fused last layer + head")
+        weight, bias = weight.contiguous(), bias.contiguous()
+        wg, cg = gate_w.contiguous().view(-1), gate_b.contiguous().view(-1)
+        bn_w, bn_b, w_out, b_out = bn_w.contiguous(), bn_b.contiguous(), w_out.contiguous(), b_out.contiguous()
+        need_bwd = training and any(ctx.needs_input_grad[:9])
+        lib = _lib.load()
+        xn = torch.empty_like(x)
+        gate = torch.empty((S, n), device=x.device, dtype=torch.float32)
+        z = torch.empty_like(x) if need_bwd else None
+        h = torch.empty_like(x) if need_bwd else None
+        _lib.check(lib.cgcn_layer_fwd(_lib.stream_ptr(), n, S, d, _lib.ptr(graph.rowptr), _lib.ptr(graph.col),
+                                      _lib.ptr(graph.val), _lib.ptr(graph.row_scale), x.data_ptr(), weight.data_ptr(),
+                                      bias.data_ptr(), wg.data_ptr(), cg.data_ptr(), xn.data_ptr(), _lib.ptr(z),
+                                      _lib.ptr(h), gate.data_ptr(), 0.0, None, int(layer_id)), "cgcn_layer_fwd")
+        ws_bytes = lib.cgcn_head_workspace_bytes(n, S, d, C)
+        if ws_bytes == 0:
+            raise RuntimeError("chromegcn_amd: fused head does not support S=%d n=%d d=%d C=%d" % (S, n, d, C))
+        ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8)
+        probs = torch.empty((n, C), device=x.device, dtype=torch.float32)
+        loss = torch.empty(1, device=x.device, dtype=torch.float32)
+        dpred = torch.empty((n, C), device=x.device, dtype=torch.float32) if need_bwd else None
+        save_mean = torch.empty((S, d), device=x.device, dtype=torch.float32) if training else None
+        save_invstd = torch.empty((S, d), device=x.device, dtype=torch.float32) if training else None
+        drop = bool(training) and dropout_p > 0
+        if (drop or dropout_in > 0) and rng_state is None:
+            raise RuntimeError("chromegcn_amd: fused dropout needs the model's rng_state tensor")
+        _lib.check(lib.cgcn_head_fwd(_lib.stream_ptr(), n, S, d, C, xn.data_ptr(), bn_w.data_ptr(), bn_b.data_ptr(),
+                                     run_mean.data_ptr(), run_var.data_ptr(), _lib.ptr(nbt), float(momentum), float(eps),
+                                     1 if training else 0, w_out.data_ptr(), b_out.data_ptr(), target.data_ptr(),
+                                     float(dropout_p), _lib.ptr(rng_state) if drop else None, probs.data_ptr(),
+                                     loss.data_ptr(), _lib.ptr(dpred), _lib.ptr(save_mean), _lib.ptr(save_invstd),
+                                     ws.data_ptr(), ws_bytes), "cgcn_head_fwd")
+        if need_bwd:
+            ctx.save_for_backward(x, z, h, gate, weight, wg, xn, bn_w, bn_b, w_out, dpred, save_mean, save_invstd,
+                                  rng_state if (drop or dropout_in > 0) else None)
+            ctx.graph = graph
+            ctx.dropout_p = float(dropout_p) if drop else 0.0
+            ctx.dropout_in = float(dropout_in)
+            ctx.layer_id = int(layer_id)
+            ctx.shapes = (gate_w.shape, gate_b.shape)
+            ctx.layer_sink = layer_sink if _sink_ok(layer_sink, ((d, d), (d,), gate_w.shape, gate_b.shape)) else None
+            ctx.head_sink = head_sink if _sink_ok(head_sink, ((d,), (d,), (C, d), (C,))) else None
+        ctx.mark_non_differentiable(probs, gate)
+        return loss.view(()), probs, gate
+
+    @staticmethod
+    def backward(ctx, dloss, _dprobs, _dgate):
+        (x, z, h, gate, weight, wg, xn, bn_w, bn_b, w_out, dpred, save_mean, save_invstd, rng_state) = ctx.saved_tensors
+        g = ctx.graph
+        S, n, d = x.shape
+        C = w_out.shape[0]
+        dev = x.device
+        lib = _lib.load()
+        f32 = dict(device=dev, dtype=torch.float32)
+        if ctx.head_sink is not None:
+            dbn_w, dbn_b, dw_out, db_out = ctx.head_sink
+        else:
+            dw_out, db_out = torch.empty_like(w_out), torch.empty(C, **f32)
+            dbn_w, dbn_b = torch.empty(d, **f32), torch.empty(d, **f32)
+        if ctx.layer_sink is not None:
+            dw, db, dwg, dcg = ctx.layer_sink
+        else:
+            dw, db, dwg, dcg = torch.empty_like(weight), torch.empty(d, **f32), torch.empty(d, **f32), torch.empty(1, **f32)
+        hws_bytes = lib.cgcn_head_workspace_bytes(n, S, d, C)
+        hws = torch.empty(hws_bytes, device=dev, dtype=torch.uint8)
+        dloss = dloss.contiguous().view(1)
+        _lib.check(lib.cgcn_head_bwd(_lib.stream_ptr(), n, S, d, C, xn.data_ptr(), bn_w.data_ptr(), bn_b.data_ptr(),
+                                     save_mean.data_ptr(), save_invstd.data_ptr(), w_out.data_ptr(), dpred.data_ptr(),
+                                     dloss.data_ptr(), ctx.dropout_p, _lib.ptr(rng_state), None,
+                                     dw_out.data_ptr(), db_out.data_ptr(), dbn_w.data_ptr(), dbn_b.data_ptr(), 0,
+                                     hws.data_ptr(), hws_bytes), "cgcn_head_bwd")
+        import ctypes
+        o_dym, o_bnc = ctypes.c_size_t(), ctypes.c_size_t()
+        _lib.check(lib.cgcn_head_workspace_layout(n, S, d, C, ctypes.byref(o_dym), ctypes.byref(o_bnc)), "cgcn_head_workspace_layout")
+        hg = _lib.HeadGrad(hws.data_ptr() + o_dym.value, hws.data_ptr() + o_bnc.value, save_mean.data_ptr(),
+                           save_invstd.data_ptr(), bn_w.data_ptr(), ctx.dropout_p, _lib.ptr(rng_state))
+        dx = torch.empty_like(x)
+        dus = torch.empty_like(x)
+        ws_bytes = lib.cgcn_layer_bwd_workspace_bytes(n, S, d)
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        _lib.check(lib.cgcn_layer_bwd(_lib.stream_ptr(), n, S, d, _lib.ptr(g.rowptr_t), _lib.ptr(g.col_t),
+                                      _lib.ptr(g.val_t), _lib.ptr(g.row_scale), x.data_ptr(), z.data_ptr(),
+                                      h.data_ptr(), gate.data_ptr(), weight.data_ptr(), wg.data_ptr(),
+                                      None, None, dx.data_ptr(), dus.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                      dwg.data_ptr(), dcg.data_ptr(), 0, ctx.dropout_in, _lib.ptr(rng_state),
+                                      max(ctx.layer_id - 1, 0), ctypes.byref(hg), ws.data_ptr(), ws_bytes), "cgcn_layer_bwd")
+        gl = (None,) * 4 if ctx.layer_sink is not None else (dw, db, dwg.view(ctx.shapes[0]), dcg.view(ctx.shapes[1]))
+        gh = (None,) * 4 if ctx.head_sink is not None else (dbn_w, dbn_b, dw_out, db_out)
+        return (dx,) + gl + gh + (None,) * 14
+
+
+def last_layer_head_loss(x, gc, wk, bn, out, graph, target, training, dropout_p, dropout_in, rng_state, layer_id,
+                         layer_sink=None, head_sink=None):
+    return LastLayerHeadLossFn.apply(x, gc.weight, gc.bias, wk.weight, wk.bias, bn.weight, bn.bias, out.weight, out.bias,
+                                     graph, target, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum,
+                                     bn.eps, bool(training), float(dropout_p), float(dropout_in), rng_state, int(layer_id),
+                                     layer_sink, head_sink)
 
 
 def head_loss(x, bn: torch.nn.BatchNorm1d, out: torch.nn.Linear, target, training, dropout_p, rng_state, grad_sink=None):

@@ -47,7 +47,7 @@ extern "C" {
 #define CGCN_ERR_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after a launch      */
 #define CGCN_ERR_WORKSPACE (-4)   /* workspace too small (see cgcn_*_workspace_bytes)    */
 
-#define CGCN_ABI_VERSION 2
+#define CGCN_ABI_VERSION 3
 
 typedef void *cgcn_stream_t; /* hipStream_t */
 
@@ -87,6 +87,22 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d,
                    float *Xn, float *Z, float *H, float *gate,
                    float dropout_p, const unsigned long long *rng_state, unsigned int stream_id);
 
+/*
+ * State the fused head's backward leaves for the LAST gated layer's backward (cgcn_head_bwd with
+ * dX == NULL fills dym / bnc inside its workspace; cgcn_head_workspace_layout gives their offsets).
+ * With it, cgcn_layer_bwd recomputes dL/dXn per row (BatchNorm backward, ReLU mask, dropout mask)
+ * instead of reading it: one launch and one [S,n,d] round trip less.
+ */
+typedef struct cgcn_head_grad {
+  const float *dym;         /* [n,d]    */
+  const float *bnc;         /* [S,2,d]  */
+  const float *save_mean;   /* [S,d]    */
+  const float *save_invstd; /* [S,d]    */
+  const float *bn_w;        /* [d]      */
+  float dropout_p;          /* head dropout probability (0 = none) */
+  const unsigned long long *rng_state;
+} cgcn_head_grad;
+
 /* Bytes of scratch cgcn_layer_bwd needs for (n, S, d).  0 on unsupported shapes. */
 size_t cgcn_layer_bwd_workspace_bytes(int n, int S, int d);
 
@@ -104,6 +120,7 @@ size_t cgcn_layer_bwd_workspace_bytes(int n, int S, int d);
  * (no float atomics): results are bit-reproducible run to run.
  * in_dropout_p > 0: X was produced by a layer that applied dropout (in_stream_id = that layer's
  * stream_id); dX is then the gradient w.r.t. the pre-dropout tensor (mask / (1-p) applied).
+ * Exactly one of dXn and head must be non-NULL (head: see cgcn_head_grad).
  */
 int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d,
                    const int32_t *rowptr_t, const int32_t *col_t, const float *val_t, const float *row_scale,
@@ -112,10 +129,15 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d,
                    const float *dXn, const float *dgate,
                    float *dX, float *dUs, float *dW, float *db, float *dwg, float *dcg,
                    int accumulate, float in_dropout_p, const unsigned long long *rng_state,
-                   unsigned int in_stream_id, void *workspace, size_t workspace_bytes);
+                   unsigned int in_stream_id, const cgcn_head_grad *head,
+                   void *workspace, size_t workspace_bytes);
 
 /* Bytes of scratch cgcn_head_fwd / cgcn_head_bwd need for (n, S, d, C).  0 on unsupported shapes. */
 size_t cgcn_head_workspace_bytes(int n, int S, int d, int C);
+
+/* Byte offsets, inside that workspace, of the dym [n,d] and bnc [S,2,d] regions cgcn_head_bwd fills
+ * (host pointers; see cgcn_head_grad). */
+int cgcn_head_workspace_layout(int n, int S, int d, int C, size_t *dym_offset, size_t *bnc_offset);
 
 /*
  * Classifier head + loss of the GCN-stage step, fused (models/ChromeModels.py:48-51 applied to each
@@ -141,7 +163,8 @@ int cgcn_head_fwd(cgcn_stream_t stream, int n, int S, int d, int C, const float 
 
 /*
  * Backward of cgcn_head_fwd (training mode).  dloss: [1] upstream gradient of the loss or NULL (= 1).
- * Outputs dX [S,n,d] and, overwritten (accumulate == 0) or added to (accumulate != 0): dW_out [C,d],
+ * Outputs dX [S,n,d] (or, with dX == NULL, only the dym / bnc state for cgcn_layer_bwd's head mode)
+ * and, overwritten (accumulate == 0) or added to (accumulate != 0): dW_out [C,d],
  * db_out [C], dbn_w [d], dbn_b [d].  rng_state: same contents as in the forward.  Deterministic.
  */
 int cgcn_head_bwd(cgcn_stream_t stream, int n, int S, int d, int C, const float *X, const float *bn_w,
