@@ -21,10 +21,10 @@
 //   k_head_bn_bwd_apply<D> dX = bn_w invstd (dy - mean(dy) - xhat mean(dy xhat)) [x > 0]
 #include "cgcn_common.hpp"
 
-#define HEAD_STAT_BLOCKS 128
+#define HEAD_STAT_BLOCKS 256
 #define HEAD_TILE 16
 #define HEADB_TILE 32
-#define HEAD_MAX_PARTIALS 256
+#define HEAD_MAX_PARTIALS 128
 
 // ------------------------------------------------------------------------------------------
 // BatchNorm statistics
@@ -39,34 +39,50 @@ __device__ __forceinline__ void chan_combine(float& nA, float& meanA, float& m2A
   }
 }
 
+// Per-block (mean, M2) of relu(X) per column and strand over a contiguous chunk of nodes.  Sums are taken
+// relative to a pivot (the chunk's first row), so there is no division in the loop and no catastrophic
+// cancellation; blocks are merged exactly with Chan's formula in k_head_bn_finalize.
 template <int D>
 __global__ __launch_bounds__(256) void k_head_colstats(int n, int S, int rows_per_blk, const float* __restrict__ X,
                                                        float* __restrict__ part) {
   constexpr int RL = 256 / D;  // row lanes per column
-  __shared__ float sm[3][256];
+  __shared__ float sm[2][256];
   const int c = threadIdx.x % D, rl = threadIdx.x / D;
   const int r0 = blockIdx.x * rows_per_blk, r1 = min(n, r0 + rows_per_blk);
   for (int s = 0; s < S; ++s) {
-    float mean = 0.f, m2 = 0.f, k = 0.f;
-    for (int i = r0 + rl; i < r1; i += RL) {
-      const float x = fmaxf(X[((size_t)s * n + i) * D + c], 0.f);
-      k += 1.f;
-      const float delta = x - mean;
-      mean += delta / k;
-      m2 += delta * (x - mean);
+    const float* Xs = X + (size_t)s * n * D + c;
+    const float pivot = r0 < n ? fmaxf(Xs[(size_t)r0 * D], 0.f) : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    int i = r0 + rl;
+    for (; i + 3 * RL < r1; i += 4 * RL) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = Xs[(size_t)(i + u * RL) * D];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float dlt = fmaxf(v[u], 0.f) - pivot;
+        s1 += dlt;
+        s2 += dlt * dlt;
+      }
+    }
+    for (; i < r1; i += RL) {
+      const float dlt = fmaxf(Xs[(size_t)i * D], 0.f) - pivot;
+      s1 += dlt;
+      s2 += dlt * dlt;
     }
     if (RL > 1) {
-      if (rl > 0) { sm[0][threadIdx.x] = k; sm[1][threadIdx.x] = mean; sm[2][threadIdx.x] = m2; }
+      if (rl > 0) { sm[0][threadIdx.x] = s1; sm[1][threadIdx.x] = s2; }
       __syncthreads();
       if (rl == 0) {
-        for (int o = 1; o < RL; ++o) chan_combine(k, mean, m2, sm[0][o * D + c], sm[1][o * D + c], sm[2][o * D + c]);
+        for (int o = 1; o < RL; ++o) { s1 += sm[0][o * D + c]; s2 += sm[1][o * D + c]; }
       }
       __syncthreads();
     }
     if (rl == 0) {
+      const float k = (float)max(r1 - r0, 1);
       float* p = part + (((size_t)blockIdx.x * S + s) * D + c) * 2;
-      p[0] = mean;
-      p[1] = m2;
+      p[0] = pivot + s1 / k;
+      p[1] = fmaxf(s2 - s1 * s1 / k, 0.f);
     }
   }
 }
@@ -161,8 +177,8 @@ __device__ __forceinline__ void head_row(int n, int S, int i, int lane, const fl
 // MFMA K index is permuted so that both operands are 16-byte reads: lane (q = l>>4) owns the K range
 // [q*D/4, (q+1)*D/4); step (t,u) uses k = q*D/4 + 4t + u for A (LDS) and B (W_out row) alike.
 // ------------------------------------------------------------------------------------------
-template <int D>
-__global__ __launch_bounds__(256) void k_head_fwd(int n, int S, int C, const float* __restrict__ X,
+template <int D, int NCBW>
+__global__ __launch_bounds__(512) void k_head_fwd(int n, int S, int C, const float* __restrict__ X,
                                                   const float* __restrict__ bn_w, const float* __restrict__ bn_b,
                                                   const float* __restrict__ mean, const float* __restrict__ vr,
                                                   int use_running, float eps, const float* __restrict__ Wout,
@@ -171,67 +187,128 @@ __global__ __launch_bounds__(256) void k_head_fwd(int n, int S, int C, const flo
                                                   const unsigned long long* __restrict__ rng_state, float inv_count,
                                                   float* __restrict__ probs, float* __restrict__ dpred,
                                                   float* __restrict__ loss_part) {
-  constexpr int R = HEAD_TILE, LD = D + 4, EPL = D / 64, NW = 4, KQ = D / 4;
+  // 8 waves; wave w owns label blocks w, w+8 (NCBW of them; C <= 128*NCBW) and rows w, w+8 of the 16-node tile.
+  constexpr int R = HEAD_TILE, LD = D + 4, EPL = D / 64, NW = 8, KQ = D / 4, RPW = R / NW;
+  constexpr bool PRE = (D == 128);
   __shared__ __attribute__((aligned(16))) float Y[R * LD];
   __shared__ float lsum[NW];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int node0 = blockIdx.x * R;
+  const int r = lane & 15, q = lane >> 4;
+  const int CB = (C + 15) / 16;
+
+  // B fragments of W_out for this wave's label blocks, fetched before anything else (D = 128)
+  float bw[NCBW][PRE ? KQ : 1];
+  if (PRE) {
+#pragma unroll
+    for (int cbi = 0; cbi < NCBW; ++cbi) {
+      const int j = (wave + NW * cbi) * 16 + r;
+#pragma unroll
+      for (int t = 0; t < KQ / 4; ++t) {
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (j < C) v = *(const f32x4*)&Wout[(size_t)j * D + q * KQ + 4 * t];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bw[cbi][4 * t + u] = v[u];
+      }
+    }
+  }
   const uint32_t key = thresh ? dropout_key(rng_state, HEAD_STREAM_ID) : 0u;
 
-  for (int rr = wave; rr < R; rr += NW) {
-    const int i = node0 + rr;
-    float ym[EPL];
-    if (i < n) {
-      head_row<D>(n, S, i, lane, X, bn_w, bn_b, mean, vr, use_running, eps, keep_scale, thresh, key, ym);
-    } else {
+  // ---- ym tile: all X loads of this wave's rows first, then the BatchNorm / dropout arithmetic
+  float xv[RPW][2][EPL];
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) ym[e] = 0.f;
+  for (int t = 0; t < RPW; ++t) {
+    const int i = node0 + wave + t * NW;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int e = 0; e < EPL; ++e)
+        xv[t][s][e] = (i < n && s < S) ? X[((size_t)s * n + i) * D + lane * EPL + e] : 0.f;
+  }
+  float mu[2][EPL], is[2][EPL], gw[EPL], gb[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    const int c = lane * EPL + e;
+    gw[e] = bn_w[c];
+    gb[e] = bn_b[c];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int ss = s < S ? s : 0;
+      mu[s][e] = use_running ? mean[c] : mean[ss * D + c];
+      is[s][e] = use_running ? rsqrtf(vr[c] + eps) : vr[ss * D + c];
     }
+  }
+  const float invS = 1.f / (float)S;
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) Y[rr * LD + lane * EPL + e] = ym[e];
+  for (int t = 0; t < RPW; ++t) {
+    const int rr = wave + t * NW;
+    const int i = node0 + rr;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      float ym = 0.f;
+      if (i < n) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          if (s < S) {
+            float y = (fmaxf(xv[t][s][e], 0.f) - mu[s][e]) * is[s][e] * gw[e] + gb[e];
+            if (thresh) y = dropout_keep(key, (uint32_t)(((size_t)s * n + i) * D + lane * EPL + e), thresh) ? y * keep_scale : 0.f;
+            ym += y;
+          }
+        }
+      }
+      Y[rr * LD + lane * EPL + e] = ym * invS;
+    }
   }
   __syncthreads();
 
-  const int r = lane & 15, q = lane >> 4;
-  float lacc = 0.f;
-  for (int c0 = 0; c0 < C; c0 += 256) {
-    const int CB = min(16, (C - c0 + 15) / 16);
-    f32x4 acc[4];
+  // ---- pred = ym W_out^T on the matrix cores (K permuted: k = q*D/4 + kk for both operands)
+  f32x4 acc[NCBW];
 #pragma unroll
-    for (int cbi = 0; cbi < 4; ++cbi) acc[cbi] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-    for (int t = 0; t < KQ / 4; ++t) {
-      const f32x4 a = *(const f32x4*)&Y[r * LD + q * KQ + 4 * t];
+  for (int cbi = 0; cbi < NCBW; ++cbi) acc[cbi] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int cbi = 0; cbi < 4; ++cbi) {
-        const int cb = wave + 4 * cbi;
-        if (cb < CB) {
-          const int j = c0 + cb * 16 + r;
-          f32x4 b = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < KQ / 4; ++t) {
+    const f32x4 a = *(const f32x4*)&Y[r * LD + q * KQ + 4 * t];
+#pragma unroll
+    for (int cbi = 0; cbi < NCBW; ++cbi) {
+      if (wave + NW * cbi < CB) {
+        f32x4 b;
+        if (PRE) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) b[u] = bw[cbi][4 * t + u];
+        } else {
+          const int j = (wave + NW * cbi) * 16 + r;
+          b = (f32x4){0.f, 0.f, 0.f, 0.f};
           if (j < C) b = *(const f32x4*)&Wout[(size_t)j * D + q * KQ + 4 * t];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) acc[cbi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc[cbi], 0, 0, 0);
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[cbi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc[cbi], 0, 0, 0);
       }
     }
+  }
+  // ---- sigmoid / BCE / d loss / d pred epilogue straight from the accumulators
+  float lacc = 0.f;
 #pragma unroll
-    for (int cbi = 0; cbi < 4; ++cbi) {
-      const int cb = wave + 4 * cbi;
-      const int j = c0 + cb * 16 + r;
-      if (cb < CB && j < C) {
-        const float bj = bout[j];
+  for (int cbi = 0; cbi < NCBW; ++cbi) {
+    const int cb = wave + NW * cbi;
+    const int j = cb * 16 + r;
+    if (cb < CB && j < C) {
+      const float bj = bout[j];
+      float tg[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int i = node0 + q * 4 + e;
-          if (i < n) {
-            const float pred = acc[cbi][e] + bj;
-            const float tg = target[(size_t)i * C + j];
-            const float p = sigmoidf_(pred);
-            lacc += fmaxf(pred, 0.f) - pred * tg + log1pf(expf(-fabsf(pred)));
-            probs[(size_t)i * C + j] = p;
-            if (dpred) dpred[(size_t)i * C + j] = (p - tg) * inv_count;
-          }
+      for (int e = 0; e < 4; ++e) {
+        const int i = node0 + q * 4 + e;
+        tg[e] = i < n ? target[(size_t)i * C + j] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = node0 + q * 4 + e;
+        if (i < n) {
+          const float pred = acc[cbi][e] + bj;
+          const float p = sigmoidf_(pred);
+          lacc += fmaxf(pred, 0.f) - pred * tg[e] + log1pf(expf(-fabsf(pred)));
+          probs[(size_t)i * C + j] = p;
+          if (dpred) dpred[(size_t)i * C + j] = (p - tg[e]) * inv_count;
         }
       }
     }
@@ -239,7 +316,12 @@ __global__ __launch_bounds__(256) void k_head_fwd(int n, int S, int C, const flo
   lacc = wave_sum(lacc);
   if (lane == 0) lsum[wave] = lacc;
   __syncthreads();
-  if (threadIdx.x == 0) loss_part[blockIdx.x] = ((lsum[0] + lsum[1]) + lsum[2]) + lsum[3];
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t += lsum[w];
+    loss_part[blockIdx.x] = t;
+  }
 }
 
 // out[0] = scale * sum(part[0..m)), one workgroup, fixed-order tree => deterministic
@@ -261,19 +343,20 @@ __global__ __launch_bounds__(256) void k_sum_scale(int m, const float* __restric
 //   partial layout per workgroup: [CP*D dW_out][CP db_out][S*D sum dy][S*D sum dy*xhat]
 // ------------------------------------------------------------------------------------------
 template <int D, int CBMAX>
-__global__ __launch_bounds__(256) void k_head_bwd(int n, int S, int C, const float* __restrict__ X,
+__global__ __launch_bounds__(512) void k_head_bwd(int n, int S, int C, const float* __restrict__ X,
                                                   const float* __restrict__ bn_w, const float* __restrict__ bn_b,
                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
                                                   const float* __restrict__ Wout, const float* __restrict__ dpred,
                                                   const float* __restrict__ dloss, float keep_scale, uint32_t thresh,
                                                   const unsigned long long* __restrict__ rng_state,
                                                   float* __restrict__ dym, float* __restrict__ part) {
-  constexpr int TR = HEADB_TILE, NW = 4, EPL = D / 64;
+  constexpr int TR = HEADB_TILE, NW = 8, EPL = D / 64, RPW = TR / NW;
   constexpr int CP = CBMAX * 16;
   constexpr int LDP = CP + ((CP & 16) ? 2 : 18);  // = 18 (mod 32): row reads and transposed reads both (nearly) conflict-free
   constexpr int LDY = D + 16;                      // = 16 (mod 32): conflict-free transposed reads
-  constexpr int JBW = D / 64;                      // 16-wide column blocks of D owned by one wave
+  constexpr int JBW = D / 128;                     // 16-wide column blocks of D owned by one wave
   constexpr int PS = CP * D + CP + 2 * 2 * D;      // partial stride (S <= 2)
+  constexpr int NLD = TR * CP / 512;               // dpred elements staged per thread per tile
   __shared__ __attribute__((aligned(16))) float Pt[TR * LDP];
   __shared__ __attribute__((aligned(16))) float Yt[TR * LDY];
 
@@ -283,6 +366,7 @@ __global__ __launch_bounds__(256) void k_head_bwd(int n, int S, int C, const flo
   const uint32_t key = thresh ? dropout_key(rng_state, HEAD_STREAM_ID) : 0u;
   const float gl = dloss ? dloss[0] : 1.f;
   const int CB = (C + 15) / 16;
+  const float invS = 1.f / (float)S;
 
   f32x4 accW[CBMAX][JBW];
 #pragma unroll
@@ -291,31 +375,67 @@ __global__ __launch_bounds__(256) void k_head_bwd(int n, int S, int C, const flo
     for (int jb = 0; jb < JBW; ++jb) accW[ib][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float dbo = 0.f;                       // thread j < CP: column sum of dpred
   float sdy[2][EPL], sdyx[2][EPL];
+  float mu[2][EPL], is[2][EPL], gw[EPL], gb[EPL];
 #pragma unroll
-  for (int s = 0; s < 2; ++s)
+  for (int e = 0; e < EPL; ++e) {
+    const int c = lane * EPL + e;
+    gw[e] = bn_w[c];
+    gb[e] = bn_b[c];
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) sdy[s][e] = sdyx[s][e] = 0.f;
+    for (int s = 0; s < 2; ++s) {
+      sdy[s][e] = sdyx[s][e] = 0.f;
+      mu[s][e] = mean[(s < S ? s : 0) * D + c];
+      is[s][e] = invstd[(s < S ? s : 0) * D + c];
+    }
+  }
 
   const int ntiles = (n + TR - 1) / TR;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int node0 = tile * TR;
-    // ---- stage dpred tile (scaled by the upstream d loss) and recompute ym tile
-    for (int idx = threadIdx.x; idx < TR * CP; idx += 256) {
+    // ---- issue every global load of the tile first: dpred elements and this wave's X rows
+    float pv[NLD];
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int idx = threadIdx.x + u * 512;
       const int row = idx / CP, j = idx % CP;
       const int i = node0 + row;
-      Pt[row * LDP + j] = (i < n && j < C) ? dpred[(size_t)i * C + j] * gl : 0.f;
+      pv[u] = (i < n && j < C) ? dpred[(size_t)i * C + j] : 0.f;
     }
-    for (int t = wave; t < TR; t += NW) {
-      const int i = node0 + t;
-      float ym[EPL];
-      if (i < n) {
-        head_row<D>(n, S, i, lane, X, bn_w, bn_b, mean, invstd, 0, 0.f, keep_scale, thresh, key, ym);
-      } else {
+    float xv[RPW][2][EPL];
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) ym[e] = 0.f;
+    for (int t = 0; t < RPW; ++t) {
+      const int i = node0 + wave + t * NW;
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e)
+          xv[t][s][e] = (i < n && s < S) ? X[((size_t)s * n + i) * D + lane * EPL + e] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int idx = threadIdx.x + u * 512;
+      Pt[(idx / CP) * LDP + (idx % CP)] = pv[u] * gl;
+    }
+    // ym rows (mean over strands of the dropped BatchNorm output), recomputed
+#pragma unroll
+    for (int t = 0; t < RPW; ++t) {
+      const int rr = wave + t * NW;
+      const int i = node0 + rr;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        float ym = 0.f;
+        if (i < n) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            if (s < S) {
+              float y = (fmaxf(xv[t][s][e], 0.f) - mu[s][e]) * is[s][e] * gw[e] + gb[e];
+              if (thresh) y = dropout_keep(key, (uint32_t)(((size_t)s * n + i) * D + lane * EPL + e), thresh) ? y * keep_scale : 0.f;
+              ym += y;
+            }
+          }
+        }
+        Yt[rr * LDY + lane * EPL + e] = ym * invS;
       }
-#pragma unroll
-      for (int e = 0; e < EPL; ++e) Yt[t * LDY + lane * EPL + e] = ym[e];
     }
     __syncthreads();
     if (threadIdx.x < CP) {
@@ -340,12 +460,13 @@ __global__ __launch_bounds__(256) void k_head_bwd(int n, int S, int C, const flo
         }
       }
     }
-    // ---- dym tile = Pt W_out   (M = TR rows, K = labels, N = D); wave owns columns [32w, 32w+32) (D=128)
+    // ---- dym tile = Pt W_out   (M = TR rows, K = labels, N = D)
     f32x4 accY[2][JBW];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
       for (int jb = 0; jb < JBW; ++jb) accY[mb][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
     for (int kk = 0; kk < CB * 4; ++kk) {
       const int k = 4 * kk + q;  // label index
       float b[JBW];
@@ -366,23 +487,25 @@ __global__ __launch_bounds__(256) void k_head_bwd(int n, int S, int C, const flo
 #pragma unroll
         for (int e = 0; e < 4; ++e) Yt[(mb * 16 + q * 4 + e) * LDY + (wave * JBW + jb) * 16 + r] = accY[mb][jb][e];
     __syncthreads();
-    // ---- row pass: write dym, accumulate the BatchNorm-backward column sums
-    for (int t = wave; t < TR; t += NW) {
-      const int i = node0 + t;
-      if (i >= n) continue;
-      const float invS = 1.f / (float)S;
+    // ---- row pass: write dym, accumulate the BatchNorm-backward column sums (X rows still in registers)
+#pragma unroll
+    for (int t = 0; t < RPW; ++t) {
+      const int rr = wave + t * NW;
+      const int i = node0 + rr;
 #pragma unroll
       for (int e = 0; e < EPL; ++e) {
         const int c = lane * EPL + e;
-        const float g = Yt[t * LDY + c];
-        dym[(size_t)i * D + c] = g;
-        for (int s = 0; s < S; ++s) {
-          const uint32_t el = (uint32_t)(((size_t)s * n + i) * D + c);
-          float dy = g * invS;
-          if (thresh) dy = dropout_keep(key, el, thresh) ? dy * keep_scale : 0.f;
-          const float xh = (fmaxf(X[el], 0.f) - mean[s * D + c]) * invstd[s * D + c];
-          sdy[s][e] += dy;
-          sdyx[s][e] += dy * xh;
+        const float g = i < n ? Yt[rr * LDY + c] : 0.f;
+        if (i < n) dym[(size_t)i * D + c] = g;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          if (s < S) {
+            float dy = g * invS;
+            if (thresh) dy = dropout_keep(key, (uint32_t)(((size_t)s * n + i) * D + c), thresh) ? dy * keep_scale : 0.f;
+            const float xh = (fmaxf(xv[t][s][e], 0.f) - mu[s][e]) * is[s][e];
+            sdy[s][e] += dy;
+            sdyx[s][e] += dy * xh;
+          }
         }
       }
     }
@@ -400,6 +523,7 @@ __global__ __launch_bounds__(256) void k_head_bwd(int n, int S, int C, const flo
   if (threadIdx.x < CP) P[CP * D + threadIdx.x] = dbo;
   float* red = Yt;  // [NW][4*D]
   constexpr int RS = 4 * D;
+  static_assert(NW * RS <= TR * LDY, "reduction scratch must fit in Yt");
 #pragma unroll
   for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -408,7 +532,7 @@ __global__ __launch_bounds__(256) void k_head_bwd(int n, int S, int C, const flo
       red[wave * RS + 2 * D + s * D + lane * EPL + e] = sdyx[s][e];
     }
   __syncthreads();
-  for (int c = threadIdx.x; c < RS; c += 256) {
+  for (int c = threadIdx.x; c < RS; c += 512) {
     float s = 0.f;
     for (int w = 0; w < NW; ++w) s += red[w * RS + c];
     P[CP * D + CP + c] = s;
@@ -518,7 +642,7 @@ static int head_check(int n, int S, int d, int C) {
 static inline int head_cp(int C) { return C <= 128 ? 128 : 256; }
 static inline int head_stat_blocks(int n, int* rows_per_blk) {
   int rpb = (n + HEAD_STAT_BLOCKS - 1) / HEAD_STAT_BLOCKS;
-  if (rpb < 32) rpb = 32;
+  if (rpb < 8) rpb = 8;
   *rows_per_blk = rpb;
   int nb = (n + rpb - 1) / rpb;
   return nb < 1 ? 1 : nb;
@@ -589,10 +713,12 @@ int cgcn_head_fwd(cgcn_stream_t stream, int n, int S, int d, int C, const float*
   const float inv_count = 1.f / ((float)n * (float)C);
   const float* mean = training ? save_mean : run_mean;
   const float* vr = training ? save_invstd : run_var;
-#define HF(D_)                                                                                                        \
-  hipLaunchKernelGGL((k_head_fwd<D_>), dim3(blocks), dim3(256), 0, st, n, S, C, X, bn_w, bn_b, mean, vr, training ? 0 : 1, \
-                     eps, Wout, bout, target, keep_scale, thresh, rng_state, inv_count, probs, training ? dpred : nullptr, w_loss)
-  if (d == 128) HF(128); else HF(256);
+#define HF(D_, NC_)                                                                                                   \
+  hipLaunchKernelGGL((k_head_fwd<D_, NC_>), dim3(blocks), dim3(512), 0, st, n, S, C, X, bn_w, bn_b, mean, vr,         \
+                     training ? 0 : 1, eps, Wout, bout, target, keep_scale, thresh, rng_state, inv_count, probs,      \
+                     training ? dpred : nullptr, w_loss)
+  if (d == 128) { if (C <= 128) HF(128, 1); else HF(128, 2); }
+  else { if (C <= 128) HF(256, 1); else HF(256, 2); }
 #undef HF
   if ((rc = launch_status())) return rc;
   hipLaunchKernelGGL(k_sum_scale, dim3(1), dim3(256), 0, st, blocks, w_loss, inv_count, loss);
@@ -622,7 +748,7 @@ int cgcn_head_bwd(cgcn_stream_t stream, int n, int S, int d, int C, const float*
   const float keep_scale = drop ? 1.f / (1.f - dropout_p) : 1.f;
   const uint32_t thresh = drop ? dropout_threshold(dropout_p) : 0u;
 #define HB(D_, CB_)                                                                                                   \
-  hipLaunchKernelGGL((k_head_bwd<D_, CB_>), dim3(P), dim3(256), 0, st, n, S, C, X, bn_w, bn_b, save_mean, save_invstd, Wout, \
+  hipLaunchKernelGGL((k_head_bwd<D_, CB_>), dim3(P), dim3(512), 0, st, n, S, C, X, bn_w, bn_b, save_mean, save_invstd, Wout, \
                      dpred, dloss, keep_scale, thresh, rng_state, w_dym, w_part)
   if (d == 128) { if (CP == 128) HB(128, 8); else HB(128, 16); }
   else { if (CP == 128) HB(256, 8); else HB(256, 16); }
