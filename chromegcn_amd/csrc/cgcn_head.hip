@@ -445,7 +445,7 @@ __global__ __launch_bounds__(512) void k_head_bwd(int n, int S, int C, const flo
       dbo += sacc;
     }
     // ---- dW_out += Pt^T Yt   (K = TR rows)
-#pragma unroll
+#pragma unroll 2
     for (int kk = 0; kk < TR / 4; ++kk) {
       const int k = 4 * kk + q;
       float b[JBW];
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(512) void k_head_bwd(int n, int S, int C, const flo
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
       for (int jb = 0; jb < JBW; ++jb) accY[mb][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
+#pragma unroll 2
     for (int kk = 0; kk < CB * 4; ++kk) {
       const int k = 4 * kk + q;  // label index
       float b[JBW];
