@@ -68,3 +68,25 @@ def test_captured_step_equals_eager_step_bitwise(golden):
     for k in outs[0][0]:
         assert torch.equal(outs[0][0][k], outs[1][0][k]), k
     assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
+def test_step_group_path_equals_single_rank_step(golden):
+    """train_group (the multi-rank path: captured fwd+bwd, all-reduce, optimizer step) with a group of one
+    must reproduce train_step bit for bit."""
+    z = golden("g4_finetune_loop.npz")
+    chroms, feats, graphs = _load(z)
+    init = state_from(z, "init")
+    outs = []
+    for use_group in (False, True):
+        m = C.ChromeGCN(128, 128, init["out.weight"].shape[0], 0.0, True, 2)
+        m.load_state_dict(init); m.to(DEV)
+        optim = torch.optim.SGD(m.parameters(), lr=0.25, weight_decay=1e-6, momentum=0.9)
+        st = GCNStage(m, optim, "hic", DEV, hip_graphs=True)
+        st.load(feats, graphs)
+        for _ in range(2):
+            for c in chroms:
+                loss, probs, dx = st.train_group(c, 1) if use_group else st.train_step(c)
+        outs.append(({k: v.clone() for k, v in m.state_dict().items()}, loss.clone()))
+    for k in outs[0][0]:
+        assert torch.equal(outs[0][0][k], outs[1][0][k]), k
+    assert torch.equal(outs[0][1], outs[1][1])
