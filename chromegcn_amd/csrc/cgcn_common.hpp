@@ -9,7 +9,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define WAVE 64
 #define TILE_NODES 16   // nodes per workgroup tile in the gather kernels
-#define BWD_TILE_ROWS 32  // rows per MFMA K-step group in k_bwd_rowlocal
+#define BWD_TILE_ROWS 64  // rows per tile of k_bwd_rowlocal
 #define BWD_MAX_PARTIALS 256
 
 // ------------------------------------------------------------------------------------------

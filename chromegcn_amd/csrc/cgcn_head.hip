@@ -21,7 +21,7 @@
 //   k_head_bn_bwd_apply<D> dX = bn_w invstd (dy - mean(dy) - xhat mean(dy xhat)) [x > 0]
 #include "cgcn_common.hpp"
 
-#define HEAD_STAT_BLOCKS 256
+#define HEAD_STAT_BLOCKS 128
 #define HEAD_TILE 16
 #define HEADB_TILE 32
 #define HEAD_MAX_PARTIALS 128
@@ -260,6 +260,18 @@ __global__ __launch_bounds__(512) void k_head_fwd(int n, int S, int C, const flo
       Y[rr * LD + lane * EPL + e] = ym * invS;
     }
   }
+  // targets / bias of this lane's output elements: issued now, consumed after the MFMA phase
+  float tgv[NCBW][4], bjv[NCBW];
+#pragma unroll
+  for (int cbi = 0; cbi < NCBW; ++cbi) {
+    const int j = (wave + NW * cbi) * 16 + r;
+    bjv[cbi] = j < C ? bout[j] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = node0 + q * 4 + e;
+      tgv[cbi][e] = (i < n && j < C) ? target[(size_t)i * C + j] : 0.f;
+    }
+  }
   __syncthreads();
 
   // ---- pred = ym W_out^T on the matrix cores (K permuted: k = q*D/4 + kk for both operands)
@@ -293,22 +305,15 @@ __global__ __launch_bounds__(512) void k_head_fwd(int n, int S, int C, const flo
     const int cb = wave + NW * cbi;
     const int j = cb * 16 + r;
     if (cb < CB && j < C) {
-      const float bj = bout[j];
-      float tg[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int i = node0 + q * 4 + e;
-        tg[e] = i < n ? target[(size_t)i * C + j] : 0.f;
-      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int i = node0 + q * 4 + e;
         if (i < n) {
-          const float pred = acc[cbi][e] + bj;
+          const float pred = acc[cbi][e] + bjv[cbi];
           const float p = sigmoidf_(pred);
-          lacc += fmaxf(pred, 0.f) - pred * tg[e] + log1pf(expf(-fabsf(pred)));
+          lacc += fmaxf(pred, 0.f) - pred * tgv[cbi][e] + log1pf(expf(-fabsf(pred)));
           probs[(size_t)i * C + j] = p;
-          if (dpred) dpred[(size_t)i * C + j] = (p - tg[e]) * inv_count;
+          if (dpred) dpred[(size_t)i * C + j] = (p - tgv[cbi][e]) * inv_count;
         }
       }
     }
@@ -389,6 +394,20 @@ __global__ __launch_bounds__(512) void k_head_bwd(int n, int S, int C, const flo
     }
   }
 
+  // B operand of dym = dpred W_out: B[k = label][col] -- fetched once per workgroup (D = 128; at D = 256
+  // the register budget goes to the accumulators and it is read in the K loop instead)
+  constexpr bool PREB = (D == 128);
+  float bwo[JBW][PREB ? CBMAX * 4 : 1];
+  if (PREB) {
+#pragma unroll
+    for (int jb = 0; jb < JBW; ++jb)
+#pragma unroll
+      for (int kk = 0; kk < CBMAX * 4; ++kk) {
+        const int k = 4 * kk + q;
+        bwo[jb][kk] = (k < C) ? Wout[(size_t)k * D + (wave * JBW + jb) * 16 + r] : 0.f;
+      }
+  }
+
   const int ntiles = (n + TR - 1) / TR;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int node0 = tile * TR;
@@ -466,17 +485,33 @@ __global__ __launch_bounds__(512) void k_head_bwd(int n, int S, int C, const flo
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
       for (int jb = 0; jb < JBW; ++jb) accY[mb][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (PREB) {
+#pragma unroll
+      for (int kk = 0; kk < CBMAX * 4; ++kk) {
+        if (kk < CB * 4) {  // wave-uniform
+          const int k = 4 * kk + q;  // label index
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb) {
+            const float a = Pt[(mb * 16 + r) * LDP + k];
+#pragma unroll
+            for (int jb = 0; jb < JBW; ++jb)
+              accY[mb][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bwo[jb][PREB ? kk : 0], accY[mb][jb], 0, 0, 0);
+          }
+        }
+      }
+    } else {
 #pragma unroll 2
-    for (int kk = 0; kk < CB * 4; ++kk) {
-      const int k = 4 * kk + q;  // label index
-      float b[JBW];
+      for (int kk = 0; kk < CB * 4; ++kk) {
+        const int k = 4 * kk + q;
+        float b[JBW];
 #pragma unroll
-      for (int jb = 0; jb < JBW; ++jb) b[jb] = (k < C) ? Wout[(size_t)k * D + (wave * JBW + jb) * 16 + r] : 0.f;
+        for (int jb = 0; jb < JBW; ++jb) b[jb] = (k < C) ? Wout[(size_t)k * D + (wave * JBW + jb) * 16 + r] : 0.f;
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
-        const float a = Pt[(mb * 16 + r) * LDP + k];
+        for (int mb = 0; mb < 2; ++mb) {
+          const float a = Pt[(mb * 16 + r) * LDP + k];
 #pragma unroll
-        for (int jb = 0; jb < JBW; ++jb) accY[mb][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[jb], accY[mb][jb], 0, 0, 0);
+          for (int jb = 0; jb < JBW; ++jb) accY[mb][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[jb], accY[mb][jb], 0, 0, 0);
+        }
       }
     }
     __syncthreads();  // all reads of Yt / Pt done

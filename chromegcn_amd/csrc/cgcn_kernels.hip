@@ -400,7 +400,7 @@ __global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float*
                                                       float* __restrict__ dxn_store) {
   constexpr int NW = 8;
   constexpr int IBW = D / 128;        // 16-row blocks of dW owned by one wave (i index)
-  constexpr int TR = BWD_TILE_ROWS;
+  constexpr int TR = (D == 128) ? BWD_TILE_ROWS : 32;  // 64-row tiles at D = 128; 32 at D = 256 (register budget)
   constexpr int LD = D + 16;          // stride = 16 (mod 32): conflict-free transposed ds_read_b32
   constexpr int EPL = D / 64;
   constexpr int JB = D / 16;
@@ -801,16 +801,17 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   return launch_status();
 }
 
-static int bwd_partials(int n, int S) {
+static int bwd_partials(int n, int S, int d) {
   const int M = n * S;
-  const int ntiles = (M + BWD_TILE_ROWS - 1) / BWD_TILE_ROWS;
+  const int tr = d == 128 ? BWD_TILE_ROWS : 32;
+  const int ntiles = (M + tr - 1) / tr;
   int P = ntiles < BWD_MAX_PARTIALS ? ntiles : BWD_MAX_PARTIALS;
   return P < 1 ? 1 : P;
 }
 
 size_t cgcn_layer_bwd_workspace_bytes(int n, int S, int d) {
   if (check_shape(n, S, d) != CGCN_OK) return 0;
-  return (size_t)bwd_partials(n, S) * ((size_t)d * d + 2 * d + 4) * sizeof(float);
+  return (size_t)bwd_partials(n, S, d) * ((size_t)d * d + 2 * d + 4) * sizeof(float);
 }
 
 int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* rowptr_t, const int32_t* col_t,
@@ -838,7 +839,7 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   uint32_t th;
   if ((rc = dropout_args(in_dropout_p, rng_state, &ks, &th))) return rc;
   hipStream_t st = (hipStream_t)stream;
-  const int P = bwd_partials(n, S);
+  const int P = bwd_partials(n, S, d);
   float* part = (float*)workspace;
   const int M = n * S;
   if (d == 128)

@@ -71,6 +71,7 @@ class GCNStage:
         self._flat_mom: Optional[torch.Tensor] = None
         self._fused_sgd = False
         self._captured_lr = None
+        self._one: Optional[torch.Tensor] = None
         self._int_synced: Dict[str, torch.Tensor] = {}
 
     # ------------------------------------------------------------------ data
@@ -191,7 +192,9 @@ class GCNStage:
         if not getattr(self.model, "_grad_sink", False):
             self._flat_grad.zero_()                                        # finetune.py:39 (sinks overwrite instead)
         loss, probs = self._forward_loss(c, x)
-        loss.backward()                                                    # finetune.py:48
+        if self._one is None or self._one.device != loss.device:
+            self._one = torch.ones((), device=loss.device)
+        loss.backward(self._one)                                           # finetune.py:48 (root gradient reused: no fill kernel)
         return loss.detach(), probs, (x.grad if self.input_grad else None)
 
     def _eval(self, c: _Chrom):

@@ -293,6 +293,7 @@ class LastLayerHeadLossFn(torch.autograd.Function):
             ctx.layer_sink = layer_sink if _sink_ok(layer_sink, ((d, d), (d,), gate_w.shape, gate_b.shape)) else None
             ctx.head_sink = head_sink if _sink_ok(head_sink, ((d,), (d,), (C, d), (C,))) else None
         ctx.mark_non_differentiable(probs, gate)
+        ctx.set_materialize_grads(False)  # no zero-fill kernels for the two non-differentiable outputs
         return loss.view(()), probs, gate
 
     @staticmethod
@@ -315,6 +316,8 @@ class LastLayerHeadLossFn(torch.autograd.Function):
             dw, db, dwg, dcg = torch.empty_like(weight), torch.empty(d, **f32), torch.empty(d, **f32), torch.empty(1, **f32)
         hws_bytes = lib.cgcn_head_workspace_bytes(n, S, d, C)
         hws = torch.empty(hws_bytes, device=dev, dtype=torch.uint8)
+        if dloss is None:
+            return (None,) * 23
         dloss = dloss.contiguous().view(1)
         _lib.check(lib.cgcn_head_bwd(_lib.stream_ptr(), n, S, d, C, xn.data_ptr(), bn_w.data_ptr(), bn_b.data_ptr(),
                                      save_mean.data_ptr(), save_invstd.data_ptr(), w_out.data_ptr(), dpred.data_ptr(),
