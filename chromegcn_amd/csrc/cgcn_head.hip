@@ -174,8 +174,8 @@ __device__ __forceinline__ void head_row(int n, int S, int i, int lane, const fl
 
 // ------------------------------------------------------------------------------------------
 // k_head_fwd
-// MFMA K index is permuted so that both operands are 16-byte reads: lane (q = l>>4) owns the K range
-// [q*D/4, (q+1)*D/4); step (t,u) uses k = q*D/4 + 4t + u for A (LDS) and B (W_out row) alike.
+// MFMA K index is permuted so that both operands are 16-byte reads and the four k-slots of a step read
+// 64 contiguous bytes: step (t,u) of k-slot q (= l>>4) uses k = 16t + 4q + u for A (LDS) and B (W_out row).
 // ------------------------------------------------------------------------------------------
 template <int D, int NCBW>
 __global__ __launch_bounds__(512) void k_head_fwd(int n, int S, int C, const float* __restrict__ X,
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(512) void k_head_fwd(int n, int S, int C, const flo
 #pragma unroll
       for (int t = 0; t < KQ / 4; ++t) {
         f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (j < C) v = *(const f32x4*)&Wout[(size_t)j * D + q * KQ + 4 * t];
+        if (j < C) v = *(const f32x4*)&Wout[(size_t)j * D + 16 * t + 4 * q];
 #pragma unroll
         for (int u = 0; u < 4; ++u) bw[cbi][4 * t + u] = v[u];
       }
@@ -274,13 +274,13 @@ __global__ __launch_bounds__(512) void k_head_fwd(int n, int S, int C, const flo
   }
   __syncthreads();
 
-  // ---- pred = ym W_out^T on the matrix cores (K permuted: k = q*D/4 + kk for both operands)
+  // ---- pred = ym W_out^T on the matrix cores (K permuted, see above)
   f32x4 acc[NCBW];
 #pragma unroll
   for (int cbi = 0; cbi < NCBW; ++cbi) acc[cbi] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < KQ / 4; ++t) {
-    const f32x4 a = *(const f32x4*)&Y[r * LD + q * KQ + 4 * t];
+    const f32x4 a = *(const f32x4*)&Y[r * LD + 16 * t + 4 * q];
 #pragma unroll
     for (int cbi = 0; cbi < NCBW; ++cbi) {
       if (wave + NW * cbi < CB) {
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(512) void k_head_fwd(int n, int S, int C, const flo
         } else {
           const int j = (wave + NW * cbi) * 16 + r;
           b = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (j < C) b = *(const f32x4*)&Wout[(size_t)j * D + q * KQ + 4 * t];
+          if (j < C) b = *(const f32x4*)&Wout[(size_t)j * D + 16 * t + 4 * q];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc[cbi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc[cbi], 0, 0, 0);
@@ -310,8 +310,10 @@ __global__ __launch_bounds__(512) void k_head_fwd(int n, int S, int C, const flo
         const int i = node0 + q * 4 + e;
         if (i < n) {
           const float pred = acc[cbi][e] + bjv[cbi];
-          const float p = sigmoidf_(pred);
-          lacc += fmaxf(pred, 0.f) - pred * tgv[cbi][e] + log1pf(expf(-fabsf(pred)));
+          const float en = __expf(-fabsf(pred));            // exp(-|x|) in (0,1]
+          const float inv = 1.f / (1.f + en);
+          const float p = pred >= 0.f ? inv : en * inv;      // sigmoid(x), no overflow
+          lacc += fmaxf(pred, 0.f) - pred * tgv[cbi][e] + __logf(1.f + en);
           probs[(size_t)i * C + j] = p;
           if (dpred) dpred[(size_t)i * C + j] = (p - tgv[cbi][e]) * inv_count;
         }

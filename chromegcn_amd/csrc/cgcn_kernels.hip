@@ -170,8 +170,9 @@ __global__ __launch_bounds__(256) void k_spmm(int n_rows, int n_cols, const int*
 //
 // Tile: TN = 16*MB/S nodes x S strands = 16*MB MFMA rows, staged in LDS as T[row][D+4].
 // MFMA: v_mfma_f32_16x16x4_f32.  A lane l: A[row l&15][k-slot l>>4]; B lane l: B[k-slot l>>4][col l&15];
-// C: col l&15, row 4*(l>>4)+reg.  The K index is permuted so that operand reads are 16 bytes wide:
-// k-slot q (= l>>4) owns k in [q*D/4, (q+1)*D/4); step kk uses k = q*D/4 + kk for A and B alike.
+// C: col l&15, row 4*(l>>4)+reg.  The K index is permuted so that operand reads are 16 bytes wide and the
+// four k-slots of one step read 64 contiguous bytes of a row: step (t,u) of k-slot q (= l>>4) uses
+// k = 16t + 4q + u, for A and B alike.
 // Wave w owns output columns [32w, 32w+32) as two 16-wide blocks.
 //   TRANS_W == false: B(k,j) = W[k][j]   (forward,  U = H W)
 //   TRANS_W == true : B(k,j) = W[j][k]   (backward, dS W^T)
@@ -195,13 +196,13 @@ __device__ __forceinline__ void load_wfrag(const float* __restrict__ W, int wave
     if (TRANS_W) {
 #pragma unroll
       for (int t = 0; t < KQ / 4; ++t) {
-        const f32x4 v = *(const f32x4*)&W[(size_t)j * D + q * KQ + 4 * t];
+        const f32x4 v = *(const f32x4*)&W[(size_t)j * D + 16 * t + 4 * q];
 #pragma unroll
         for (int u = 0; u < 4; ++u) bw[cb][4 * t + u] = v[u];
       }
     } else {
 #pragma unroll
-      for (int kk = 0; kk < KQ; ++kk) bw[cb][kk] = W[(size_t)(q * KQ + kk) * D + j];
+      for (int kk = 0; kk < KQ; ++kk) bw[cb][kk] = W[(size_t)(16 * (kk >> 2) + 4 * q + (kk & 3)) * D + j];
     }
   }
 }
@@ -220,7 +221,7 @@ __device__ __forceinline__ void tile_mfma(const float* __restrict__ T, const flo
     for (int t = 0; t < KQ / 4; ++t) {
       f32x4 a[MB];
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) a[mb] = *(const f32x4*)&T[(mb * 16 + r) * LD + q * KQ + 4 * t];
+      for (int mb = 0; mb < MB; ++mb) a[mb] = *(const f32x4*)&T[(mb * 16 + r) * LD + 16 * t + 4 * q];
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -235,15 +236,15 @@ __device__ __forceinline__ void tile_mfma(const float* __restrict__ T, const flo
     for (int t = 0; t < KQ / 4; ++t) {
       f32x4 a[MB];
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) a[mb] = *(const f32x4*)&T[(mb * 16 + r) * LD + q * KQ + 4 * t];
+      for (int mb = 0; mb < MB; ++mb) a[mb] = *(const f32x4*)&T[(mb * 16 + r) * LD + 16 * t + 4 * q];
       f32x4 b[CBW];
 #pragma unroll
       for (int cb = 0; cb < CBW; ++cb) {
         if (TRANS_W) {
-          b[cb] = *(const f32x4*)&W[(size_t)(j0 + 16 * cb) * D + q * KQ + 4 * t];
+          b[cb] = *(const f32x4*)&W[(size_t)(j0 + 16 * cb) * D + 16 * t + 4 * q];
         } else {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) b[cb][u] = W[(size_t)(q * KQ + 4 * t + u) * D + j0 + 16 * cb];
+          for (int u = 0; u < 4; ++u) b[cb][u] = W[(size_t)(16 * t + 4 * q + u) * D + j0 + 16 * cb];
         }
       }
 #pragma unroll
