@@ -24,7 +24,9 @@
 #define HEAD_STAT_BLOCKS 128
 #define HEAD_TILE 16
 #define HEADB_TILE 32
+#ifndef HEAD_MAX_PARTIALS
 #define HEAD_MAX_PARTIALS 128
+#endif
 
 // ------------------------------------------------------------------------------------------
 // BatchNorm statistics

@@ -727,7 +727,10 @@ static int check_shape(int n, int S, int d) {
 // otherwise 16 rows (MB = 1) so small chromosomes fill the 256 CUs.
 static inline int pick_mb(int n, int S) {
   const int tn2 = 32 / S;
-  return ((n + tn2 - 1) / tn2 >= 1024) ? 2 : 1;
+#ifndef MB2_MIN_TILES
+#define MB2_MIN_TILES 1024
+#endif
+  return ((n + tn2 - 1) / tn2 >= MB2_MIN_TILES) ? 2 : 1;
 }
 
 static int dropout_args(float p, const unsigned long long* rng_state, float* keep_scale, uint32_t* thresh) {
