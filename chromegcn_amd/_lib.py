@@ -29,9 +29,12 @@ _SIGNATURES = {
     "cgcn_head_fwd": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp] * 6 + [_c_float, _c_float, _c_int] + [_c_vp] * 3
                       + [_c_float] + [_c_vp] * 7 + [_c_sz]),
     "cgcn_head_bwd": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp] * 8 + [_c_float] + [_c_vp] * 6 + [_c_int, _c_vp, _c_sz]),
+    "cgcn_sddmm": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 5),
+    "cgcn_graph_count": (_c_int, [_c_vp, _c_int, _c_int] + [_c_vp] * 5),
+    "cgcn_graph_fill": (_c_int, [_c_vp, _c_int, _c_int] + [_c_vp] * 8),
     "cgcn_sgd_step": (_c_int, [_c_vp, ctypes.c_longlong, _c_vp, _c_vp, _c_vp, _c_float, _c_float, _c_float, _c_int, _c_vp]),
 }
-ABI_VERSION = 3
+ABI_VERSION = 4
 _lib = None
 
 

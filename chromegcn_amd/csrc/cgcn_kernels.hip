@@ -681,6 +681,64 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) void k_bwd_g
 }
 
 // ------------------------------------------------------------------------------------------
+// k_sddmm: out[k] = sum_s < A[s,i,:], B[s,col[k],:] >  for every stored entry k of row i  (SURVEY.md row f4:
+// the adjacency-saliency product of scripts/visualize.py:29-49 restricted to the sparsity pattern, instead
+// of a dense n x n autograd gradient).  One wave per row; the row of A stays in registers, neighbour rows of
+// B are fetched 8 at a time like the gather kernels.
+// ------------------------------------------------------------------------------------------
+template <int S, int D>
+__global__ __launch_bounds__(256) void k_sddmm(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                               const float* __restrict__ A, const float* __restrict__ B,
+                                               float* __restrict__ out) {
+  using G = Geo<S, D>;
+  constexpr int NV = G::NV;
+  constexpr unsigned ROWB = D * 4;
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  unsigned lane_off[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) lane_off[v] = ((unsigned)G::strand(v, lane) * (unsigned)n * D + G::column(v, lane)) * 4u;
+  for (int i = wave; i < n; i += nwaves) {
+    f32x4 a[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      a[v] = *(const f32x4*)((const char*)A + (size_t)i * ROWB + lane_off[v]);
+      if (G::HALF && lane >= 32) a[v] = (f32x4){0.f, 0.f, 0.f, 0.f};  // the row is held once, by lanes 0-31
+    }
+    const int k0 = rowptr[i], k1 = rowptr[i + 1];
+    for (int kb = k0; kb < k1; kb += WAVE) {
+      const int cnt = min(WAVE, k1 - kb);
+      const int myc = lane < cnt ? col[kb + lane] : 0;
+      float mine = 0.f;  // lane u ends up with the dot product of neighbour kb + u
+      for (int j = 0; j < cnt; j += 8) {
+        f32x4 t[8][NV];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const char* rowp = (const char*)B + (size_t)(unsigned)rl_i(myc, min(j + u, cnt - 1)) * ROWB;
+#pragma unroll
+          for (int v = 0; v < NV; ++v) {
+            const unsigned off = G::HALF ? (unsigned)((lane & 31) * 16) : lane_off[v];
+            t[u][v] = *(const f32x4*)(rowp + off);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          float d = 0.f;
+#pragma unroll
+          for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d += a[v][e] * t[u][v][e];
+          d = wave_sum(d);
+          if (lane == j + u) mine = d;
+        }
+      }
+      if (lane < cnt) out[kb + lane] = mine;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_sgd: torch.optim.SGD semantics on one flat buffer (utils/util_methods.py:14-19 builds
 // SGD(lr, momentum=0.9, weight_decay=1e-6)):  d = g + wd p;  m = mu m + d;  p -= lr (nesterov ? d + mu m : m).
 // A zero-initialised m reproduces torch's first step (m = d).  Also advances the dropout step counter:
@@ -870,6 +928,21 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   } while (0)
   DISPATCH_SDV(S, d, val_t != nullptr, CALL);
 #undef CALL
+  return launch_status();
+}
+
+int cgcn_sddmm(cgcn_stream_t stream, int n, int S, int d, const int32_t* rowptr, const int32_t* col, const float* A,
+               const float* B, float* out) {
+  int rc = check_shape(n, S, d);
+  if (rc) return rc;
+  if (n == 0) return CGCN_OK;
+  if (!rowptr || !col || !A || !B || !out || misaligned16(A) || misaligned16(B)) return CGCN_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = (n + 3) / 4 < 4096 ? (n + 3) / 4 : 4096;
+  if (S == 1 && d == 128) hipLaunchKernelGGL((k_sddmm<1, 128>), dim3(blocks), dim3(256), 0, st, n, rowptr, col, A, B, out);
+  else if (S == 2 && d == 128) hipLaunchKernelGGL((k_sddmm<2, 128>), dim3(blocks), dim3(256), 0, st, n, rowptr, col, A, B, out);
+  else if (S == 1 && d == 256) hipLaunchKernelGGL((k_sddmm<1, 256>), dim3(blocks), dim3(256), 0, st, n, rowptr, col, A, B, out);
+  else hipLaunchKernelGGL((k_sddmm<2, 256>), dim3(blocks), dim3(256), 0, st, n, rowptr, col, A, B, out);
   return launch_status();
 }
 

@@ -163,14 +163,134 @@ def upload(h: HostCSR, device) -> ChromGraph:
                       rowptr_t=rowptr_t, col_t=col_t, val_t=val_t, symmetric=h.symmetric, host=h)
 
 
+ADJ_CODES = {"hic": 0, "constant": 1, "both": 2, "none": 3}  # CGCN_ADJ_* in include/chromegcn.h
+
+
+def normalize_graph_device(adj_type: str, hic: Optional[sp.spmatrix], n: int, device="cuda") -> ChromGraph:
+    """process_graph on the GPU (cgcn_graph_count / cgcn_graph_fill): the raw Hi-C CSR is uploaded once
+    (int32 + fp32, canonical form) and A-hat, 1/rowsum and the symmetry flag are produced on the device.
+    Same result as upload(normalize_graph(...)) -- tests/test_gpu_graph.py."""
+    from . import _lib
+    if adj_type not in ADJ_CODES:
+        raise ValueError("unsupported adj_type %r (reference: UnboundLocalError)" % (adj_type,))
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("normalize_graph_device needs a GPU; use normalize_graph + upload on the host")
+    code = ADJ_CODES[adj_type]
+    rp = ci = va = None
+    if adj_type in ("hic", "both"):
+        if hic is None:
+            raise ValueError("adj_type %r needs a Hi-C matrix" % adj_type)
+        a = sp.csr_matrix(hic)
+        if a.shape != (n, n):
+            raise ValueError("graph is %s but the chromosome has %d windows" % (a.shape, n))
+        a.sum_duplicates()
+        a.sort_indices()
+        if a.nnz >= 2 ** 31:
+            raise ValueError("graph too large for int32 CSR")
+        rp = torch.from_numpy(a.indptr.astype(np.int32)).to(dev)
+        ci = torch.from_numpy(a.indices.astype(np.int32)).to(dev)
+        if not np.all(a.data == 1.0):
+            va = torch.from_numpy(a.data.astype(np.float32)).to(dev)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        counts = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        _lib.check(lib.cgcn_graph_count(_lib.stream_ptr(), n, code, _lib.ptr(rp), _lib.ptr(ci), _lib.ptr(va),
+                                        counts.data_ptr(), rowptr.data_ptr()), "cgcn_graph_count")
+        nnz = int(rowptr[n].item())  # the one host sync of the build (sizes col[])
+        col = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)[:nnz]
+        val = torch.empty(max(nnz, 1), dtype=torch.float32, device=dev)[:nnz] if adj_type == "both" else None
+        rs = torch.empty(max(n, 1), dtype=torch.float32, device=dev)[:n]
+        flag = torch.ones(1, dtype=torch.int32, device=dev)
+        _lib.check(lib.cgcn_graph_fill(_lib.stream_ptr(), n, code, _lib.ptr(rp), _lib.ptr(ci), _lib.ptr(va),
+                                       rowptr.data_ptr(), col.data_ptr(), _lib.ptr(val), rs.data_ptr(), flag.data_ptr()),
+                   "cgcn_graph_fill")
+        symmetric = bool(flag.item())
+    if val is not None and bool((val == 1).all().item()):
+        val = None  # a 'both' graph whose entries are all ones can use the implicit-value kernels
+    if symmetric:
+        return ChromGraph(n=n, nnz=nnz, rowptr=rowptr, col=col, val=val, row_scale=rs, rowptr_t=rowptr, col_t=col,
+                          val_t=val, symmetric=True, host=None)
+    # asymmetric input (outside the reference's data contract): build the transpose on the host
+    h = HostCSR(n=n, rowptr=rowptr.cpu().numpy(), col=col.cpu().numpy(), val=None if val is None else val.cpu().numpy(),
+                row_scale=rs.cpu().numpy(), symmetric=False)
+    return upload(h, dev)
+
+
 def process_graph(adj_type: str, split_adj_dict_chrom: Optional[Dict[str, sp.spmatrix]], x_size: int, chrom: str,
                   device="cuda") -> ChromGraph:
     """Drop-in for the reference's process_graph (utils/util_methods.py:146): same arguments, but the
-    result is the device CSR handle (ChromeGCN.forward accepts it wherever it accepts `adj`)."""
+    result is the device CSR handle (ChromeGCN.forward accepts it wherever it accepts `adj`).  On a GPU
+    the normalisation itself runs on the device."""
     hic = None
     if adj_type in ("hic", "both"):
         hic = split_adj_dict_chrom[chrom]
+    if torch.device(device).type == "cuda":
+        return normalize_graph_device(adj_type, hic, x_size, device)
     return upload(normalize_graph(adj_type, hic, x_size), device)
+
+
+def to_host(g: ChromGraph) -> HostCSR:
+    """download a device graph (HostCSR), e.g. to write it to the binary cache"""
+    if g.host is not None:
+        return g.host
+    return HostCSR(n=g.n, rowptr=g.rowptr.cpu().numpy(), col=g.col.cpu().numpy(),
+                   val=None if g.val is None else g.val.cpu().numpy(),
+                   row_scale=None if g.row_scale is None else g.row_scale.cpu().numpy(), symmetric=g.symmetric)
+
+
+# ----------------------------------------------------------------------------------------------
+# binary CSR cache: replaces the pickle of SciPy objects (finetune.py:20-23, data/7create_graph_new.py:197-202)
+# ----------------------------------------------------------------------------------------------
+_MAGIC = b"CGCSR01\0"
+
+
+def save_csr_cache(path: str, h: HostCSR):
+    """Flat little-endian file: magic, int64 header [n, nnz, has_val, has_scale, symmetric], then
+    rowptr int32[n+1], col int32[nnz], val fp32[nnz]?, row_scale fp32[n]?  -- loadable with np.memmap,
+    no unpickling, already in the layout the kernels consume."""
+    hdr = np.array([h.n, h.nnz, int(h.val is not None), int(h.row_scale is not None), int(h.symmetric)], dtype="<i8")
+    with open(path, "wb") as f:
+        f.write(_MAGIC)
+        f.write(hdr.tobytes())
+        f.write(np.ascontiguousarray(h.rowptr, dtype="<i4").tobytes())
+        f.write(np.ascontiguousarray(h.col, dtype="<i4").tobytes())
+        if h.val is not None:
+            f.write(np.ascontiguousarray(h.val, dtype="<f4").tobytes())
+        if h.row_scale is not None:
+            f.write(np.ascontiguousarray(h.row_scale, dtype="<f4").tobytes())
+
+
+def load_csr_cache(path: str) -> HostCSR:
+    with open(path, "rb") as f:
+        if f.read(8) != _MAGIC:
+            raise ValueError("%s is not a chromegcn CSR cache" % path)
+        n, nnz, has_val, has_scale, sym = np.frombuffer(f.read(40), dtype="<i8").tolist()
+        rowptr = np.frombuffer(f.read(4 * (n + 1)), dtype="<i4").copy()
+        col = np.frombuffer(f.read(4 * nnz), dtype="<i4").copy()
+        val = np.frombuffer(f.read(4 * nnz), dtype="<f4").copy() if has_val else None
+        rs = np.frombuffer(f.read(4 * n), dtype="<f4").copy() if has_scale else None
+    if rowptr.shape[0] != n + 1 or col.shape[0] != nnz or int(rowptr[-1]) != nnz:
+        raise ValueError("%s is truncated or corrupt" % path)
+    return HostCSR(n=n, rowptr=rowptr, col=col, val=val, row_scale=rs, symmetric=bool(sym))
+
+
+def convert_graph_pickle(pkl_path: str, out_dir: str, adj_type: str = "hic") -> Dict[str, str]:
+    """{split}_graphs_{hicsize}_{hicnorm}norm.pkl (dict chrom -> scipy CSR, data/7create_graph_new.py:197-202)
+    -> one normalised .cgcsr file per chromosome.  Returns {chrom: path}."""
+    import os
+    import pickle
+    with open(pkl_path, "rb") as f:
+        graphs = pickle.load(f)
+    os.makedirs(out_dir, exist_ok=True)
+    out = {}
+    for chrom, a in graphs.items():
+        h = normalize_graph(adj_type, a, a.shape[0])
+        path = os.path.join(out_dir, "%s.%s.cgcsr" % (chrom, adj_type))
+        save_csr_cache(path, h)
+        out[chrom] = path
+    return out
 
 
 # ----------------------------------------------------------------------------------------------

@@ -62,6 +62,23 @@ def spmm(x, graph):
     return SpmmFn.apply(x, graph)
 
 
+def sddmm(a, b, graph: ChromGraph, transposed=False):
+    """out[k] = sum_s <a[s,i,:], b[s,col[k],:]> on the graph's pattern (cgcn_sddmm).  No autograd."""
+    _check_feat(a, graph, "a")
+    _check_feat(b, graph, "b")
+    a, b = a.contiguous(), b.contiguous()
+    S, n, d = a.shape
+    rowptr, col = (graph.rowptr_t, graph.col_t) if transposed else (graph.rowptr, graph.col)
+    out = torch.empty(col.shape[0], device=a.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.cgcn_sddmm(_lib.stream_ptr(), n, S, d, rowptr.data_ptr(), col.data_ptr(), a.data_ptr(), b.data_ptr(),
+                              out.data_ptr()), "cgcn_sddmm")
+    return out
+
+
+_saliency_tap = None  # set by chromegcn_amd.saliency while it collects per-layer (X, dUs, W)
+
+
 def _sink_ok(sink, shapes):
     return sink is not None and all(t is not None and tuple(t.shape) == tuple(sh) and t.is_contiguous()
                                     for t, sh in zip(sink, shapes))
@@ -144,6 +161,8 @@ class GatedLayerFn(torch.autograd.Function):
                                       db.data_ptr(), dwg.data_ptr(), dcg.data_ptr(), 0, ctx.dropout_in,
                                       _lib.ptr(rng_state), max(ctx.layer_id - 1, 0), None, ws.data_ptr(), ws_bytes),
                    "cgcn_layer_bwd")
+        if _saliency_tap is not None:
+            _saliency_tap.append((x, dus, weight, g))  # dus = diag(row_scale) dL/dU of this layer
         if ctx.sink is not None:
             return (dx, None, None, None, None) + (None,) * 6
         return (dx, dw, db, dwg.view(ctx.gate_w_shape), dcg.view(ctx.gate_b_shape)) + (None,) * 6

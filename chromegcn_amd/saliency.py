@@ -1,0 +1,47 @@
+"""Adjacency saliency on the sparsity pattern.
+
+The reference computes it by making the adjacency a DENSE n x n tensor with requires_grad on the CPU
+(scripts/visualize.py:29-49): adj_grad = |adj * d sum(sigmoid(pred) * targets) / d adj|, then a row-sum and a
+row-max normalisation.  Entries outside the pattern have adj = 0 and drop out of the product, so only
+    dL/dA_ij = sum over layers and strands of < dL/dU_i , (X W)_j >      for stored (i, j)
+is needed: one SDDMM per layer (cgcn_sddmm) instead of an O(n^2) gradient (3.6 GB at n = 30k)."""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .graph import ChromGraph, as_graph
+
+
+def adjacency_saliency(model, x_f: torch.Tensor, x_r: torch.Tensor, adj, targets: torch.Tensor, normalize: bool = True):
+    """Returns (graph, sal) with sal[k] the saliency of stored entry k of the graph's CSR (row-major).
+    model: chromegcn_amd.ChromeGCN; x_f, x_r: [n,d]; targets: [n,C] -- the arguments of scripts/visualize.py:37-49."""
+    graph: ChromGraph = as_graph(adj, x_f.device)
+    if not graph.symmetric and graph.val_t is not graph.val:
+        raise NotImplementedError("saliency is implemented for symmetric A-hat (every graph the reference writes)")
+    x = torch.stack([x_f, x_r]).detach().requires_grad_(True)
+    tap = []
+    ops._saliency_tap = tap
+    try:
+        logits, _ = model.forward_strands(x, graph)
+        pred = (logits[0] + logits[1]) / 2                       # visualize.py:39
+        torch.sigmoid(pred).backward(gradient=targets)           # visualize.py:40,47
+    finally:
+        ops._saliency_tap = None
+    # dL/dA_ij (A = diag(rs) Ahat) = <dU_i, (XW)_j>;  a_ij * dL/dA_ij = ahat_ij * <rs_i dU_i, (XW)_j> = ahat_ij * <dUs_i, Q_j>
+    total = torch.zeros(graph.col.shape[0], device=x.device)
+    for (xin, dus, w, g) in tap:
+        q = torch.matmul(xin, w)                                  # S = X W of models/SubLayers.py:43
+        total += ops.sddmm(dus, q, graph)
+    if graph.val is not None:
+        total = total * graph.val
+    sal = total.abs()                                             # visualize.py:49  |adj * adj.grad|
+    if normalize:
+        rows = torch.repeat_interleave(torch.arange(graph.n, device=x.device), (graph.rowptr[1:] - graph.rowptr[:-1]).long())
+        s = torch.zeros(graph.n, device=x.device).index_add_(0, rows, sal)
+        s[s == 0] = 1                                             # :50-52
+        sal = sal / s[rows]
+        m = torch.zeros(graph.n, device=x.device).index_reduce_(0, rows, sal, "amax", include_self=True)
+        m[m == 0] = 1                                             # :53-55
+        sal = sal / m[rows]
+    return graph, sal

@@ -47,7 +47,7 @@ extern "C" {
 #define CGCN_ERR_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after a launch      */
 #define CGCN_ERR_WORKSPACE (-4)   /* workspace too small (see cgcn_*_workspace_bytes)    */
 
-#define CGCN_ABI_VERSION 3
+#define CGCN_ABI_VERSION 4
 
 typedef void *cgcn_stream_t; /* hipStream_t */
 
@@ -172,6 +172,39 @@ int cgcn_head_bwd(cgcn_stream_t stream, int n, int S, int d, int C, const float 
                   const float *dpred, const float *dloss, float dropout_p, const unsigned long long *rng_state,
                   float *dX, float *dW_out, float *db_out, float *dbn_w, float *dbn_b, int accumulate,
                   void *workspace, size_t workspace_bytes);
+
+/*
+ * Sampled dense-dense product on the graph's sparsity pattern:
+ *     out[k] = sum_s < A[s,i,:], B[s,col[k],:] >     for every stored entry k of row i.
+ * With A = dL/dU and B = X W of one layer this is dL/dA_ij on the pattern, i.e. the adjacency saliency
+ * of scripts/visualize.py:29-49 (which materialises a dense n x n gradient on the CPU).  A, B: [S,n,d].
+ */
+int cgcn_sddmm(cgcn_stream_t stream, int n, int S, int d, const int32_t *rowptr, const int32_t *col,
+               const float *A, const float *B, float *out);
+
+/* adj_type codes of the device-side normaliser: the branches of process_graph, utils/util_methods.py:148-174 */
+#define CGCN_ADJ_HIC 0
+#define CGCN_ADJ_CONSTANT 1
+#define CGCN_ADJ_BOTH 2
+#define CGCN_ADJ_NONE 3
+
+/*
+ * Device-side process_graph (utils/util_methods.py:146-180), step 1 of 2: per-row entry counts of
+ * A-hat (row_counts[n]) and their exclusive prefix sum (rowptr_out[n+1]; rowptr_out[n] = nnz(A-hat),
+ * which the caller reads back once to size col_out).  Input: canonical CSR (sorted columns, no
+ * duplicates) of the raw Hi-C matrix, fp32 values or NULL = ones; ignored for CONSTANT / NONE.
+ */
+int cgcn_graph_count(cgcn_stream_t stream, int n, int adj_type, const int32_t *rowptr_in, const int32_t *col_in,
+                     const float *val_in, int32_t *row_counts, int32_t *rowptr_out);
+
+/*
+ * Step 2: columns of A-hat (sorted), values (val_out; required for BOTH, optional/ignored otherwise: HIC,
+ * CONSTANT and NONE graphs are all-ones), row_scale = fp32(1 / rowsum) with 1/0 -> 0.
+ * symmetric_flag (int32[1], caller sets it to 1; may be NULL): cleared if A-hat != A-hat^T.
+ */
+int cgcn_graph_fill(cgcn_stream_t stream, int n, int adj_type, const int32_t *rowptr_in, const int32_t *col_in,
+                    const float *val_in, const int32_t *rowptr_out, int32_t *col_out, float *val_out,
+                    float *row_scale, int32_t *symmetric_flag);
 
 /*
  * torch.optim.SGD step on one flat fp32 buffer (utils/util_methods.py:14-19 builds

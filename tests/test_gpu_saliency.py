@@ -1,0 +1,69 @@
+"""SDDMM and the adjacency saliency of scripts/visualize.py:29-55, against the reference's own method
+(dense adjacency with requires_grad on the CPU, here driven through the oracle model)."""
+import numpy as np
+import pytest
+import torch
+
+import chromegcn_amd as C
+from chromegcn_amd import graph as G
+from chromegcn_amd import ops
+from chromegcn_amd.saliency import adjacency_saliency
+from oracle import chromegcn_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("S,d", [(1, 128), (2, 128), (1, 256), (2, 256)])
+def test_sddmm_matches_numpy(S, d):
+    for n, pairs, seed in [(257, 1500, 1), (1, 0, 2), (300, 9000, 3)]:
+        h = G.normalize_graph("hic", O.random_symmetric_graph(n, pairs, seed), n)
+        g = G.upload(h, DEV)
+        rng = np.random.RandomState(seed)
+        a = rng.randn(S, n, d).astype(np.float32); b = rng.randn(S, n, d).astype(np.float32)
+        out = ops.sddmm(torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV), g).cpu().numpy()
+        rows = np.repeat(np.arange(n), np.diff(h.rowptr))
+        want = np.einsum("skd,skd->k", a[:, rows, :].astype(np.float64), b[:, h.col, :].astype(np.float64))
+        np.testing.assert_allclose(out, want, atol=1e-4, rtol=1e-4)
+
+
+def test_adjacency_saliency_matches_dense_autograd():
+    n, d, c = 120, 128, 7
+    a = O.random_symmetric_graph(n, 500, 4)
+    torch.manual_seed(2)
+    orc = O.GatedGCNOracle(d, c, 0.0, 2).eval()
+    with torch.no_grad():
+        for k, p in orc.named_parameters():
+            if "GC" in k and k.endswith("weight"):
+                p.copy_(torch.randn_like(p) / np.sqrt(d) * 1.5)
+    x_f, x_r = torch.randn(n, d), torch.randn(n, d)
+    targets = (torch.rand(n, c) < 0.3).float()
+    # the reference's way: dense adjacency with requires_grad (scripts/visualize.py:29-55)
+    adj = O.process_graph("hic", {"c": a}, n, "c").to_dense().requires_grad_(True)
+
+    def dense_forward(x):
+        h = x
+        for k in (1, 2):
+            gc, wk = getattr(orc, "GC%d" % k), getattr(orc, "W%d" % k)
+            z = torch.tanh(adj @ (h @ gc.weight) + gc.bias)
+            g = torch.sigmoid(wk(z))
+            h = (1 - g) * h + g * z
+        return orc.out(orc.batch_norm(torch.relu(h)))
+    pred = (dense_forward(x_f) + dense_forward(x_r)) / 2
+    torch.sigmoid(pred).backward(gradient=targets)
+    adj_grad = torch.abs(adj * adj.grad).detach()
+    s = adj_grad.sum(1); s[s == 0] = 1
+    adj_grad = adj_grad / s.view(-1, 1)
+    m, _ = torch.max(adj_grad, 1); m[m == 0] = 1
+    adj_grad = adj_grad / m.view(-1, 1)
+
+    model = C.ChromeGCN(d, d, c, 0.0, True, 2)
+    model.load_state_dict(orc.state_dict())
+    model.to(DEV).eval()
+    g, sal = adjacency_saliency(model, x_f.to(DEV), x_r.to(DEV), C.process_graph("hic", {"c": a}, n, "c", device=DEV), targets.to(DEV))
+    rows = np.repeat(np.arange(n), np.diff(g.rowptr.cpu().numpy()))
+    want = adj_grad.numpy()[rows, g.col.cpu().numpy()]
+    np.testing.assert_allclose(sal.cpu().numpy(), want, atol=2e-4, rtol=2e-3)
+    # nothing outside the pattern
+    mask = np.zeros((n, n), bool); mask[rows, g.col.cpu().numpy()] = True
+    assert np.all(adj_grad.numpy()[~mask] == 0)

@@ -65,3 +65,38 @@ def test_asymmetric_matrix_detected():
     h = G.host_csr_from_matrix(m)
     assert not h.symmetric and h.row_scale is None
     np.testing.assert_array_equal(h.to_scipy().toarray(), m.toarray())
+
+
+def test_binary_csr_cache_roundtrip(tmp_path):
+    for adj_type, hic in [("hic", O.random_symmetric_graph(50, 120, 1)), ("both", O.random_symmetric_graph(40, 60, 2)),
+                          ("constant", None), ("none", None)]:
+        n = 50 if adj_type == "hic" else 40
+        h = G.normalize_graph(adj_type, hic, n)
+        p = str(tmp_path / ("g_%s.cgcsr" % adj_type))
+        G.save_csr_cache(p, h)
+        h2 = G.load_csr_cache(p)
+        assert h2.n == h.n and h2.symmetric == h.symmetric
+        np.testing.assert_array_equal(h2.rowptr, h.rowptr)
+        np.testing.assert_array_equal(h2.col, h.col)
+        np.testing.assert_array_equal(h2.row_scale, h.row_scale)
+        assert (h2.val is None) == (h.val is None)
+        if h.val is not None:
+            np.testing.assert_array_equal(h2.val, h.val)
+    with open(str(tmp_path / "bad.cgcsr"), "wb") as f:
+        f.write(b"not a cache file at all")
+    with pytest.raises(ValueError):
+        G.load_csr_cache(str(tmp_path / "bad.cgcsr"))
+
+
+def test_convert_graph_pickle(tmp_path):
+    """the reference's on-disk graph contract (data/7create_graph_new.py:197-202) -> flat per-chromosome files"""
+    import pickle
+    graphs = {"chr21": O.random_symmetric_graph(30, 80, 3), "chr22": O.random_symmetric_graph(17, 30, 4)}
+    pkl = str(tmp_path / "train_graphs_500000_SQRTVCnorm.pkl")
+    with open(pkl, "wb") as f:
+        pickle.dump(graphs, f)
+    out = G.convert_graph_pickle(pkl, str(tmp_path / "csr"), "hic")
+    assert sorted(out) == ["chr21", "chr22"]
+    for c, path in out.items():
+        h = G.load_csr_cache(path)
+        np.testing.assert_allclose(h.to_scipy().toarray(), O.normalized_adjacency("hic", graphs[c], graphs[c].shape[0]).toarray(), rtol=2e-7)
