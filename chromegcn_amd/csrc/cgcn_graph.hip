@@ -122,7 +122,7 @@ int cgcn_graph_count(cgcn_stream_t stream, int n, int adj_type, const int32_t* r
   if (n < 0 || adj_type < CGCN_ADJ_HIC || adj_type > CGCN_ADJ_NONE) return CGCN_ERR_BAD_ARG;
   if (!row_counts || !rowptr_out) return CGCN_ERR_BAD_ARG;
   const bool use_hic = adj_type == CGCN_ADJ_HIC || adj_type == CGCN_ADJ_BOTH;
-  if (use_hic && n > 0 && (!rowptr_in || !col_in)) return CGCN_ERR_BAD_ARG;
+  if (use_hic && n > 0 && !rowptr_in) return CGCN_ERR_BAD_ARG;  // col_in may be NULL for an empty matrix
   hipStream_t st = (hipStream_t)stream;
   if (n > 0) hipLaunchKernelGGL(k_graph_count, dim3((n + 255) / 256), dim3(256), 0, st, n, adj_type, rowptr_in, col_in, val_in, row_counts);
   hipLaunchKernelGGL(k_graph_scan, dim3(1), dim3(1024), 0, st, n, row_counts, rowptr_out);
