@@ -90,15 +90,14 @@ struct Gather {
   }
 };
 
+// accumulate neighbours k0..k1 of one row into acc (no initialisation, no half-wave fold)
 template <int S, int D, bool HAS_VAL>
-__device__ __forceinline__ void gather_node(const int* __restrict__ col, const float* __restrict__ val,
-                                            int k0, int k1, const char* __restrict__ Xb,
-                                            const unsigned (&lane_off)[Geo<S, D>::NV], f32x4 (&acc)[Geo<S, D>::NV],
-                                            int lane) {
+__device__ __forceinline__ void gather_range(const int* __restrict__ col, const float* __restrict__ val,
+                                             int k0, int k1, const char* __restrict__ Xb,
+                                             const unsigned (&lane_off)[Geo<S, D>::NV], f32x4 (&acc)[Geo<S, D>::NV],
+                                             int lane) {
   using GA = Gather<S, D, HAS_VAL>;
   constexpr int NV = GA::NV;
-#pragma unroll
-  for (int v = 0; v < NV; ++v) acc[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
   for (int kb = k0; kb < k1; kb += WAVE) {
     const int cnt = min(WAVE, k1 - kb);
     int myc = 0;
@@ -127,10 +126,103 @@ __device__ __forceinline__ void gather_node(const int* __restrict__ col, const f
     }
 #endif
   }
+}
+
+template <int S, int D>
+__device__ __forceinline__ void gather_fold(int lane, f32x4 (&acc)[Geo<S, D>::NV]) {
+  (void)lane;
   if (Geo<S, D>::HALF) {
     // fold the odd-neighbour half onto the even one; afterwards both halves hold the row sum
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[0][e] += __shfl_xor(acc[0][e], 32, WAVE);
+  }
+}
+
+template <int S, int D, bool HAS_VAL>
+__device__ __forceinline__ void gather_node(const int* __restrict__ col, const float* __restrict__ val,
+                                            int k0, int k1, const char* __restrict__ Xb,
+                                            const unsigned (&lane_off)[Geo<S, D>::NV], f32x4 (&acc)[Geo<S, D>::NV],
+                                            int lane) {
+#pragma unroll
+  for (int v = 0; v < Geo<S, D>::NV; ++v) acc[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  gather_range<S, D, HAS_VAL>(col, val, k0, k1, Xb, lane_off, acc, lane);
+  gather_fold<S, D>(lane, acc);
+}
+
+// Phase 1 of the two gather kernels: aggregate the R nodes of a tile into the LDS tile T (and Hout).
+// Ordinary rows: one wave per row.  Rows with more than LONG_ROW neighbours (Hi-C hubs) are split across all
+// NW waves of the workgroup in 64-neighbour chunks and combined through LDS in wave order, so one hub row
+// costs len/NW instead of len serial batches and the result stays bit-reproducible.
+#ifndef LONG_ROW
+#define LONG_ROW 512
+#endif
+template <int S, int D, bool HAS_VAL, int R, int NW, int LD>
+__device__ __forceinline__ void gather_tile(int n, int node0, const int* __restrict__ rowptr,
+                                            const int* __restrict__ col, const float* __restrict__ val,
+                                            const float* __restrict__ rs, const char* __restrict__ Xb,
+                                            const unsigned (&lane_off)[Geo<S, D>::NV], float* __restrict__ T,
+                                            float* __restrict__ Hout, float* __restrict__ scratch, int wave, int lane) {
+  using G = Geo<S, D>;
+  constexpr int NV = G::NV;
+  constexpr int PAY = S * D;
+  bool any_long = false;
+  for (int rr = wave; rr < R; rr += NW) {
+    const int i = node0 + rr;
+    f32x4 acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bool is_long = false;
+    if (i < n) {
+      const int k0 = rowptr[i], k1 = rowptr[i + 1];
+      is_long = (k1 - k0) > LONG_ROW;
+      if (!is_long) {
+        gather_range<S, D, HAS_VAL>(col, val, k0, k1, Xb, lane_off, acc, lane);
+        gather_fold<S, D>(lane, acc);
+        const float sc = rs ? rs[i] : 1.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] *= sc;
+      }
+    }
+    any_long |= is_long;
+    if (!is_long && (!G::HALF || lane < 32)) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int s = G::strand(v, lane), c = G::column(v, lane);
+        *(f32x4*)&T[(s * R + rr) * LD + c] = acc[v];
+        if (Hout && i < n) *(f32x4*)&Hout[((size_t)s * n + i) * D + c] = acc[v];
+      }
+    }
+  }
+  if (!__syncthreads_or(any_long)) return;  // block-uniform: no hub row in this tile
+  for (int rr = 0; rr < R; ++rr) {
+    const int i = node0 + rr;
+    if (i >= n) break;
+    const int k0 = rowptr[i], k1 = rowptr[i + 1];
+    if (k1 - k0 <= LONG_ROW) continue;  // same decision in every wave
+    f32x4 acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kb = k0 + WAVE * wave; kb < k1; kb += WAVE * NW)
+      gather_range<S, D, HAS_VAL>(col, val, kb, min(kb + WAVE, k1), Xb, lane_off, acc, lane);
+    gather_fold<S, D>(lane, acc);
+    if (!G::HALF || lane < 32) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) *(f32x4*)&scratch[wave * PAY + G::strand(v, lane) * D + G::column(v, lane)] = acc[v];
+    }
+    __syncthreads();
+    if (wave == rr % NW && (!G::HALF || lane < 32)) {
+      const float sc = rs ? rs[i] : 1.f;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int s = G::strand(v, lane), c = G::column(v, lane);
+        f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int w = 0; w < NW; ++w) t += *(const f32x4*)&scratch[w * PAY + s * D + c];
+        t *= sc;
+        *(f32x4*)&T[(s * R + rr) * LD + c] = t;
+        if (Hout) *(f32x4*)&Hout[((size_t)s * n + i) * D + c] = t;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -285,6 +377,7 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) void k_layer
   constexpr int RPW = (ROWS + NW - 1) / NW;  // epilogue rows per wave
   constexpr bool PRE = (D == 128);
   __shared__ __attribute__((aligned(16))) float T[ROWS * LD];
+  __shared__ __attribute__((aligned(16))) float LR[NW * S * D];  // hub-row partial sums (gather_tile)
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -298,28 +391,7 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) void k_layer
   for (int v = 0; v < G::NV; ++v) lane_off[v] = ((unsigned)G::strand(v, lane) * (unsigned)n * D + G::column(v, lane)) * 4u;
 
   // ---- phase 1
-  for (int rr = wave; rr < R; rr += NW) {
-    const int i = node0 + rr;
-    f32x4 acc[G::NV];
-    if (i < n) {
-      const int k0 = rowptr[i], k1 = rowptr[i + 1];
-      gather_node<S, D, HAS_VAL>(col, val, k0, k1, (const char*)X, lane_off, acc, lane);
-      const float sc = rs ? rs[i] : 1.f;
-#pragma unroll
-      for (int v = 0; v < G::NV; ++v) acc[v] *= sc;
-    } else {
-#pragma unroll
-      for (int v = 0; v < G::NV; ++v) acc[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    if (!G::HALF || lane < 32) {
-#pragma unroll
-      for (int v = 0; v < G::NV; ++v) {
-        const int s = G::strand(v, lane), c = G::column(v, lane);
-        *(f32x4*)&T[(s * R + rr) * LD + c] = acc[v];
-        if (Hout && i < n) *(f32x4*)&Hout[((size_t)s * n + i) * D + c] = acc[v];
-      }
-    }
-  }
+  gather_tile<S, D, HAS_VAL, R, NW, LD>(n, node0, rowptr, col, val, rs, (const char*)X, lane_off, T, Hout, LR, wave, lane);
   // prefetch the residual rows this wave will mix in phase 3 (latency hides behind the MFMA phase)
   float xres[RPW][EPL];
 #pragma unroll
@@ -607,6 +679,7 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) void k_bwd_g
   constexpr int RPW = (ROWS + NW - 1) / NW;
   constexpr bool PRE = (D == 128);
   __shared__ __attribute__((aligned(16))) float T[ROWS * LD];
+  __shared__ __attribute__((aligned(16))) float LR[NW * S * D];  // hub-row partial sums (gather_tile)
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -619,20 +692,7 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) void k_bwd_g
 #pragma unroll
   for (int v = 0; v < G::NV; ++v) lane_off[v] = ((unsigned)G::strand(v, lane) * (unsigned)n * D + G::column(v, lane)) * 4u;
 
-  for (int rr = wave; rr < R; rr += NW) {
-    const int i = node0 + rr;
-    f32x4 acc[G::NV];
-    if (i < n) {
-      gather_node<S, D, HAS_VAL>(col, val, rowptr[i], rowptr[i + 1], (const char*)dUs, lane_off, acc, lane);
-    } else {
-#pragma unroll
-      for (int v = 0; v < G::NV; ++v) acc[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    if (!G::HALF || lane < 32) {
-#pragma unroll
-      for (int v = 0; v < G::NV; ++v) *(f32x4*)&T[(G::strand(v, lane) * R + rr) * LD + G::column(v, lane)] = acc[v];
-    }
-  }
+  gather_tile<S, D, HAS_VAL, R, NW, LD>(n, node0, rowptr, col, val, nullptr, (const char*)dUs, lane_off, T, nullptr, LR, wave, lane);
   // prefetch (1-g) dXn for the rows this wave finishes
   float res[RPW][EPL];
 #pragma unroll

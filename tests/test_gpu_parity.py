@@ -38,6 +38,17 @@ def graph_cases():
     m[i, j] = 1; m[j, i] = 1; np.fill_diagonal(m, 0)
     m[77, :] = 0; m[:, 77] = 0; m[77, 77] = -1  # empty row after +I
     out.append(("dense300", G.normalize_graph("hic", sp.csr_matrix(m), 300)))
+    # Hi-C hub: one node in contact with 1500 others (> LONG_ROW = 512 -> split across the workgroup's
+    # waves), plus a second hub in the same 8-node tile
+    hub = np.zeros((1700, 1700))
+    sel = rng.choice(1700, 1500, replace=False)
+    hub[40, sel] = 1; hub[sel, 40] = 1
+    sel2 = rng.choice(1700, 700, replace=False)
+    hub[43, sel2] = 1; hub[sel2, 43] = 1
+    i, j = rng.randint(0, 1700, 6000), rng.randint(0, 1700, 6000)
+    hub[i, j] = 1; hub[j, i] = 1; np.fill_diagonal(hub, 0)
+    out.append(("hub1700", G.normalize_graph("hic", sp.csr_matrix(hub), 1700)))
+    out.append(("hubboth", G.normalize_graph("both", sp.csr_matrix(hub[:900, :900]), 900)))
     # an asymmetric, arbitrary-valued operator (what a torch-COO caller may hand in)
     r = sp.random(90, 90, 0.08, format="csr", random_state=4, dtype=np.float32)
     out.append(("asym90", G.host_csr_from_matrix(r)))
