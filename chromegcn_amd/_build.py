@@ -7,7 +7,7 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 SRC = [os.path.join(PKG, "csrc", "cgcn_kernels.hip"), os.path.join(PKG, "csrc", "cgcn_head.hip"),
-       os.path.join(PKG, "csrc", "cgcn_graph.hip")]
+       os.path.join(PKG, "csrc", "cgcn_graph.hip"), os.path.join(PKG, "csrc", "cgcn_metrics.hip")]
 HDR = [os.path.join(ROOT, "include", "chromegcn.h"), os.path.join(PKG, "csrc", "cgcn_common.hpp")]
 LIB = os.path.join(PKG, "libchromegcn_hip.so")
 

@@ -47,7 +47,7 @@ extern "C" {
 #define CGCN_ERR_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after a launch      */
 #define CGCN_ERR_WORKSPACE (-4)   /* workspace too small (see cgcn_*_workspace_bytes)    */
 
-#define CGCN_ABI_VERSION 4
+#define CGCN_ABI_VERSION 5
 
 typedef void *cgcn_stream_t; /* hipStream_t */
 
@@ -205,6 +205,22 @@ int cgcn_graph_count(cgcn_stream_t stream, int n, int adj_type, const int32_t *r
 int cgcn_graph_fill(cgcn_stream_t stream, int n, int adj_type, const int32_t *rowptr_in, const int32_t *col_in,
                     const float *val_in, const int32_t *rowptr_out, int32_t *col_out, float *val_out,
                     float *row_scale, int32_t *symmetric_flag);
+
+/* Bytes of scratch cgcn_multilabel_metrics needs (sort buffers + rocPRIM temporary storage). */
+size_t cgcn_metrics_workspace_bytes(long long n, int C);
+
+/*
+ * Per-label ranking metrics of the reference's compute_metrics (utils/evals.py:89-92, utils/metrics.py),
+ * computed on the device from probs [n,C] and 0/1 targets [n,C]:
+ *   out[0*C + c] AUROC (roc_auc_score; NaN when label c has a single class present)
+ *   out[1*C + c] area under sklearn's precision_recall_curve by the trapezoid rule (utils/metrics.py:168-176)
+ *   out[2*C + c] recall at the first curve point (from the low-threshold end) with FDR <= fdr_cutoff
+ *                (utils/metrics.py:148-160, cutoff 0.5 there)
+ *   out[3*C + c] average precision (mean over labels = mean_average_precision, utils/metrics.py:25-26)
+ * Tied scores form one curve point, as in sklearn.  n*C < 2^31.
+ */
+int cgcn_multilabel_metrics(cgcn_stream_t stream, long long n, int C, const float *probs, const float *targets,
+                            float fdr_cutoff, float *out, void *workspace, size_t workspace_bytes);
 
 /*
  * torch.optim.SGD step on one flat fp32 buffer (utils/util_methods.py:14-19 builds

@@ -284,3 +284,33 @@ def random_symmetric_graph(n: int, pairs: int, seed: int, hic_like: bool = False
     a.data[:] = 1.0
     a.sort_indices()
     return sp.csr_matrix(a, dtype=np.float64)
+
+
+# --------------------------------------------------------------------------- #
+# Multi-label metrics (utils/metrics.py:25-26,148-183,238-253; utils/evals.py:89-92)
+# --------------------------------------------------------------------------- #
+def multilabel_metrics_np(targets: np.ndarray, preds: np.ndarray, fdr_cutoff: float = 0.5):
+    """Per-label arrays exactly as the reference's helpers compute them with scikit-learn (its dependency):
+    roc_auc_score (metrics.py:243), auc(recall, precision) of precision_recall_curve (:171-173), recall at the
+    first index with 1 - precision <= cutoff (:152-156), average_precision_score (:25-26).  NaN where sklearn
+    raises or returns NaN (the reference skips those labels)."""
+    import warnings
+    from sklearn import metrics as skm
+    C = targets.shape[1]
+    out = {k: np.full(C, np.nan) for k in ("auroc", "aupr", "recall_at_fdr", "average_precision")}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for c in range(C):
+            try:
+                out["auroc"][c] = skm.roc_auc_score(targets[:, c], preds[:, c])
+            except ValueError:
+                pass
+            try:
+                precision, recall, _ = skm.precision_recall_curve(targets[:, c], preds[:, c], pos_label=1)
+                out["aupr"][c] = skm.auc(recall, precision)
+                idx = next(i for i, x in enumerate(1 - precision) if x <= fdr_cutoff)
+                out["recall_at_fdr"][c] = recall[idx]
+                out["average_precision"][c] = skm.average_precision_score(targets[:, c], preds[:, c], pos_label=1)
+            except Exception:
+                pass
+    return out

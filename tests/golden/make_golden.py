@@ -14,6 +14,7 @@ Entry points exercised (reference file:line):
   G3  models/ChromeModels.py:34  ChromeGCN.forward (eval; train w/ dropout=0 + one SGD step)
   G4  finetune.py:29-53          the per-chromosome loop, re-driven on CPU (the original
       hard-codes .cuda(), finetune.py:30-36), 2 train epochs + 1 eval pass
+  G5  utils/metrics.py:148,168,238,25  fdr / aupr / auroc / mean_average_precision per label
 """
 import json
 import os
@@ -270,10 +271,47 @@ def make_g4():
     np.savez_compressed(os.path.join(HERE, "g4_finetune_loop.npz"), **out)
 
 
+# ----------------------------------------------------------------------------- G5
+def make_g5():
+    """utils/metrics.py auroc / aupr / fdr / mean_average_precision (the per-label arrays compute_metrics
+    aggregates, utils/evals.py:89-92) on scores with ties, a label without positives and one without negatives."""
+    from utils import metrics as ref_metrics
+    rng = np.random.RandomState(51)
+    n, c = 3000, 9
+    tg = (rng.rand(n, c) < np.linspace(0.02, 0.6, c)).astype(np.float64)
+    tg[:, 3] = 0.0
+    tg[:, 6] = 1.0
+    pr = rng.rand(n, c) * 0.6 + 0.4 * tg * rng.rand(n, c)
+    pr[:, 1] = np.round(pr[:, 1], 2)      # heavy ties
+    pr[:, 2] = np.round(pr[:, 2], 1)
+    pr[:, 8] = 0.5                        # all scores equal
+    pr = pr.astype(np.float32)
+    out = {"targets": tg.astype(np.float32), "preds": pr}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        per_label = {"auroc": [], "aupr": [], "fdr": [], "ap": []}
+        for j in range(c):  # the reference helpers drop undefined labels from their arrays; record per label
+            t1, p1 = tg[:, j:j + 1], pr[:, j:j + 1]
+            a = ref_metrics.auroc(t1, p1)[3]
+            per_label["auroc"].append(a[0] if len(a) else np.nan)
+            a = ref_metrics.aupr(t1, p1)[3]
+            per_label["aupr"].append(a[0] if len(a) else np.nan)
+            a = ref_metrics.fdr(t1, p1)[3]
+            per_label["fdr"].append(a[0] if len(a) else np.nan)
+            try:
+                per_label["ap"].append(ref_metrics.mean_average_precision(t1[:, 0], p1[:, 0]))
+            except Exception:
+                per_label["ap"].append(np.nan)
+    for k, v in per_label.items():
+        out["ref_" + k] = np.array(v, dtype=np.float64)
+    out["meta"] = np.array(json.dumps(META))
+    np.savez_compressed(os.path.join(HERE, "g5_metrics.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(1)  # fixed reduction order for the recorded values
-    make_g1(); make_g2(); make_g3(); make_g4()
+    make_g1(); make_g2(); make_g3(); make_g4(); make_g5()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

@@ -1,0 +1,47 @@
+"""Device metrics (cgcn_multilabel_metrics) against the per-label values recorded from the reference's
+utils/metrics.py helpers (G5) and against the oracle (scikit-learn, the reference's dependency) on larger
+random inputs.  Curve arithmetic is fp64 on the device; results are returned as fp32."""
+import numpy as np
+import pytest
+import torch
+
+from chromegcn_amd import metrics as M
+from oracle import chromegcn_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+PAIRS = [("ref_auroc", "auroc"), ("ref_aupr", "aupr"), ("ref_fdr", "recall_at_fdr"), ("ref_ap", "average_precision")]
+
+
+def test_metrics_match_reference_golden(golden):
+    z = golden("g5_metrics.npz")
+    m = M.multilabel_metrics(torch.from_numpy(z["preds"]).to(DEV), torch.from_numpy(z["targets"]).to(DEV))
+    for k_ref, k in PAIRS:
+        np.testing.assert_allclose(m[k].cpu().numpy(), z[k_ref], rtol=2e-6, atol=2e-7, equal_nan=True, err_msg=k)
+
+
+@pytest.mark.parametrize("n,C", [(1, 3), (65, 2), (5000, 103), (40000, 17)])
+def test_metrics_match_oracle(n, C):
+    rng = np.random.RandomState(n + C)
+    tg = (rng.rand(n, C) < rng.rand(C) * 0.5).astype(np.float32)
+    pr = (rng.rand(n, C) * 0.7 + 0.3 * tg * rng.rand(n, C)).astype(np.float32)
+    pr[:, 0] = np.round(pr[:, 0], 2)
+    want = O.multilabel_metrics_np(tg.astype(np.float64), pr)
+    got = M.multilabel_metrics(torch.from_numpy(pr).to(DEV), torch.from_numpy(tg).to(DEV))
+    for k in ("auroc", "aupr", "recall_at_fdr", "average_precision"):
+        np.testing.assert_allclose(got[k].cpu().numpy(), want[k], rtol=3e-6, atol=3e-7, equal_nan=True, err_msg=k)
+
+
+def test_compute_metrics_keys_and_aggregation(golden):
+    z = golden("g5_metrics.npz")
+    out = M.compute_metrics(torch.from_numpy(z["preds"]), torch.from_numpy(z["targets"]), 1.25, None, 0.5)
+    for k in ["mAP", "meanAUC", "medianAUC", "allAUC", "allFDR", "meanAUPR", "medianAUPR", "allAUPR", "meanFDR",
+              "medianFDR", "loss", "time"]:  # utils/evals.py:107-118
+        assert k in out
+    assert abs(out["meanAUC"] - np.nanmean(z["ref_auroc"])) < 1e-6
+    assert abs(out["meanAUPR"] - np.mean(z["ref_aupr"])) < 1e-6
+    assert abs(out["meanFDR"] - np.mean(z["ref_fdr"])) < 1e-6
+    assert abs(out["mAP"] - np.mean(z["ref_ap"])) < 1e-6
+    assert out["loss"] == 1.25 and out["time"] == 0.5
+    with pytest.raises(RuntimeError):
+        M.multilabel_metrics(torch.zeros(4, 2), torch.zeros(4, 2))

@@ -172,3 +172,11 @@ def test_g4_finetune_loop(golden):
     for k, v in m.state_dict().items():
         np.testing.assert_allclose(v.numpy(), final[k].numpy(), atol=5e-5, rtol=5e-5, err_msg=k)
     assert tg.shape[0] == sum(feats[c]["target"].shape[0] for c in chroms)
+
+
+# ------------------------------------------------------------------ G5: metrics
+def test_g5_metrics_oracle_matches_reference(golden):
+    z = golden("g5_metrics.npz")
+    m = O.multilabel_metrics_np(z["targets"].astype(np.float64), z["preds"])
+    for k_ref, k in [("ref_auroc", "auroc"), ("ref_aupr", "aupr"), ("ref_fdr", "recall_at_fdr"), ("ref_ap", "average_precision")]:
+        np.testing.assert_allclose(m[k], z[k_ref], rtol=1e-12, atol=1e-12, equal_nan=True, err_msg=k)
