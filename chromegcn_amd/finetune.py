@@ -73,6 +73,7 @@ class GCNStage:
         self._captured_lr = None
         self._one: Optional[torch.Tensor] = None
         self._int_synced: Dict[str, torch.Tensor] = {}
+        self._targets_cpu: Dict[tuple, torch.Tensor] = {}
 
     # ------------------------------------------------------------------ data
     def add_chromosome(self, name: str, feats: Dict[str, torch.Tensor], hic=None):
@@ -86,6 +87,7 @@ class GCNStage:
         d = x.shape[2]
         cost = float(h.nnz) * d + 3.0 * n * d * d / 16.0
         self.chroms[name] = _Chrom(name, n, g, x, t, cost)
+        self._targets_cpu.clear()
         self._graphs = {k: v for k, v in self._graphs.items() if k[0] != name}
 
     def load(self, chrom_feature_dict, split_adj_dict=None, only: Optional[Iterable[str]] = None):
@@ -340,21 +342,30 @@ class GCNStage:
                 self._int_synced[k] = b.clone()
 
     # ------------------------------------------------------------------ a whole split
-    def run_split(self, split: str, names: Optional[Sequence[str]] = None):
+    def run_split(self, split: str, names: Optional[Sequence[str]] = None, to_cpu: bool = True):
         """(all_preds, all_targets, total_loss) with finetune.py:67's meaning: sigmoid probabilities and
-        targets concatenated in chromosome order (CPU tensors), total_loss = sum of per-chromosome
-        mean BCE.  Multi-rank: every rank returns the full concatenation."""
+        targets concatenated in chromosome order, total_loss = sum of per-chromosome mean BCE.
+        to_cpu=True returns CPU tensors like the reference (finetune.py:52-53 moves every chromosome's
+        predictions to the host); to_cpu=False leaves them on the device for chromegcn_amd.metrics.
+        Multi-rank: every rank returns the full concatenation (CPU)."""
         names = list(self.chroms) if names is None else list(names)
         train = split == "train"
         C = next(iter(self.chroms.values())).target.shape[1] if self.chroms else 0
         if self.world == 1:
-            losses, probs = [], []
+            total_n = sum(self.chroms[nm].n for nm in names)
+            preds_dev = torch.empty((total_n, C), device=self.device, dtype=torch.float32)
+            loss_dev = torch.zeros((), device=self.device, dtype=torch.float32)
+            off = 0
             for nm in names:
                 loss, p, _ = self.train_step(nm) if train else (*self.eval_step(nm), None)
-                losses.append(loss.clone())
-                probs.append(p.clone())
-            total = float(torch.stack(losses).sum().item()) if losses else 0.0
-            preds = torch.cat(probs, 0).cpu() if probs else torch.empty(0, C)
+                loss_dev += loss                      # stays on the device: no per-chromosome sync (finetune.py:51)
+                preds_dev[off:off + p.shape[0]].copy_(p)
+                off += p.shape[0]
+            if not to_cpu:
+                targets_dev = torch.cat([self.chroms[nm].target for nm in names], 0) if names else torch.empty(0, C, device=self.device)
+                return preds_dev, targets_dev, float(loss_dev.item())
+            total = float(loss_dev.item())
+            preds = preds_dev.cpu()
         else:
             plan = plan_shards({nm: self.chroms[nm].cost for nm in names}, self.world) if train else \
                 plan_shards({nm: self.chroms[nm].cost for nm in names}, self.world)
@@ -377,8 +388,10 @@ class GCNStage:
             torch.distributed.all_reduce(loss_sum, group=self.group)
             total = float(loss_sum.item())
             preds = _gather_predictions(mine, names, {nm: self.chroms[nm].n for nm in names}, C, plan, self)
-        targets = torch.cat([self.chroms[nm].target for nm in names], 0).cpu() if names else torch.empty(0, C)
-        return preds, targets, total
+        key = tuple(names)
+        if key not in self._targets_cpu:  # targets never change: one D2H per split, not one per epoch
+            self._targets_cpu[key] = torch.cat([self.chroms[nm].target for nm in names], 0).cpu() if names else torch.empty(0, C)
+        return preds, self._targets_cpu[key], total
 
 
 def _gather_predictions(mine, names, sizes, C, plan: ShardPlan, stage: GCNStage):

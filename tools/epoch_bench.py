@@ -43,10 +43,10 @@ def main():
     times = []
     for e in range(args.epochs + 1):  # epoch 0 = capture
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        preds, targets, loss = stage.run_split("train", splits["train"])
+        preds, targets, loss = stage.run_split("train", splits["train"], to_cpu=False)
         torch.cuda.synchronize(); t1 = time.perf_counter()
-        pv, tv, lv = stage.run_split("valid", splits["valid"])
-        pt, tt, lt = stage.run_split("test", splits["test"])
+        pv, tv, lv = stage.run_split("valid", splits["valid"], to_cpu=False)
+        pt, tt, lt = stage.run_split("test", splits["test"], to_cpu=False)
         torch.cuda.synchronize(); t2 = time.perf_counter()
         mv = M.compute_metrics(pv, tv, lv, None, 0.0)
         mt = M.compute_metrics(pt, tt, lt, None, 0.0)
@@ -64,7 +64,7 @@ def main():
     if args.sklearn:
         from oracle import chromegcn_oracle as O
         t0 = time.perf_counter()
-        O.multilabel_metrics_np(tv.numpy().astype("float64"), pv.numpy())
+        O.multilabel_metrics_np(tv.cpu().numpy().astype("float64"), pv.cpu().numpy())
         out["sklearn_valid_split_s"] = time.perf_counter() - t0
         out["valid_windows"] = int(tv.shape[0])
     print(json.dumps(out))
