@@ -23,7 +23,7 @@ _SIGNATURES = {
     "cgcn_spmm": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp]),
     "cgcn_layer_fwd": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 13 + [_c_float, _c_vp, _c_uint]),
     "cgcn_layer_bwd_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
-    "cgcn_layer_bwd": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 18 + [_c_int, _c_float, _c_vp, _c_uint, _c_vp, _c_vp, _c_sz]),
+    "cgcn_layer_bwd": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 18 + [_c_int, _c_float, _c_vp, _c_uint, _c_vp, _c_vp, _c_sz, _c_vp]),
     "cgcn_head_workspace_bytes": (_c_sz, [_c_int] * 4),
     "cgcn_head_workspace_layout": (_c_int, [_c_int] * 4 + [ctypes.POINTER(_c_sz), ctypes.POINTER(_c_sz)]),
     "cgcn_head_fwd": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp] * 6 + [_c_float, _c_float, _c_int] + [_c_vp] * 3
@@ -36,7 +36,7 @@ _SIGNATURES = {
     "cgcn_multilabel_metrics": (_c_int, [_c_vp, ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_float, _c_vp, _c_vp, _c_sz]),
     "cgcn_sgd_step": (_c_int, [_c_vp, ctypes.c_longlong, _c_vp, _c_vp, _c_vp, _c_float, _c_float, _c_float, _c_int, _c_vp]),
 }
-ABI_VERSION = 5
+ABI_VERSION = 6
 _lib = None
 
 
@@ -94,3 +94,17 @@ def ptr(t):
 
 def stream_ptr():
     return torch.cuda.current_stream().cuda_stream
+
+
+_aux_streams = {}
+
+
+def aux_stream_ptr():
+    """a per-device side stream for cgcn_layer_bwd's concurrent partial reduction (0 = disabled)"""
+    if os.environ.get("CHROMEGCN_NO_AUX_STREAM"):
+        return None
+    dev = torch.cuda.current_device()
+    s = _aux_streams.get(dev)
+    if s is None:
+        s = _aux_streams[dev] = torch.cuda.Stream(device=dev)
+    return s.cuda_stream

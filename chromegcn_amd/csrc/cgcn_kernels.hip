@@ -851,6 +851,21 @@ static inline int pick_mb(int n, int S) {
   return ((n + tn2 - 1) / tn2 >= MB2_MIN_TILES) ? 2 : 1;
 }
 
+// Events for fork/join edges between the main and the auxiliary stream.  A small pool reused round-robin;
+// never destroyed (an event may still be referenced by a captured graph).  This is the only state the
+// library keeps, and it holds no caller memory.
+static hipEvent_t pooled_event() {
+  static hipEvent_t pool[64];
+  static unsigned next = 0;
+  static bool init = false;
+  if (!init) {
+    for (auto& e : pool)
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+    init = true;
+  }
+  return pool[(next++) & 63];
+}
+
 static int dropout_args(float p, const unsigned long long* rng_state, float* keep_scale, uint32_t* thresh) {
   *keep_scale = 1.f;
   *thresh = 0u;
@@ -941,7 +956,7 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
                    const float* gate, const float* W, const float* wg, const float* dXn, const float* dgate, float* dX,
                    float* dUs, float* dW, float* db, float* dwg, float* dcg, int accumulate, float in_dropout_p,
                    const unsigned long long* rng_state, unsigned int in_stream_id, const cgcn_head_grad* head,
-                   void* workspace, size_t workspace_bytes) {
+                   void* workspace, size_t workspace_bytes, cgcn_stream_t aux_stream) {
   int rc = check_shape(n, S, d);
   if (rc) return rc;
   if (!rowptr_t || !col_t || !X || !Z || !H || !gate || !W || !wg || !dX || !dUs || !dW || !db || !dwg || !dcg)
@@ -969,9 +984,22 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   else
     hipLaunchKernelGGL((k_bwd_rowlocal<256>), dim3(P), dim3(512), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dUs, part, hp, dX);
   if ((rc = launch_status())) return rc;
+  // The reduction of the per-tile partials and the gather kernel are independent: with an auxiliary stream
+  // they run side by side (fork after k_bwd_rowlocal, join before returning; both edges are events, so the
+  // fork/join is captured as graph dependencies under HIP-graph capture).
   const int total = d * d + 2 * d + 1;
-  hipLaunchKernelGGL(k_reduce_partials, dim3((total + 63) / 64), dim3(256), 0, st, P, d, part, dW, db, dwg, dcg, accumulate);
+  hipStream_t rs_stream = st;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  if (aux_stream && aux_stream != stream && n > 0) {
+    ev_fork = pooled_event();
+    ev_join = pooled_event();
+    if (ev_fork && ev_join && hipEventRecord(ev_fork, st) == hipSuccess &&
+        hipStreamWaitEvent((hipStream_t)aux_stream, ev_fork, 0) == hipSuccess)
+      rs_stream = (hipStream_t)aux_stream;
+  }
+  hipLaunchKernelGGL(k_reduce_partials, dim3((total + 63) / 64), dim3(256), 0, rs_stream, P, d, part, dW, db, dwg, dcg, accumulate);
   if ((rc = launch_status())) return rc;
+  if (rs_stream != st && hipEventRecord(ev_join, rs_stream) != hipSuccess) return CGCN_ERR_LAUNCH;
   if (n == 0) return CGCN_OK;
   const int mb = pick_mb(n, S);
   const int tn = 16 * mb / S;
@@ -988,7 +1016,9 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   } while (0)
   DISPATCH_SDV(S, d, val_t != nullptr, CALL);
 #undef CALL
-  return launch_status();
+  if ((rc = launch_status())) return rc;
+  if (rs_stream != st && hipStreamWaitEvent(st, ev_join, 0) != hipSuccess) return CGCN_ERR_LAUNCH;  // join
+  return CGCN_OK;
 }
 
 int cgcn_sddmm(cgcn_stream_t stream, int n, int S, int d, const int32_t* rowptr, const int32_t* col, const float* A,

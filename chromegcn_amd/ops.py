@@ -159,7 +159,7 @@ class GatedLayerFn(torch.autograd.Function):
                                       h.data_ptr(), gate.data_ptr(), weight.data_ptr(), wg.data_ptr(),
                                       dxn.data_ptr(), _lib.ptr(dgate), dx.data_ptr(), dus.data_ptr(), dw.data_ptr(),
                                       db.data_ptr(), dwg.data_ptr(), dcg.data_ptr(), 0, ctx.dropout_in,
-                                      _lib.ptr(rng_state), max(ctx.layer_id - 1, 0), None, ws.data_ptr(), ws_bytes),
+                                      _lib.ptr(rng_state), max(ctx.layer_id - 1, 0), None, ws.data_ptr(), ws_bytes, _lib.aux_stream_ptr()),
                    "cgcn_layer_bwd")
         if _saliency_tap is not None:
             _saliency_tap.append((x, dus, weight, g))  # dus = diag(row_scale) dL/dU of this layer
@@ -357,7 +357,7 @@ class LastLayerHeadLossFn(torch.autograd.Function):
                                       h.data_ptr(), gate.data_ptr(), weight.data_ptr(), wg.data_ptr(),
                                       None, None, dx.data_ptr(), dus.data_ptr(), dw.data_ptr(), db.data_ptr(),
                                       dwg.data_ptr(), dcg.data_ptr(), 0, ctx.dropout_in, _lib.ptr(rng_state),
-                                      max(ctx.layer_id - 1, 0), ctypes.byref(hg), ws.data_ptr(), ws_bytes), "cgcn_layer_bwd")
+                                      max(ctx.layer_id - 1, 0), ctypes.byref(hg), ws.data_ptr(), ws_bytes, _lib.aux_stream_ptr()), "cgcn_layer_bwd")
         gl = (None,) * 4 if ctx.layer_sink is not None else (dw, db, dwg.view(ctx.shapes[0]), dcg.view(ctx.shapes[1]))
         gh = (None,) * 4 if ctx.head_sink is not None else (dbn_w, dbn_b, dw_out, db_out)
         return (dx,) + gl + gh + (None,) * 14

@@ -10,8 +10,9 @@
  *
  * Conventions
  *   - Every pointer is a DEVICE pointer unless marked "host".  No torch types.
- *   - All work is enqueued on `stream` (a hipStream_t passed as void*); nothing here
- *     synchronises, allocates or frees device memory, or keeps a pointer after return.
+ *   - All work is enqueued on `stream` (a hipStream_t passed as void*; cgcn_layer_bwd may also use
+ *     a caller-provided auxiliary stream); nothing here synchronises the host, allocates or frees
+ *     device memory, or keeps a caller pointer after return.
  *     All entry points are therefore legal inside HIP-graph stream capture.
  *   - Return value: CGCN_OK (0) or a negative CGCN_ERR_* code; cgcn_strerror() names it.
  *   - Dense matrices are row-major fp32.  Node features are laid out [S, n, d]:
@@ -47,7 +48,7 @@ extern "C" {
 #define CGCN_ERR_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after a launch      */
 #define CGCN_ERR_WORKSPACE (-4)   /* workspace too small (see cgcn_*_workspace_bytes)    */
 
-#define CGCN_ABI_VERSION 5
+#define CGCN_ABI_VERSION 6
 
 typedef void *cgcn_stream_t; /* hipStream_t */
 
@@ -121,6 +122,8 @@ size_t cgcn_layer_bwd_workspace_bytes(int n, int S, int d);
  * in_dropout_p > 0: X was produced by a layer that applied dropout (in_stream_id = that layer's
  * stream_id); dX is then the gradient w.r.t. the pre-dropout tensor (mask / (1-p) applied).
  * Exactly one of dXn and head must be non-NULL (head: see cgcn_head_grad).
+ * aux_stream (may be NULL): a second stream on which the partial-sum reduction runs concurrently with the
+ * gather kernel; forked from and joined back into `stream` with events inside this call.
  */
 int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d,
                    const int32_t *rowptr_t, const int32_t *col_t, const float *val_t, const float *row_scale,
@@ -130,7 +133,7 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d,
                    float *dX, float *dUs, float *dW, float *db, float *dwg, float *dcg,
                    int accumulate, float in_dropout_p, const unsigned long long *rng_state,
                    unsigned int in_stream_id, const cgcn_head_grad *head,
-                   void *workspace, size_t workspace_bytes);
+                   void *workspace, size_t workspace_bytes, cgcn_stream_t aux_stream);
 
 /* Bytes of scratch cgcn_head_fwd / cgcn_head_bwd need for (n, S, d, C).  0 on unsupported shapes. */
 size_t cgcn_head_workspace_bytes(int n, int S, int d, int C);
