@@ -100,8 +100,10 @@ _aux_streams = {}
 
 
 def aux_stream_ptr():
-    """a per-device side stream for cgcn_layer_bwd's concurrent partial reduction (0 = disabled)"""
-    if os.environ.get("CHROMEGCN_NO_AUX_STREAM"):
+    """a per-device side stream for cgcn_layer_bwd's concurrent partial reduction.  OFF by default: measured on
+    MI355X (chr21-like step, HIP graph) the fork/join edges cost more than the 7.5 us reduction they hide
+    (0.295 ms with, 0.277 ms without).  CHROMEGCN_AUX_STREAM=1 turns it on."""
+    if not os.environ.get("CHROMEGCN_AUX_STREAM"):
         return None
     dev = torch.cuda.current_device()
     s = _aux_streams.get(dev)
