@@ -806,12 +806,12 @@ __global__ __launch_bounds__(256) void k_sddmm(int n, const int* __restrict__ ro
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_sgd(int count, float* __restrict__ p, const float* __restrict__ g,
                                              float* __restrict__ m, float lr, float mu, float wd, int nesterov,
-                                             unsigned long long* __restrict__ rng_state) {
+                                             float grad_scale, unsigned long long* __restrict__ rng_state) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0 && rng_state) rng_state[1] += 1ull;
   if (i >= count) return;
   const float pi = p[i];
-  float d = g[i] + wd * pi;
+  float d = g[i] * grad_scale + wd * pi;
   float upd = d;
   if (m) {
     const float b = mu * m[i] + d;
@@ -1037,7 +1037,7 @@ int cgcn_sddmm(cgcn_stream_t stream, int n, int S, int d, const int32_t* rowptr,
 }
 
 int cgcn_sgd_step(cgcn_stream_t stream, long long count, float* param, const float* grad, float* momentum_buf, float lr,
-                  float momentum, float weight_decay, int nesterov, unsigned long long* rng_state) {
+                  float momentum, float weight_decay, int nesterov, float grad_scale, unsigned long long* rng_state) {
   if (count < 0 || count > 2147483647LL) return CGCN_ERR_UNSUPPORTED;
   if (count > 0 && (!param || !grad)) return CGCN_ERR_BAD_ARG;
   if (momentum != 0.f && !momentum_buf) return CGCN_ERR_BAD_ARG;
@@ -1045,7 +1045,7 @@ int cgcn_sgd_step(cgcn_stream_t stream, long long count, float* param, const flo
   hipStream_t st = (hipStream_t)stream;
   const int blocks = count > 0 ? (int)((count + 255) / 256) : 1;
   hipLaunchKernelGGL(k_sgd, dim3(blocks), dim3(256), 0, st, (int)count, param, grad, momentum != 0.f ? momentum_buf : nullptr,
-                     lr, momentum, weight_decay, nesterov, rng_state);
+                     lr, momentum, weight_decay, nesterov, grad_scale, rng_state);
   return launch_status();
 }
 

@@ -165,16 +165,19 @@ class GCNStage:
         self.model._grad_sink = dev.type == "cuda" and hasattr(self.model, "forward_loss") and self.fused_head
         self._graphs.clear()
 
-    def _optimizer_step(self):
+    def _optimizer_step(self, grad_scale: float = 1.0):
         """finetune.py:49.  Plain torch SGD runs as one fused launch over the flat buffers (which also
-        advances the dropout counter); anything else goes through optimizer.step()."""
+        advances the dropout counter and applies the 1/k of a k-rank step group); anything else goes
+        through optimizer.step()."""
         rng = self.model._rng_state if getattr(self.model, "_rng_managed", False) else None
         if self._fused_sgd:
             from . import ops
             g = self.optimizer.param_groups[0]
             ops.sgd_step(self._flat_param, self._flat_grad, self._flat_mom, g["lr"], g.get("momentum", 0),
-                         g.get("weight_decay", 0), g.get("nesterov", False), rng)
+                         g.get("weight_decay", 0), g.get("nesterov", False), rng, grad_scale)
         else:
+            if grad_scale != 1.0:
+                self._flat_grad.mul_(grad_scale)
             self.optimizer.step()
             if rng is not None:
                 rng[1] += 1
@@ -311,9 +314,7 @@ class GCNStage:
             self._flat_grad.zero_()
         if self.world > 1:
             torch.distributed.all_reduce(self._flat_grad, op=torch.distributed.ReduceOp.SUM, group=self.group)
-        if group_size > 1:
-            self._flat_grad.div_(group_size)
-        self._optimizer_step()
+        self._optimizer_step(1.0 / group_size if group_size > 1 else 1.0)
         return out
 
     def sync_running_stats(self):

@@ -377,9 +377,9 @@ def head_loss(x, bn: torch.nn.BatchNorm1d, out: torch.nn.Linear, target, trainin
                             grad_sink)
 
 
-def sgd_step(flat_param, flat_grad, flat_mom, lr, momentum, weight_decay, nesterov, rng_state=None):
+def sgd_step(flat_param, flat_grad, flat_mom, lr, momentum, weight_decay, nesterov, rng_state=None, grad_scale=1.0):
     """torch.optim.SGD step on flat buffers in one launch (cgcn_sgd_step); also advances the dropout counter."""
     lib = _lib.load()
     _lib.check(lib.cgcn_sgd_step(_lib.stream_ptr(), flat_param.numel(), flat_param.data_ptr(), flat_grad.data_ptr(),
                                  _lib.ptr(flat_mom), float(lr), float(momentum), float(weight_decay),
-                                 1 if nesterov else 0, _lib.ptr(rng_state)), "cgcn_sgd_step")
+                                 1 if nesterov else 0, float(grad_scale), _lib.ptr(rng_state)), "cgcn_sgd_step")

@@ -48,7 +48,7 @@ extern "C" {
 #define CGCN_ERR_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after a launch      */
 #define CGCN_ERR_WORKSPACE (-4)   /* workspace too small (see cgcn_*_workspace_bytes)    */
 
-#define CGCN_ABI_VERSION 6
+#define CGCN_ABI_VERSION 7
 
 typedef void *cgcn_stream_t; /* hipStream_t */
 
@@ -228,13 +228,15 @@ int cgcn_multilabel_metrics(cgcn_stream_t stream, long long n, int C, const floa
 /*
  * torch.optim.SGD step on one flat fp32 buffer (utils/util_methods.py:14-19 builds
  * SGD(lr, momentum=0.9, weight_decay=1e-6); dampening 0):
- *     d = grad + weight_decay * param;  buf = momentum * buf + d;
+ *     d = grad_scale * grad + weight_decay * param;  buf = momentum * buf + d;
  *     param -= lr * (nesterov ? d + momentum * buf : buf)
  * momentum_buf zero-initialised reproduces torch's first step (buf = d); may be NULL when momentum == 0.
+ * grad_scale: 1, or 1/k when grad holds the all-reduced SUM of k ranks' gradients (multi-GPU step group).
  * rng_state (may be NULL): its step counter is advanced by one -- this is the last kernel of a train step.
  */
 int cgcn_sgd_step(cgcn_stream_t stream, long long count, float *param, const float *grad, float *momentum_buf,
-                  float lr, float momentum, float weight_decay, int nesterov, unsigned long long *rng_state);
+                  float lr, float momentum, float weight_decay, int nesterov, float grad_scale,
+                  unsigned long long *rng_state);
 
 #ifdef __cplusplus
 }

@@ -123,6 +123,6 @@ def test_fused_sgd_matches_torch(momentum, wd, nesterov):
         g = torch.randn(n, device=DEV)
         par.grad = g.clone()
         opt.step()
-        ops.sgd_step(p, g, mom if momentum else None, 0.25, momentum, wd, nesterov, rng)
+        ops.sgd_step(p, g * 4.0, mom if momentum else None, 0.25, momentum, wd, nesterov, rng, grad_scale=0.25)
         np.testing.assert_allclose(p.cpu().numpy(), par.detach().cpu().numpy(), atol=1e-6, rtol=1e-6)
     assert int(rng[1].item()) == 13
