@@ -260,7 +260,8 @@ class GCNStage:
         graph = torch.cuda.CUDAGraph()
         if self._pool is None:
             self._pool = torch.cuda.graph_pool_handle()
-        with torch.cuda.graph(graph, pool=self._pool):
+        # thread_local: an RCCL watchdog thread polling events while we capture must not invalidate the capture
+        with torch.cuda.graph(graph, pool=self._pool, capture_error_mode="thread_local"):
             loss, probs, dx = body()
         self._restore(snap)  # capture launches nothing, but keep state bit-identical regardless
         self.model.train(was_training)

@@ -90,3 +90,47 @@ def test_step_group_path_equals_single_rank_step(golden):
     for k in outs[0][0]:
         assert torch.equal(outs[0][0][k], outs[1][0][k]), k
     assert torch.equal(outs[0][1], outs[1][1])
+
+
+def test_finetune_reads_graph_pickle_like_the_reference(tmp_path, golden):
+    """finetune.py:20-23: graphs come from <graph_root>/<split>_graphs_<hicsize>_<hicnorm>norm.pkl"""
+    import pickle
+    z = golden("g4_finetune_loop.npz")
+    chroms, feats, graphs = _load(z)
+    with open(str(tmp_path / "valid_graphs_500000_SQRTVCnorm.pkl"), "wb") as f:
+        pickle.dump(graphs, f)
+    init = state_from(z, "final")
+    m = C.ChromeGCN(128, 128, init["out.weight"].shape[0], 0.0, True, 2)
+    m.load_state_dict(init); m.to(DEV)
+    opt = types.SimpleNamespace(adj_type="hic", graph_root=str(tmp_path), hicsize="500000", hicnorm="SQRTVC")
+    preds, targets, total = finetune(None, m, feats, None, None, 1, None, opt, "valid")
+    np.testing.assert_allclose(preds.numpy(), z["eval_preds"], atol=1e-4, rtol=1e-4)
+    assert abs(total - z["eval_losses"].sum()) < 2e-4
+
+
+def test_training_with_dropout_learns_a_planted_signal():
+    """end-to-end sanity with everything on (dropout 0.2, captured graphs, fused SGD): targets planted by a
+    teacher network of the same family must become predictable -- the loss has to fall well below chance."""
+    from chromegcn_amd import synth
+    torch.manual_seed(0)
+    n, d, c = 1500, 128, 12
+    hic = synth.contact_graph(n, 12000, 3)
+    feats = synth.chrom_features(n, d, c, 4)
+    teacher = C.ChromeGCN(d, d, c, 0.0, True, 2).to(DEV).eval()
+    with torch.no_grad():
+        for k, p in teacher.named_parameters():
+            if p.dim() == 2:
+                p.copy_(torch.randn_like(p) / np.sqrt(p.shape[-1]) * 2.0)
+        g = C.process_graph("hic", {"c": hic}, n, "c", device=DEV)
+        logits, _ = teacher.forward_strands(torch.stack([feats["forward"], feats["backward"]]).to(DEV), g)
+        feats["target"] = ((logits[0] + logits[1]) / 2 > 0).float().cpu()
+    model = C.ChromeGCN(d, d, c, 0.2, True, 2).to(DEV)
+    optim = torch.optim.SGD(model.parameters(), lr=0.25, momentum=0.9, weight_decay=1e-6)
+    st = GCNStage(model, optim, "hic", DEV, hip_graphs=True)
+    st.add_chromosome("c", feats, hic)
+    first = st.train_step("c")[0].item()
+    for _ in range(150):
+        loss = st.train_step("c")[0]
+    ev, probs = st.eval_step("c")
+    acc = ((probs > 0.5).float().cpu() == feats["target"]).float().mean().item()
+    assert loss.item() < 0.6 * first and acc > 0.75, (first, loss.item(), ev.item(), acc)
