@@ -630,21 +630,21 @@ __global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float*
   }
 }
 
-// Second stage: out[e] (+)= sum_p part[p][e].  64 elements x 4 partial-slices per workgroup: every
-// thread sums P/4 partials with 16 loads in flight, the 4 slices are combined through LDS in a fixed
-// order => deterministic, and latency is ~P/64 dependent round trips instead of P.
-__global__ __launch_bounds__(256) void k_reduce_partials(int P, int D, const float* __restrict__ part,
-                                                         float* __restrict__ dW, float* __restrict__ db,
-                                                         float* __restrict__ dwg, float* __restrict__ dcg,
-                                                         int accumulate) {
+// One 64-element slab of the second-stage sum, computed by a workgroup of NT threads (NT/64 partial slices).
+// Used by k_reduce_partials and, fused "horizontally", by the extra workgroups at the end of k_bwd_gather's grid.
+template <int NT>
+__device__ __forceinline__ void reduce_slab(int slab, int P, int D, const float* __restrict__ part,
+                                            float* __restrict__ dW, float* __restrict__ db, float* __restrict__ dwg,
+                                            float* __restrict__ dcg, int accumulate) {
+  constexpr int NS = NT / 64;
   const int PSTRIDE = D * D + 2 * D + 4;
   const int total = D * D + 2 * D + 1;
-  __shared__ float red[4][64];
+  __shared__ float red[NS][64];
   const int el = threadIdx.x & 63, slice = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + el;
+  const int e = slab * 64 + el;
   float s = 0.f;
   if (e < total) {
-    const int per = (P + 3) / 4;
+    const int per = (P + NS - 1) / NS;
     const int p0 = slice * per, p1 = min(P, p0 + per);
     int p = p0;
     for (; p + 16 <= p1; p += 16) {
@@ -659,7 +659,9 @@ __global__ __launch_bounds__(256) void k_reduce_partials(int P, int D, const flo
   red[slice][el] = s;
   __syncthreads();
   if (slice == 0 && e < total) {
-    s = ((red[0][el] + red[1][el]) + red[2][el]) + red[3][el];
+    s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NS; ++w) s += red[w][el];
     float* dst;
     if (e < D * D) dst = dW + e;
     else if (e < D * D + D) dst = db + (e - D * D);
@@ -667,6 +669,14 @@ __global__ __launch_bounds__(256) void k_reduce_partials(int P, int D, const flo
     else dst = dcg;
     *dst = accumulate ? (*dst + s) : s;
   }
+}
+
+// Second stage: out[e] (+)= sum_p part[p][e], fixed order => deterministic.
+__global__ __launch_bounds__(256) void k_reduce_partials(int P, int D, const float* __restrict__ part,
+                                                         float* __restrict__ dW, float* __restrict__ db,
+                                                         float* __restrict__ dwg, float* __restrict__ dcg,
+                                                         int accumulate) {
+  reduce_slab<256>(blockIdx.x, P, D, part, dW, db, dwg, dcg, accumulate);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -680,7 +690,10 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) void k_bwd_g
                                                       const float* __restrict__ gate, float* dX,
                                                       float keep_scale, uint32_t thresh,
                                                       const unsigned long long* __restrict__ rng_state,
-                                                      uint32_t stream_id) {
+                                                      uint32_t stream_id, int gather_blocks, int P,
+                                                      const float* __restrict__ part, float* __restrict__ dW,
+                                                      float* __restrict__ db, float* __restrict__ dwg,
+                                                      float* __restrict__ dcg, int accumulate) {
   using G = Geo<S, D>;
   constexpr int ROWS = 16 * MB;
   constexpr int R = ROWS / S;
@@ -690,12 +703,18 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) void k_bwd_g
   constexpr int EPL = D / 64;
   constexpr int RPW = (ROWS + NW - 1) / NW;
   constexpr bool PRE = (D == 128);
+  // Horizontal fusion: the workgroups past the gather tiles do the (independent) second-stage sum of the
+  // row-local kernel's partials, so that reduction costs no launch of its own and overlaps the gather's tail.
+  if ((int)blockIdx.x >= gather_blocks) {
+    reduce_slab<NW * 64>(blockIdx.x - gather_blocks, P, D, part, dW, db, dwg, dcg, accumulate);
+    return;
+  }
   __shared__ __attribute__((aligned(16))) float T[ROWS * LD];
   __shared__ __attribute__((aligned(16))) float LR[NW * S * D];  // hub-row partial sums (gather_tile)
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int node0 = xcd_contiguous(blockIdx.x, gridDim.x) * R;
+  const int node0 = xcd_contiguous(blockIdx.x, gather_blocks) * R;
 
   float bw[CBW][D / 4];
   if (PRE) load_wfrag<D, CBW, true>(W, wave, lane, bw);
@@ -1009,9 +1028,13 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
         hipStreamWaitEvent((hipStream_t)aux_stream, ev_fork, 0) == hipSuccess)
       rs_stream = (hipStream_t)aux_stream;
   }
-  hipLaunchKernelGGL(k_reduce_partials, dim3((total + 63) / 64), dim3(256), 0, rs_stream, P, d, part, dW, db, dwg, dcg, accumulate);
-  if ((rc = launch_status())) return rc;
-  if (rs_stream != st && hipEventRecord(ev_join, rs_stream) != hipSuccess) return CGCN_ERR_LAUNCH;
+  const int slabs = (total + 63) / 64;
+  const bool fuse_reduce = (rs_stream == st) && n > 0;  // default: the sum rides at the end of the gather launch
+  if (!fuse_reduce) {
+    hipLaunchKernelGGL(k_reduce_partials, dim3(slabs), dim3(256), 0, rs_stream, P, d, part, dW, db, dwg, dcg, accumulate);
+    if ((rc = launch_status())) return rc;
+    if (rs_stream != st && hipEventRecord(ev_join, rs_stream) != hipSuccess) return CGCN_ERR_LAUNCH;
+  }
   if (n == 0) return CGCN_OK;
   const int mb = pick_mb(n, S);
   const int tn = 16 * mb / S;
@@ -1020,11 +1043,13 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
 #define CALL(S_, D_, V_)                                                                                             \
   do {                                                                                                               \
     if (mb == 2)                                                                                                     \
-      hipLaunchKernelGGL((k_bwd_gather<S_, D_, 2, V_>), dim3(blocks), dim3((D_ == 128 && CBW128 == 2) ? 256 : 512), 0, st, n, rowptr_t, col_t, val_t, dUs, \
-                         W, dXn, gate, dX, ks, th, rng_state, in_stream_id);                                         \
+      hipLaunchKernelGGL((k_bwd_gather<S_, D_, 2, V_>), dim3(blocks + (fuse_reduce ? slabs : 0)),                    \
+                         dim3((D_ == 128 && CBW128 == 2) ? 256 : 512), 0, st, n, rowptr_t, col_t, val_t, dUs,       \
+                         W, dXn, gate, dX, ks, th, rng_state, in_stream_id, blocks, P, part, dW, db, dwg, dcg, accumulate); \
     else                                                                                                             \
-      hipLaunchKernelGGL((k_bwd_gather<S_, D_, 1, V_>), dim3(blocks), dim3((D_ == 128 && CBW128 == 2) ? 256 : 512), 0, st, n, rowptr_t, col_t, val_t, dUs, \
-                         W, dXn, gate, dX, ks, th, rng_state, in_stream_id);                                         \
+      hipLaunchKernelGGL((k_bwd_gather<S_, D_, 1, V_>), dim3(blocks + (fuse_reduce ? slabs : 0)),                    \
+                         dim3((D_ == 128 && CBW128 == 2) ? 256 : 512), 0, st, n, rowptr_t, col_t, val_t, dUs,       \
+                         W, dXn, gate, dX, ks, th, rng_state, in_stream_id, blocks, P, part, dW, db, dwg, dcg, accumulate); \
   } while (0)
   DISPATCH_SDV(S, d, val_t != nullptr, CALL);
 #undef CALL
