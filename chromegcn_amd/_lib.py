@@ -25,7 +25,8 @@ _SIGNATURES = {
     "cgcn_layer_bwd_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
     "cgcn_layer_bwd": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 18 + [_c_int, _c_float, _c_vp, _c_uint, _c_vp, _c_vp, _c_sz, _c_vp]),
     "cgcn_head_workspace_bytes": (_c_sz, [_c_int] * 4),
-    "cgcn_head_workspace_layout": (_c_int, [_c_int] * 4 + [ctypes.POINTER(_c_sz), ctypes.POINTER(_c_sz)]),
+    "cgcn_head_workspace_layout": (_c_int, [_c_int] * 4 + [ctypes.POINTER(_c_sz)] * 3),
+    "cgcn_head_bwd_partials": (_c_int, [_c_int]),
     "cgcn_head_fwd": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp] * 6 + [_c_float, _c_float, _c_int] + [_c_vp] * 3
                       + [_c_float] + [_c_vp] * 7 + [_c_sz]),
     "cgcn_head_bwd": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp] * 8 + [_c_float] + [_c_vp] * 6 + [_c_int, _c_vp, _c_sz]),
@@ -36,7 +37,7 @@ _SIGNATURES = {
     "cgcn_multilabel_metrics": (_c_int, [_c_vp, ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_float, _c_vp, _c_vp, _c_sz]),
     "cgcn_sgd_step": (_c_int, [_c_vp, ctypes.c_longlong, _c_vp, _c_vp, _c_vp, _c_float, _c_float, _c_float, _c_int, _c_float, _c_vp]),
 }
-ABI_VERSION = 7
+ABI_VERSION = 8
 _lib = None
 
 
@@ -84,7 +85,8 @@ def check(rc, what):
 class HeadGrad(ctypes.Structure):
     """mirror of cgcn_head_grad (include/chromegcn.h)"""
     _fields_ = [("dym", _c_vp), ("bnc", _c_vp), ("save_mean", _c_vp), ("save_invstd", _c_vp), ("bn_w", _c_vp),
-                ("dropout_p", _c_float), ("rng_state", _c_vp)]
+                ("dropout_p", _c_float), ("rng_state", _c_vp), ("part", _c_vp), ("n_partials", _c_int), ("C", _c_int),
+                ("dW_out", _c_vp), ("db_out", _c_vp), ("accumulate", _c_int)]
 
 
 def ptr(t):

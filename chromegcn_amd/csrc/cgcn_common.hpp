@@ -72,7 +72,77 @@ struct HeadApply {
   float keep_scale;
   uint32_t thresh;
   int S;
+  // deferred second stage of the head's dW_out / db_out sums (run by extra workgroups of k_bwd_rowlocal)
+  const float* hf_part;  // [P][CP*D + CP + 4*D] partials of k_head_bwd
+  float* hf_dWout;       // [C][D]
+  float* hf_dbout;       // [C]
+  int hf_P, hf_C, hf_CP, hf_accumulate;
 };
+
+// One 64-element slab of the head backward's second stage.  Elements: [CP*D dW_out][CP db_out][D BatchNorm columns].
+// BatchNorm columns reduce (sum dy, sum dy*xhat) of both strands -> d(bn bias), d(bn weight), bnc = means.
+template <int NT>
+__device__ __forceinline__ void head_finalize_slab(int slab, int P, int n, int S, int D, int C, int CP,
+                                                   const float* __restrict__ part, float* __restrict__ dWout,
+                                                   float* __restrict__ dbout, float* __restrict__ dbn_w,
+                                                   float* __restrict__ dbn_b, float* __restrict__ bnc, int accumulate) {
+  constexpr int NS = NT / 64;
+  const int PS = CP * D + CP + 4 * D;
+  const int total = CP * D + CP + D;
+  __shared__ float hred[NS][4][64];
+  const int el = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int e = slab * 64 + el;
+  const bool stats = e >= CP * D + CP;
+  const int nq = stats ? 4 : 1;  // a stats element reduces (sdy_0, sdy_1, sdyx_0, sdyx_1) of one column
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (e < total) {
+    const int per = (P + NS - 1) / NS;
+    const int p0 = slice * per, p1 = min(P, p0 + per);
+    const int base = stats ? (CP * D + CP + (e - CP * D - CP)) : e;
+    for (int qd = 0; qd < nq; ++qd) {
+      float a = 0.f;
+      int p = p0;
+      for (; p + 8 <= p1; p += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = part[(size_t)(p + u) * PS + base + qd * D];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += t[u];
+      }
+      for (; p < p1; ++p) a += part[(size_t)p * PS + base + qd * D];
+      s[qd] = a;
+    }
+  }
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) hred[slice][qd][el] = s[qd];
+  __syncthreads();
+  if (slice != 0 || e >= total) return;
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) {
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < NS; ++w) a += hred[w][qd][el];
+    s[qd] = a;
+  }
+  if (e < CP * D) {
+    const int i = e / D;
+    if (i < C) dWout[e] = accumulate ? dWout[e] + s[0] : s[0];
+  } else if (e < CP * D + CP) {
+    const int j = e - CP * D;
+    if (j < C) dbout[j] = accumulate ? dbout[j] + s[0] : s[0];
+  } else {
+    const int c = e - CP * D - CP;
+    // s[0], s[1] = sum dy (strand 0, 1); s[2], s[3] = sum dy*xhat (strand 0, 1); strand 1 is zero when S == 1
+    const float db_ = s[0] + s[1], dg_ = s[2] + s[3];
+    dbn_b[c] = accumulate ? dbn_b[c] + db_ : db_;
+    dbn_w[c] = accumulate ? dbn_w[c] + dg_ : dg_;
+    const float invn = 1.f / (float)n;
+    for (int st = 0; st < S; ++st) {
+      bnc[(st * 2 + 0) * D + c] = s[st] * invn;
+      bnc[(st * 2 + 1) * D + c] = s[2 + st] * invn;
+    }
+  }
+}
 
 static inline bool misaligned16(const void* p) { return ((uintptr_t)p & 15u) != 0; }
 static inline int launch_status() { return hipGetLastError() == hipSuccess ? CGCN_OK : CGCN_ERR_LAUNCH; }

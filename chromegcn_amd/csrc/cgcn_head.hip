@@ -578,62 +578,13 @@ __global__ __launch_bounds__(512) void k_head_bwd(int n, int S, int C, const flo
   }
 }
 
-// second stage.  Elements: [CP*D dW_out][CP db_out][D columns of the BatchNorm sums]
-__global__ __launch_bounds__(256) void k_head_bwd_finalize(int P, int n, int S, int D, int C, int CP,
+// second stage (see head_finalize_slab): slabs [slab0, slab0 + gridDim.x)
+__global__ __launch_bounds__(256) void k_head_bwd_finalize(int slab0, int P, int n, int S, int D, int C, int CP,
                                                            const float* __restrict__ part, float* __restrict__ dWout,
                                                            float* __restrict__ dbout, float* __restrict__ dbn_w,
                                                            float* __restrict__ dbn_b, float* __restrict__ bnc,
                                                            int accumulate) {
-  const int PS = CP * D + CP + 4 * D;
-  const int total = CP * D + CP + D;
-  __shared__ float red[4][4][64];
-  const int el = threadIdx.x & 63, slice = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + el;
-  const bool stats = e >= CP * D + CP;
-  const int nq = stats ? 4 : 1;  // a stats element reduces (sdy_0, sdy_1, sdyx_0, sdyx_1) of one column
-  float s[4] = {0.f, 0.f, 0.f, 0.f};
-  if (e < total) {
-    const int per = (P + 3) / 4;
-    const int p0 = slice * per, p1 = min(P, p0 + per);
-    const int base = stats ? (CP * D + CP + (e - CP * D - CP)) : e;
-    for (int qd = 0; qd < nq; ++qd) {
-      float a = 0.f;
-      int p = p0;
-      for (; p + 8 <= p1; p += 8) {
-        float t[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = part[(size_t)(p + u) * PS + base + qd * D];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) a += t[u];
-      }
-      for (; p < p1; ++p) a += part[(size_t)p * PS + base + qd * D];
-      s[qd] = a;
-    }
-  }
-#pragma unroll
-  for (int qd = 0; qd < 4; ++qd) red[slice][qd][el] = s[qd];
-  __syncthreads();
-  if (slice != 0 || e >= total) return;
-#pragma unroll
-  for (int qd = 0; qd < 4; ++qd) s[qd] = ((red[0][qd][el] + red[1][qd][el]) + red[2][qd][el]) + red[3][qd][el];
-  if (e < CP * D) {
-    const int i = e / D;
-    if (i < C) dWout[e] = accumulate ? dWout[e] + s[0] : s[0];
-  } else if (e < CP * D + CP) {
-    const int j = e - CP * D;
-    if (j < C) dbout[j] = accumulate ? dbout[j] + s[0] : s[0];
-  } else {
-    const int c = e - CP * D - CP;
-    // s[0], s[1] = sum dy (strand 0, 1); s[2], s[3] = sum dy*xhat (strand 0, 1); strand 1 is zero when S == 1
-    const float db_ = s[0] + s[1], dg_ = s[2] + s[3];
-    dbn_b[c] = accumulate ? dbn_b[c] + db_ : db_;
-    dbn_w[c] = accumulate ? dbn_w[c] + dg_ : dg_;
-    const float invn = 1.f / (float)n;
-    for (int st = 0; st < S; ++st) {
-      bnc[(st * 2 + 0) * D + c] = s[st] * invn;
-      bnc[(st * 2 + 1) * D + c] = s[2 + st] * invn;
-    }
-  }
+  head_finalize_slab<256>(slab0 + blockIdx.x, P, n, S, D, C, CP, part, dWout, dbout, dbn_w, dbn_b, bnc, accumulate);
 }
 
 template <int D>
@@ -701,14 +652,17 @@ static inline size_t align4(size_t x) { return (x + 3) & ~(size_t)3; }
 
 extern "C" {
 
-int cgcn_head_workspace_layout(int n, int S, int d, int C, size_t* dym_offset, size_t* bnc_offset) {
+int cgcn_head_workspace_layout(int n, int S, int d, int C, size_t* dym_offset, size_t* bnc_offset, size_t* part_offset) {
   int rc = head_check(n, S, d, C);
   if (rc) return rc;
-  if (!dym_offset || !bnc_offset) return CGCN_ERR_BAD_ARG;
+  if (!dym_offset || !bnc_offset || !part_offset) return CGCN_ERR_BAD_ARG;
   *dym_offset = 4 * (align4(ws_stats(S, d)) + align4(ws_loss(n)));
   *bnc_offset = *dym_offset + 4 * align4(ws_dym(n, d));
+  *part_offset = *bnc_offset + 4 * align4(ws_bnc(d));
   return CGCN_OK;
 }
+
+int cgcn_head_bwd_partials(int n) { return head_bwd_partials(n); }
 
 size_t cgcn_head_workspace_bytes(int n, int S, int d, int C) {
   if (head_check(n, S, d, C) != CGCN_OK) return 0;
@@ -794,10 +748,17 @@ int cgcn_head_bwd(cgcn_stream_t stream, int n, int S, int d, int C, const float*
 #undef HB
   if ((rc = launch_status())) return rc;
   const int total = CP * d + CP + d;
-  hipLaunchKernelGGL(k_head_bwd_finalize, dim3((total + 63) / 64), dim3(256), 0, st, P, n, S, d, C, CP, w_part, dWout, dbout,
+  const int slabs = (total + 63) / 64, wslabs = (CP * d + CP) / 64;  // CP is 128 or 256: the split is slab aligned
+  if (!dX) {
+    // deferred mode: only the BatchNorm columns now (cgcn_layer_bwd needs bnc); the dW_out / db_out slabs ride at the
+    // end of k_bwd_rowlocal's grid (cgcn_head_grad.part / dW_out / db_out)
+    hipLaunchKernelGGL(k_head_bwd_finalize, dim3(slabs - wslabs), dim3(256), 0, st, wslabs, P, n, S, d, C, CP, w_part, dWout,
+                       dbout, dbn_w, dbn_b, w_bnc, accumulate);
+    return launch_status();
+  }
+  hipLaunchKernelGGL(k_head_bwd_finalize, dim3(slabs), dim3(256), 0, st, 0, P, n, S, d, C, CP, w_part, dWout, dbout,
                      dbn_w, dbn_b, w_bnc, accumulate);
   if ((rc = launch_status())) return rc;
-  if (!dX) return CGCN_OK;  // deferred: cgcn_layer_bwd (head mode) applies the BatchNorm backward itself
   const size_t total4 = (size_t)S * n * d / 4;
   int blocks = (int)((total4 + 255) / 256);
   if (blocks > 2048) blocks = 2048;

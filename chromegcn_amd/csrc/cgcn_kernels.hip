@@ -482,8 +482,15 @@ __global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float*
                                                       const float* __restrict__ H, const float* __restrict__ wg,
                                                       const float* __restrict__ rs, float* __restrict__ dUs,
                                                       float* __restrict__ part, HeadApply hp,
-                                                      float* __restrict__ dxn_store) {
+                                                      float* __restrict__ dxn_store, int row_blocks) {
   constexpr int NW = 8;
+  // extra workgroups past the row tiles: the head's deferred dW_out / db_out second stage (independent work,
+  // fused "horizontally" so it costs no launch of its own)
+  if ((int)blockIdx.x >= row_blocks) {
+    head_finalize_slab<512>(blockIdx.x - row_blocks, hp.hf_P, n, hp.S, D, hp.hf_C, hp.hf_CP, hp.hf_part, hp.hf_dWout,
+                            hp.hf_dbout, nullptr, nullptr, nullptr, hp.hf_accumulate);
+    return;
+  }
   constexpr int IBW = D / 128;        // 16-row blocks of dW owned by one wave (i index)
   constexpr int TR = (D == 128) ? BWD_TILE_ROWS : 32;  // 64-row tiles at D = 128; 32 at D = 256 (register budget)
   constexpr int LD = D + 16;          // stride = 16 (mod 32): conflict-free transposed ds_read_b32
@@ -514,7 +521,7 @@ __global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float*
   const uint32_t hkey = (hp.dym && hp.thresh) ? dropout_key(hp.rng_state, HEAD_STREAM_ID) : 0u;
 
   const int ntiles = (M + TR - 1) / TR;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int tile = blockIdx.x; tile < ntiles; tile += row_blocks) {
     // ---- row pass: all loads of the wave's RPW rows are issued before the first use
     float gup[RPW][EPL], z[RPW][EPL], x[RPW][EPL], h[RPW][EPL], gt[RPW], dgt[RPW];
 #pragma unroll
@@ -994,13 +1001,18 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
     return CGCN_ERR_BAD_ARG;
   if ((dXn == nullptr) == (head == nullptr)) return CGCN_ERR_BAD_ARG;  // exactly one source of dL/dXn
   if (dX == dXn || misaligned16(dUs) || misaligned16(dX) || misaligned16(W)) return CGCN_ERR_BAD_ARG;
-  HeadApply hp = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1.f, 0u, S};
+  HeadApply hp = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1.f, 0u, S, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+  int head_slabs = 0;
   if (head) {
     if (!head->dym || !head->bnc || !head->save_mean || !head->save_invstd || !head->bn_w) return CGCN_ERR_BAD_ARG;
+    if (!head->part || !head->dW_out || !head->db_out || head->C < 1 || head->C > 256) return CGCN_ERR_BAD_ARG;
     float hks;
     uint32_t hth;
     if ((rc = dropout_args(head->dropout_p, head->rng_state, &hks, &hth))) return rc;
-    hp = HeadApply{head->dym, head->bnc, head->save_mean, head->save_invstd, head->bn_w, head->rng_state, hks, hth, S};
+    const int CP = head->C <= 128 ? 128 : 256;
+    hp = HeadApply{head->dym, head->bnc, head->save_mean, head->save_invstd, head->bn_w, head->rng_state, hks, hth, S,
+                   head->part, head->dW_out, head->db_out, head->n_partials, head->C, CP, head->accumulate};
+    head_slabs = (CP * d + CP) / 64;
   }
   if (!workspace || workspace_bytes < cgcn_layer_bwd_workspace_bytes(n, S, d)) return CGCN_ERR_WORKSPACE;
   float ks;
@@ -1011,9 +1023,9 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   float* part = (float*)workspace;
   const int M = n * S;
   if (d == 128)
-    hipLaunchKernelGGL((k_bwd_rowlocal<128>), dim3(P), dim3(512), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dUs, part, hp, dX);
+    hipLaunchKernelGGL((k_bwd_rowlocal<128>), dim3(P + head_slabs), dim3(512), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dUs, part, hp, dX, P);
   else
-    hipLaunchKernelGGL((k_bwd_rowlocal<256>), dim3(P), dim3(512), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dUs, part, hp, dX);
+    hipLaunchKernelGGL((k_bwd_rowlocal<256>), dim3(P + head_slabs), dim3(512), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dUs, part, hp, dX, P);
   if ((rc = launch_status())) return rc;
   // The reduction of the per-tile partials and the gather kernel are independent: with an auxiliary stream
   // they run side by side (fork after k_bwd_rowlocal, join before returning; both edges are events, so the

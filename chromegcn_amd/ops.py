@@ -344,10 +344,13 @@ class LastLayerHeadLossFn(torch.autograd.Function):
                                      dw_out.data_ptr(), db_out.data_ptr(), dbn_w.data_ptr(), dbn_b.data_ptr(), 0,
                                      hws.data_ptr(), hws_bytes), "cgcn_head_bwd")
         import ctypes
-        o_dym, o_bnc = ctypes.c_size_t(), ctypes.c_size_t()
-        _lib.check(lib.cgcn_head_workspace_layout(n, S, d, C, ctypes.byref(o_dym), ctypes.byref(o_bnc)), "cgcn_head_workspace_layout")
+        o_dym, o_bnc, o_part = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+        _lib.check(lib.cgcn_head_workspace_layout(n, S, d, C, ctypes.byref(o_dym), ctypes.byref(o_bnc), ctypes.byref(o_part)),
+                   "cgcn_head_workspace_layout")
         hg = _lib.HeadGrad(hws.data_ptr() + o_dym.value, hws.data_ptr() + o_bnc.value, save_mean.data_ptr(),
-                           save_invstd.data_ptr(), bn_w.data_ptr(), ctx.dropout_p, _lib.ptr(rng_state))
+                           save_invstd.data_ptr(), bn_w.data_ptr(), ctx.dropout_p, _lib.ptr(rng_state),
+                           hws.data_ptr() + o_part.value, lib.cgcn_head_bwd_partials(n), C, dw_out.data_ptr(),
+                           db_out.data_ptr(), 0)
         dx = torch.empty_like(x)
         dus = torch.empty_like(x)
         ws_bytes = lib.cgcn_layer_bwd_workspace_bytes(n, S, d)

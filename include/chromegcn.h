@@ -48,7 +48,7 @@ extern "C" {
 #define CGCN_ERR_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after a launch      */
 #define CGCN_ERR_WORKSPACE (-4)   /* workspace too small (see cgcn_*_workspace_bytes)    */
 
-#define CGCN_ABI_VERSION 7
+#define CGCN_ABI_VERSION 8
 
 typedef void *cgcn_stream_t; /* hipStream_t */
 
@@ -102,6 +102,14 @@ typedef struct cgcn_head_grad {
   const float *bn_w;        /* [d]      */
   float dropout_p;          /* head dropout probability (0 = none) */
   const unsigned long long *rng_state;
+  /* in deferred mode cgcn_head_bwd leaves the second stage of dW_out / db_out to cgcn_layer_bwd, which runs it in
+   * extra workgroups of its row-local kernel: */
+  const float *part;        /* partials region of the head workspace (cgcn_head_workspace_layout) */
+  int n_partials;           /* cgcn_head_bwd_partials(n) */
+  int C;
+  float *dW_out;            /* [C,d] */
+  float *db_out;            /* [C]   */
+  int accumulate;
 } cgcn_head_grad;
 
 /* Bytes of scratch cgcn_layer_bwd needs for (n, S, d).  0 on unsupported shapes. */
@@ -138,9 +146,11 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d,
 /* Bytes of scratch cgcn_head_fwd / cgcn_head_bwd need for (n, S, d, C).  0 on unsupported shapes. */
 size_t cgcn_head_workspace_bytes(int n, int S, int d, int C);
 
-/* Byte offsets, inside that workspace, of the dym [n,d] and bnc [S,2,d] regions cgcn_head_bwd fills
- * (host pointers; see cgcn_head_grad). */
-int cgcn_head_workspace_layout(int n, int S, int d, int C, size_t *dym_offset, size_t *bnc_offset);
+/* Byte offsets, inside that workspace, of the dym [n,d], bnc [S,2,d] and per-workgroup partials regions
+ * cgcn_head_bwd fills (host pointers; see cgcn_head_grad), and the number of partial blocks. */
+int cgcn_head_workspace_layout(int n, int S, int d, int C, size_t *dym_offset, size_t *bnc_offset,
+                               size_t *part_offset);
+int cgcn_head_bwd_partials(int n);
 
 /*
  * Classifier head + loss of the GCN-stage step, fused (models/ChromeModels.py:48-51 applied to each
@@ -166,9 +176,10 @@ int cgcn_head_fwd(cgcn_stream_t stream, int n, int S, int d, int C, const float 
 
 /*
  * Backward of cgcn_head_fwd (training mode).  dloss: [1] upstream gradient of the loss or NULL (= 1).
- * Outputs dX [S,n,d] (or, with dX == NULL, only the dym / bnc state for cgcn_layer_bwd's head mode)
- * and, overwritten (accumulate == 0) or added to (accumulate != 0): dW_out [C,d],
- * db_out [C], dbn_w [d], dbn_b [d].  rng_state: same contents as in the forward.  Deterministic.
+ * Outputs dX [S,n,d] and, overwritten (accumulate == 0) or added to (accumulate != 0): dW_out [C,d],
+ * db_out [C], dbn_w [d], dbn_b [d].  With dX == NULL ("deferred mode") only dbn_w, dbn_b and the dym / bnc /
+ * partials state are produced; dX, dW_out and db_out are then finished by cgcn_layer_bwd given a
+ * cgcn_head_grad that points at this workspace.  rng_state: same contents as in the forward.  Deterministic.
  */
 int cgcn_head_bwd(cgcn_stream_t stream, int n, int S, int d, int C, const float *X, const float *bn_w,
                   const float *bn_b, const float *save_mean, const float *save_invstd, const float *W_out,
