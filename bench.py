@@ -82,7 +82,7 @@ def time_dominant_kernel(stage, name, reps):
     def launch():
         _lib.check(lib.cgcn_layer_fwd(_lib.stream_ptr(), n, S, d, _lib.ptr(g.rowptr), _lib.ptr(g.col), _lib.ptr(g.val),
                                       _lib.ptr(g.row_scale), c.x.data_ptr(), w.data_ptr(), b.data_ptr(), wg.data_ptr(),
-                                      cg.data_ptr(), xn.data_ptr(), z.data_ptr(), h.data_ptr(), gate.data_ptr(), 0.0, None, 0), "fwd")
+                                      cg.data_ptr(), xn.data_ptr(), z.data_ptr(), h.data_ptr(), gate.data_ptr(), 0.0, None, 0, None), "fwd")
     for _ in range(5):
         launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -183,8 +183,11 @@ def main():
     torch.manual_seed(0)  # identical initial parameters on every rank
     model = C.ChromeGCN(args.d, args.d, synth.N_LABELS, args.dropout, True, args.layers).to(dev)
     opt = torch.optim.SGD(model.parameters(), lr=0.25, momentum=0.9, weight_decay=1e-6)  # README.md:45 flags
+    # Headline configuration: EVERY step redoes all four sparse aggregations, like the reference.  (The engine's
+    # default additionally caches A X of the first layer, which is loop invariant because the node features are
+    # fixed -- measured separately below and reported as an extra field, never as `value`.)
     stage = GCNStage(model, opt, "hic", dev, hip_graphs=not args.no_hip_graph, input_grad=True,
-                     group=dist.group.WORLD if world > 1 else None)
+                     group=dist.group.WORLD if world > 1 else None, cache_input_aggregation=False)
     name = "%s_r%d" % (cname, rank)
     stage.add_chromosome(name, feats, hic)
     nnz = stage.chroms[name].graph.nnz
@@ -223,6 +226,22 @@ def main():
     fence()
     eval_elapsed = time.perf_counter() - t1
 
+    # extra: the same step with the first layer's aggregation cached (engine default)
+    stage.cache_input_aggregation = True
+    stage._graphs.clear()
+    for _ in range(max(args.warmup, 1)):
+        step()
+    fence()
+    t2 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    cached_elapsed = time.perf_counter() - t2
+    if world > 1:
+        t = torch.tensor([cached_elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        cached_elapsed = float(t.item())
+
     out = None
     if rank == 0:
         k_s = time_dominant_kernel(stage, name, 200)
@@ -257,6 +276,7 @@ def main():
                        "hip_graph": not args.no_hip_graph, "parallelism": "chromosome-per-rank x%d" % world},
             "roofline": roof, "cpu_baseline": cpu,
             "inference_windows_per_s": world * n * args.steps / eval_elapsed,
+            "value_with_cached_input_aggregation": world * n * args.steps / cached_elapsed,
             "final_loss": final_loss,
         }
         print(json.dumps(out))

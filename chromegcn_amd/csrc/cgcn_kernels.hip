@@ -378,7 +378,7 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) void k_layer
                                                      float* __restrict__ Zout, float* __restrict__ Hout,
                                                      float* __restrict__ gate, float keep_scale, uint32_t thresh,
                                                      const unsigned long long* __restrict__ rng_state,
-                                                     uint32_t stream_id) {
+                                                     uint32_t stream_id, const float* __restrict__ Hin) {
   using G = Geo<S, D>;
   constexpr int ROWS = 16 * MB;      // MFMA rows in the tile
   constexpr int R = ROWS / S;        // nodes in the tile
@@ -403,7 +403,24 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) void k_layer
   for (int v = 0; v < G::NV; ++v) lane_off[v] = ((unsigned)G::strand(v, lane) * (unsigned)n * D + G::column(v, lane)) * 4u;
 
   // ---- phase 1
-  gather_tile<S, D, HAS_VAL, R, NW, LD>(n, node0, rowptr, col, val, rs, (const char*)X, lane_off, T, Hout, LR, wave, lane);
+  if (Hin) {
+    // the aggregation was computed before (it does not depend on the weights: the engine caches A X of the
+    // first layer, whose input features never change): stream the rows in instead of gathering
+    for (int rr = wave; rr < R; rr += NW) {
+      const int i = node0 + rr;
+      if (!G::HALF || lane < 32) {
+#pragma unroll
+        for (int v = 0; v < G::NV; ++v) {
+          const int s = G::strand(v, lane), c = G::column(v, lane);
+          f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (i < n) t = *(const f32x4*)&Hin[((size_t)s * n + i) * D + c];
+          *(f32x4*)&T[(s * R + rr) * LD + c] = t;
+        }
+      }
+    }
+  } else {
+    gather_tile<S, D, HAS_VAL, R, NW, LD>(n, node0, rowptr, col, val, rs, (const char*)X, lane_off, T, Hout, LR, wave, lane);
+  }
   // prefetch the residual rows this wave will mix in phase 3 (latency hides behind the MFMA phase)
   float xres[RPW][EPL];
 #pragma unroll
@@ -948,13 +965,14 @@ int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d, const 
 int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* rowptr, const int32_t* col, const float* val,
                    const float* row_scale, const float* X, const float* W, const float* b, const float* wg,
                    const float* cg, float* Xn, float* Z, float* H, float* gate, float dropout_p,
-                   const unsigned long long* rng_state, unsigned int stream_id) {
+                   const unsigned long long* rng_state, unsigned int stream_id, const float* H_in) {
   int rc = check_shape(n, S, d);
   if (rc) return rc;
   if (n == 0) return CGCN_OK;
   if (!rowptr || !col || !X || !W || !b || !wg || !cg || !Xn || !gate || X == Xn) return CGCN_ERR_BAD_ARG;
   if (misaligned16(X) || misaligned16(Xn) || misaligned16(W) || (Z && misaligned16(Z)) || (H && misaligned16(H)))
     return CGCN_ERR_BAD_ARG;
+  if (H_in && (misaligned16(H_in) || H_in == H)) return CGCN_ERR_BAD_ARG;
   float ks;
   uint32_t th;
   if ((rc = dropout_args(dropout_p, rng_state, &ks, &th))) return rc;
@@ -966,10 +984,10 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   do {                                                                                                              \
     if (mb == 2)                                                                                                    \
       hipLaunchKernelGGL((k_layer_fwd<S_, D_, 2, V_>), dim3(blocks), dim3((D_ == 128 && CBW128 == 2) ? 256 : 512), 0, st, n, rowptr, col, val, row_scale, \
-                         X, W, b, wg, cg, Xn, Z, H, gate, ks, th, rng_state, stream_id);                            \
+                         X, W, b, wg, cg, Xn, Z, H, gate, ks, th, rng_state, stream_id, H_in);                      \
     else                                                                                                            \
       hipLaunchKernelGGL((k_layer_fwd<S_, D_, 1, V_>), dim3(blocks), dim3((D_ == 128 && CBW128 == 2) ? 256 : 512), 0, st, n, rowptr, col, val, row_scale, \
-                         X, W, b, wg, cg, Xn, Z, H, gate, ks, th, rng_state, stream_id);                            \
+                         X, W, b, wg, cg, Xn, Z, H, gate, ks, th, rng_state, stream_id, H_in);                      \
   } while (0)
   DISPATCH_SDV(S, d, val != nullptr, CALL);
 #undef CALL

@@ -33,10 +33,11 @@ from .dist import ShardPlan, plan_shards
 
 
 class _Chrom:
-    __slots__ = ("name", "n", "graph", "x", "target", "cost")
+    __slots__ = ("name", "n", "graph", "x", "target", "cost", "h1")
 
     def __init__(self, name, n, graph, x, target, cost):
         self.name, self.n, self.graph, self.x, self.target, self.cost = name, n, graph, x, target, cost
+        self.h1 = {"h": None}  # cached A X of the first layer (features and graph are fixed per chromosome)
 
 
 class GCNStage:
@@ -49,9 +50,12 @@ class GCNStage:
     group      : torch.distributed process group (None = single process)"""
 
     def __init__(self, model, optimizer=None, adj_type: str = "hic", device="cuda", hip_graphs: bool = True,
-                 input_grad: bool = True, group=None, fused_head: bool = True):
+                 input_grad: bool = True, group=None, fused_head: bool = True, cache_input_aggregation: bool = True):
         self.model = model
         self.fused_head = fused_head
+        # A X of the first layer is loop invariant across steps and epochs (like the normalised CSR): compute it once
+        # per chromosome and stream it afterwards.  False = redo that gather every step, as the reference does.
+        self.cache_input_aggregation = cache_input_aggregation
         self.optimizer = optimizer
         self.adj_type = adj_type
         self.device = torch.device(device)
@@ -185,7 +189,8 @@ class GCNStage:
     # ------------------------------------------------------------------ one chromosome, eager
     def _forward_loss(self, c: _Chrom, x):
         if self.fused_head and hasattr(self.model, "forward_loss"):
-            loss, probs, _ = self.model.forward_loss(x, c.graph, c.target)  # fused head + loss kernels
+            loss, probs, _ = self.model.forward_loss(x, c.graph, c.target,   # fused head + loss kernels
+                                                     h1_cache=c.h1 if self.cache_input_aggregation else None)
             return loss, probs
         logits, _ = self.model.forward_strands(x, c.graph)
         pred = (logits[0] + logits[1]) / 2                                # finetune.py:43

@@ -118,7 +118,7 @@ class ChromeGCN(nn.Module):
         return None if any(g is None for g in grads) else grads
 
     # -- the gated stack on a [S, n, d] block -------------------------------------------------
-    def _gated_stack(self, x, graph, rng, upto=None):
+    def _gated_stack(self, x, graph, rng, upto=None, h1_cache=None):
         gates = []
         L = self.n_layers
         p = float(self.dropout) if (self.training and rng is not None) else 0.0
@@ -129,7 +129,8 @@ class ChromeGCN(nn.Module):
             # output (k < L) and un-drops the gradient of its input (k > 1)
             x, g = ops.gated_layer(x, gc.weight, gc.bias, wk.weight, wk.bias, graph,
                                    dropout_out=p if k < L else 0.0, dropout_in=p if k > 1 else 0.0,
-                                   rng_state=rng, layer_id=k, grad_sink=self._sink(gc.weight, gc.bias, wk.weight, wk.bias))
+                                   rng_state=rng, layer_id=k, grad_sink=self._sink(gc.weight, gc.bias, wk.weight, wk.bias),
+                                   h_cache=h1_cache if k == 1 else None)
             gates.append(g)
         return x, gates
 
@@ -160,20 +161,23 @@ class ChromeGCN(nn.Module):
         x, gates = self._gated_stack(x_fr, graph, self._step_rng())
         return self._head(x), gates
 
-    def forward_loss(self, x_fr, adj, target):
+    def forward_loss(self, x_fr, adj, target, h1_cache=None):
         """The whole per-chromosome forward of the GCN stage (finetune.py:41-45,52) in fused kernels:
         gated stack on both strands, then ReLU/BatchNorm/dropout/Linear/strand-mean/BCE.  The last gated
         layer and the head form one autograd node (ops.LastLayerHeadLossFn).
+        h1_cache: optional dict holder for H1 = A X of the FIRST layer.  H1 depends on the graph and the input
+        features only, not on any weight, so a caller whose features are fixed (GCNStage: they never change
+        across epochs) computes it on the first call and streams it afterwards instead of repeating the gather.
         Returns (loss [], probs [n,C] = sigmoid(pred), gates)."""
         ops._require_cuda(x_fr, "x_fr")
         graph = as_graph(adj, x_fr.device)
         rng = self._step_rng()
         L = self.n_layers
-        x, gates = self._gated_stack(x_fr, graph, rng, upto=L - 1)
+        x, gates = self._gated_stack(x_fr, graph, rng, upto=L - 1, h1_cache=h1_cache)
         p = float(self.dropout) if (self.training and rng is not None) else 0.0
         gc, wk, bn, out = getattr(self, "GC%d" % L), getattr(self, "W%d" % L), self.batch_norm, self.out
         loss, probs, g = ops.last_layer_head_loss(
             x, gc, wk, bn, out, graph, target, self.training, p, p if L > 1 else 0.0, rng, L,
             layer_sink=self._sink(gc.weight, gc.bias, wk.weight, wk.bias),
-            head_sink=self._sink(bn.weight, bn.bias, out.weight, out.bias))
+            head_sink=self._sink(bn.weight, bn.bias, out.weight, out.bias), h_cache=h1_cache if L == 1 else None)
         return loss, probs, gates + [g]

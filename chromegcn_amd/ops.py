@@ -79,6 +79,27 @@ def sddmm(a, b, graph: ChromGraph, transposed=False):
 _saliency_tap = None  # set by chromegcn_amd.saliency while it collects per-layer (X, dUs, W)
 
 
+def _resolve_h_cache(h_cache, x, need_bwd):
+    """h_cache: None, or a dict holder {'h': tensor-or-None} for H = A X of a layer whose input never changes
+    (the engine keeps one per chromosome for the first layer).  Returns (H_in to stream, H buffer to write)."""
+    if h_cache is not None and h_cache.get("h") is not None:
+        hc = h_cache["h"]
+        if hc.shape != x.shape or hc.device != x.device:
+            raise RuntimeError("chromegcn_amd: cached aggregation does not match the input")
+        return hc, None
+    if need_bwd or h_cache is not None:
+        return None, torch.empty_like(x)
+    return None, None
+
+
+def _store_h_cache(h_cache, h_in, h):
+    if h_in is not None:
+        return h_in
+    if h_cache is not None and h is not None:
+        h_cache["h"] = h
+    return h
+
+
 def _sink_ok(sink, shapes):
     return sink is not None and all(t is not None and tuple(t.shape) == tuple(sh) and t.is_contiguous()
                                     for t, sh in zip(sink, shapes))
@@ -96,7 +117,7 @@ class GatedLayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gate_w, gate_b, graph: ChromGraph, dropout_out, dropout_in, rng_state,
-                layer_id, grad_sink):
+                layer_id, grad_sink, h_cache):
         _check_feat(x, graph)
         for t, nm in ((weight, "weight"), (bias, "bias"), (gate_w, "gate weight"), (gate_b, "gate bias")):
             _require_cuda(t, nm)
@@ -112,7 +133,7 @@ class GatedLayerFn(torch.autograd.Function):
         xn = torch.empty_like(x)
         gate = torch.empty((S, n), device=x.device, dtype=torch.float32)
         z = torch.empty_like(x) if need_bwd else None
-        h = torch.empty_like(x) if need_bwd else None
+        h_in, h = _resolve_h_cache(h_cache, x, need_bwd)
         if (dropout_out > 0 or dropout_in > 0) and rng_state is None:
             raise RuntimeError("chromegcn_amd: fused dropout needs the model's rng_state tensor")
         lib = _lib.load()
@@ -120,8 +141,9 @@ class GatedLayerFn(torch.autograd.Function):
                                       _lib.ptr(graph.val), _lib.ptr(graph.row_scale), x.data_ptr(), weight.data_ptr(),
                                       bias.data_ptr(), wg.data_ptr(), cg.data_ptr(), xn.data_ptr(), _lib.ptr(z),
                                       _lib.ptr(h), gate.data_ptr(), float(dropout_out),
-                                      _lib.ptr(rng_state) if dropout_out > 0 else None, int(layer_id)),
+                                      _lib.ptr(rng_state) if dropout_out > 0 else None, int(layer_id), _lib.ptr(h_in)),
                    "cgcn_layer_fwd")
+        h = _store_h_cache(h_cache, h_in, h)
         if need_bwd:
             ctx.save_for_backward(x, z, h, gate, weight, wg, rng_state if dropout_in > 0 else None)
         ctx.graph = graph
@@ -139,7 +161,7 @@ class GatedLayerFn(torch.autograd.Function):
         g = ctx.graph
         S, n, d = x.shape
         if dxn is None and dgate is None:
-            return (None,) * 11
+            return (None,) * 12
         dxn = torch.zeros_like(x) if dxn is None else dxn.contiguous()
         dgate = None if dgate is None else dgate.contiguous()
         dx = torch.empty_like(x)
@@ -164,14 +186,14 @@ class GatedLayerFn(torch.autograd.Function):
         if _saliency_tap is not None:
             _saliency_tap.append((x, dus, weight, g))  # dus = diag(row_scale) dL/dU of this layer
         if ctx.sink is not None:
-            return (dx, None, None, None, None) + (None,) * 6
-        return (dx, dw, db, dwg.view(ctx.gate_w_shape), dcg.view(ctx.gate_b_shape)) + (None,) * 6
+            return (dx, None, None, None, None) + (None,) * 7
+        return (dx, dw, db, dwg.view(ctx.gate_w_shape), dcg.view(ctx.gate_b_shape)) + (None,) * 7
 
 
 def gated_layer(x, weight, bias, gate_w, gate_b, graph, dropout_out=0.0, dropout_in=0.0, rng_state=None,
-                layer_id=0, grad_sink=None):
+                layer_id=0, grad_sink=None, h_cache=None):
     return GatedLayerFn.apply(x, weight, bias, gate_w, gate_b, graph, float(dropout_out), float(dropout_in),
-                              rng_state, int(layer_id), grad_sink)
+                              rng_state, int(layer_id), grad_sink, h_cache)
 
 
 class HeadLossFn(torch.autograd.Function):
@@ -257,7 +279,7 @@ class LastLayerHeadLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gate_w, gate_b, bn_w, bn_b, w_out, b_out, graph, target, run_mean, run_var, nbt,
-                momentum, eps, training, dropout_p, dropout_in, rng_state, layer_id, layer_sink, head_sink):
+                momentum, eps, training, dropout_p, dropout_in, rng_state, layer_id, layer_sink, head_sink, h_cache):
         _check_feat(x, graph)
         for t, nm in ((weight, "weight"), (bias, "bias"), (gate_w, "gate weight"), (gate_b, "gate bias"),
                       (bn_w, "bn weight"), (bn_b, "bn bias"), (w_out, "out.weight"), (b_out, "out.bias"), (target, "target")):
@@ -278,11 +300,12 @@ class LastLayerHeadLossFn(torch.autograd.Function):
         xn = torch.empty_like(x)
         gate = torch.empty((S, n), device=x.device, dtype=torch.float32)
         z = torch.empty_like(x) if need_bwd else None
-        h = torch.empty_like(x) if need_bwd else None
+        h_in, h = _resolve_h_cache(h_cache, x, need_bwd)
         _lib.check(lib.cgcn_layer_fwd(_lib.stream_ptr(), n, S, d, _lib.ptr(graph.rowptr), _lib.ptr(graph.col),
                                       _lib.ptr(graph.val), _lib.ptr(graph.row_scale), x.data_ptr(), weight.data_ptr(),
                                       bias.data_ptr(), wg.data_ptr(), cg.data_ptr(), xn.data_ptr(), _lib.ptr(z),
-                                      _lib.ptr(h), gate.data_ptr(), 0.0, None, int(layer_id)), "cgcn_layer_fwd")
+                                      _lib.ptr(h), gate.data_ptr(), 0.0, None, int(layer_id), _lib.ptr(h_in)), "cgcn_layer_fwd")
+        h = _store_h_cache(h_cache, h_in, h)
         ws_bytes = lib.cgcn_head_workspace_bytes(n, S, d, C)
         if ws_bytes == 0:
             raise RuntimeError("chromegcn_amd: fused head does not support S=%d n=%d d=%d C=%d" % (S, n, d, C))
@@ -336,7 +359,7 @@ class LastLayerHeadLossFn(torch.autograd.Function):
         hws_bytes = lib.cgcn_head_workspace_bytes(n, S, d, C)
         hws = torch.empty(hws_bytes, device=dev, dtype=torch.uint8)
         if dloss is None:
-            return (None,) * 23
+            return (None,) * 24
         dloss = dloss.contiguous().view(1)
         _lib.check(lib.cgcn_head_bwd(_lib.stream_ptr(), n, S, d, C, xn.data_ptr(), bn_w.data_ptr(), bn_b.data_ptr(),
                                      save_mean.data_ptr(), save_invstd.data_ptr(), w_out.data_ptr(), dpred.data_ptr(),
@@ -363,15 +386,15 @@ class LastLayerHeadLossFn(torch.autograd.Function):
                                       max(ctx.layer_id - 1, 0), ctypes.byref(hg), ws.data_ptr(), ws_bytes, _lib.aux_stream_ptr()), "cgcn_layer_bwd")
         gl = (None,) * 4 if ctx.layer_sink is not None else (dw, db, dwg.view(ctx.shapes[0]), dcg.view(ctx.shapes[1]))
         gh = (None,) * 4 if ctx.head_sink is not None else (dbn_w, dbn_b, dw_out, db_out)
-        return (dx,) + gl + gh + (None,) * 14
+        return (dx,) + gl + gh + (None,) * 15
 
 
 def last_layer_head_loss(x, gc, wk, bn, out, graph, target, training, dropout_p, dropout_in, rng_state, layer_id,
-                         layer_sink=None, head_sink=None):
+                         layer_sink=None, head_sink=None, h_cache=None):
     return LastLayerHeadLossFn.apply(x, gc.weight, gc.bias, wk.weight, wk.bias, bn.weight, bn.bias, out.weight, out.bias,
                                      graph, target, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum,
                                      bn.eps, bool(training), float(dropout_p), float(dropout_in), rng_state, int(layer_id),
-                                     layer_sink, head_sink)
+                                     layer_sink, head_sink, h_cache)
 
 
 def head_loss(x, bn: torch.nn.BatchNorm1d, out: torch.nn.Linear, target, training, dropout_p, rng_state, grad_sink=None):

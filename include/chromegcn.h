@@ -48,7 +48,7 @@ extern "C" {
 #define CGCN_ERR_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after a launch      */
 #define CGCN_ERR_WORKSPACE (-4)   /* workspace too small (see cgcn_*_workspace_bytes)    */
 
-#define CGCN_ABI_VERSION 8
+#define CGCN_ABI_VERSION 9
 
 typedef void *cgcn_stream_t; /* hipStream_t */
 
@@ -81,12 +81,16 @@ int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d,
  * backward needs).  Xn must not alias X.
  * dropout_p > 0 additionally applies the inter-layer dropout of models/ChromeModels.py:42 to Xn
  * (Xn <- mask * Xn / (1-p), mask from (rng_state, stream_id)); pass 0 / NULL / 0 for none.
+ * H_in (may be NULL): a previously computed H = diag(row_scale) Ahat X for this X and graph (H does not
+ * depend on the layer's weights).  When given, the gather is skipped and H_in is streamed instead; H is
+ * then not written (pass H = NULL, the saved tensor for the backward is H_in itself).
  */
 int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d,
                    const int32_t *rowptr, const int32_t *col, const float *val, const float *row_scale,
                    const float *X, const float *W, const float *b, const float *wg, const float *cg,
                    float *Xn, float *Z, float *H, float *gate,
-                   float dropout_p, const unsigned long long *rng_state, unsigned int stream_id);
+                   float dropout_p, const unsigned long long *rng_state, unsigned int stream_id,
+                   const float *H_in);
 
 /*
  * State the fused head's backward leaves for the LAST gated layer's backward (cgcn_head_bwd with

@@ -134,3 +134,29 @@ def test_training_with_dropout_learns_a_planted_signal():
     ev, probs = st.eval_step("c")
     acc = ((probs > 0.5).float().cpu() == feats["target"]).float().mean().item()
     assert loss.item() < 0.6 * first and acc > 0.75, (first, loss.item(), ev.item(), acc)
+
+
+def test_cached_input_aggregation_is_bitwise_identical(golden):
+    """A X of the first layer is loop invariant; streaming the cached copy must not change a single bit of the
+    training trajectory, the predictions or d loss / d features."""
+    z = golden("g4_finetune_loop.npz")
+    chroms, feats, graphs = _load(z)
+    init = state_from(z, "init")
+    outs = []
+    for cache in (False, True):
+        m = C.ChromeGCN(128, 128, init["out.weight"].shape[0], 0.0, True, 2)
+        m.load_state_dict(init); m.to(DEV)
+        optim = torch.optim.SGD(m.parameters(), lr=0.25, weight_decay=1e-6, momentum=0.9)
+        st = GCNStage(m, optim, "hic", DEV, hip_graphs=True, cache_input_aggregation=cache)
+        st.load(feats, graphs)
+        for _ in range(3):
+            for c in chroms:
+                loss, probs, dx = st.train_step(c)
+        ev = [st.eval_step(c)[1].clone() for c in chroms]
+        assert (st.chroms[chroms[0]].h1["h"] is not None) == cache
+        outs.append(({k: v.clone() for k, v in m.state_dict().items()}, loss.clone(), dx.clone(), ev))
+    for k in outs[0][0]:
+        assert torch.equal(outs[0][0][k], outs[1][0][k]), k
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    for a, b in zip(outs[0][3], outs[1][3]):
+        assert torch.equal(a, b)
