@@ -228,7 +228,7 @@ def main():
 
     # extra: the same step with the first layer's aggregation cached (engine default)
     stage.cache_input_aggregation = True
-    stage._graphs.clear()
+    stage._drop_graphs()
     for _ in range(max(args.warmup, 1)):
         step()
     fence()

@@ -79,6 +79,11 @@ class GCNStage:
         self._int_synced: Dict[str, torch.Tensor] = {}
         self._targets_cpu: Dict[tuple, torch.Tensor] = {}
 
+    def _drop_graphs(self):
+        """forget every captured HIP graph (and the memory pool they shared, which dies with the last of them)"""
+        self._graphs.clear()
+        self._pool = None
+
     # ------------------------------------------------------------------ data
     def add_chromosome(self, name: str, feats: Dict[str, torch.Tensor], hic=None):
         """feats: {'forward': [n,d], 'backward': [n,d], 'target': [n,C]} (utils/util_methods.py:183-199);
@@ -167,7 +172,7 @@ class GCNStage:
         managed = dev.type == "cuda" and hasattr(self.model, "_rng_state")
         self.model._rng_managed = managed
         self.model._grad_sink = dev.type == "cuda" and hasattr(self.model, "forward_loss") and self.fused_head
-        self._graphs.clear()
+        self._drop_graphs()
 
     def _optimizer_step(self, grad_scale: float = 1.0):
         """finetune.py:49.  Plain torch SGD runs as one fused launch over the flat buffers (which also
@@ -274,7 +279,7 @@ class GCNStage:
 
     def _replay(self, c: _Chrom, kind: str):
         if self._captured_lr != self._lr_signature():
-            self._graphs.clear()  # the learning rate is baked into the captured optimizer kernels
+            self._drop_graphs()  # the learning rate is baked into the captured optimizer kernels
             self._captured_lr = self._lr_signature()
         key = (c.name, kind)
         ent = self._graphs.get(key)
