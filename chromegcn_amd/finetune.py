@@ -98,6 +98,8 @@ class GCNStage:
         self.chroms[name] = _Chrom(name, n, g, x, t, cost)
         self._targets_cpu.clear()
         self._graphs = {k: v for k, v in self._graphs.items() if k[0] != name}
+        if not self._graphs:
+            self._pool = None
 
     def load(self, chrom_feature_dict, split_adj_dict=None, only: Optional[Iterable[str]] = None):
         for name in chrom_feature_dict:
