@@ -579,7 +579,7 @@ __global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float*
             const float xh = (fmaxf(xn, 0.f) - hp.mean[s * D + c]) * is;
             const float dr = hp.bn_w[c] * is * (dy - hp.bnc[(s * 2 + 0) * D + c] - xh * hp.bnc[(s * 2 + 1) * D + c]);
             gup[t][e] = xn > 0.f ? dr : 0.f;
-            dxn_store[off + e] = gup[t][e];  // k_bwd_gather reads it back as dL/dXn for the (1-g) dXn term
+            if (dxn_store) dxn_store[off + e] = gup[t][e];  // k_bwd_gather reads it back as dL/dXn for the (1-g) dXn term
           }
         }
         float dg = 0.f;
@@ -1015,10 +1015,10 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
                    void* workspace, size_t workspace_bytes, cgcn_stream_t aux_stream) {
   int rc = check_shape(n, S, d);
   if (rc) return rc;
-  if (!rowptr_t || !col_t || !X || !Z || !H || !gate || !W || !wg || !dX || !dUs || !dW || !db || !dwg || !dcg)
+  if (!rowptr_t || !col_t || !X || !Z || !H || !gate || !W || !wg || !dUs || !dW || !db || !dwg || !dcg)
     return CGCN_ERR_BAD_ARG;
   if ((dXn == nullptr) == (head == nullptr)) return CGCN_ERR_BAD_ARG;  // exactly one source of dL/dXn
-  if (dX == dXn || misaligned16(dUs) || misaligned16(dX) || misaligned16(W)) return CGCN_ERR_BAD_ARG;
+  if ((dX && dX == dXn) || misaligned16(dUs) || (dX && misaligned16(dX)) || misaligned16(W)) return CGCN_ERR_BAD_ARG;
   HeadApply hp = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1.f, 0u, S, nullptr, nullptr, nullptr, 0, 0, 0, 0};
   int head_slabs = 0;
   if (head) {
@@ -1059,13 +1059,17 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
       rs_stream = (hipStream_t)aux_stream;
   }
   const int slabs = (total + 63) / 64;
-  const bool fuse_reduce = (rs_stream == st) && n > 0;  // default: the sum rides at the end of the gather launch
+  // default: the sum rides at the end of the gather launch; no gather when the caller does not want dX
+  const bool fuse_reduce = (rs_stream == st) && n > 0 && dX != nullptr;
   if (!fuse_reduce) {
     hipLaunchKernelGGL(k_reduce_partials, dim3(slabs), dim3(256), 0, rs_stream, P, d, part, dW, db, dwg, dcg, accumulate);
     if ((rc = launch_status())) return rc;
     if (rs_stream != st && hipEventRecord(ev_join, rs_stream) != hipSuccess) return CGCN_ERR_LAUNCH;
   }
-  if (n == 0) return CGCN_OK;
+  if (n == 0 || !dX) {
+    if (rs_stream != st && hipStreamWaitEvent(st, ev_join, 0) != hipSuccess) return CGCN_ERR_LAUNCH;
+    return CGCN_OK;  // parameter gradients only (the input is a leaf nobody differentiates)
+  }
   const int mb = pick_mb(n, S);
   const int tn = 16 * mb / S;
   const int blocks = (n + tn - 1) / tn;

@@ -46,11 +46,14 @@ class GCNStage:
     model      : ChromeGCN-like module with forward_strands(x_fr [2,n,d], graph) -> (logits [2,n,C], gates)
     optimizer  : torch optimizer over model.parameters() (utils/util_methods.py:14-19 builds SGD/Adam)
     hip_graphs : capture each chromosome's step into a HIP graph (needs a GPU)
-    input_grad : also produce d loss / d features, as finetune.py:33-34 asks autograd to
+    input_grad : also produce d loss / d features.  finetune.py:33-34 sets requires_grad on the features, but the
+                 resulting x.grad is unobservable there (the tensors are loop-local and finetune returns only
+                 predictions, targets and the loss), so the default skips that last gather; train_step returns
+                 dx = None then
     group      : torch.distributed process group (None = single process)"""
 
     def __init__(self, model, optimizer=None, adj_type: str = "hic", device="cuda", hip_graphs: bool = True,
-                 input_grad: bool = True, group=None, fused_head: bool = True, cache_input_aggregation: bool = True):
+                 input_grad: bool = False, group=None, fused_head: bool = True, cache_input_aggregation: bool = True):
         self.model = model
         self.fused_head = fused_head
         # A X of the first layer is loop invariant across steps and epochs (like the normalised CSR): compute it once

@@ -164,7 +164,7 @@ class GatedLayerFn(torch.autograd.Function):
             return (None,) * 12
         dxn = torch.zeros_like(x) if dxn is None else dxn.contiguous()
         dgate = None if dgate is None else dgate.contiguous()
-        dx = torch.empty_like(x)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None  # None: skip the gather over Ahat^T
         dus = torch.empty_like(x)
         if ctx.sink is not None:
             dw, db, dwg, dcg = ctx.sink
@@ -179,7 +179,7 @@ class GatedLayerFn(torch.autograd.Function):
         _lib.check(lib.cgcn_layer_bwd(_lib.stream_ptr(), n, S, d, _lib.ptr(g.rowptr_t), _lib.ptr(g.col_t),
                                       _lib.ptr(g.val_t), _lib.ptr(g.row_scale), x.data_ptr(), z.data_ptr(),
                                       h.data_ptr(), gate.data_ptr(), weight.data_ptr(), wg.data_ptr(),
-                                      dxn.data_ptr(), _lib.ptr(dgate), dx.data_ptr(), dus.data_ptr(), dw.data_ptr(),
+                                      dxn.data_ptr(), _lib.ptr(dgate), _lib.ptr(dx), dus.data_ptr(), dw.data_ptr(),
                                       db.data_ptr(), dwg.data_ptr(), dcg.data_ptr(), 0, ctx.dropout_in,
                                       _lib.ptr(rng_state), max(ctx.layer_id - 1, 0), None, ws.data_ptr(), ws_bytes, _lib.aux_stream_ptr()),
                    "cgcn_layer_bwd")
@@ -374,14 +374,14 @@ class LastLayerHeadLossFn(torch.autograd.Function):
                            save_invstd.data_ptr(), bn_w.data_ptr(), ctx.dropout_p, _lib.ptr(rng_state),
                            hws.data_ptr() + o_part.value, lib.cgcn_head_bwd_partials(n), C, dw_out.data_ptr(),
                            db_out.data_ptr(), 0)
-        dx = torch.empty_like(x)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dus = torch.empty_like(x)
         ws_bytes = lib.cgcn_layer_bwd_workspace_bytes(n, S, d)
         ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
         _lib.check(lib.cgcn_layer_bwd(_lib.stream_ptr(), n, S, d, _lib.ptr(g.rowptr_t), _lib.ptr(g.col_t),
                                       _lib.ptr(g.val_t), _lib.ptr(g.row_scale), x.data_ptr(), z.data_ptr(),
                                       h.data_ptr(), gate.data_ptr(), weight.data_ptr(), wg.data_ptr(),
-                                      None, None, dx.data_ptr(), dus.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                      None, None, _lib.ptr(dx), dus.data_ptr(), dw.data_ptr(), db.data_ptr(),
                                       dwg.data_ptr(), dcg.data_ptr(), 0, ctx.dropout_in, _lib.ptr(rng_state),
                                       max(ctx.layer_id - 1, 0), ctypes.byref(hg), ws.data_ptr(), ws_bytes, _lib.aux_stream_ptr()), "cgcn_layer_bwd")
         gl = (None,) * 4 if ctx.layer_sink is not None else (dw, db, dwg.view(ctx.shapes[0]), dcg.view(ctx.shapes[1]))

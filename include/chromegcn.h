@@ -127,7 +127,8 @@ size_t cgcn_layer_bwd_workspace_bytes(int n, int S, int d);
  *     dU    = (g dXn + gamma wg^T) (1 - Z^2)
  *     db = sum_rows dU,  dwg = sum_rows gamma Z,  dcg = sum gamma,  dW = H^T dU
  *     dX    = (1-g) dXn + (Ahat^T (diag(row_scale) dU)) W^T
- * dX: [S,n,d], must not alias dXn.  dW [d,d], db [d], dwg [d], dcg [1] are overwritten
+ * dX: [S,n,d], must not alias dXn; NULL = parameter gradients only (the gather over Ahat^T is skipped:
+ * use it for the first layer when nobody needs d loss / d features).  dW [d,d], db [d], dwg [d], dcg [1] are overwritten
  * when accumulate == 0 and added to when accumulate != 0.  dUs is a [S,n,d] scratch output
  * (holds diag(row_scale) dU on return).  Sums over rows are two-stage and deterministic
  * (no float atomics): results are bit-reproducible run to run.

@@ -88,7 +88,7 @@ def test_whole_step_is_bit_reproducible_and_matches_torch_head(big):
         with torch.no_grad():
             m.GC1.weight.mul_(40); m.GC2.weight.mul_(40)   # the reference init (gain 0.02) leaves z ~ 0
         opt = torch.optim.SGD(m.parameters(), lr=0.25, momentum=0.9, weight_decay=1e-6)
-        st = GCNStage(m, opt, "hic", DEV, hip_graphs=True, fused_head=fused)
+        st = GCNStage(m, opt, "hic", DEV, hip_graphs=True, fused_head=fused, input_grad=True)
         st.add_chromosome("c", feats, hic)
         for _ in range(3):
             loss, probs, dx = st.train_step("c")

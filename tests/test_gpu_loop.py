@@ -59,7 +59,7 @@ def test_captured_step_equals_eager_step_bitwise(golden):
         m = C.ChromeGCN(128, 128, init["out.weight"].shape[0], 0.0, True, 2)
         m.load_state_dict(init); m.to(DEV)
         optim = torch.optim.SGD(m.parameters(), lr=0.25, weight_decay=1e-6, momentum=0.9)
-        st = GCNStage(m, optim, "hic", DEV, hip_graphs=hip_graphs)
+        st = GCNStage(m, optim, "hic", DEV, hip_graphs=hip_graphs, input_grad=True)
         st.load(feats, graphs)
         for _ in range(2):
             for c in chroms:
@@ -147,7 +147,7 @@ def test_cached_input_aggregation_is_bitwise_identical(golden):
         m = C.ChromeGCN(128, 128, init["out.weight"].shape[0], 0.0, True, 2)
         m.load_state_dict(init); m.to(DEV)
         optim = torch.optim.SGD(m.parameters(), lr=0.25, weight_decay=1e-6, momentum=0.9)
-        st = GCNStage(m, optim, "hic", DEV, hip_graphs=True, cache_input_aggregation=cache)
+        st = GCNStage(m, optim, "hic", DEV, hip_graphs=True, cache_input_aggregation=cache, input_grad=True)
         st.load(feats, graphs)
         for _ in range(3):
             for c in chroms:
