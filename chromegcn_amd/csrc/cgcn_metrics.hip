@@ -5,8 +5,9 @@
 // utils/evals.py:89-92 -> utils/metrics.py:148-183,238-253): AUROC, area under the precision-recall curve
 // (trapezoid over sklearn's precision_recall_curve points), recall at the first point with FDR <= cutoff,
 // and average precision (mAP).  Here: one segmented radix sort of all (score, label) pairs by descending
-// score (rocPRIM through hipCUB) and one wave per label that walks the sorted list once, treating tied scores
-// as one curve point exactly like sklearn's distinct-threshold curves.  All curve arithmetic is fp64.
+// score (rocPRIM through hipCUB) and a chunked scan of the sorted lists (one wave per 4096-element chunk),
+// treating tied scores as one curve point exactly like sklearn's distinct-threshold curves.  All curve
+// arithmetic is fp64 and summed in a fixed order.
 #include <hipcub/hipcub.hpp>
 
 #include "cgcn_common.hpp"
@@ -49,46 +50,113 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
-// One wave per label over its descending-sorted (score, positive) list.
-// Curve points are the ends of runs of equal scores: (tp_k, fp_k), k = 1..K, plus the origin.
+// Curve points are the ends of runs of equal scores in the descending-sorted list of one label:
+// (tp_k, fp_k), k = 1..K, plus the origin.
 //   AUROC   = sum (fp_k - fp_{k-1}) (tp_k + tp_{k-1}) / 2 / (P N)                       roc_auc_score
 //   AUPR    = sum (r_k - r_{k-1}) (p_k + p_{k-1}) / 2, (r_0, p_0) = (0, 1)              auc(recall, precision)
 //   AP      = sum (r_k - r_{k-1}) p_k                                                   average_precision_score
 //   R@FDR   = r_k of the LAST point with 1 - p_k <= cutoff, 0 if none                   utils/metrics.py:148-166
-// with p_k = tp_k / (tp_k + fp_k), r_k = tp_k / P (sklearn: r_k = 1 when P = 0).  out[m*C + c], m = 0..3.
-__global__ __launch_bounds__(64) void k_metrics_scan(long long n, int C, const float* __restrict__ keys,
-                                                     const unsigned char* __restrict__ vals, double fdr_cutoff,
-                                                     float* __restrict__ out) {
-  const int c = blockIdx.x;
-  const int lane = threadIdx.x;
+// with p_k = tp_k / (tp_k + fp_k), r_k = tp_k / P (sklearn: r_k = 1 when P = 0).
+// Each label's list is cut into chunks of METRIC_CHUNK elements, one wave per (label, chunk):
+//   k_metrics_summary  per chunk: positives, and the position / local tp of its last run end
+//   k_metrics_prefix   per label (serial over <= a few hundred chunk records): positives before each chunk and
+//                      the curve point preceding it; total positives
+//   k_metrics_chunks   per chunk: the trapezoid / step sums of its own curve points (fp64) + R@FDR candidate
+//   k_metrics_final    per label: fixed-order sum over chunks  => deterministic
+#define METRIC_CHUNK 4096
+
+struct ChunkRec {      // written by k_metrics_summary, completed by k_metrics_prefix
+  double pos;          // positives in the chunk
+  double end_tp;       // positives in the chunk up to and including its last run end
+  long long end_idx;   // global index + 1 of that run end, 0 if the chunk has none
+  double carry_tp;     // positives before the chunk
+  double prev_tp, prev_fp;  // curve point preceding the chunk's first run end
+};
+struct ChunkOut { double auc, aupr, ap, rfdr; int has_fdr; int pad; };
+
+__device__ __forceinline__ double wave_incl_scan_d(double v, int lane) {
+#pragma unroll
+  for (int off = 1; off < WAVE; off <<= 1) {
+    const double o = __shfl_up(v, off, WAVE);
+    if (lane >= off) v += o;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(64) void k_metrics_summary(long long n, int nch, const float* __restrict__ keys,
+                                                        const unsigned char* __restrict__ vals, ChunkRec* __restrict__ rec) {
+  const int c = blockIdx.y, ch = blockIdx.x, lane = threadIdx.x;
   const float* k = keys + (long long)c * n;
   const unsigned char* v = vals + (long long)c * n;
-  // pass 0: number of positives
-  double P = 0.0;
-  for (long long i = lane; i < n; i += WAVE) P += v[i];
-  P = wave_sum_d(P);
-  const double N = (double)n - P;
-
-  double carry_tp = 0.0;                       // positives before this chunk
-  double prev_tp = 0.0, prev_fp = 0.0;         // previous curve point (origin at start)
-  double s_auc = 0.0, s_aupr = 0.0, s_ap = 0.0, r_fdr = 0.0;
-  for (long long base = 0; base < n; base += WAVE) {
+  const long long i0 = (long long)ch * METRIC_CHUNK, i1 = min(n, i0 + METRIC_CHUNK);
+  double carry = 0.0, end_tp = 0.0;
+  long long end_idx = 0;
+  for (long long base = i0; base < i1; base += WAVE) {
     const long long i = base + lane;
-    const bool ok = i < n;
+    const bool ok = i < i1;
     const float sc = ok ? k[i] : 0.f;
     const float nx = (i + 1 < n) ? k[i + 1] : 0.f;
     const double t = ok ? (double)v[i] : 0.0;
-    // inclusive scan of positives over the wave
-    double cum = t;
-#pragma unroll
-    for (int off = 1; off < WAVE; off <<= 1) {
-      const double o = __shfl_up(cum, off, WAVE);
-      if (lane >= off) cum += o;
+    const double tp = carry + wave_incl_scan_d(t, lane);
+    const bool end = ok && ((i + 1 == n) || sc != nx);
+    const unsigned long long bal = __ballot(end);
+    if (bal) {
+      const int hi = 63 - __builtin_clzll(bal);
+      end_tp = __shfl(tp, hi, WAVE);
+      end_idx = base + hi + 1;
     }
-    const double tp = carry_tp + cum;
+    carry = __shfl(tp, WAVE - 1, WAVE);
+  }
+  if (lane == 0) {
+    ChunkRec& r = rec[(size_t)c * nch + ch];
+    r.pos = carry;
+    r.end_tp = end_tp;
+    r.end_idx = end_idx;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_metrics_prefix(int nch, ChunkRec* __restrict__ rec, double* __restrict__ Ptot) {
+  const int c = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  ChunkRec* r = rec + (size_t)c * nch;
+  double carry = 0.0, ptp = 0.0, pfp = 0.0;
+  for (int k = 0; k < nch; ++k) {
+    r[k].carry_tp = carry;
+    r[k].prev_tp = ptp;
+    r[k].prev_fp = pfp;
+    if (r[k].end_idx > 0) {
+      ptp = carry + r[k].end_tp;
+      pfp = (double)r[k].end_idx - ptp;
+    }
+    carry += r[k].pos;
+  }
+  Ptot[c] = carry;
+}
+
+__global__ __launch_bounds__(64) void k_metrics_chunks(long long n, int nch, const float* __restrict__ keys,
+                                                       const unsigned char* __restrict__ vals,
+                                                       const ChunkRec* __restrict__ rec, const double* __restrict__ Ptot,
+                                                       double fdr_cutoff, ChunkOut* __restrict__ outp) {
+  const int c = blockIdx.y, ch = blockIdx.x, lane = threadIdx.x;
+  const float* k = keys + (long long)c * n;
+  const unsigned char* v = vals + (long long)c * n;
+  const long long i0 = (long long)ch * METRIC_CHUNK, i1 = min(n, i0 + METRIC_CHUNK);
+  const ChunkRec r = rec[(size_t)c * nch + ch];
+  const double P = Ptot[c];
+  double carry_tp = r.carry_tp;
+  double prev_tp = r.prev_tp, prev_fp = r.prev_fp;
+  double s_auc = 0.0, s_aupr = 0.0, s_ap = 0.0, r_fdr = 0.0;
+  int has_fdr = 0;
+  for (long long base = i0; base < i1; base += WAVE) {
+    const long long i = base + lane;
+    const bool ok = i < i1;
+    const float sc = ok ? k[i] : 0.f;
+    const float nx = (i + 1 < n) ? k[i + 1] : 0.f;
+    const double t = ok ? (double)v[i] : 0.0;
+    const double tp = carry_tp + wave_incl_scan_d(t, lane);
     const double fp = (double)(i + 1) - tp;
     const bool end = ok && ((i + 1 == n) || sc != nx);   // last element of a run of tied scores
-    // index of the previous run end inside this chunk (-1: it is the carried point)
+    // lane of the previous run end inside this wave-chunk (-1: it is the carried point)
     int pe = end ? lane : -1;
 #pragma unroll
     for (int off = 1; off < WAVE; off <<= 1) {
@@ -102,27 +170,26 @@ __global__ __launch_bounds__(64) void k_metrics_scan(long long n, int C, const f
     const double ptp = pprev < 0 ? prev_tp : ptp_l;
     const double pfp = pprev < 0 ? prev_fp : pfp_l;
     double d_auc = 0.0, d_aupr = 0.0, d_ap = 0.0;
-    double prec = 1.0, rec = 0.0;
+    double prec = 1.0, rec_ = 0.0;
     if (end) {
       prec = tp / (tp + fp);
-      rec = P > 0.0 ? tp / P : 1.0;
-      const double pp = (ptp + pfp) > 0.0 ? ptp / (ptp + pfp) : 1.0;     // origin: precision 1
-      const double pr = (ptp + pfp) > 0.0 ? (P > 0.0 ? ptp / P : 1.0) : 0.0;  // origin: recall 0
+      rec_ = P > 0.0 ? tp / P : 1.0;
+      const double pp = (ptp + pfp) > 0.0 ? ptp / (ptp + pfp) : 1.0;              // origin: precision 1
+      const double pr = (ptp + pfp) > 0.0 ? (P > 0.0 ? ptp / P : 1.0) : 0.0;      // origin: recall 0
       d_auc = (fp - pfp) * (tp + ptp) * 0.5;
-      d_aupr = (rec - pr) * (prec + pp) * 0.5;
-      d_ap = (rec - pr) * prec;
+      d_aupr = (rec_ - pr) * (prec + pp) * 0.5;
+      d_ap = (rec_ - pr) * prec;
     }
     s_auc += wave_sum_d(d_auc);
     s_aupr += wave_sum_d(d_aupr);
     s_ap += wave_sum_d(d_ap);
-    // last point (deepest in the list) with FDR <= cutoff: keep the one with the largest index
     const bool q = end && (1.0 - prec) <= fdr_cutoff;
     const unsigned long long bal = __ballot(q);
     if (bal) {
       const int hi = 63 - __builtin_clzll(bal);
-      r_fdr = __shfl(rec, hi, WAVE);
+      r_fdr = __shfl(rec_, hi, WAVE);
+      has_fdr = 1;
     }
-    // carry to the next chunk: totals and the last run end seen so far
     const int last_end = __shfl(pe, WAVE - 1, WAVE);
     if (last_end >= 0) {
       prev_tp = __shfl(tp, last_end, WAVE);
@@ -131,13 +198,30 @@ __global__ __launch_bounds__(64) void k_metrics_scan(long long n, int C, const f
     carry_tp = __shfl(tp, WAVE - 1, WAVE);
   }
   if (lane == 0) {
-    const float nanv = __int_as_float(0x7fc00000);
-    out[0 * C + c] = (P > 0.0 && N > 0.0) ? (float)(s_auc / (P * N)) : nanv;  // undefined with one class present
-    out[1 * C + c] = n > 0 ? (float)s_aupr : nanv;
-    out[2 * C + c] = n > 0 ? (float)r_fdr : nanv;
-    out[3 * C + c] = n > 0 ? (float)s_ap : nanv;  // 0 when the label has no positive (as sklearn)
+    ChunkOut& o = outp[(size_t)c * nch + ch];
+    o.auc = s_auc; o.aupr = s_aupr; o.ap = s_ap; o.rfdr = r_fdr; o.has_fdr = has_fdr;
   }
 }
+
+__global__ __launch_bounds__(64) void k_metrics_final(long long n, int C, int nch, const ChunkOut* __restrict__ outp,
+                                                      const double* __restrict__ Ptot, float* __restrict__ out) {
+  const int c = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  const ChunkOut* o = outp + (size_t)c * nch;
+  double s_auc = 0.0, s_aupr = 0.0, s_ap = 0.0, r_fdr = 0.0;
+  for (int k = 0; k < nch; ++k) {
+    s_auc += o[k].auc; s_aupr += o[k].aupr; s_ap += o[k].ap;
+    if (o[k].has_fdr) r_fdr = o[k].rfdr;   // the deepest chunk with a qualifying point wins
+  }
+  const double P = Ptot[c], N = (double)n - P;
+  const float nanv = __int_as_float(0x7fc00000);
+  out[0 * C + c] = (P > 0.0 && N > 0.0) ? (float)(s_auc / (P * N)) : nanv;  // undefined with one class present
+  out[1 * C + c] = n > 0 ? (float)s_aupr : nanv;
+  out[2 * C + c] = n > 0 ? (float)r_fdr : nanv;
+  out[3 * C + c] = n > 0 ? (float)s_ap : nanv;  // 0 when the label has no positive (as sklearn)
+}
+
+static inline int metric_chunks(long long n) { long long k = (n + METRIC_CHUNK - 1) / METRIC_CHUNK; return k < 1 ? 1 : (int)k; }
 
 static size_t sort_temp_bytes(long long n, int C) {
   size_t bytes = 0;
@@ -153,7 +237,9 @@ extern "C" {
 size_t cgcn_metrics_workspace_bytes(long long n, int C) {
   if (n < 0 || C < 1 || (double)n * C >= 2147483647.0) return 0;
   const size_t items = (size_t)n * C;
-  return 2 * al(items * 4) + 2 * al(items) + al((size_t)(C + 1) * 4) + al(sort_temp_bytes(n, C)) + 256;
+  const size_t nrec = (size_t)C * metric_chunks(n);
+  return 2 * al(items * 4) + 2 * al(items) + al((size_t)(C + 1) * 4) + al(nrec * sizeof(ChunkRec)) + al(nrec * sizeof(ChunkOut)) +
+         al((size_t)C * 8) + al(sort_temp_bytes(n, C)) + 256;
 }
 
 int cgcn_multilabel_metrics(cgcn_stream_t stream, long long n, int C, const float* probs, const float* targets,
@@ -170,6 +256,10 @@ int cgcn_multilabel_metrics(cgcn_stream_t stream, long long n, int C, const floa
   unsigned char* vals_in = (unsigned char*)w; w += al(items);
   unsigned char* vals_out = (unsigned char*)w; w += al(items);
   int* off = (int*)w; w += al((size_t)(C + 1) * 4);
+  const int nch = metric_chunks(n);
+  ChunkRec* rec = (ChunkRec*)w; w += al((size_t)C * nch * sizeof(ChunkRec));
+  ChunkOut* outp = (ChunkOut*)w; w += al((size_t)C * nch * sizeof(ChunkOut));
+  double* Ptot = (double*)w; w += al((size_t)C * 8);
   size_t temp = sort_temp_bytes(n, C);
   if (n > 0) {
     dim3 grid((unsigned)((n + 31) / 32), (unsigned)((C + 31) / 32));
@@ -179,7 +269,10 @@ int cgcn_multilabel_metrics(cgcn_stream_t stream, long long n, int C, const floa
                                                               off + 1, 0, 32, st) != hipSuccess)
       return CGCN_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL(k_metrics_scan, dim3(C), dim3(64), 0, st, n, C, keys_out, vals_out, (double)fdr_cutoff, out);
+  hipLaunchKernelGGL(k_metrics_summary, dim3(nch, C), dim3(64), 0, st, n, nch, keys_out, vals_out, rec);
+  hipLaunchKernelGGL(k_metrics_prefix, dim3(C), dim3(64), 0, st, nch, rec, Ptot);
+  hipLaunchKernelGGL(k_metrics_chunks, dim3(nch, C), dim3(64), 0, st, n, nch, keys_out, vals_out, rec, Ptot, (double)fdr_cutoff, outp);
+  hipLaunchKernelGGL(k_metrics_final, dim3(C), dim3(64), 0, st, n, C, nch, outp, Ptot, out);
   return launch_status();
 }
 

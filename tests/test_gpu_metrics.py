@@ -25,7 +25,11 @@ def test_metrics_match_oracle(n, C):
     rng = np.random.RandomState(n + C)
     tg = (rng.rand(n, C) < rng.rand(C) * 0.5).astype(np.float32)
     pr = (rng.rand(n, C) * 0.7 + 0.3 * tg * rng.rand(n, C)).astype(np.float32)
-    pr[:, 0] = np.round(pr[:, 0], 2)
+    pr[:, 0] = np.round(pr[:, 0], 2)   # heavy ties: runs of equal scores cross the 4096-element chunk boundaries
+    if C > 1:
+        pr[:, 1] = 0.5                 # one run spanning every chunk
+    if C > 2:
+        pr[:, 2] = np.round(pr[:, 2], 1)
     want = O.multilabel_metrics_np(tg.astype(np.float64), pr)
     got = M.multilabel_metrics(torch.from_numpy(pr).to(DEV), torch.from_numpy(tg).to(DEV))
     for k in ("auroc", "aupr", "recall_at_fdr", "average_precision"):
