@@ -255,7 +255,7 @@ def main():
                 traffic = json.load(open(tpath)).get("%s_d%d" % (args.workload, args.d))
             except Exception:
                 traffic = None
-        roof = {"bound": "hbm", "kernel": "k_layer_fwd<S=2,D=%d> (training variant)" % args.d,
+        roof = {"bound": "hbm", "kernel": "k_layer_fwd<S=2,D=%d,MB=1,HAS_VAL=false,FROM_CACHE=false> (training variant: writes Z,H)" % args.d,
                 "achieved": alg / k_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": alg / k_s / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg, "avg_kernel_us": k_s * 1e6,

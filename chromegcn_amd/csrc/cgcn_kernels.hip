@@ -369,7 +369,7 @@ __device__ __forceinline__ void tile_mfma(const float* __restrict__ T, const flo
 //   phase 2  U = H W on the matrix cores; the residual rows of X are prefetched meanwhile
 //   phase 3  Z = tanh(U + b) -> LDS -> row-wise gate (wave reduction), mix, optional dropout, stores
 // ------------------------------------------------------------------------------------------
-template <int S, int D, int MB, bool HAS_VAL>
+template <int S, int D, int MB, bool HAS_VAL, bool FROM_CACHE>
 __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) void k_layer_fwd(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
                                                      const float* __restrict__ val, const float* __restrict__ rs,
                                                      const float* __restrict__ X, const float* __restrict__ W,
@@ -402,8 +402,8 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) void k_layer
 #pragma unroll
   for (int v = 0; v < G::NV; ++v) lane_off[v] = ((unsigned)G::strand(v, lane) * (unsigned)n * D + G::column(v, lane)) * 4u;
 
-  // ---- phase 1
-  if (Hin) {
+  // ---- phase 1 (FROM_CACHE is a template parameter so that profiles list the two variants separately)
+  if (FROM_CACHE) {
     // the aggregation was computed before (it does not depend on the weights: the engine caches A X of the
     // first layer, whose input features never change): stream the rows in instead of gathering
     for (int rr = wave; rr < R; rr += NW) {
@@ -982,11 +982,18 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   const int blocks = (n + tn - 1) / tn;
 #define CALL(S_, D_, V_)                                                                                            \
   do {                                                                                                              \
-    if (mb == 2)                                                                                                    \
-      hipLaunchKernelGGL((k_layer_fwd<S_, D_, 2, V_>), dim3(blocks), dim3((D_ == 128 && CBW128 == 2) ? 256 : 512), 0, st, n, rowptr, col, val, row_scale, \
+    const dim3 blk((D_ == 128 && CBW128 == 2) ? 256 : 512);                                                         \
+    if (mb == 2 && H_in)                                                                                            \
+      hipLaunchKernelGGL((k_layer_fwd<S_, D_, 2, V_, true>), dim3(blocks), blk, 0, st, n, rowptr, col, val, row_scale, \
+                         X, W, b, wg, cg, Xn, Z, H, gate, ks, th, rng_state, stream_id, H_in);                      \
+    else if (mb == 2)                                                                                               \
+      hipLaunchKernelGGL((k_layer_fwd<S_, D_, 2, V_, false>), dim3(blocks), blk, 0, st, n, rowptr, col, val, row_scale, \
+                         X, W, b, wg, cg, Xn, Z, H, gate, ks, th, rng_state, stream_id, H_in);                      \
+    else if (H_in)                                                                                                  \
+      hipLaunchKernelGGL((k_layer_fwd<S_, D_, 1, V_, true>), dim3(blocks), blk, 0, st, n, rowptr, col, val, row_scale, \
                          X, W, b, wg, cg, Xn, Z, H, gate, ks, th, rng_state, stream_id, H_in);                      \
     else                                                                                                            \
-      hipLaunchKernelGGL((k_layer_fwd<S_, D_, 1, V_>), dim3(blocks), dim3((D_ == 128 && CBW128 == 2) ? 256 : 512), 0, st, n, rowptr, col, val, row_scale, \
+      hipLaunchKernelGGL((k_layer_fwd<S_, D_, 1, V_, false>), dim3(blocks), blk, 0, st, n, rowptr, col, val, row_scale, \
                          X, W, b, wg, cg, Xn, Z, H, gate, ks, th, rng_state, stream_id, H_in);                      \
   } while (0)
   DISPATCH_SDV(S, d, val != nullptr, CALL);
