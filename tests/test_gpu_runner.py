@@ -43,3 +43,32 @@ def test_run_model_writes_reference_style_artifacts(tmp_path):
     # the learning-rate change of the scheduler reached the captured optimizer kernel (graphs re-captured)
     assert optim.param_groups[0]["lr"] < 0.25
     assert np.isfinite(hist[-1]["valid"]["meanAUC"]) and hist[-1]["train"]["loss"] < hist[0]["train"]["loss"]
+
+
+def test_cli_trains_from_reference_format_files(tmp_path):
+    """chromegcn_amd.train reads chrom_feature_dict_{split}.pt (utils/util_methods.py:183-199) and the graph pickles
+    (data/7create_graph_new.py:197-202), optionally takes the head from a window-model checkpoint (main.py:74-81)."""
+    import pickle
+    from chromegcn_amd import train as T
+    feat_dir, graph_root = tmp_path / "cnn_run", tmp_path / "graphs"
+    feat_dir.mkdir(); graph_root.mkdir()
+    names = {"train": ["chr2", "chr4"], "valid": ["chr3"], "test": ["chr1"]}
+    for sp, chroms in names.items():
+        feats, graphs = {}, {}
+        for i, c in enumerate(chroms):
+            n = 200 + 30 * i
+            feats[c] = synth.chrom_features(n, 128, 6, hash(c) % 100, positive_rate=0.3)
+            graphs[c] = synth.contact_graph(n, 5 * n, i)
+        torch.save(feats, str(feat_dir / ("chrom_feature_dict_%s.pt" % sp)))
+        with open(str(graph_root / ("%s_graphs_500000_SQRTVCnorm.pkl" % sp)), "wb") as f:
+            pickle.dump(graphs, f)
+    cnn = {"model": {"module.model.classifier.weight": torch.randn(6, 128), "module.model.classifier.bias": torch.randn(6),
+                     "module.model.batch_norm.weight": torch.rand(128) + 0.5, "module.model.batch_norm.bias": torch.randn(128)}}
+    torch.save(cnn, str(tmp_path / "cnn.chkpt"))
+    out = str(tmp_path / "gcn_run")
+    hist = T.main(["-feat_dir", str(feat_dir), "-graph_root", str(graph_root), "-epochs", "2", "-model_name", out,
+                   "-cnn_chkpt", str(tmp_path / "cnn.chkpt"), "-gate"])
+    assert len(hist) == 2 and os.path.exists(os.path.join(out, "model.chkpt"))
+    hist2 = T.main(["-feat_dir", str(feat_dir), "-graph_root", str(graph_root), "-epochs", "1", "-model_name", out + "_eval",
+                    "-load_gcn", os.path.join(out, "model.chkpt")])
+    assert set(hist2[0]) == {"test"}
