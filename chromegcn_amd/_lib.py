@@ -29,6 +29,8 @@ _SIGNATURES = {
     "cgcn_head_bwd_partials": (_c_int, [_c_int]),
     "cgcn_head_fwd": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp] * 6 + [_c_float, _c_float, _c_int] + [_c_vp] * 3
                       + [_c_float] + [_c_vp] * 7 + [_c_sz]),
+    "cgcn_head_train": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp] * 6 + [_c_float, _c_float] + [_c_vp] * 3 + [_c_float]
+                        + [_c_vp] * 6 + [_c_sz]),
     "cgcn_head_bwd": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp] * 8 + [_c_float] + [_c_vp] * 6 + [_c_int, _c_vp, _c_sz]),
     "cgcn_sddmm": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 5),
     "cgcn_graph_count": (_c_int, [_c_vp, _c_int, _c_int] + [_c_vp] * 5),
@@ -37,7 +39,7 @@ _SIGNATURES = {
     "cgcn_multilabel_metrics": (_c_int, [_c_vp, ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_float, _c_vp, _c_vp, _c_sz]),
     "cgcn_sgd_step": (_c_int, [_c_vp, ctypes.c_longlong, _c_vp, _c_vp, _c_vp, _c_float, _c_float, _c_float, _c_int, _c_float, _c_vp]),
 }
-ABI_VERSION = 9
+ABI_VERSION = 10
 _lib = None
 
 
@@ -86,7 +88,7 @@ class HeadGrad(ctypes.Structure):
     """mirror of cgcn_head_grad (include/chromegcn.h)"""
     _fields_ = [("dym", _c_vp), ("bnc", _c_vp), ("save_mean", _c_vp), ("save_invstd", _c_vp), ("bn_w", _c_vp),
                 ("dropout_p", _c_float), ("rng_state", _c_vp), ("part", _c_vp), ("n_partials", _c_int), ("C", _c_int),
-                ("dW_out", _c_vp), ("db_out", _c_vp), ("accumulate", _c_int)]
+                ("dW_out", _c_vp), ("db_out", _c_vp), ("accumulate", _c_int), ("dloss", _c_vp)]
 
 
 def ptr(t):

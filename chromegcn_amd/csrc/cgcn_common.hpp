@@ -77,6 +77,7 @@ struct HeadApply {
   float* hf_dWout;       // [C][D]
   float* hf_dbout;       // [C]
   int hf_P, hf_C, hf_CP, hf_accumulate;
+  const float* dloss;    // [1] upstream d loss, or nullptr when dym / the partials already include it
 };
 
 // One 64-element slab of the head backward's second stage.  Elements: [CP*D dW_out][CP db_out][D BatchNorm columns].
@@ -85,8 +86,10 @@ template <int NT>
 __device__ __forceinline__ void head_finalize_slab(int slab, int P, int n, int S, int D, int C, int CP,
                                                    const float* __restrict__ part, float* __restrict__ dWout,
                                                    float* __restrict__ dbout, float* __restrict__ dbn_w,
-                                                   float* __restrict__ dbn_b, float* __restrict__ bnc, int accumulate) {
+                                                   float* __restrict__ dbn_b, float* __restrict__ bnc, int accumulate,
+                                                   const float* __restrict__ dloss) {
   constexpr int NS = NT / 64;
+  const float gl = dloss ? dloss[0] : 1.f;  // everything summed here is linear in the upstream d loss
   const int PS = CP * D + CP + 4 * D;
   const int total = CP * D + CP + D;
   __shared__ float hred[NS][4][64];
@@ -122,7 +125,7 @@ __device__ __forceinline__ void head_finalize_slab(int slab, int P, int n, int S
     float a = 0.f;
 #pragma unroll
     for (int w = 0; w < NS; ++w) a += hred[w][qd][el];
-    s[qd] = a;
+    s[qd] = a * gl;
   }
   if (e < CP * D) {
     const int i = e / D;

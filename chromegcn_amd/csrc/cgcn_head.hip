@@ -461,6 +461,315 @@ __global__ __launch_bounds__(512) void k_head_bwd(int n, int S, int C, const flo
       }
     }
     __syncthreads();
+#ifndef HB_SKIP_DBO
+    if (threadIdx.x < CP) {
+      float sacc = 0.f;
+#pragma unroll 8
+      for (int row = 0; row < TR; ++row) sacc += Pt[row * LDP + threadIdx.x];
+      dbo += sacc;
+    }
+#endif
+#ifndef HB_SKIP_DW
+    // ---- dW_out += Pt^T Yt   (K = TR rows)
+#pragma unroll 2
+    for (int kk = 0; kk < TR / 4; ++kk) {
+      const int k = 4 * kk + q;
+      float b[JBW];
+#pragma unroll
+      for (int jb = 0; jb < JBW; ++jb) b[jb] = Yt[k * LDY + (wave * JBW + jb) * 16 + r];
+#pragma unroll
+      for (int ib = 0; ib < CBMAX; ++ib) {
+        if (ib < CB) {
+          const float a = Pt[k * LDP + ib * 16 + r];
+#pragma unroll
+          for (int jb = 0; jb < JBW; ++jb) accW[ib][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[jb], accW[ib][jb], 0, 0, 0);
+        }
+      }
+    }
+#endif
+    // ---- dym tile = Pt W_out   (M = TR rows, K = labels, N = D)
+    f32x4 accY[2][JBW];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int jb = 0; jb < JBW; ++jb) accY[mb][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifndef HB_SKIP_DYM
+    if (PREB) {
+#pragma unroll
+      for (int kk = 0; kk < CBMAX * 4; ++kk) {
+        if (kk < CB * 4) {  // wave-uniform
+          const int k = 4 * kk + q;  // label index
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb) {
+            const float a = Pt[(mb * 16 + r) * LDP + k];
+#pragma unroll
+            for (int jb = 0; jb < JBW; ++jb)
+              accY[mb][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bwo[jb][PREB ? kk : 0], accY[mb][jb], 0, 0, 0);
+          }
+        }
+      }
+    } else {
+#pragma unroll 2
+      for (int kk = 0; kk < CB * 4; ++kk) {
+        const int k = 4 * kk + q;
+        float b[JBW];
+#pragma unroll
+        for (int jb = 0; jb < JBW; ++jb) b[jb] = (k < C) ? Wout[(size_t)k * D + (wave * JBW + jb) * 16 + r] : 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          const float a = Pt[(mb * 16 + r) * LDP + k];
+#pragma unroll
+          for (int jb = 0; jb < JBW; ++jb) accY[mb][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[jb], accY[mb][jb], 0, 0, 0);
+        }
+      }
+    }
+#endif
+    __syncthreads();  // all reads of Yt / Pt done
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int jb = 0; jb < JBW; ++jb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Yt[(mb * 16 + q * 4 + e) * LDY + (wave * JBW + jb) * 16 + r] = accY[mb][jb][e];
+    __syncthreads();
+    // ---- row pass: write dym, accumulate the BatchNorm-backward column sums (X rows still in registers)
+#pragma unroll
+    for (int t = 0; t < RPW; ++t) {
+      const int rr = wave + t * NW;
+      const int i = node0 + rr;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        const int c = lane * EPL + e;
+        const float g = i < n ? Yt[rr * LDY + c] : 0.f;
+        if (i < n) dym[(size_t)i * D + c] = g;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          if (s < S) {
+            float dy = g * invS;
+            if (thresh) dy = dropout_keep(key, (uint32_t)(((size_t)s * n + i) * D + c), thresh) ? dy * keep_scale : 0.f;
+            const float xh = (fmaxf(xv[t][s][e], 0.f) - mu[s][e]) * is[s][e];
+            sdy[s][e] += dy;
+            sdyx[s][e] += dy * xh;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- partials
+  float* P = part + (size_t)blockIdx.x * PS;
+#ifndef HB_SKIP_PART
+#pragma unroll
+  for (int ib = 0; ib < CBMAX; ++ib)
+#pragma unroll
+    for (int jb = 0; jb < JBW; ++jb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) P[(ib * 16 + q * 4 + e) * D + (wave * JBW + jb) * 16 + r] = accW[ib][jb][e];
+#endif
+  if (threadIdx.x < CP) P[CP * D + threadIdx.x] = dbo;
+  float* red = Yt;  // [NW][4*D]
+  constexpr int RS = 4 * D;
+  static_assert(NW * RS <= TR * LDY, "reduction scratch must fit in Yt");
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      red[wave * RS + s * D + lane * EPL + e] = sdy[s][e];
+      red[wave * RS + 2 * D + s * D + lane * EPL + e] = sdyx[s][e];
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < RS; c += 512) {
+    float s = 0.f;
+    for (int w = 0; w < NW; ++w) s += red[w * RS + c];
+    P[CP * D + CP + c] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_head_fused: training-mode head forward AND the tile-local part of its backward in one pass.
+// d loss / d pred = (sigmoid(pred) - target) / (n C) is known as soon as a tile's logits are, and everything the
+// head's backward does with it is tile-local (dym = dpred W_out, dW_out += dpred^T ym, db_out, the BatchNorm
+// column sums) -- only the *consumers* of those sums need a global barrier.  So the forward kernel keeps going:
+// no dpred round trip through memory, no second read of X, no recomputation of ym / dropout masks, one launch
+// less.  Everything is computed for an upstream gradient of 1; cgcn_head_bwd / cgcn_layer_bwd scale by the
+// actual d loss (all of it is linear in that scalar).
+// Persistent over 32-node tiles like k_head_bwd; same partial layout.
+// ------------------------------------------------------------------------------------------
+template <int D, int CBMAX>
+__global__ __launch_bounds__(512) void k_head_fused(int n, int S, int C, const float* __restrict__ X,
+                                                    const float* __restrict__ bn_w, const float* __restrict__ bn_b,
+                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                    const float* __restrict__ Wout, const float* __restrict__ bout,
+                                                    const float* __restrict__ target, float keep_scale, uint32_t thresh,
+                                                    const unsigned long long* __restrict__ rng_state, float inv_count,
+                                                    float* __restrict__ probs, float* __restrict__ loss_part,
+                                                    float* __restrict__ dym, float* __restrict__ part) {
+  constexpr int TR = HEADB_TILE, NW = 8, EPL = D / 64, RPW = TR / NW, KQ = D / 4;
+  constexpr int CP = CBMAX * 16, NCBW = CBMAX / 8;
+  constexpr int LDP = CP + ((CP & 16) ? 2 : 18);
+  constexpr int LDY = D + 16;
+  constexpr int JBW = D / 128;
+  constexpr int PS = CP * D + CP + 2 * 2 * D;
+  constexpr bool PRE = (D == 128);
+  __shared__ __attribute__((aligned(16))) float Pt[TR * LDP];
+  __shared__ __attribute__((aligned(16))) float Yt[TR * LDY];
+  __shared__ float lsum[NW];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const uint32_t key = thresh ? dropout_key(rng_state, HEAD_STREAM_ID) : 0u;
+  const int CB = (C + 15) / 16;
+  const float invS = 1.f / (float)S;
+
+  // operand fragments of W_out, fetched once per workgroup (D = 128): B of pred = ym W_out^T and B of dym = dpred W_out
+  float bw[NCBW][PRE ? KQ : 1];
+  float bwo[JBW][PRE ? CBMAX * 4 : 1];
+  if (PRE) {
+#pragma unroll
+    for (int cbi = 0; cbi < NCBW; ++cbi) {
+      const int j = (wave + NW * cbi) * 16 + r;
+#pragma unroll
+      for (int t = 0; t < KQ / 4; ++t) {
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (j < C) v = *(const f32x4*)&Wout[(size_t)j * D + 16 * t + 4 * q];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bw[cbi][4 * t + u] = v[u];
+      }
+    }
+#pragma unroll
+    for (int jb = 0; jb < JBW; ++jb)
+#pragma unroll
+      for (int kk = 0; kk < CBMAX * 4; ++kk) {
+        const int k = 4 * kk + q;
+        bwo[jb][kk] = (k < C) ? Wout[(size_t)k * D + (wave * JBW + jb) * 16 + r] : 0.f;
+      }
+  }
+  f32x4 accW[CBMAX][JBW];
+#pragma unroll
+  for (int ib = 0; ib < CBMAX; ++ib)
+#pragma unroll
+    for (int jb = 0; jb < JBW; ++jb) accW[ib][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float dbo = 0.f, lacc = 0.f;
+  float sdy[2][EPL], sdyx[2][EPL];
+  float mu[2][EPL], is[2][EPL], gw[EPL], gb[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    const int c = lane * EPL + e;
+    gw[e] = bn_w[c];
+    gb[e] = bn_b[c];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      sdy[s][e] = sdyx[s][e] = 0.f;
+      mu[s][e] = mean[(s < S ? s : 0) * D + c];
+      is[s][e] = invstd[(s < S ? s : 0) * D + c];
+    }
+  }
+
+  const int ntiles = (n + TR - 1) / TR;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int node0 = tile * TR;
+    // ---- all global loads of the tile first: this wave's X rows, the targets / bias of this lane's logits
+    float xv[RPW][2][EPL];
+#pragma unroll
+    for (int t = 0; t < RPW; ++t) {
+      const int i = node0 + wave + t * NW;
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e)
+          xv[t][s][e] = (i < n && s < S) ? X[((size_t)s * n + i) * D + lane * EPL + e] : 0.f;
+    }
+    float tgv[NCBW][2][4], bjv[NCBW];
+#pragma unroll
+    for (int cbi = 0; cbi < NCBW; ++cbi) {
+      const int j = (wave + NW * cbi) * 16 + r;
+      bjv[cbi] = j < C ? bout[j] : 0.f;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = node0 + mb * 16 + q * 4 + e;
+          tgv[cbi][mb][e] = (i < n && j < C) ? target[(size_t)i * C + j] : 0.f;
+        }
+    }
+    // ---- ym rows -> Yt
+#pragma unroll
+    for (int t = 0; t < RPW; ++t) {
+      const int rr = wave + t * NW;
+      const int i = node0 + rr;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        float ym = 0.f;
+        if (i < n) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            if (s < S) {
+              float y = (fmaxf(xv[t][s][e], 0.f) - mu[s][e]) * is[s][e] * gw[e] + gb[e];
+              if (thresh) y = dropout_keep(key, (uint32_t)(((size_t)s * n + i) * D + lane * EPL + e), thresh) ? y * keep_scale : 0.f;
+              ym += y;
+            }
+          }
+        }
+        Yt[rr * LDY + lane * EPL + e] = ym * invS;
+      }
+    }
+    __syncthreads();
+    // ---- pred = ym W_out^T  (M = 32 rows, K = D permuted, N = this wave's label block(s))
+    f32x4 acc[NCBW][2];
+#pragma unroll
+    for (int cbi = 0; cbi < NCBW; ++cbi)
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) acc[cbi][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < KQ / 4; ++t) {
+      f32x4 a[2];
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) a[mb] = *(const f32x4*)&Yt[(mb * 16 + r) * LDY + 16 * t + 4 * q];
+#pragma unroll
+      for (int cbi = 0; cbi < NCBW; ++cbi) {
+        if (wave + NW * cbi < CB) {
+          f32x4 b;
+          if (PRE) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) b[u] = bw[cbi][PRE ? 4 * t + u : 0];
+          } else {
+            const int j = (wave + NW * cbi) * 16 + r;
+            b = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (j < C) b = *(const f32x4*)&Wout[(size_t)j * D + 16 * t + 4 * q];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) acc[cbi][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb][u], b[u], acc[cbi][mb], 0, 0, 0);
+        }
+      }
+    }
+    // ---- sigmoid / BCE; d loss / d pred goes straight into the LDS tile (zero outside the valid region)
+#pragma unroll
+    for (int cbi = 0; cbi < NCBW; ++cbi) {
+      const int j = (wave + NW * cbi) * 16 + r;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = mb * 16 + q * 4 + e;
+          const int i = node0 + row;
+          float dp = 0.f;
+          if (i < n && j < C) {
+            const float pred = acc[cbi][mb][e] + bjv[cbi];
+            const float en = __expf(-fabsf(pred));
+            const float inv = 1.f / (1.f + en);
+            const float p = pred >= 0.f ? inv : en * inv;
+            lacc += fmaxf(pred, 0.f) - pred * tgv[cbi][mb][e] + __logf(1.f + en);
+            probs[(size_t)i * C + j] = p;
+            dp = (p - tgv[cbi][mb][e]) * inv_count;
+          }
+          Pt[row * LDP + j] = dp;
+        }
+    }
+    __syncthreads();
     if (threadIdx.x < CP) {
       float sacc = 0.f;
 #pragma unroll 8
@@ -489,17 +798,17 @@ __global__ __launch_bounds__(512) void k_head_bwd(int n, int S, int C, const flo
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
       for (int jb = 0; jb < JBW; ++jb) accY[mb][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (PREB) {
+    if (PRE) {
 #pragma unroll
       for (int kk = 0; kk < CBMAX * 4; ++kk) {
-        if (kk < CB * 4) {  // wave-uniform
-          const int k = 4 * kk + q;  // label index
+        if (kk < CB * 4) {
+          const int k = 4 * kk + q;
 #pragma unroll
           for (int mb = 0; mb < 2; ++mb) {
             const float a = Pt[(mb * 16 + r) * LDP + k];
 #pragma unroll
             for (int jb = 0; jb < JBW; ++jb)
-              accY[mb][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bwo[jb][PREB ? kk : 0], accY[mb][jb], 0, 0, 0);
+              accY[mb][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bwo[jb][PRE ? kk : 0], accY[mb][jb], 0, 0, 0);
           }
         }
       }
@@ -551,7 +860,7 @@ __global__ __launch_bounds__(512) void k_head_bwd(int n, int S, int C, const flo
     __syncthreads();
   }
 
-  // ---- partials
+  // ---- partials (same layout as k_head_bwd) + this workgroup's share of the loss
   float* P = part + (size_t)blockIdx.x * PS;
 #pragma unroll
   for (int ib = 0; ib < CBMAX; ++ib)
@@ -560,9 +869,10 @@ __global__ __launch_bounds__(512) void k_head_bwd(int n, int S, int C, const flo
 #pragma unroll
       for (int e = 0; e < 4; ++e) P[(ib * 16 + q * 4 + e) * D + (wave * JBW + jb) * 16 + r] = accW[ib][jb][e];
   if (threadIdx.x < CP) P[CP * D + threadIdx.x] = dbo;
+  lacc = wave_sum(lacc);
+  if (lane == 0) lsum[wave] = lacc;
   float* red = Yt;  // [NW][4*D]
   constexpr int RS = 4 * D;
-  static_assert(NW * RS <= TR * LDY, "reduction scratch must fit in Yt");
 #pragma unroll
   for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -576,6 +886,12 @@ __global__ __launch_bounds__(512) void k_head_bwd(int n, int S, int C, const flo
     for (int w = 0; w < NW; ++w) s += red[w * RS + c];
     P[CP * D + CP + c] = s;
   }
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t += lsum[w];
+    loss_part[blockIdx.x] = t;
+  }
 }
 
 // second stage (see head_finalize_slab): slabs [slab0, slab0 + gridDim.x)
@@ -583,8 +899,8 @@ __global__ __launch_bounds__(256) void k_head_bwd_finalize(int slab0, int P, int
                                                            const float* __restrict__ part, float* __restrict__ dWout,
                                                            float* __restrict__ dbout, float* __restrict__ dbn_w,
                                                            float* __restrict__ dbn_b, float* __restrict__ bnc,
-                                                           int accumulate) {
-  head_finalize_slab<256>(slab0 + blockIdx.x, P, n, S, D, C, CP, part, dWout, dbout, dbn_w, dbn_b, bnc, accumulate);
+                                                           int accumulate, const float* __restrict__ dloss) {
+  head_finalize_slab<256>(slab0 + blockIdx.x, P, n, S, D, C, CP, part, dWout, dbout, dbn_w, dbn_b, bnc, accumulate, dloss);
 }
 
 template <int D>
@@ -718,6 +1034,50 @@ int cgcn_head_fwd(cgcn_stream_t stream, int n, int S, int d, int C, const float*
   return launch_status();
 }
 
+int cgcn_head_train(cgcn_stream_t stream, int n, int S, int d, int C, const float* X, const float* bn_w,
+                    const float* bn_b, float* run_mean, float* run_var, long long* num_batches_tracked, float momentum,
+                    float eps, const float* Wout, const float* bout, const float* target, float dropout_p,
+                    const unsigned long long* rng_state, float* probs, float* loss, float* save_mean, float* save_invstd,
+                    void* workspace, size_t workspace_bytes) {
+  int rc = head_check(n, S, d, C);
+  if (rc) return rc;
+  if (!X || !bn_w || !bn_b || !Wout || !bout || !target || !probs || !loss || !workspace || !run_mean || !run_var ||
+      !save_mean || !save_invstd || n < 2)
+    return CGCN_ERR_BAD_ARG;
+  const bool drop = dropout_p > 0.f;
+  if (drop && (!rng_state || dropout_p >= 1.f)) return CGCN_ERR_BAD_ARG;
+  if (workspace_bytes < cgcn_head_workspace_bytes(n, S, d, C)) return CGCN_ERR_WORKSPACE;
+  if (misaligned16(Wout) || misaligned16(workspace) || misaligned16(X)) return CGCN_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  float* w_stats = (float*)workspace;
+  float* w_loss = w_stats + align4(ws_stats(S, d));
+  float* w_dym = w_loss + align4(ws_loss(n));
+  float* w_bnc = w_dym + align4(ws_dym(n, d));
+  float* w_part = w_bnc + align4(ws_bnc(d));
+  int rpb;
+  const int nblk = head_stat_blocks(n, &rpb);
+  if (d == 128) hipLaunchKernelGGL((k_head_colstats<128>), dim3(nblk), dim3(256), 0, st, n, S, rpb, X, w_stats);
+  else hipLaunchKernelGGL((k_head_colstats<256>), dim3(nblk), dim3(256), 0, st, n, S, rpb, X, w_stats);
+  if ((rc = launch_status())) return rc;
+  hipLaunchKernelGGL(k_head_bn_finalize, dim3((d + 15) / 16), dim3(256), 0, st, n, S, d, nblk, rpb, w_stats, momentum, eps,
+                     run_mean, run_var, num_batches_tracked, save_mean, save_invstd);
+  if ((rc = launch_status())) return rc;
+  const int P = head_bwd_partials(n);
+  const int CP = head_cp(C);
+  const float keep_scale = drop ? 1.f / (1.f - dropout_p) : 1.f;
+  const uint32_t thresh = drop ? dropout_threshold(dropout_p) : 0u;
+  const float inv_count = 1.f / ((float)n * (float)C);
+#define HFU(D_, CB_)                                                                                                  \
+  hipLaunchKernelGGL((k_head_fused<D_, CB_>), dim3(P), dim3(512), 0, st, n, S, C, X, bn_w, bn_b, save_mean, save_invstd, \
+                     Wout, bout, target, keep_scale, thresh, rng_state, inv_count, probs, w_loss, w_dym, w_part)
+  if (d == 128) { if (CP == 128) HFU(128, 8); else HFU(128, 16); }
+  else { if (CP == 128) HFU(256, 8); else HFU(256, 16); }
+#undef HFU
+  if ((rc = launch_status())) return rc;
+  hipLaunchKernelGGL(k_sum_scale, dim3(1), dim3(256), 0, st, P, w_loss, inv_count, loss);
+  return launch_status();
+}
+
 int cgcn_head_bwd(cgcn_stream_t stream, int n, int S, int d, int C, const float* X, const float* bn_w,
                   const float* bn_b, const float* save_mean, const float* save_invstd, const float* Wout,
                   const float* dpred, const float* dloss, float dropout_p, const unsigned long long* rng_state,
@@ -725,8 +1085,10 @@ int cgcn_head_bwd(cgcn_stream_t stream, int n, int S, int d, int C, const float*
                   size_t workspace_bytes) {
   int rc = head_check(n, S, d, C);
   if (rc) return rc;
-  if (!X || !bn_w || !bn_b || !save_mean || !save_invstd || !Wout || !dpred || !dWout || !dbout || !dbn_w || !dbn_b || !workspace)
+  if (!X || !bn_w || !bn_b || !save_mean || !save_invstd || !Wout || !dWout || !dbout || !dbn_w || !dbn_b || !workspace)
     return CGCN_ERR_BAD_ARG;
+  const bool fused = dpred == nullptr;  // the workspace already holds dym + partials from cgcn_head_train
+  if (fused && dX) return CGCN_ERR_UNSUPPORTED;  // the fused path exists only in deferred mode (dX == NULL)
   const bool drop = dropout_p > 0.f;
   if (drop && (!rng_state || dropout_p >= 1.f)) return CGCN_ERR_BAD_ARG;
   if (workspace_bytes < cgcn_head_workspace_bytes(n, S, d, C)) return CGCN_ERR_WORKSPACE;
@@ -743,21 +1105,24 @@ int cgcn_head_bwd(cgcn_stream_t stream, int n, int S, int d, int C, const float*
 #define HB(D_, CB_)                                                                                                   \
   hipLaunchKernelGGL((k_head_bwd<D_, CB_>), dim3(P), dim3(512), 0, st, n, S, C, X, bn_w, bn_b, save_mean, save_invstd, Wout, \
                      dpred, dloss, keep_scale, thresh, rng_state, w_dym, w_part)
-  if (d == 128) { if (CP == 128) HB(128, 8); else HB(128, 16); }
-  else { if (CP == 128) HB(256, 8); else HB(256, 16); }
+  if (!fused) {
+    if (d == 128) { if (CP == 128) HB(128, 8); else HB(128, 16); }
+    else { if (CP == 128) HB(256, 8); else HB(256, 16); }
+  }
 #undef HB
   if ((rc = launch_status())) return rc;
+  const float* fin_scale = fused ? dloss : nullptr;  // the unfused kernel already multiplied dpred by d loss
   const int total = CP * d + CP + d;
   const int slabs = (total + 63) / 64, wslabs = (CP * d + CP) / 64;  // CP is 128 or 256: the split is slab aligned
   if (!dX) {
     // deferred mode: only the BatchNorm columns now (cgcn_layer_bwd needs bnc); the dW_out / db_out slabs ride at the
     // end of k_bwd_rowlocal's grid (cgcn_head_grad.part / dW_out / db_out)
     hipLaunchKernelGGL(k_head_bwd_finalize, dim3(slabs - wslabs), dim3(256), 0, st, wslabs, P, n, S, d, C, CP, w_part, dWout,
-                       dbout, dbn_w, dbn_b, w_bnc, accumulate);
+                       dbout, dbn_w, dbn_b, w_bnc, accumulate, fin_scale);
     return launch_status();
   }
   hipLaunchKernelGGL(k_head_bwd_finalize, dim3(slabs), dim3(256), 0, st, 0, P, n, S, d, C, CP, w_part, dWout, dbout,
-                     dbn_w, dbn_b, w_bnc, accumulate);
+                     dbn_w, dbn_b, w_bnc, accumulate, fin_scale);
   if ((rc = launch_status())) return rc;
   const size_t total4 = (size_t)S * n * d / 4;
   int blocks = (int)((total4 + 255) / 256);

@@ -505,7 +505,7 @@ __global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float*
   // fused "horizontally" so it costs no launch of its own)
   if ((int)blockIdx.x >= row_blocks) {
     head_finalize_slab<512>(blockIdx.x - row_blocks, hp.hf_P, n, hp.S, D, hp.hf_C, hp.hf_CP, hp.hf_part, hp.hf_dWout,
-                            hp.hf_dbout, nullptr, nullptr, nullptr, hp.hf_accumulate);
+                            hp.hf_dbout, nullptr, nullptr, nullptr, hp.hf_accumulate, hp.dloss);
     return;
   }
   constexpr int IBW = D / 128;        // 16-row blocks of dW owned by one wave (i index)
@@ -536,6 +536,7 @@ __global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float*
 #pragma unroll
     for (int jb = 0; jb < JB; ++jb) acc[ib][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const uint32_t hkey = (hp.dym && hp.thresh) ? dropout_key(hp.rng_state, HEAD_STREAM_ID) : 0u;
+  const float hgl = (hp.dym && hp.dloss) ? hp.dloss[0] : 1.f;
 
   const int ntiles = (M + TR - 1) / TR;
   for (int tile = blockIdx.x; tile < ntiles; tile += row_blocks) {
@@ -573,7 +574,7 @@ __global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float*
           for (int e = 0; e < EPL; ++e) {
             const int c = lane * EPL + e;
             const float xn = (1.f - g) * x[t][e] + g * z[t][e];
-            float dy = gup[t][e] * invS;
+            float dy = gup[t][e] * invS * hgl;
             if (hp.thresh) dy = dropout_keep(hkey, (uint32_t)(off + e), hp.thresh) ? dy * hp.keep_scale : 0.f;
             const float is = hp.invstd[s * D + c];
             const float xh = (fmaxf(xn, 0.f) - hp.mean[s * D + c]) * is;
@@ -1026,7 +1027,7 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
     return CGCN_ERR_BAD_ARG;
   if ((dXn == nullptr) == (head == nullptr)) return CGCN_ERR_BAD_ARG;  // exactly one source of dL/dXn
   if ((dX && dX == dXn) || misaligned16(dUs) || (dX && misaligned16(dX)) || misaligned16(W)) return CGCN_ERR_BAD_ARG;
-  HeadApply hp = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1.f, 0u, S, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+  HeadApply hp = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1.f, 0u, S, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr};
   int head_slabs = 0;
   if (head) {
     if (!head->dym || !head->bnc || !head->save_mean || !head->save_invstd || !head->bn_w) return CGCN_ERR_BAD_ARG;
@@ -1036,7 +1037,7 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
     if ((rc = dropout_args(head->dropout_p, head->rng_state, &hks, &hth))) return rc;
     const int CP = head->C <= 128 ? 128 : 256;
     hp = HeadApply{head->dym, head->bnc, head->save_mean, head->save_invstd, head->bn_w, head->rng_state, hks, hth, S,
-                   head->part, head->dW_out, head->db_out, head->n_partials, head->C, CP, head->accumulate};
+                   head->part, head->dW_out, head->db_out, head->n_partials, head->C, CP, head->accumulate, head->dloss};
     head_slabs = (CP * d + CP) / 64;
   }
   if (!workspace || workspace_bytes < cgcn_layer_bwd_workspace_bytes(n, S, d)) return CGCN_ERR_WORKSPACE;

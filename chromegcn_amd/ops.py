@@ -312,20 +312,28 @@ class LastLayerHeadLossFn(torch.autograd.Function):
         ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8)
         probs = torch.empty((n, C), device=x.device, dtype=torch.float32)
         loss = torch.empty(1, device=x.device, dtype=torch.float32)
-        dpred = torch.empty((n, C), device=x.device, dtype=torch.float32) if need_bwd else None
         save_mean = torch.empty((S, d), device=x.device, dtype=torch.float32) if training else None
         save_invstd = torch.empty((S, d), device=x.device, dtype=torch.float32) if training else None
         drop = bool(training) and dropout_p > 0
         if (drop or dropout_in > 0) and rng_state is None:
             raise RuntimeError("chromegcn_amd: fused dropout needs the model's rng_state tensor")
-        _lib.check(lib.cgcn_head_fwd(_lib.stream_ptr(), n, S, d, C, xn.data_ptr(), bn_w.data_ptr(), bn_b.data_ptr(),
-                                     run_mean.data_ptr(), run_var.data_ptr(), _lib.ptr(nbt), float(momentum), float(eps),
-                                     1 if training else 0, w_out.data_ptr(), b_out.data_ptr(), target.data_ptr(),
-                                     float(dropout_p), _lib.ptr(rng_state) if drop else None, probs.data_ptr(),
-                                     loss.data_ptr(), _lib.ptr(dpred), _lib.ptr(save_mean), _lib.ptr(save_invstd),
-                                     ws.data_ptr(), ws_bytes), "cgcn_head_fwd")
         if need_bwd:
-            ctx.save_for_backward(x, z, h, gate, weight, wg, xn, bn_w, bn_b, w_out, dpred, save_mean, save_invstd,
+            # forward of the head + the tile-local half of its backward in one pass (cgcn_head_train); the workspace
+            # carries dym and the partial sums to backward()
+            _lib.check(lib.cgcn_head_train(_lib.stream_ptr(), n, S, d, C, xn.data_ptr(), bn_w.data_ptr(), bn_b.data_ptr(),
+                                           run_mean.data_ptr(), run_var.data_ptr(), _lib.ptr(nbt), float(momentum), float(eps),
+                                           w_out.data_ptr(), b_out.data_ptr(), target.data_ptr(), float(dropout_p) if drop else 0.0,
+                                           _lib.ptr(rng_state) if drop else None, probs.data_ptr(), loss.data_ptr(),
+                                           save_mean.data_ptr(), save_invstd.data_ptr(), ws.data_ptr(), ws_bytes), "cgcn_head_train")
+        else:
+            _lib.check(lib.cgcn_head_fwd(_lib.stream_ptr(), n, S, d, C, xn.data_ptr(), bn_w.data_ptr(), bn_b.data_ptr(),
+                                         run_mean.data_ptr(), run_var.data_ptr(), _lib.ptr(nbt), float(momentum), float(eps),
+                                         1 if training else 0, w_out.data_ptr(), b_out.data_ptr(), target.data_ptr(),
+                                         float(dropout_p), _lib.ptr(rng_state) if drop else None, probs.data_ptr(),
+                                         loss.data_ptr(), None, _lib.ptr(save_mean), _lib.ptr(save_invstd),
+                                         ws.data_ptr(), ws_bytes), "cgcn_head_fwd")
+        if need_bwd:
+            ctx.save_for_backward(x, z, h, gate, weight, wg, xn, bn_w, bn_b, w_out, ws, save_mean, save_invstd,
                                   rng_state if (drop or dropout_in > 0) else None)
             ctx.graph = graph
             ctx.dropout_p = float(dropout_p) if drop else 0.0
@@ -340,7 +348,7 @@ class LastLayerHeadLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dloss, _dprobs, _dgate):
-        (x, z, h, gate, weight, wg, xn, bn_w, bn_b, w_out, dpred, save_mean, save_invstd, rng_state) = ctx.saved_tensors
+        (x, z, h, gate, weight, wg, xn, bn_w, bn_b, w_out, hws, save_mean, save_invstd, rng_state) = ctx.saved_tensors
         g = ctx.graph
         S, n, d = x.shape
         C = w_out.shape[0]
@@ -356,13 +364,13 @@ class LastLayerHeadLossFn(torch.autograd.Function):
             dw, db, dwg, dcg = ctx.layer_sink
         else:
             dw, db, dwg, dcg = torch.empty_like(weight), torch.empty(d, **f32), torch.empty(d, **f32), torch.empty(1, **f32)
-        hws_bytes = lib.cgcn_head_workspace_bytes(n, S, d, C)
-        hws = torch.empty(hws_bytes, device=dev, dtype=torch.uint8)
+        hws_bytes = hws.numel()
         if dloss is None:
             return (None,) * 24
         dloss = dloss.contiguous().view(1)
+        # fused mode (dpred = NULL): dym and the partials are already in the workspace cgcn_head_train filled
         _lib.check(lib.cgcn_head_bwd(_lib.stream_ptr(), n, S, d, C, xn.data_ptr(), bn_w.data_ptr(), bn_b.data_ptr(),
-                                     save_mean.data_ptr(), save_invstd.data_ptr(), w_out.data_ptr(), dpred.data_ptr(),
+                                     save_mean.data_ptr(), save_invstd.data_ptr(), w_out.data_ptr(), None,
                                      dloss.data_ptr(), ctx.dropout_p, _lib.ptr(rng_state), None,
                                      dw_out.data_ptr(), db_out.data_ptr(), dbn_w.data_ptr(), dbn_b.data_ptr(), 0,
                                      hws.data_ptr(), hws_bytes), "cgcn_head_bwd")
@@ -373,7 +381,7 @@ class LastLayerHeadLossFn(torch.autograd.Function):
         hg = _lib.HeadGrad(hws.data_ptr() + o_dym.value, hws.data_ptr() + o_bnc.value, save_mean.data_ptr(),
                            save_invstd.data_ptr(), bn_w.data_ptr(), ctx.dropout_p, _lib.ptr(rng_state),
                            hws.data_ptr() + o_part.value, lib.cgcn_head_bwd_partials(n), C, dw_out.data_ptr(),
-                           db_out.data_ptr(), 0)
+                           db_out.data_ptr(), 0, dloss.data_ptr())
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dus = torch.empty_like(x)
         ws_bytes = lib.cgcn_layer_bwd_workspace_bytes(n, S, d)

@@ -48,7 +48,7 @@ extern "C" {
 #define CGCN_ERR_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after a launch      */
 #define CGCN_ERR_WORKSPACE (-4)   /* workspace too small (see cgcn_*_workspace_bytes)    */
 
-#define CGCN_ABI_VERSION 9
+#define CGCN_ABI_VERSION 10
 
 typedef void *cgcn_stream_t; /* hipStream_t */
 
@@ -114,6 +114,8 @@ typedef struct cgcn_head_grad {
   float *dW_out;            /* [C,d] */
   float *db_out;            /* [C]   */
   int accumulate;
+  const float *dloss;       /* [1] upstream d loss when the workspace came from cgcn_head_train (whose results are for
+                               d loss = 1); NULL when it came from cgcn_head_bwd with dpred (already scaled) */
 } cgcn_head_grad;
 
 /* Bytes of scratch cgcn_layer_bwd needs for (n, S, d).  0 on unsupported shapes. */
@@ -180,11 +182,26 @@ int cgcn_head_fwd(cgcn_stream_t stream, int n, int S, int d, int C, const float 
                   void *workspace, size_t workspace_bytes);
 
 /*
+ * Training-mode head forward fused with the tile-local half of its backward (one pass over X): same outputs as
+ * cgcn_head_fwd(training = 1) -- probs, loss, save_mean / save_invstd, running-stat update -- and, left in
+ * `workspace` for the backward, dym = d loss / d (mean_s y_s) and the per-workgroup partials of dW_out, db_out and
+ * the BatchNorm sums, all for an upstream d loss of 1.  The same workspace must then be handed to cgcn_head_bwd with
+ * dpred == NULL and dX == NULL (which only finalises the BatchNorm sums, scaled by dloss) and to cgcn_layer_bwd via
+ * cgcn_head_grad (with .dloss set).  d loss / d pred never touches memory.
+ */
+int cgcn_head_train(cgcn_stream_t stream, int n, int S, int d, int C, const float *X, const float *bn_w,
+                    const float *bn_b, float *run_mean, float *run_var, long long *num_batches_tracked,
+                    float momentum, float eps, const float *W_out, const float *b_out, const float *target,
+                    float dropout_p, const unsigned long long *rng_state, float *probs, float *loss,
+                    float *save_mean, float *save_invstd, void *workspace, size_t workspace_bytes);
+
+/*
  * Backward of cgcn_head_fwd (training mode).  dloss: [1] upstream gradient of the loss or NULL (= 1).
  * Outputs dX [S,n,d] and, overwritten (accumulate == 0) or added to (accumulate != 0): dW_out [C,d],
  * db_out [C], dbn_w [d], dbn_b [d].  With dX == NULL ("deferred mode") only dbn_w, dbn_b and the dym / bnc /
  * partials state are produced; dX, dW_out and db_out are then finished by cgcn_layer_bwd given a
- * cgcn_head_grad that points at this workspace.  rng_state: same contents as in the forward.  Deterministic.
+ * cgcn_head_grad that points at this workspace.  dpred == NULL (with dX == NULL): the workspace comes from
+ * cgcn_head_train and already holds dym and the partials.  rng_state: same contents as in the forward.  Deterministic.
  */
 int cgcn_head_bwd(cgcn_stream_t stream, int n, int S, int d, int C, const float *X, const float *bn_w,
                   const float *bn_b, const float *save_mean, const float *save_invstd, const float *W_out,

@@ -28,7 +28,8 @@ def _probe_layer_mask(S, n, d, p, rng, layer_id):
     return (xn > 0.5).cpu()
 
 
-def test_two_layer_model_with_dropout_matches_float64_with_explicit_masks():
+@pytest.mark.parametrize("scale", [1.0, 1.7])
+def test_two_layer_model_with_dropout_matches_float64_with_explicit_masks(scale):
     S, n, d, c, p = 2, 97, 128, 9, 0.2
     a = O.random_symmetric_graph(n, 500, 3)
     graph = C.process_graph("hic", {"c": a}, n, "c", device=DEV)
@@ -68,11 +69,11 @@ def test_two_layer_model_with_dropout_matches_float64_with_explicit_masks():
         y = m64.batch_norm(F.relu(h)) * maskh[s] / (1 - p)
         logits.append(m64.out(y))
     loss64 = F.binary_cross_entropy_with_logits(sum(logits) / S, tgt.double())
-    loss64.backward()
+    (loss64 * scale).backward()   # scale != 1: the fused head computes its backward half for d loss = 1 and rescales
 
     xg = x.to(DEV).requires_grad_(True)
     loss, probs, gates = m.forward_loss(xg, graph, tgt.to(DEV))
-    loss.backward()
+    (loss * scale).backward()
     assert int(m._rng_state[1].item()) == 3
     assert abs(loss.item() - loss64.item()) < 2e-5
     ref = x64.grad.numpy()
