@@ -25,7 +25,7 @@
 #define HEAD_TILE 16
 #define HEADB_TILE 32
 #ifndef HEAD_MAX_PARTIALS
-#define HEAD_MAX_PARTIALS 128
+#define HEAD_MAX_PARTIALS 256  // one 32-node tile per workgroup up to 8k nodes: the kernel is a latency chain per tile
 #endif
 
 // ------------------------------------------------------------------------------------------
