@@ -92,33 +92,48 @@ __device__ __forceinline__ void head_finalize_slab(int slab, int P, int n, int S
   const float gl = dloss ? dloss[0] : 1.f;  // everything summed here is linear in the upstream d loss
   const int PS = CP * D + CP + 4 * D;
   const int total = CP * D + CP + D;
-  __shared__ float hred[NS][4][64];
-  const int el = threadIdx.x & 63, slice = threadIdx.x >> 6;
-  const int e = slab * 64 + el;
-  const bool stats = e >= CP * D + CP;
-  const int nq = stats ? 4 : 1;  // a stats element reduces (sdy_0, sdy_1, sdyx_0, sdyx_1) of one column
-  float s[4] = {0.f, 0.f, 0.f, 0.f};
-  if (e < total) {
-    const int per = (P + NS - 1) / NS;
-    const int p0 = slice * per, p1 = min(P, p0 + per);
-    const int base = stats ? (CP * D + CP + (e - CP * D - CP)) : e;
+  __shared__ __attribute__((aligned(16))) float hred[NS][4][64];
+  // lane = (el4, sub): 16 lanes x float4 cover the slab's 64 elements, the 4 sub-groups of a wave and the NS
+  // waves each take a contiguous range of the P partials -> one or two batches of independent 16-byte loads
+  // per thread instead of a long chain of 4-byte ones (the kernel is latency-, not bandwidth-limited).
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int el4 = lane & 15, sub = lane >> 4;
+  const int e0 = slab * 64 + el4 * 4;  // region boundaries are multiples of 4: a float4 never straddles one
+  const int nq = e0 >= CP * D + CP ? 4 : 1;  // a stats element reduces (sdy_0, sdy_1, sdyx_0, sdyx_1) of one column
+  f32x4 s4[4];
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) s4[qd] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (e0 < total) {
+    const int per = (P + NS * 4 - 1) / (NS * 4);
+    const int p0 = (wave * 4 + sub) * per, p1 = min(P, p0 + per);
     for (int qd = 0; qd < nq; ++qd) {
-      float a = 0.f;
-      int p = p0;
-      for (; p + 8 <= p1; p += 8) {
-        float t[8];
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      for (int p = p0; p < p1; p += 8) {
+        f32x4 t[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = part[(size_t)(p + u) * PS + base + qd * D];
+        for (int u = 0; u < 8; ++u) t[u] = *(const f32x4*)(part + (size_t)min(p + u, p1 - 1) * PS + e0 + qd * D);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) a += t[u];
+        for (int u = 0; u < 8; ++u)
+          if (p + u < p1) a += t[u];
       }
-      for (; p < p1; ++p) a += part[(size_t)p * PS + base + qd * D];
-      s[qd] = a;
+      s4[qd] = a;
     }
   }
 #pragma unroll
-  for (int qd = 0; qd < 4; ++qd) hred[slice][qd][el] = s[qd];
+  for (int qd = 0; qd < 4; ++qd) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float v = s4[qd][k];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      s4[qd][k] = v;
+    }
+    if (sub == 0) *(f32x4*)&hred[wave][qd][el4 * 4] = s4[qd];
+  }
   __syncthreads();
+  const int el = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int e = slab * 64 + el;
+  float s[4];
   if (slice != 0 || e >= total) return;
 #pragma unroll
   for (int qd = 0; qd < 4; ++qd) {

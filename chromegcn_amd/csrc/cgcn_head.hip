@@ -599,7 +599,10 @@ __global__ __launch_bounds__(512) void k_head_bwd(int n, int S, int C, const flo
 template <int D, int CBMAX>
 __global__ __launch_bounds__(512) void k_head_fused(int n, int S, int C, const float* __restrict__ X,
                                                     const float* __restrict__ bn_w, const float* __restrict__ bn_b,
-                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                    const float* __restrict__ spart, int nblk, int rows_per_blk,
+                                                    float momentum, float eps, float* __restrict__ run_mean,
+                                                    float* __restrict__ run_var, long long* __restrict__ nbt,
+                                                    float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                                     const float* __restrict__ Wout, const float* __restrict__ bout,
                                                     const float* __restrict__ target, float keep_scale, uint32_t thresh,
                                                     const unsigned long long* __restrict__ rng_state, float inv_count,
@@ -615,6 +618,7 @@ __global__ __launch_bounds__(512) void k_head_fused(int n, int S, int C, const f
   __shared__ __attribute__((aligned(16))) float Pt[TR * LDP];
   __shared__ __attribute__((aligned(16))) float Yt[TR * LDY];
   __shared__ float lsum[NW];
+  __shared__ float s_mean[2 * D], s_invstd[2 * D];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -622,6 +626,65 @@ __global__ __launch_bounds__(512) void k_head_fused(int n, int S, int C, const f
   const uint32_t key = thresh ? dropout_key(rng_state, HEAD_STREAM_ID) : 0u;
   const int CB = (C + 15) / 16;
   const float invS = 1.f / (float)S;
+
+  // ---- BatchNorm batch statistics: every workgroup merges the column partials of k_head_colstats itself (Chan's
+  // formula, fixed order => identical in every workgroup); workgroup 0 also publishes them for the backward and does
+  // the running-stat update, strand 0 then strand 1 like the reference's two forward calls.  This replaces a
+  // separate one-workgroup-wide finalize launch that cost more than the redundant arithmetic.
+  {
+    float* sc = Pt;  // scratch [2 halves][3][S*D] + [S*D]
+    static_assert(7 * 2 * D <= TR * LDP, "statistics scratch must fit in Pt");
+    const int SD = S * D;
+    for (int idx = threadIdx.x; idx < 2 * SD; idx += 512) {
+      const int half = idx / SD, col = idx % SD;  // col = s*D + c
+      const int b0 = half * ((nblk + 1) / 2), b1 = min(nblk, b0 + (nblk + 1) / 2);
+      float cnt = 0.f, mean_ = 0.f, m2 = 0.f;
+      for (int b = b0; b < b1; b += 8) {
+        float pm[8], p2[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int bb = min(b + u, b1 - 1);
+          const float* pp = spart + ((size_t)bb * SD + col) * 2;
+          pm[u] = pp[0];
+          p2[u] = pp[1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (b + u < b1) {
+            const float nb = (float)max(0, min(n, (b + u + 1) * rows_per_blk) - (b + u) * rows_per_blk);
+            chan_combine(cnt, mean_, m2, nb, pm[u], p2[u]);
+          }
+        }
+      }
+      sc[(half * 3 + 0) * SD + col] = cnt;
+      sc[(half * 3 + 1) * SD + col] = mean_;
+      sc[(half * 3 + 2) * SD + col] = m2;
+    }
+    __syncthreads();
+    for (int col = threadIdx.x; col < SD; col += 512) {
+      float cnt = sc[0 * SD + col], mean_ = sc[1 * SD + col], m2 = sc[2 * SD + col];
+      chan_combine(cnt, mean_, m2, sc[3 * SD + col], sc[4 * SD + col], sc[5 * SD + col]);
+      s_mean[col] = mean_;
+      s_invstd[col] = rsqrtf(m2 / (float)n + eps);
+      sc[6 * SD + col] = m2;  // for the running variance below
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {
+      for (int c = threadIdx.x; c < D; c += 512) {
+        float rm = run_mean[c], rv = run_var[c];
+        for (int s = 0; s < S; ++s) {
+          save_mean[s * D + c] = s_mean[s * D + c];
+          save_invstd[s * D + c] = s_invstd[s * D + c];
+          rm = (1.f - momentum) * rm + momentum * s_mean[s * D + c];
+          rv = (1.f - momentum) * rv + momentum * (sc[6 * SD + s * D + c] / (float)(n - 1));
+        }
+        run_mean[c] = rm;
+        run_var[c] = rv;
+      }
+      if (threadIdx.x == 0 && nbt) nbt[0] += S;
+    }
+    __syncthreads();  // Pt is reused below
+  }
 
   // operand fragments of W_out, fetched once per workgroup (D = 128): B of pred = ym W_out^T and B of dym = dpred W_out
   float bw[NCBW][PRE ? KQ : 1];
@@ -662,8 +725,8 @@ __global__ __launch_bounds__(512) void k_head_fused(int n, int S, int C, const f
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       sdy[s][e] = sdyx[s][e] = 0.f;
-      mu[s][e] = mean[(s < S ? s : 0) * D + c];
-      is[s][e] = invstd[(s < S ? s : 0) * D + c];
+      mu[s][e] = s_mean[(s < S ? s : 0) * D + c];
+      is[s][e] = s_invstd[(s < S ? s : 0) * D + c];
     }
   }
 
@@ -895,12 +958,12 @@ __global__ __launch_bounds__(512) void k_head_fused(int n, int S, int C, const f
 }
 
 // second stage (see head_finalize_slab): slabs [slab0, slab0 + gridDim.x)
-__global__ __launch_bounds__(256) void k_head_bwd_finalize(int slab0, int P, int n, int S, int D, int C, int CP,
+__global__ __launch_bounds__(512) void k_head_bwd_finalize(int slab0, int P, int n, int S, int D, int C, int CP,
                                                            const float* __restrict__ part, float* __restrict__ dWout,
                                                            float* __restrict__ dbout, float* __restrict__ dbn_w,
                                                            float* __restrict__ dbn_b, float* __restrict__ bnc,
                                                            int accumulate, const float* __restrict__ dloss) {
-  head_finalize_slab<256>(slab0 + blockIdx.x, P, n, S, D, C, CP, part, dWout, dbout, dbn_w, dbn_b, bnc, accumulate, dloss);
+  head_finalize_slab<512>(slab0 + blockIdx.x, P, n, S, D, C, CP, part, dWout, dbout, dbn_w, dbn_b, bnc, accumulate, dloss);
 }
 
 template <int D>
@@ -1059,17 +1122,15 @@ int cgcn_head_train(cgcn_stream_t stream, int n, int S, int d, int C, const floa
   if (d == 128) hipLaunchKernelGGL((k_head_colstats<128>), dim3(nblk), dim3(256), 0, st, n, S, rpb, X, w_stats);
   else hipLaunchKernelGGL((k_head_colstats<256>), dim3(nblk), dim3(256), 0, st, n, S, rpb, X, w_stats);
   if ((rc = launch_status())) return rc;
-  hipLaunchKernelGGL(k_head_bn_finalize, dim3((d + 15) / 16), dim3(256), 0, st, n, S, d, nblk, rpb, w_stats, momentum, eps,
-                     run_mean, run_var, num_batches_tracked, save_mean, save_invstd);
-  if ((rc = launch_status())) return rc;
   const int P = head_bwd_partials(n);
   const int CP = head_cp(C);
   const float keep_scale = drop ? 1.f / (1.f - dropout_p) : 1.f;
   const uint32_t thresh = drop ? dropout_threshold(dropout_p) : 0u;
   const float inv_count = 1.f / ((float)n * (float)C);
 #define HFU(D_, CB_)                                                                                                  \
-  hipLaunchKernelGGL((k_head_fused<D_, CB_>), dim3(P), dim3(512), 0, st, n, S, C, X, bn_w, bn_b, save_mean, save_invstd, \
-                     Wout, bout, target, keep_scale, thresh, rng_state, inv_count, probs, w_loss, w_dym, w_part)
+  hipLaunchKernelGGL((k_head_fused<D_, CB_>), dim3(P), dim3(512), 0, st, n, S, C, X, bn_w, bn_b, w_stats, nblk, rpb,  \
+                     momentum, eps, run_mean, run_var, num_batches_tracked, save_mean, save_invstd, Wout, bout, target, \
+                     keep_scale, thresh, rng_state, inv_count, probs, w_loss, w_dym, w_part)
   if (d == 128) { if (CP == 128) HFU(128, 8); else HFU(128, 16); }
   else { if (CP == 128) HFU(256, 8); else HFU(256, 16); }
 #undef HFU
@@ -1117,11 +1178,11 @@ int cgcn_head_bwd(cgcn_stream_t stream, int n, int S, int d, int C, const float*
   if (!dX) {
     // deferred mode: only the BatchNorm columns now (cgcn_layer_bwd needs bnc); the dW_out / db_out slabs ride at the
     // end of k_bwd_rowlocal's grid (cgcn_head_grad.part / dW_out / db_out)
-    hipLaunchKernelGGL(k_head_bwd_finalize, dim3(slabs - wslabs), dim3(256), 0, st, wslabs, P, n, S, d, C, CP, w_part, dWout,
+    hipLaunchKernelGGL(k_head_bwd_finalize, dim3(slabs - wslabs), dim3(512), 0, st, wslabs, P, n, S, d, C, CP, w_part, dWout,
                        dbout, dbn_w, dbn_b, w_bnc, accumulate, fin_scale);
     return launch_status();
   }
-  hipLaunchKernelGGL(k_head_bwd_finalize, dim3(slabs), dim3(256), 0, st, 0, P, n, S, d, C, CP, w_part, dWout, dbout,
+  hipLaunchKernelGGL(k_head_bwd_finalize, dim3(slabs), dim3(512), 0, st, 0, P, n, S, d, C, CP, w_part, dWout, dbout,
                      dbn_w, dbn_b, w_bnc, accumulate, fin_scale);
   if ((rc = launch_status())) return rc;
   const size_t total4 = (size_t)S * n * d / 4;
