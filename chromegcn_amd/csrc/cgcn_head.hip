@@ -89,56 +89,74 @@ __global__ __launch_bounds__(256) void k_head_colstats(int n, int S, int rows_pe
   }
 }
 
-// 16 columns x 16 partial-slices per workgroup: each thread Chan-combines nblk/16 partials (independent
-// loads), the 16 slices are merged through LDS in a fixed order, then one thread per column finishes
-// both strands (the running-stat update is sequential in the strand index).
-__global__ __launch_bounds__(256) void k_head_bn_finalize(int n, int S, int D, int nblk, int rows_per_blk,
-                                                          const float* __restrict__ part, float momentum, float eps,
-                                                          float* __restrict__ run_mean, float* __restrict__ run_var,
-                                                          long long* __restrict__ nbt, float* __restrict__ save_mean,
-                                                          float* __restrict__ save_invstd) {
-  __shared__ float sm[2][3][16][17];
+// Second stage of the statistics.  One workgroup = 16 (strand, channel) columns x 64 slices of the partial list: every
+// thread Chan-combines its few partials (one batch of independent loads), the 64 slices are merged through LDS in two
+// fixed-order steps, and one thread per channel finishes both strands (the running-stat update is sequential in the
+// strand index).  The kernel is a pure latency chain, so it is laid out wide and shallow.
+__global__ __launch_bounds__(1024) void k_head_bn_finalize(int n, int S, int D, int nblk, int rows_per_blk,
+                                                           const float* __restrict__ part, float momentum, float eps,
+                                                           float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                           long long* __restrict__ nbt, float* __restrict__ save_mean,
+                                                           float* __restrict__ save_invstd) {
+  __shared__ float sm[3][64][17];
   const int cl = threadIdx.x & 15, slice = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+  const int CPB = 16 / S;  // channels per workgroup (S is 1 or 2)
+  const int s = cl / CPB, c = blockIdx.x * CPB + cl % CPB;
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += S;
-  const int per = (nblk + 15) / 16;
+  const int per = (nblk + 63) / 64;
   const int b0 = slice * per, b1 = min(nblk, b0 + per);
-  for (int s = 0; s < S; ++s) {
-    float cnt = 0.f, mean = 0.f, m2 = 0.f;
-    if (c < D) {
-      for (int b = b0; b < b1; b += 8) {
-        float pm[8], p2[8];
+  float cnt = 0.f, mean = 0.f, m2 = 0.f;
+  if (c < D) {
+    for (int b = b0; b < b1; b += 8) {
+      float pm[8], p2[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int bb = min(b + u, b1 - 1);
-          const float* p = part + (((size_t)bb * S + s) * D + c) * 2;
-          pm[u] = p[0];
-          p2[u] = p[1];
-        }
+      for (int u = 0; u < 8; ++u) {
+        const int bb = min(b + u, b1 - 1);
+        const float* p = part + (((size_t)bb * S + s) * D + c) * 2;
+        pm[u] = p[0];
+        p2[u] = p[1];
+      }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          if (b + u < b1) {
-            const float nb = (float)max(0, min(n, (b + u + 1) * rows_per_blk) - (b + u) * rows_per_blk);
-            chan_combine(cnt, mean, m2, nb, pm[u], p2[u]);
-          }
+      for (int u = 0; u < 8; ++u) {
+        if (b + u < b1) {
+          const float nb = (float)max(0, min(n, (b + u + 1) * rows_per_blk) - (b + u) * rows_per_blk);
+          chan_combine(cnt, mean, m2, nb, pm[u], p2[u]);
         }
       }
     }
-    sm[s][0][slice][cl] = cnt;
-    sm[s][1][slice][cl] = mean;
-    sm[s][2][slice][cl] = m2;
+  }
+  sm[0][slice][cl] = cnt;
+  sm[1][slice][cl] = mean;
+  sm[2][slice][cl] = m2;
+  __syncthreads();
+  if (slice < 8) {  // slices 8*slice .. 8*slice+7
+    cnt = mean = m2 = 0.f;
+    for (int o = 0; o < 8; ++o) chan_combine(cnt, mean, m2, sm[0][slice * 8 + o][cl], sm[1][slice * 8 + o][cl], sm[2][slice * 8 + o][cl]);
   }
   __syncthreads();
-  if (slice != 0 || c >= D) return;
+  if (slice < 8) {
+    sm[0][slice][cl] = cnt;
+    sm[1][slice][cl] = mean;
+    sm[2][slice][cl] = m2;
+  }
+  __syncthreads();
+  if (slice == 0) {
+    cnt = mean = m2 = 0.f;
+    for (int o = 0; o < 8; ++o) chan_combine(cnt, mean, m2, sm[0][o][cl], sm[1][o][cl], sm[2][o][cl]);
+    sm[1][8][cl] = mean;
+    sm[2][8][cl] = m2;
+    if (c < D) {
+      save_mean[s * D + c] = mean;
+      save_invstd[s * D + c] = rsqrtf(m2 / (float)n + eps);
+    }
+  }
+  __syncthreads();
+  if (slice != 0 || s != 0 || c >= D) return;
   float rm = run_mean[c], rv = run_var[c];
-  for (int s = 0; s < S; ++s) {
-    float cnt = 0.f, mean = 0.f, m2 = 0.f;
-    for (int o = 0; o < 16; ++o) chan_combine(cnt, mean, m2, sm[s][0][o][cl], sm[s][1][o][cl], sm[s][2][o][cl]);
-    save_mean[s * D + c] = mean;
-    save_invstd[s * D + c] = rsqrtf(m2 / (float)n + eps);
+  for (int st = 0; st < S; ++st) {
     // sequential update: the reference calls the model on the forward strand, then the reverse one
-    rm = (1.f - momentum) * rm + momentum * mean;
-    rv = (1.f - momentum) * rv + momentum * (m2 / (float)(n - 1));
+    rm = (1.f - momentum) * rm + momentum * sm[1][8][st * CPB + cl];
+    rv = (1.f - momentum) * rv + momentum * (sm[2][8][st * CPB + cl] / (float)(n - 1));
   }
   run_mean[c] = rm;
   run_var[c] = rv;
@@ -596,13 +614,21 @@ __global__ __launch_bounds__(512) void k_head_bwd(int n, int S, int C, const flo
 // actual d loss (all of it is linear in that scalar).
 // Persistent over 32-node tiles like k_head_bwd; same partial layout.
 // ------------------------------------------------------------------------------------------
+#ifdef HF_TIMING  // tuning build only (tools/khead.py --stamps): phase timestamps of a few workgroups
+__device__ unsigned long long hf_stamps[8 * 16];
+#define HF_STAMP(i)                                                                      \
+  do {                                                                                   \
+    __builtin_amdgcn_s_waitcnt(0);                                                       \
+    if (threadIdx.x == 0 && (blockIdx.x & 31) == 0) hf_stamps[(blockIdx.x >> 5) * 16 + (i)] = wall_clock64(); \
+  } while (0)
+#else
+#define HF_STAMP(i)
+#endif
+
 template <int D, int CBMAX>
 __global__ __launch_bounds__(512) void k_head_fused(int n, int S, int C, const float* __restrict__ X,
                                                     const float* __restrict__ bn_w, const float* __restrict__ bn_b,
-                                                    const float* __restrict__ spart, int nblk, int rows_per_blk,
-                                                    float momentum, float eps, float* __restrict__ run_mean,
-                                                    float* __restrict__ run_var, long long* __restrict__ nbt,
-                                                    float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
                                                     const float* __restrict__ Wout, const float* __restrict__ bout,
                                                     const float* __restrict__ target, float keep_scale, uint32_t thresh,
                                                     const unsigned long long* __restrict__ rng_state, float inv_count,
@@ -618,7 +644,6 @@ __global__ __launch_bounds__(512) void k_head_fused(int n, int S, int C, const f
   __shared__ __attribute__((aligned(16))) float Pt[TR * LDP];
   __shared__ __attribute__((aligned(16))) float Yt[TR * LDY];
   __shared__ float lsum[NW];
-  __shared__ float s_mean[2 * D], s_invstd[2 * D];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -627,65 +652,8 @@ __global__ __launch_bounds__(512) void k_head_fused(int n, int S, int C, const f
   const int CB = (C + 15) / 16;
   const float invS = 1.f / (float)S;
 
-  // ---- BatchNorm batch statistics: every workgroup merges the column partials of k_head_colstats itself (Chan's
-  // formula, fixed order => identical in every workgroup); workgroup 0 also publishes them for the backward and does
-  // the running-stat update, strand 0 then strand 1 like the reference's two forward calls.  This replaces a
-  // separate one-workgroup-wide finalize launch that cost more than the redundant arithmetic.
-  {
-    float* sc = Pt;  // scratch [2 halves][3][S*D] + [S*D]
-    static_assert(7 * 2 * D <= TR * LDP, "statistics scratch must fit in Pt");
-    const int SD = S * D;
-    for (int idx = threadIdx.x; idx < 2 * SD; idx += 512) {
-      const int half = idx / SD, col = idx % SD;  // col = s*D + c
-      const int b0 = half * ((nblk + 1) / 2), b1 = min(nblk, b0 + (nblk + 1) / 2);
-      float cnt = 0.f, mean_ = 0.f, m2 = 0.f;
-      for (int b = b0; b < b1; b += 8) {
-        float pm[8], p2[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int bb = min(b + u, b1 - 1);
-          const float* pp = spart + ((size_t)bb * SD + col) * 2;
-          pm[u] = pp[0];
-          p2[u] = pp[1];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          if (b + u < b1) {
-            const float nb = (float)max(0, min(n, (b + u + 1) * rows_per_blk) - (b + u) * rows_per_blk);
-            chan_combine(cnt, mean_, m2, nb, pm[u], p2[u]);
-          }
-        }
-      }
-      sc[(half * 3 + 0) * SD + col] = cnt;
-      sc[(half * 3 + 1) * SD + col] = mean_;
-      sc[(half * 3 + 2) * SD + col] = m2;
-    }
-    __syncthreads();
-    for (int col = threadIdx.x; col < SD; col += 512) {
-      float cnt = sc[0 * SD + col], mean_ = sc[1 * SD + col], m2 = sc[2 * SD + col];
-      chan_combine(cnt, mean_, m2, sc[3 * SD + col], sc[4 * SD + col], sc[5 * SD + col]);
-      s_mean[col] = mean_;
-      s_invstd[col] = rsqrtf(m2 / (float)n + eps);
-      sc[6 * SD + col] = m2;  // for the running variance below
-    }
-    __syncthreads();
-    if (blockIdx.x == 0) {
-      for (int c = threadIdx.x; c < D; c += 512) {
-        float rm = run_mean[c], rv = run_var[c];
-        for (int s = 0; s < S; ++s) {
-          save_mean[s * D + c] = s_mean[s * D + c];
-          save_invstd[s * D + c] = s_invstd[s * D + c];
-          rm = (1.f - momentum) * rm + momentum * s_mean[s * D + c];
-          rv = (1.f - momentum) * rv + momentum * (sc[6 * SD + s * D + c] / (float)(n - 1));
-        }
-        run_mean[c] = rm;
-        run_var[c] = rv;
-      }
-      if (threadIdx.x == 0 && nbt) nbt[0] += S;
-    }
-    __syncthreads();  // Pt is reused below
-  }
-
+  HF_STAMP(0);
+  HF_STAMP(1);
   // operand fragments of W_out, fetched once per workgroup (D = 128): B of pred = ym W_out^T and B of dym = dpred W_out
   float bw[NCBW][PRE ? KQ : 1];
   float bwo[JBW][PRE ? CBMAX * 4 : 1];
@@ -709,6 +677,7 @@ __global__ __launch_bounds__(512) void k_head_fused(int n, int S, int C, const f
         bwo[jb][kk] = (k < C) ? Wout[(size_t)k * D + (wave * JBW + jb) * 16 + r] : 0.f;
       }
   }
+  HF_STAMP(2);
   f32x4 accW[CBMAX][JBW];
 #pragma unroll
   for (int ib = 0; ib < CBMAX; ++ib)
@@ -725,8 +694,8 @@ __global__ __launch_bounds__(512) void k_head_fused(int n, int S, int C, const f
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       sdy[s][e] = sdyx[s][e] = 0.f;
-      mu[s][e] = s_mean[(s < S ? s : 0) * D + c];
-      is[s][e] = s_invstd[(s < S ? s : 0) * D + c];
+      mu[s][e] = mean[(s < S ? s : 0) * D + c];
+      is[s][e] = invstd[(s < S ? s : 0) * D + c];
     }
   }
 
@@ -757,6 +726,7 @@ __global__ __launch_bounds__(512) void k_head_fused(int n, int S, int C, const f
           tgv[cbi][mb][e] = (i < n && j < C) ? target[(size_t)i * C + j] : 0.f;
         }
     }
+    HF_STAMP(3);
     // ---- ym rows -> Yt
 #pragma unroll
     for (int t = 0; t < RPW; ++t) {
@@ -779,6 +749,7 @@ __global__ __launch_bounds__(512) void k_head_fused(int n, int S, int C, const f
       }
     }
     __syncthreads();
+    HF_STAMP(4);
     // ---- pred = ym W_out^T  (M = 32 rows, K = D permuted, N = this wave's label block(s))
     f32x4 acc[NCBW][2];
 #pragma unroll
@@ -809,6 +780,7 @@ __global__ __launch_bounds__(512) void k_head_fused(int n, int S, int C, const f
         }
       }
     }
+    HF_STAMP(5);
     // ---- sigmoid / BCE; d loss / d pred goes straight into the LDS tile (zero outside the valid region)
 #pragma unroll
     for (int cbi = 0; cbi < NCBW; ++cbi) {
@@ -833,6 +805,7 @@ __global__ __launch_bounds__(512) void k_head_fused(int n, int S, int C, const f
         }
     }
     __syncthreads();
+    HF_STAMP(6);
     if (threadIdx.x < CP) {
       float sacc = 0.f;
 #pragma unroll 8
@@ -855,6 +828,7 @@ __global__ __launch_bounds__(512) void k_head_fused(int n, int S, int C, const f
         }
       }
     }
+    HF_STAMP(7);
     // ---- dym tile = Pt W_out   (M = TR rows, K = labels, N = D)
     f32x4 accY[2][JBW];
 #pragma unroll
@@ -890,6 +864,7 @@ __global__ __launch_bounds__(512) void k_head_fused(int n, int S, int C, const f
         }
       }
     }
+    HF_STAMP(8);
     __syncthreads();  // all reads of Yt / Pt done
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
@@ -898,6 +873,7 @@ __global__ __launch_bounds__(512) void k_head_fused(int n, int S, int C, const f
 #pragma unroll
         for (int e = 0; e < 4; ++e) Yt[(mb * 16 + q * 4 + e) * LDY + (wave * JBW + jb) * 16 + r] = accY[mb][jb][e];
     __syncthreads();
+    HF_STAMP(9);
     // ---- row pass: write dym, accumulate the BatchNorm-backward column sums (X rows still in registers)
 #pragma unroll
     for (int t = 0; t < RPW; ++t) {
@@ -923,6 +899,7 @@ __global__ __launch_bounds__(512) void k_head_fused(int n, int S, int C, const f
     __syncthreads();
   }
 
+  HF_STAMP(10);
   // ---- partials (same layout as k_head_bwd) + this workgroup's share of the loss
   float* P = part + (size_t)blockIdx.x * PS;
 #pragma unroll
@@ -932,6 +909,7 @@ __global__ __launch_bounds__(512) void k_head_fused(int n, int S, int C, const f
 #pragma unroll
       for (int e = 0; e < 4; ++e) P[(ib * 16 + q * 4 + e) * D + (wave * JBW + jb) * 16 + r] = accW[ib][jb][e];
   if (threadIdx.x < CP) P[CP * D + threadIdx.x] = dbo;
+  HF_STAMP(11);
   lacc = wave_sum(lacc);
   if (lane == 0) lsum[wave] = lacc;
   float* red = Yt;  // [NW][4*D]
@@ -955,6 +933,7 @@ __global__ __launch_bounds__(512) void k_head_fused(int n, int S, int C, const f
     for (int w = 0; w < NW; ++w) t += lsum[w];
     loss_part[blockIdx.x] = t;
   }
+  HF_STAMP(12);
 }
 
 // second stage (see head_finalize_slab): slabs [slab0, slab0 + gridDim.x)
@@ -1031,6 +1010,13 @@ static inline size_t align4(size_t x) { return (x + 3) & ~(size_t)3; }
 
 extern "C" {
 
+#ifdef HF_TIMING
+int cgcn_debug_hf_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(hf_stamps), sizeof(unsigned long long) * 8 * 16) == hipSuccess ? 0 : -1;
+}
+#endif
+
+
 int cgcn_head_workspace_layout(int n, int S, int d, int C, size_t* dym_offset, size_t* bnc_offset, size_t* part_offset) {
   int rc = head_check(n, S, d, C);
   if (rc) return rc;
@@ -1075,7 +1061,7 @@ int cgcn_head_fwd(cgcn_stream_t stream, int n, int S, int d, int C, const float*
     if (d == 128) hipLaunchKernelGGL((k_head_colstats<128>), dim3(nblk), dim3(256), 0, st, n, S, rpb, X, w_stats);
     else hipLaunchKernelGGL((k_head_colstats<256>), dim3(nblk), dim3(256), 0, st, n, S, rpb, X, w_stats);
     if ((rc = launch_status())) return rc;
-    hipLaunchKernelGGL(k_head_bn_finalize, dim3((d + 15) / 16), dim3(256), 0, st, n, S, d, nblk, rpb, w_stats, momentum, eps,
+    hipLaunchKernelGGL(k_head_bn_finalize, dim3((S * d + 15) / 16), dim3(1024), 0, st, n, S, d, nblk, rpb, w_stats, momentum, eps,
                        run_mean, run_var, num_batches_tracked, save_mean, save_invstd);
     if ((rc = launch_status())) return rc;
   }
@@ -1122,15 +1108,17 @@ int cgcn_head_train(cgcn_stream_t stream, int n, int S, int d, int C, const floa
   if (d == 128) hipLaunchKernelGGL((k_head_colstats<128>), dim3(nblk), dim3(256), 0, st, n, S, rpb, X, w_stats);
   else hipLaunchKernelGGL((k_head_colstats<256>), dim3(nblk), dim3(256), 0, st, n, S, rpb, X, w_stats);
   if ((rc = launch_status())) return rc;
+  hipLaunchKernelGGL(k_head_bn_finalize, dim3((S * d + 15) / 16), dim3(1024), 0, st, n, S, d, nblk, rpb, w_stats, momentum, eps,
+                     run_mean, run_var, num_batches_tracked, save_mean, save_invstd);
+  if ((rc = launch_status())) return rc;
   const int P = head_bwd_partials(n);
   const int CP = head_cp(C);
   const float keep_scale = drop ? 1.f / (1.f - dropout_p) : 1.f;
   const uint32_t thresh = drop ? dropout_threshold(dropout_p) : 0u;
   const float inv_count = 1.f / ((float)n * (float)C);
 #define HFU(D_, CB_)                                                                                                  \
-  hipLaunchKernelGGL((k_head_fused<D_, CB_>), dim3(P), dim3(512), 0, st, n, S, C, X, bn_w, bn_b, w_stats, nblk, rpb,  \
-                     momentum, eps, run_mean, run_var, num_batches_tracked, save_mean, save_invstd, Wout, bout, target, \
-                     keep_scale, thresh, rng_state, inv_count, probs, w_loss, w_dym, w_part)
+  hipLaunchKernelGGL((k_head_fused<D_, CB_>), dim3(P), dim3(512), 0, st, n, S, C, X, bn_w, bn_b, save_mean, save_invstd, \
+                     Wout, bout, target, keep_scale, thresh, rng_state, inv_count, probs, w_loss, w_dym, w_part)
   if (d == 128) { if (CP == 128) HFU(128, 8); else HFU(128, 16); }
   else { if (CP == 128) HFU(256, 8); else HFU(256, 16); }
 #undef HFU

@@ -24,6 +24,20 @@ def main():
     fwd = lambda: lib.cgcn_head_fwd(st(), n, S, d, C, P(x), P(bn_w), P(bn_b), P(rm), P(rv), P(nbt), 0.1, 1e-5, 1, P(W), P(b), P(tgt), 0.2, P(rng), P(probs), P(loss), P(dpred), P(sm), P(si), P(ws), wsb)
     bwd_full = lambda: lib.cgcn_head_bwd(st(), n, S, d, C, P(x), P(bn_w), P(bn_b), P(sm), P(si), P(W), P(dpred), None, 0.2, P(rng), P(dX), P(dW), P(db), P(dgw), P(dgb), 0, P(ws), wsb)
     bwd_def = lambda: lib.cgcn_head_bwd(st(), n, S, d, C, P(x), P(bn_w), P(bn_b), P(sm), P(si), P(W), P(dpred), None, 0.2, P(rng), None, P(dW), P(db), P(dgw), P(dgb), 0, P(ws), wsb)
+    if "--stamps" in sys.argv:  # needs a -DHF_TIMING build (CGCN_EXTRA_FLAGS) loaded through CHROMEGCN_LIB
+        import numpy as np
+        train = lambda: lib.cgcn_head_train(st(), n, S, d, C, P(x), P(bn_w), P(bn_b), P(rm), P(rv), P(nbt), 0.1, 1e-5, P(W), P(b), P(tgt), 0.2, P(rng), P(probs), P(loss), P(sm), P(si), P(ws), wsb)
+        for _ in range(5): assert train() == 0
+        torch.cuda.synchronize()
+        buf = np.zeros(8 * 16, dtype=np.uint64)
+        raw = ctypes.CDLL(os.environ["CHROMEGCN_LIB"])
+        assert raw.cgcn_debug_hf_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+        t = buf.reshape(8, 16).astype(np.int64)
+        t0 = t[:, 0].min()
+        for b_ in range(8):
+            print("wg", b_ * 32, "start+%.2fus" % ((t[b_, 0] - t0) / 100.0), " phases(us):", " ".join("%.2f" % ((t[b_, i + 1] - t[b_, i]) / 100.0) for i in range(12)), " total %.2f" % ((t[b_, 12] - t[b_, 0]) / 100.0))
+        print("train_us", round(timeit(train), 1))
+        return
     fwd()
     print(json.dumps({"head_fwd_us(4 launches)": round(timeit(fwd), 1), "head_bwd_full_us(3 launches)": round(timeit(bwd_full), 1),
                       "head_bwd_deferred_us(2 launches)": round(timeit(bwd_def), 1)}))
