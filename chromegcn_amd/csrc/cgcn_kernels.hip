@@ -369,8 +369,28 @@ __device__ __forceinline__ void tile_mfma(const float* __restrict__ T, const flo
 //   phase 2  U = H W on the matrix cores; the residual rows of X are prefetched meanwhile
 //   phase 3  Z = tanh(U + b) -> LDS -> row-wise gate (wave reduction), mix, optional dropout, stores
 // ------------------------------------------------------------------------------------------
+#ifndef FWD_OCC
+#define FWD_OCC
+#endif
+#ifdef KT_TIMING  // tuning build only (tools/khead.py --stamps-rowlocal): phase timestamps of a few workgroups
+__device__ unsigned long long kt_stamps[8 * 16];
+#ifndef KT_STRIDE
+#define KT_STRIDE 32
+#endif
+#define KT_STAMP(i)                                                                      \
+  do {                                                                                   \
+    __builtin_amdgcn_s_waitcnt(0);                                                       \
+    if (threadIdx.x == 0 && (blockIdx.x % KT_STRIDE) == 0 && blockIdx.x < 8 * KT_STRIDE) kt_stamps[(blockIdx.x / KT_STRIDE) * 16 + (i)] = wall_clock64(); \
+  } while (0)
+extern "C" int cgcn_debug_kt_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(kt_stamps), sizeof(unsigned long long) * 8 * 16) == hipSuccess ? 0 : -1;
+}
+#else
+#define KT_STAMP(i)
+#endif
+
 template <int S, int D, int MB, bool HAS_VAL, bool FROM_CACHE>
-__global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) void k_layer_fwd(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
+__global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) FWD_OCC void k_layer_fwd(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
                                                      const float* __restrict__ val, const float* __restrict__ rs,
                                                      const float* __restrict__ X, const float* __restrict__ W,
                                                      const float* __restrict__ bias, const float* __restrict__ wg,
@@ -395,6 +415,7 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) void k_layer
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int node0 = xcd_contiguous(blockIdx.x, gridDim.x) * R;
 
+  KT_STAMP(8);
   float bw[CBW][D / 4];
   if (PRE) load_wfrag<D, CBW, false>(W, wave, lane, bw);
 
@@ -402,6 +423,7 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) void k_layer
 #pragma unroll
   for (int v = 0; v < G::NV; ++v) lane_off[v] = ((unsigned)G::strand(v, lane) * (unsigned)n * D + G::column(v, lane)) * 4u;
 
+  KT_STAMP(9);
   // ---- phase 1 (FROM_CACHE is a template parameter so that profiles list the two variants separately)
   if (FROM_CACHE) {
     // the aggregation was computed before (it does not depend on the weights: the engine caches A X of the
@@ -421,6 +443,7 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) void k_layer
   } else {
     gather_tile<S, D, HAS_VAL, R, NW, LD>(n, node0, rowptr, col, val, rs, (const char*)X, lane_off, T, Hout, LR, wave, lane);
   }
+  KT_STAMP(10);
   // prefetch the residual rows this wave will mix in phase 3 (latency hides behind the MFMA phase)
   float xres[RPW][EPL];
 #pragma unroll
@@ -433,11 +456,13 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) void k_layer
   }
   __syncthreads();
 
+  KT_STAMP(11);
   // ---- phase 2
   f32x4 acc[MB][CBW];
   tile_mfma<MB, D, CBW, LD, false, PRE>(T, W, bw, wave, lane, acc);
   __syncthreads();  // every wave is done reading T as the A operand
 
+  KT_STAMP(12);
   // ---- phase 3a: Z = tanh(U + b) back into the tile
   {
     const int r = lane & 15, q = lane >> 4;
@@ -458,6 +483,7 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) void k_layer
   const uint32_t key = thresh ? dropout_key(rng_state, stream_id) : 0u;
   __syncthreads();
 
+  KT_STAMP(13);
   // ---- phase 3b: row-wise gate + residual mix, coalesced stores
 #pragma unroll
   for (int t = 0; t < RPW; ++t) {
@@ -484,6 +510,7 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) void k_layer
     }
     if (lane == 0) gate[(size_t)s * n + i] = g;
   }
+  KT_STAMP(14);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -492,7 +519,7 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) void k_layer
 // dW in accumulators, then writes one partial.  Rows are the flattened [S*n] axis.
 //   partial layout per workgroup: [D*D dW][D db][D dwg][1 dcg][3 pad]
 // ------------------------------------------------------------------------------------------
-template <int D>
+template <int D, int TR>
 __global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float* __restrict__ dXn,
                                                       const float* __restrict__ Z, const float* __restrict__ X,
                                                       const float* __restrict__ gate, const float* __restrict__ dgate,
@@ -508,12 +535,12 @@ __global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float*
                             hp.hf_dbout, nullptr, nullptr, nullptr, hp.hf_accumulate, hp.dloss);
     return;
   }
+  KT_STAMP(0);
   constexpr int IBW = D / 128;        // 16-row blocks of dW owned by one wave (i index)
-  constexpr int TR = (D == 128) ? BWD_TILE_ROWS : 32;  // 64-row tiles at D = 128; 32 at D = 256 (register budget)
   constexpr int LD = D + 16;          // stride = 16 (mod 32): conflict-free transposed ds_read_b32
   constexpr int EPL = D / 64;
   constexpr int JB = D / 16;
-  constexpr int RPW = TR / NW;        // rows per wave per tile (4)
+  constexpr int RPW = TR / NW;        // rows per wave per tile
   constexpr int PSTRIDE = D * D + 2 * D + 4;
   __shared__ __attribute__((aligned(16))) float Ht[TR * LD];
   __shared__ __attribute__((aligned(16))) float Ut[TR * LD];
@@ -538,6 +565,7 @@ __global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float*
   const uint32_t hkey = (hp.dym && hp.thresh) ? dropout_key(hp.rng_state, HEAD_STREAM_ID) : 0u;
   const float hgl = (hp.dym && hp.dloss) ? hp.dloss[0] : 1.f;
 
+  KT_STAMP(1);
   const int ntiles = (M + TR - 1) / TR;
   for (int tile = blockIdx.x; tile < ntiles; tile += row_blocks) {
     // ---- row pass: all loads of the wave's RPW rows are issued before the first use
@@ -558,6 +586,7 @@ __global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float*
       gt[t] = ok ? gate[m] : 0.f;
       dgt[t] = (ok && dgate) ? dgate[m] : 0.f;
     }
+    KT_STAMP(2);
 #pragma unroll
     for (int t = 0; t < RPW; ++t) {
       const int trow = wave + t * NW;
@@ -608,8 +637,10 @@ __global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float*
         Ut[trow * LD + lane * EPL + e] = du[e];
       }
     }
+    KT_STAMP(3);
     __syncthreads();
     // ---- dW += Ht^T Ut  (K = TR rows)
+    KT_STAMP(4);
 #pragma unroll
     for (int kk = 0; kk < TR / 4; ++kk) {
       const int k = 4 * kk + q;
@@ -626,6 +657,7 @@ __global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float*
     __syncthreads();
   }
 
+  KT_STAMP(5);
   // ---- write this workgroup's partial
   float* P = part + (size_t)blockIdx.x * PSTRIDE;
 #pragma unroll
@@ -638,6 +670,7 @@ __global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float*
         const int j = jb * 16 + r;
         P[i * D + j] = acc[ib][jb][e];
       }
+  KT_STAMP(6);
   // column sums: combine the NW waves through LDS in a fixed order
   float* red = Ht;  // [NW][2*D + 1]
   constexpr int RS = 2 * D + 1;
@@ -653,6 +686,7 @@ __global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float*
     for (int w = 0; w < NW; ++w) s += red[w * RS + c];
     P[D * D + c] = s;
   }
+  KT_STAMP(7);
 }
 
 // One 64-element slab of the second-stage sum, computed by a workgroup of NT threads (NT/64 partial slices).
@@ -1002,9 +1036,20 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   return launch_status();
 }
 
+// Row-tile height of k_bwd_rowlocal.  The kernel is a chain load -> row math -> LDS -> MFMA per tile, one tile in
+// flight per CU, so small graphs take the smallest tile that still gives every tile its own workgroup (more CUs
+// busy, shorter chain); large ones take 64-row tiles and loop.  D = 256 is limited to 32 rows by registers.
+static int bwd_tile_rows(int n, int S, int d) {
+  if (d != 128) return 32;
+  const int M = n * S;
+  if (M <= 32 * BWD_MAX_PARTIALS) return 32;
+  if (M <= 48 * BWD_MAX_PARTIALS) return 48;
+  return BWD_TILE_ROWS;
+}
+
 static int bwd_partials(int n, int S, int d) {
   const int M = n * S;
-  const int tr = d == 128 ? BWD_TILE_ROWS : 32;
+  const int tr = bwd_tile_rows(n, S, d);
   const int ntiles = (M + tr - 1) / tr;
   int P = ntiles < BWD_MAX_PARTIALS ? ntiles : BWD_MAX_PARTIALS;
   return P < 1 ? 1 : P;
@@ -1049,9 +1094,15 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   float* part = (float*)workspace;
   const int M = n * S;
   if (d == 128)
-    hipLaunchKernelGGL((k_bwd_rowlocal<128>), dim3(P + head_slabs), dim3(512), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dUs, part, hp, dX, P);
+    switch (bwd_tile_rows(n, S, d)) {
+#define RL(TR_) hipLaunchKernelGGL((k_bwd_rowlocal<128, TR_>), dim3(P + head_slabs), dim3(512), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dUs, part, hp, dX, P)
+      case 32: RL(32); break;
+      case 48: RL(48); break;
+      default: RL(BWD_TILE_ROWS); break;
+#undef RL
+    }
   else
-    hipLaunchKernelGGL((k_bwd_rowlocal<256>), dim3(P + head_slabs), dim3(512), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dUs, part, hp, dX, P);
+    hipLaunchKernelGGL((k_bwd_rowlocal<256, 32>), dim3(P + head_slabs), dim3(512), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dUs, part, hp, dX, P);
   if ((rc = launch_status())) return rc;
   // The reduction of the per-tile partials and the gather kernel are independent: with an auxiliary stream
   // they run side by side (fork after k_bwd_rowlocal, join before returning; both edges are events, so the
