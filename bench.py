@@ -82,7 +82,7 @@ def time_dominant_kernel(stage, name, reps):
     def launch():
         _lib.check(lib.cgcn_layer_fwd(_lib.stream_ptr(), n, S, d, _lib.ptr(g.rowptr), _lib.ptr(g.col), _lib.ptr(g.val),
                                       _lib.ptr(g.row_scale), c.x.data_ptr(), w.data_ptr(), b.data_ptr(), wg.data_ptr(),
-                                      cg.data_ptr(), xn.data_ptr(), z.data_ptr(), h.data_ptr(), gate.data_ptr(), 0.0, None, 0, None), "fwd")
+                                      cg.data_ptr(), xn.data_ptr(), z.data_ptr(), h.data_ptr(), gate.data_ptr(), 0.0, None, 0, None, None), "fwd")
     for _ in range(5):
         launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

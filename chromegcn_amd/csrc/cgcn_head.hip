@@ -1087,12 +1087,14 @@ int cgcn_head_train(cgcn_stream_t stream, int n, int S, int d, int C, const floa
                     const float* bn_b, float* run_mean, float* run_var, long long* num_batches_tracked, float momentum,
                     float eps, const float* Wout, const float* bout, const float* target, float dropout_p,
                     const unsigned long long* rng_state, float* probs, float* loss, float* save_mean, float* save_invstd,
-                    void* workspace, size_t workspace_bytes) {
+                    const float* col_stats, int col_stats_tiles, int col_stats_rows, void* workspace,
+                    size_t workspace_bytes) {
   int rc = head_check(n, S, d, C);
   if (rc) return rc;
   if (!X || !bn_w || !bn_b || !Wout || !bout || !target || !probs || !loss || !workspace || !run_mean || !run_var ||
       !save_mean || !save_invstd || n < 2)
     return CGCN_ERR_BAD_ARG;
+  if (col_stats && (col_stats_rows < 1 || col_stats_tiles != (n + col_stats_rows - 1) / col_stats_rows)) return CGCN_ERR_BAD_ARG;
   const bool drop = dropout_p > 0.f;
   if (drop && (!rng_state || dropout_p >= 1.f)) return CGCN_ERR_BAD_ARG;
   if (workspace_bytes < cgcn_head_workspace_bytes(n, S, d, C)) return CGCN_ERR_WORKSPACE;
@@ -1104,11 +1106,19 @@ int cgcn_head_train(cgcn_stream_t stream, int n, int S, int d, int C, const floa
   float* w_bnc = w_dym + align4(ws_dym(n, d));
   float* w_part = w_bnc + align4(ws_bnc(d));
   int rpb;
-  const int nblk = head_stat_blocks(n, &rpb);
-  if (d == 128) hipLaunchKernelGGL((k_head_colstats<128>), dim3(nblk), dim3(256), 0, st, n, S, rpb, X, w_stats);
-  else hipLaunchKernelGGL((k_head_colstats<256>), dim3(nblk), dim3(256), 0, st, n, S, rpb, X, w_stats);
-  if ((rc = launch_status())) return rc;
-  hipLaunchKernelGGL(k_head_bn_finalize, dim3((S * d + 15) / 16), dim3(1024), 0, st, n, S, d, nblk, rpb, w_stats, momentum, eps,
+  int nblk = head_stat_blocks(n, &rpb);
+  const float* stats = w_stats;
+  if (col_stats) {
+    // first stage already done by the producer of X (cgcn_layer_fwd's colstats output)
+    stats = col_stats;
+    nblk = col_stats_tiles;
+    rpb = col_stats_rows;
+  } else {
+    if (d == 128) hipLaunchKernelGGL((k_head_colstats<128>), dim3(nblk), dim3(256), 0, st, n, S, rpb, X, w_stats);
+    else hipLaunchKernelGGL((k_head_colstats<256>), dim3(nblk), dim3(256), 0, st, n, S, rpb, X, w_stats);
+    if ((rc = launch_status())) return rc;
+  }
+  hipLaunchKernelGGL(k_head_bn_finalize, dim3((S * d + 15) / 16), dim3(1024), 0, st, n, S, d, nblk, rpb, stats, momentum, eps,
                      run_mean, run_var, num_batches_tracked, save_mean, save_invstd);
   if ((rc = launch_status())) return rc;
   const int P = head_bwd_partials(n);

@@ -398,7 +398,8 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) FWD_OCC void
                                                      float* __restrict__ Zout, float* __restrict__ Hout,
                                                      float* __restrict__ gate, float keep_scale, uint32_t thresh,
                                                      const unsigned long long* __restrict__ rng_state,
-                                                     uint32_t stream_id, const float* __restrict__ Hin) {
+                                                     uint32_t stream_id, const float* __restrict__ Hin,
+                                                     float* __restrict__ colstats) {
   using G = Geo<S, D>;
   constexpr int ROWS = 16 * MB;      // MFMA rows in the tile
   constexpr int R = ROWS / S;        // nodes in the tile
@@ -507,8 +508,33 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) FWD_OCC void
       if (thresh) xo = dropout_keep(key, (uint32_t)(g_off + e), thresh) ? xo * keep_scale : 0.f;
       Xn[g_off + e] = xo;
       if (Zout) NT_STORE1(&Zout[g_off + e], z[e]);
+      if (colstats) T[m * LD + lane * EPL + e] = fmaxf(xo, 0.f);  // own row, already consumed above
     }
     if (lane == 0) gate[(size_t)s * n + i] = g;
+  }
+  // ---- optional: first stage of the classifier head's BatchNorm statistics (k_head_colstats' job) while the tile
+  // is still on chip: per (strand, column) the exact two-pass (mean, M2) of relu(Xn) over this tile's nodes
+  if (colstats) {
+    __syncthreads();
+    const int cnt = min(R, n - node0);
+    const float inv = 1.f / (float)cnt;
+    float* out = colstats + (size_t)(node0 / R) * S * D * 2;
+    for (int idx = threadIdx.x; idx < S * D; idx += blockDim.x) {
+      const int s = idx / D, c = idx % D;
+      float v[R];
+      float sum = 0.f;
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr) {
+        v[rr] = T[(s * R + rr) * LD + c];
+        sum += rr < cnt ? v[rr] : 0.f;
+      }
+      const float mean = sum * inv;
+      float m2 = 0.f;
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr) m2 += rr < cnt ? (v[rr] - mean) * (v[rr] - mean) : 0.f;
+      out[idx * 2] = mean;
+      out[idx * 2 + 1] = m2;
+    }
   }
   KT_STAMP(14);
 }
@@ -997,10 +1023,17 @@ int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d, const 
   return launch_status();
 }
 
+int cgcn_layer_fwd_colstats_tiles(int n, int S, int d, int* rows_per_tile) {
+  if (check_shape(n, S, d) != CGCN_OK || n == 0) return 0;
+  const int tn = 16 * pick_mb(n, S) / S;
+  if (rows_per_tile) *rows_per_tile = tn;
+  return (n + tn - 1) / tn;
+}
+
 int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* rowptr, const int32_t* col, const float* val,
                    const float* row_scale, const float* X, const float* W, const float* b, const float* wg,
                    const float* cg, float* Xn, float* Z, float* H, float* gate, float dropout_p,
-                   const unsigned long long* rng_state, unsigned int stream_id, const float* H_in) {
+                   const unsigned long long* rng_state, unsigned int stream_id, const float* H_in, float* colstats) {
   int rc = check_shape(n, S, d);
   if (rc) return rc;
   if (n == 0) return CGCN_OK;
@@ -1020,16 +1053,16 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
     const dim3 blk((D_ == 128 && CBW128 == 2) ? 256 : 512);                                                         \
     if (mb == 2 && H_in)                                                                                            \
       hipLaunchKernelGGL((k_layer_fwd<S_, D_, 2, V_, true>), dim3(blocks), blk, 0, st, n, rowptr, col, val, row_scale, \
-                         X, W, b, wg, cg, Xn, Z, H, gate, ks, th, rng_state, stream_id, H_in);                      \
+                         X, W, b, wg, cg, Xn, Z, H, gate, ks, th, rng_state, stream_id, H_in, colstats);                    \
     else if (mb == 2)                                                                                               \
       hipLaunchKernelGGL((k_layer_fwd<S_, D_, 2, V_, false>), dim3(blocks), blk, 0, st, n, rowptr, col, val, row_scale, \
-                         X, W, b, wg, cg, Xn, Z, H, gate, ks, th, rng_state, stream_id, H_in);                      \
+                         X, W, b, wg, cg, Xn, Z, H, gate, ks, th, rng_state, stream_id, H_in, colstats);                    \
     else if (H_in)                                                                                                  \
       hipLaunchKernelGGL((k_layer_fwd<S_, D_, 1, V_, true>), dim3(blocks), blk, 0, st, n, rowptr, col, val, row_scale, \
-                         X, W, b, wg, cg, Xn, Z, H, gate, ks, th, rng_state, stream_id, H_in);                      \
+                         X, W, b, wg, cg, Xn, Z, H, gate, ks, th, rng_state, stream_id, H_in, colstats);                    \
     else                                                                                                            \
       hipLaunchKernelGGL((k_layer_fwd<S_, D_, 1, V_, false>), dim3(blocks), blk, 0, st, n, rowptr, col, val, row_scale, \
-                         X, W, b, wg, cg, Xn, Z, H, gate, ks, th, rng_state, stream_id, H_in);                      \
+                         X, W, b, wg, cg, Xn, Z, H, gate, ks, th, rng_state, stream_id, H_in, colstats);                    \
   } while (0)
   DISPATCH_SDV(S, d, val != nullptr, CALL);
 #undef CALL

@@ -3,6 +3,8 @@ allocation is torch's caching allocator, every launch goes to torch's current HI
 all of it can be captured into a HIP graph.  No fallbacks: CPU tensors raise."""
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
 from . import _lib
@@ -141,7 +143,7 @@ class GatedLayerFn(torch.autograd.Function):
                                       _lib.ptr(graph.val), _lib.ptr(graph.row_scale), x.data_ptr(), weight.data_ptr(),
                                       bias.data_ptr(), wg.data_ptr(), cg.data_ptr(), xn.data_ptr(), _lib.ptr(z),
                                       _lib.ptr(h), gate.data_ptr(), float(dropout_out),
-                                      _lib.ptr(rng_state) if dropout_out > 0 else None, int(layer_id), _lib.ptr(h_in)),
+                                      _lib.ptr(rng_state) if dropout_out > 0 else None, int(layer_id), _lib.ptr(h_in), None),
                    "cgcn_layer_fwd")
         h = _store_h_cache(h_cache, h_in, h)
         if need_bwd:
@@ -301,10 +303,17 @@ class LastLayerHeadLossFn(torch.autograd.Function):
         gate = torch.empty((S, n), device=x.device, dtype=torch.float32)
         z = torch.empty_like(x) if need_bwd else None
         h_in, h = _resolve_h_cache(h_cache, x, need_bwd)
+        colstats, cs_tiles, cs_rows = None, 0, 0
+        if need_bwd:
+            # the layer kernel also emits the first stage of the head's BatchNorm statistics (tile still on chip)
+            rows = ctypes.c_int(0)
+            cs_tiles = lib.cgcn_layer_fwd_colstats_tiles(n, S, d, ctypes.byref(rows))
+            cs_rows = rows.value
+            colstats = torch.empty((cs_tiles, S, d, 2), device=x.device, dtype=torch.float32)
         _lib.check(lib.cgcn_layer_fwd(_lib.stream_ptr(), n, S, d, _lib.ptr(graph.rowptr), _lib.ptr(graph.col),
                                       _lib.ptr(graph.val), _lib.ptr(graph.row_scale), x.data_ptr(), weight.data_ptr(),
                                       bias.data_ptr(), wg.data_ptr(), cg.data_ptr(), xn.data_ptr(), _lib.ptr(z),
-                                      _lib.ptr(h), gate.data_ptr(), 0.0, None, int(layer_id), _lib.ptr(h_in)), "cgcn_layer_fwd")
+                                      _lib.ptr(h), gate.data_ptr(), 0.0, None, int(layer_id), _lib.ptr(h_in), _lib.ptr(colstats)), "cgcn_layer_fwd")
         h = _store_h_cache(h_cache, h_in, h)
         ws_bytes = lib.cgcn_head_workspace_bytes(n, S, d, C)
         if ws_bytes == 0:
@@ -324,7 +333,8 @@ class LastLayerHeadLossFn(torch.autograd.Function):
                                            run_mean.data_ptr(), run_var.data_ptr(), _lib.ptr(nbt), float(momentum), float(eps),
                                            w_out.data_ptr(), b_out.data_ptr(), target.data_ptr(), float(dropout_p) if drop else 0.0,
                                            _lib.ptr(rng_state) if drop else None, probs.data_ptr(), loss.data_ptr(),
-                                           save_mean.data_ptr(), save_invstd.data_ptr(), ws.data_ptr(), ws_bytes), "cgcn_head_train")
+                                           save_mean.data_ptr(), save_invstd.data_ptr(), _lib.ptr(colstats), cs_tiles, cs_rows,
+                                           ws.data_ptr(), ws_bytes), "cgcn_head_train")
         else:
             _lib.check(lib.cgcn_head_fwd(_lib.stream_ptr(), n, S, d, C, xn.data_ptr(), bn_w.data_ptr(), bn_b.data_ptr(),
                                          run_mean.data_ptr(), run_var.data_ptr(), _lib.ptr(nbt), float(momentum), float(eps),

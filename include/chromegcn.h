@@ -48,7 +48,7 @@ extern "C" {
 #define CGCN_ERR_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after a launch      */
 #define CGCN_ERR_WORKSPACE (-4)   /* workspace too small (see cgcn_*_workspace_bytes)    */
 
-#define CGCN_ABI_VERSION 10
+#define CGCN_ABI_VERSION 11
 
 typedef void *cgcn_stream_t; /* hipStream_t */
 
@@ -84,13 +84,21 @@ int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d,
  * H_in (may be NULL): a previously computed H = diag(row_scale) Ahat X for this X and graph (H does not
  * depend on the layer's weights).  When given, the gather is skipped and H_in is streamed instead; H is
  * then not written (pass H = NULL, the saved tensor for the backward is H_in itself).
+ * colstats (may be NULL): [tiles][S][d][2] output, tiles / rows per tile from cgcn_layer_fwd_colstats_tiles.
+ * Per node tile and (strand, column): mean and sum of squared deviations of relu(Xn) -- the first stage of
+ * the classifier head's BatchNorm batch statistics (models/ChromeModels.py:58-59, nn.BatchNorm1d in training
+ * mode), taken while the tile is on chip; hand it to cgcn_head_train as col_stats.
  */
 int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d,
                    const int32_t *rowptr, const int32_t *col, const float *val, const float *row_scale,
                    const float *X, const float *W, const float *b, const float *wg, const float *cg,
                    float *Xn, float *Z, float *H, float *gate,
                    float dropout_p, const unsigned long long *rng_state, unsigned int stream_id,
-                   const float *H_in);
+                   const float *H_in, float *colstats);
+
+/* Number of node tiles cgcn_layer_fwd(n, S, d) writes column statistics for (0 = unsupported shape);
+ * *rows_per_tile = nodes per tile (the last tile may be shorter). */
+int cgcn_layer_fwd_colstats_tiles(int n, int S, int d, int *rows_per_tile);
 
 /*
  * State the fused head's backward leaves for the LAST gated layer's backward (cgcn_head_bwd with
@@ -188,12 +196,15 @@ int cgcn_head_fwd(cgcn_stream_t stream, int n, int S, int d, int C, const float 
  * the BatchNorm sums, all for an upstream d loss of 1.  The same workspace must then be handed to cgcn_head_bwd with
  * dpred == NULL and dX == NULL (which only finalises the BatchNorm sums, scaled by dloss) and to cgcn_layer_bwd via
  * cgcn_head_grad (with .dloss set).  d loss / d pred never touches memory.
+ * col_stats (may be NULL): the colstats output of the cgcn_layer_fwd call that produced X, with its tile count and
+ * rows per tile (cgcn_layer_fwd_colstats_tiles); the head then skips its own first pass over X.
  */
 int cgcn_head_train(cgcn_stream_t stream, int n, int S, int d, int C, const float *X, const float *bn_w,
                     const float *bn_b, float *run_mean, float *run_var, long long *num_batches_tracked,
                     float momentum, float eps, const float *W_out, const float *b_out, const float *target,
                     float dropout_p, const unsigned long long *rng_state, float *probs, float *loss,
-                    float *save_mean, float *save_invstd, void *workspace, size_t workspace_bytes);
+                    float *save_mean, float *save_invstd, const float *col_stats, int col_stats_tiles,
+                    int col_stats_rows, void *workspace, size_t workspace_bytes);
 
 /*
  * Backward of cgcn_head_fwd (training mode).  dloss: [1] upstream gradient of the loss or NULL (= 1).

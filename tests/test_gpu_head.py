@@ -137,3 +137,33 @@ def test_head_dropout_keep_rate():
     pred = torch.logit(probs[:, 0].double())
     keep = (pred * (1 - p)).mean().item()
     assert abs(keep - (1 - p)) < 0.01, keep
+
+
+@pytest.mark.parametrize("S,n,d", [(2, 333, 128), (1, 37, 128), (2, 5, 128), (2, 1500, 128), (2, 70, 256), (1, 16, 256)])
+def test_layer_fwd_colstats_are_the_tile_statistics_of_relu_output(S, n, d):
+    """cgcn_layer_fwd's optional colstats output (first stage of the head's BatchNorm statistics): per node tile the
+    exact mean / sum of squared deviations of relu(Xn), ragged last tile included."""
+    import ctypes
+    from chromegcn_amd import _lib, graph as G
+    from chromegcn_amd import synth
+    lib = _lib.load()
+    g = G.upload(G.normalize_graph("hic", synth.contact_graph(n, max(1, 3 * n), n + d), n), DEV)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(S, n, d, generator=gen).to(DEV)
+    W = (torch.randn(d, d, generator=gen) / d ** 0.5).to(DEV); b = (0.1 * torch.randn(d, generator=gen)).to(DEV)
+    wg = (torch.randn(d, generator=gen) / d ** 0.5).to(DEV); cg = torch.zeros(1, device=DEV)
+    xn = torch.empty_like(x); gate = torch.empty(S, n, device=DEV)
+    rows = ctypes.c_int(0)
+    tiles = lib.cgcn_layer_fwd_colstats_tiles(n, S, d, ctypes.byref(rows))
+    R = rows.value
+    assert tiles == (n + R - 1) // R and R >= 1
+    cs = torch.full((tiles, S, d, 2), float("nan"), device=DEV)
+    P = _lib.ptr
+    _lib.check(lib.cgcn_layer_fwd(_lib.stream_ptr(), n, S, d, P(g.rowptr), P(g.col), P(g.val), P(g.row_scale), P(x), P(W), P(b),
+                                  P(wg), P(cg), P(xn), None, None, P(gate), 0.0, None, 0, None, P(cs)), "cgcn_layer_fwd")
+    y = torch.relu(xn).double().cpu().numpy()
+    cs = cs.cpu().numpy()
+    for t in range(tiles):
+        blk = y[:, t * R:min(n, (t + 1) * R), :]
+        np.testing.assert_allclose(cs[t, :, :, 0], blk.mean(axis=1), atol=1e-6, rtol=1e-5)
+        np.testing.assert_allclose(cs[t, :, :, 1], ((blk - blk.mean(axis=1, keepdims=True)) ** 2).sum(axis=1), atol=1e-5, rtol=1e-4)

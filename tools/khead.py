@@ -26,7 +26,7 @@ def main():
     bwd_def = lambda: lib.cgcn_head_bwd(st(), n, S, d, C, P(x), P(bn_w), P(bn_b), P(sm), P(si), P(W), P(dpred), None, 0.2, P(rng), None, P(dW), P(db), P(dgw), P(dgb), 0, P(ws), wsb)
     if "--stamps" in sys.argv:  # needs a -DHF_TIMING build (CGCN_EXTRA_FLAGS) loaded through CHROMEGCN_LIB
         import numpy as np
-        train = lambda: lib.cgcn_head_train(st(), n, S, d, C, P(x), P(bn_w), P(bn_b), P(rm), P(rv), P(nbt), 0.1, 1e-5, P(W), P(b), P(tgt), 0.2, P(rng), P(probs), P(loss), P(sm), P(si), P(ws), wsb)
+        train = lambda: lib.cgcn_head_train(st(), n, S, d, C, P(x), P(bn_w), P(bn_b), P(rm), P(rv), P(nbt), 0.1, 1e-5, P(W), P(b), P(tgt), 0.2, P(rng), P(probs), P(loss), P(sm), P(si), None, 0, 0, P(ws), wsb)
         for _ in range(5): assert train() == 0
         torch.cuda.synchronize()
         buf = np.zeros(8 * 16, dtype=np.uint64)
