@@ -724,24 +724,36 @@ __device__ __forceinline__ void reduce_slab(int slab, int P, int D, const float*
   constexpr int NS = NT / 64;
   const int PSTRIDE = D * D + 2 * D + 4;
   const int total = D * D + 2 * D + 1;
-  __shared__ float red[NS][64];
+  __shared__ __attribute__((aligned(16))) float red[NS][64];
+  // lane = (el4, sub): 16 lanes x float4 cover the slab, the 4 sub-groups of each of the NS waves take contiguous
+  // ranges of the P partials (see head_finalize_slab): one batch of independent 16-byte loads per thread at P <= 256
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int el4 = lane & 15, sub = lane >> 4;
+  const int e0 = slab * 64 + el4 * 4;  // PSTRIDE is a multiple of 4 and the row is padded to it
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  if (e0 < total) {
+    const int per = (P + NS * 4 - 1) / (NS * 4);
+    const int p0 = (wave * 4 + sub) * per, p1 = min(P, p0 + per);
+    for (int p = p0; p < p1; p += 8) {
+      f32x4 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = *(const f32x4*)(part + (size_t)min(p + u, p1 - 1) * PSTRIDE + e0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (p + u < p1) a += t[u];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float v = a[k];
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    a[k] = v;
+  }
+  if (sub == 0) *(f32x4*)&red[wave][el4 * 4] = a;
   const int el = threadIdx.x & 63, slice = threadIdx.x >> 6;
   const int e = slab * 64 + el;
-  float s = 0.f;
-  if (e < total) {
-    const int per = (P + NS - 1) / NS;
-    const int p0 = slice * per, p1 = min(P, p0 + per);
-    int p = p0;
-    for (; p + 16 <= p1; p += 16) {
-      float t[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) t[u] = part[(size_t)(p + u) * PSTRIDE + e];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) s += t[u];
-    }
-    for (; p < p1; ++p) s += part[(size_t)p * PSTRIDE + e];
-  }
-  red[slice][el] = s;
+  float s;
   __syncthreads();
   if (slice == 0 && e < total) {
     s = 0.f;
@@ -1119,6 +1131,7 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
     head_slabs = (CP * d + CP) / 64;
   }
   if (!workspace || workspace_bytes < cgcn_layer_bwd_workspace_bytes(n, S, d)) return CGCN_ERR_WORKSPACE;
+  if (misaligned16(workspace)) return CGCN_ERR_BAD_ARG;
   float ks;
   uint32_t th;
   if ((rc = dropout_args(in_dropout_p, rng_state, &ks, &th))) return rc;
