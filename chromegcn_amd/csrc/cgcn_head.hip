@@ -89,21 +89,26 @@ __global__ __launch_bounds__(256) void k_head_colstats(int n, int S, int rows_pe
   }
 }
 
-// Second stage of the statistics.  One workgroup = 16 (strand, channel) columns x 64 slices of the partial list: every
-// thread Chan-combines its few partials (one batch of independent loads), the 64 slices are merged through LDS in two
-// fixed-order steps, and one thread per channel finishes both strands (the running-stat update is sequential in the
-// strand index).  The kernel is a pure latency chain, so it is laid out wide and shallow.
+// Second stage of the statistics.  One workgroup = COLS (strand, channel) columns x 1024/COLS slices of the partial
+// list: every thread Chan-combines its few partials (one batch of independent loads), the slices are merged through
+// LDS in two fixed-order steps, and one thread per channel finishes both strands (the running-stat update is
+// sequential in the strand index).  The kernel is a pure latency chain, so it is laid out wide and shallow:
+// COLS = 16 for the <= 128 partials of k_head_colstats, COLS = 4 for the per-tile partials of cgcn_layer_fwd.
+template <int COLS>
 __global__ __launch_bounds__(1024) void k_head_bn_finalize(int n, int S, int D, int nblk, int rows_per_blk,
                                                            const float* __restrict__ part, float momentum, float eps,
                                                            float* __restrict__ run_mean, float* __restrict__ run_var,
                                                            long long* __restrict__ nbt, float* __restrict__ save_mean,
                                                            float* __restrict__ save_invstd) {
-  __shared__ float sm[3][64][17];
-  const int cl = threadIdx.x & 15, slice = threadIdx.x >> 4;
-  const int CPB = 16 / S;  // channels per workgroup (S is 1 or 2)
+  constexpr int NSL = 1024 / COLS;          // slices
+  constexpr int G1 = (NSL == 64) ? 8 : 16;  // first merge step: NSL -> NSL / G1 (= G1 here), second: -> 1
+  static_assert(NSL == G1 * G1, "two equal merge steps");
+  __shared__ float sm[3][NSL + 1][COLS + 1];
+  const int cl = threadIdx.x % COLS, slice = threadIdx.x / COLS;
+  const int CPB = COLS / S;  // channels per workgroup (S is 1 or 2)
   const int s = cl / CPB, c = blockIdx.x * CPB + cl % CPB;
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += S;
-  const int per = (nblk + 63) / 64;
+  const int per = (nblk + NSL - 1) / NSL;
   const int b0 = slice * per, b1 = min(nblk, b0 + per);
   float cnt = 0.f, mean = 0.f, m2 = 0.f;
   if (c < D) {
@@ -129,12 +134,12 @@ __global__ __launch_bounds__(1024) void k_head_bn_finalize(int n, int S, int D, 
   sm[1][slice][cl] = mean;
   sm[2][slice][cl] = m2;
   __syncthreads();
-  if (slice < 8) {  // slices 8*slice .. 8*slice+7
+  if (slice < G1) {  // slices G1*slice .. G1*slice + G1-1
     cnt = mean = m2 = 0.f;
-    for (int o = 0; o < 8; ++o) chan_combine(cnt, mean, m2, sm[0][slice * 8 + o][cl], sm[1][slice * 8 + o][cl], sm[2][slice * 8 + o][cl]);
+    for (int o = 0; o < G1; ++o) chan_combine(cnt, mean, m2, sm[0][slice * G1 + o][cl], sm[1][slice * G1 + o][cl], sm[2][slice * G1 + o][cl]);
   }
   __syncthreads();
-  if (slice < 8) {
+  if (slice < G1) {
     sm[0][slice][cl] = cnt;
     sm[1][slice][cl] = mean;
     sm[2][slice][cl] = m2;
@@ -142,9 +147,9 @@ __global__ __launch_bounds__(1024) void k_head_bn_finalize(int n, int S, int D, 
   __syncthreads();
   if (slice == 0) {
     cnt = mean = m2 = 0.f;
-    for (int o = 0; o < 8; ++o) chan_combine(cnt, mean, m2, sm[0][o][cl], sm[1][o][cl], sm[2][o][cl]);
-    sm[1][8][cl] = mean;
-    sm[2][8][cl] = m2;
+    for (int o = 0; o < G1; ++o) chan_combine(cnt, mean, m2, sm[0][o][cl], sm[1][o][cl], sm[2][o][cl]);
+    sm[1][NSL][cl] = mean;
+    sm[2][NSL][cl] = m2;
     if (c < D) {
       save_mean[s * D + c] = mean;
       save_invstd[s * D + c] = rsqrtf(m2 / (float)n + eps);
@@ -155,11 +160,22 @@ __global__ __launch_bounds__(1024) void k_head_bn_finalize(int n, int S, int D, 
   float rm = run_mean[c], rv = run_var[c];
   for (int st = 0; st < S; ++st) {
     // sequential update: the reference calls the model on the forward strand, then the reverse one
-    rm = (1.f - momentum) * rm + momentum * sm[1][8][st * CPB + cl];
-    rv = (1.f - momentum) * rv + momentum * (sm[2][8][st * CPB + cl] / (float)(n - 1));
+    rm = (1.f - momentum) * rm + momentum * sm[1][NSL][st * CPB + cl];
+    rv = (1.f - momentum) * rv + momentum * (sm[2][NSL][st * CPB + cl] / (float)(n - 1));
   }
   run_mean[c] = rm;
   run_var[c] = rv;
+}
+
+static void launch_bn_finalize(hipStream_t st, int n, int S, int d, int nblk, int rpb, const float* part, float momentum,
+                               float eps, float* run_mean, float* run_var, long long* nbt, float* save_mean,
+                               float* save_invstd) {
+  if (nblk > 2048)  // measured at 722 partials: 16 columns x 64 slices (2 load batches) 9.6 us, 4 x 256 (1 batch) 11 us
+    hipLaunchKernelGGL(k_head_bn_finalize<4>, dim3((S * d + 3) / 4), dim3(1024), 0, st, n, S, d, nblk, rpb, part, momentum, eps,
+                       run_mean, run_var, nbt, save_mean, save_invstd);
+  else
+    hipLaunchKernelGGL(k_head_bn_finalize<16>, dim3((S * d + 15) / 16), dim3(1024), 0, st, n, S, d, nblk, rpb, part, momentum,
+                       eps, run_mean, run_var, nbt, save_mean, save_invstd);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1061,8 +1077,7 @@ int cgcn_head_fwd(cgcn_stream_t stream, int n, int S, int d, int C, const float*
     if (d == 128) hipLaunchKernelGGL((k_head_colstats<128>), dim3(nblk), dim3(256), 0, st, n, S, rpb, X, w_stats);
     else hipLaunchKernelGGL((k_head_colstats<256>), dim3(nblk), dim3(256), 0, st, n, S, rpb, X, w_stats);
     if ((rc = launch_status())) return rc;
-    hipLaunchKernelGGL(k_head_bn_finalize, dim3((S * d + 15) / 16), dim3(1024), 0, st, n, S, d, nblk, rpb, w_stats, momentum, eps,
-                       run_mean, run_var, num_batches_tracked, save_mean, save_invstd);
+    launch_bn_finalize(st, n, S, d, nblk, rpb, w_stats, momentum, eps, run_mean, run_var, num_batches_tracked, save_mean, save_invstd);
     if ((rc = launch_status())) return rc;
   }
   const int blocks = (n + HEAD_TILE - 1) / HEAD_TILE;
@@ -1118,8 +1133,7 @@ int cgcn_head_train(cgcn_stream_t stream, int n, int S, int d, int C, const floa
     else hipLaunchKernelGGL((k_head_colstats<256>), dim3(nblk), dim3(256), 0, st, n, S, rpb, X, w_stats);
     if ((rc = launch_status())) return rc;
   }
-  hipLaunchKernelGGL(k_head_bn_finalize, dim3((S * d + 15) / 16), dim3(1024), 0, st, n, S, d, nblk, rpb, stats, momentum, eps,
-                     run_mean, run_var, num_batches_tracked, save_mean, save_invstd);
+  launch_bn_finalize(st, n, S, d, nblk, rpb, stats, momentum, eps, run_mean, run_var, num_batches_tracked, save_mean, save_invstd);
   if ((rc = launch_status())) return rc;
   const int P = head_bwd_partials(n);
   const int CP = head_cp(C);
