@@ -15,6 +15,8 @@ Entry points exercised (reference file:line):
   G4  finetune.py:29-53          the per-chromosome loop, re-driven on CPU (the original
       hard-codes .cuda(), finetune.py:30-36), 2 train epochs + 1 eval pass
   G5  utils/metrics.py:148,168,238,25  fdr / aupr / auroc / mean_average_precision per label
+  G6  utils/util_methods.py:183-199    save_feats: encoder outputs regrouped per chromosome (the
+      chrom_feature_dict_<split>.pt contract between the window encoder and the GCN stage)
 """
 import json
 import os
@@ -308,10 +310,37 @@ def make_g5():
     np.savez_compressed(os.path.join(HERE, "g5_metrics.npz"), **out)
 
 
+def make_g6():
+    """save_feats on interleaved chromosomes: rows keep their order of appearance inside each chromosome, the
+    dict iterates chromosomes in order of first appearance."""
+    import tempfile
+    g = torch.Generator().manual_seed(66)
+    n, d, c = 157, 16, 7
+    chroms = ["chr8", "chr21", "chrX", "chr1"]
+    which = torch.randint(0, len(chroms), (n,), generator=g).tolist()
+    locs = [(chroms[w], 1000 * i, 1000 * i + 1000) for i, w in enumerate(which)]
+    x_f = torch.randn(n, d, generator=g); x_r = torch.randn(n, d, generator=g)
+    targs = (torch.rand(n, c, generator=g) < 0.3).float()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, "run"))  # save_feats writes into <model_name before '.finetune'>/
+        util_methods.save_feats(os.path.join(tmp, "run.finetune.x"), "train", targs, locs, x_f, x_r)
+        saved = torch.load(os.path.join(tmp, "run", "chrom_feature_dict_train.pt"))
+    out = {"meta": np.array(json.dumps(META)), "chrom_of_row": np.array([l[0] for l in locs]), "x_f": x_f.numpy(),
+           "x_r": x_r.numpy(), "targs": targs.numpy(), "order": np.array(list(saved.keys()))}
+    for ch, v in saved.items():
+        for k in ("forward", "backward", "target"):
+            out["%s_%s" % (ch, k)] = v[k].numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "g6_save_feats.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(1)  # fixed reduction order for the recorded values
-    make_g1(); make_g2(); make_g3(); make_g4(); make_g5()
+    if sys.argv[1:]:
+        for name in sys.argv[1:]:
+            globals()["make_" + name]()
+    else:
+        make_g1(); make_g2(); make_g3(); make_g4(); make_g5(); make_g6()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
