@@ -40,7 +40,7 @@ _SIGNATURES = {
     "cgcn_multilabel_metrics": (_c_int, [_c_vp, ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_float, _c_vp, _c_vp, _c_sz]),
     "cgcn_sgd_step": (_c_int, [_c_vp, ctypes.c_longlong, _c_vp, _c_vp, _c_vp, _c_float, _c_float, _c_float, _c_int, _c_float, _c_vp]),
 }
-ABI_VERSION = 11
+ABI_VERSION = 12
 _lib = None
 
 
@@ -89,7 +89,8 @@ class HeadGrad(ctypes.Structure):
     """mirror of cgcn_head_grad (include/chromegcn.h)"""
     _fields_ = [("dym", _c_vp), ("bnc", _c_vp), ("save_mean", _c_vp), ("save_invstd", _c_vp), ("bn_w", _c_vp),
                 ("dropout_p", _c_float), ("rng_state", _c_vp), ("part", _c_vp), ("n_partials", _c_int), ("C", _c_int),
-                ("dW_out", _c_vp), ("db_out", _c_vp), ("accumulate", _c_int), ("dloss", _c_vp)]
+                ("dW_out", _c_vp), ("db_out", _c_vp), ("accumulate", _c_int), ("dloss", _c_vp), ("dbn_w", _c_vp),
+                ("dbn_b", _c_vp)]
 
 
 def ptr(t):

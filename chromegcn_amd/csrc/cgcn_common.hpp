@@ -78,6 +78,8 @@ struct HeadApply {
   float* hf_dbout;       // [C]
   int hf_P, hf_C, hf_CP, hf_accumulate;
   const float* dloss;    // [1] upstream d loss, or nullptr when dym / the partials already include it
+  float* hf_dbn_w;       // [D] when set, the extra workgroups also finish d(bn weight) / d(bn bias) (workspace of
+  float* hf_dbn_b;       //     cgcn_head_train: nobody has summed the BatchNorm columns for the parameters yet)
 };
 
 // One 64-element slab of the head backward's second stage.  Elements: [CP*D dW_out][CP db_out][D BatchNorm columns].
@@ -152,12 +154,14 @@ __device__ __forceinline__ void head_finalize_slab(int slab, int P, int n, int S
     const int c = e - CP * D - CP;
     // s[0], s[1] = sum dy (strand 0, 1); s[2], s[3] = sum dy*xhat (strand 0, 1); strand 1 is zero when S == 1
     const float db_ = s[0] + s[1], dg_ = s[2] + s[3];
-    dbn_b[c] = accumulate ? dbn_b[c] + db_ : db_;
-    dbn_w[c] = accumulate ? dbn_w[c] + dg_ : dg_;
-    const float invn = 1.f / (float)n;
-    for (int st = 0; st < S; ++st) {
-      bnc[(st * 2 + 0) * D + c] = s[st] * invn;
-      bnc[(st * 2 + 1) * D + c] = s[2 + st] * invn;
+    if (dbn_b) dbn_b[c] = accumulate ? dbn_b[c] + db_ : db_;
+    if (dbn_w) dbn_w[c] = accumulate ? dbn_w[c] + dg_ : dg_;
+    if (bnc) {
+      const float invn = 1.f / (float)n;
+      for (int st = 0; st < S; ++st) {
+        bnc[(st * 2 + 0) * D + c] = s[st] * invn;
+        bnc[(st * 2 + 1) * D + c] = s[2 + st] * invn;
+      }
     }
   }
 }

@@ -961,6 +961,30 @@ __global__ __launch_bounds__(512) void k_head_bwd_finalize(int slab0, int P, int
   head_finalize_slab<512>(slab0 + blockIdx.x, P, n, S, D, C, CP, part, dWout, dbout, dbn_w, dbn_b, bnc, accumulate, dloss);
 }
 
+// Last launch of cgcn_head_train: workgroup 0 adds up the loss shares (fixed-order tree); the others sum the
+// BatchNorm-backward columns of the partials into bnc = (mean dy, mean dy*xhat) per strand, for an upstream d loss of
+// 1 (the consumer, k_bwd_rowlocal's head prologue, scales by the real one).  One launch instead of a loss-sum launch
+// in the forward plus a finalize launch in the backward.
+__global__ __launch_bounds__(512) void k_head_train_finish(int wslab0, int P, int n, int S, int D, int C, int CP,
+                                                           const float* __restrict__ part, float* __restrict__ bnc,
+                                                           const float* __restrict__ loss_part, float inv_count,
+                                                           float* __restrict__ loss) {
+  if (blockIdx.x == 0) {
+    __shared__ float sm[512];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < P; i += 512) s += loss_part[i];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 256; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = sm[0] * inv_count;
+    return;
+  }
+  head_finalize_slab<512>(wslab0 + blockIdx.x - 1, P, n, S, D, C, CP, part, nullptr, nullptr, nullptr, nullptr, bnc, 0, nullptr);
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void k_head_bn_bwd_apply(int n, int S, const float* __restrict__ X,
                                                            const float* __restrict__ bn_w, const float* __restrict__ mean,
@@ -1011,9 +1035,16 @@ static inline int head_stat_blocks(int n, int* rows_per_blk) {
   int nb = (n + rpb - 1) / rpb;
   return nb < 1 ? 1 : nb;
 }
+// Workgroups (= partials) of k_head_fused / k_head_bwd: one 32-node tile each up to HEAD_MAX_PARTIALS (one per CU).
+// Larger chromosomes take twice as many, two resident per CU (108 VGPRs, 37 KB LDS), so that one workgroup's loads
+// overlap the other's MFMA phases instead of a longer serial walk over tiles.
+#ifndef HEAD_LARGE_PARTIALS
+#define HEAD_LARGE_PARTIALS 512
+#endif
 static inline int head_bwd_partials(int n) {
   int t = (n + HEADB_TILE - 1) / HEADB_TILE;
-  if (t > HEAD_MAX_PARTIALS) t = HEAD_MAX_PARTIALS;
+  const int cap = t > 2 * HEAD_MAX_PARTIALS ? HEAD_LARGE_PARTIALS : HEAD_MAX_PARTIALS;
+  if (t > cap) t = cap;
   return t < 1 ? 1 : t;
 }
 // workspace regions (floats), in this order
@@ -1147,7 +1178,10 @@ int cgcn_head_train(cgcn_stream_t stream, int n, int S, int d, int C, const floa
   else { if (CP == 128) HFU(256, 8); else HFU(256, 16); }
 #undef HFU
   if ((rc = launch_status())) return rc;
-  hipLaunchKernelGGL(k_sum_scale, dim3(1), dim3(256), 0, st, P, w_loss, inv_count, loss);
+  const int total = CP * d + CP + d;
+  const int slabs = (total + 63) / 64, wslabs = (CP * d + CP) / 64;  // CP is 128 or 256: the split is slab aligned
+  hipLaunchKernelGGL(k_head_train_finish, dim3(1 + slabs - wslabs), dim3(512), 0, st, wslabs, P, n, S, d, C, CP, w_part, w_bnc,
+                     w_loss, inv_count, loss);
   return launch_status();
 }
 
@@ -1187,6 +1221,12 @@ int cgcn_head_bwd(cgcn_stream_t stream, int n, int S, int d, int C, const float*
   const float* fin_scale = fused ? dloss : nullptr;  // the unfused kernel already multiplied dpred by d loss
   const int total = CP * d + CP + d;
   const int slabs = (total + 63) / 64, wslabs = (CP * d + CP) / 64;  // CP is 128 or 256: the split is slab aligned
+  if (fused) {
+    // cgcn_head_train left dym, bnc (for d loss = 1) and the partials; every remaining sum -- dW_out, db_out, d(bn
+    // weight), d(bn bias) -- rides in k_bwd_rowlocal's extra workgroups (cgcn_head_grad.part / dW_out / db_out /
+    // dbn_w / dbn_b), scaled there by d loss.  Nothing to launch.
+    return CGCN_OK;
+  }
   if (!dX) {
     // deferred mode: only the BatchNorm columns now (cgcn_layer_bwd needs bnc); the dW_out / db_out slabs ride at the
     // end of k_bwd_rowlocal's grid (cgcn_head_grad.part / dW_out / db_out)

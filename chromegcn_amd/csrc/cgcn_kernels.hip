@@ -558,7 +558,7 @@ __global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float*
   // fused "horizontally" so it costs no launch of its own)
   if ((int)blockIdx.x >= row_blocks) {
     head_finalize_slab<512>(blockIdx.x - row_blocks, hp.hf_P, n, hp.S, D, hp.hf_C, hp.hf_CP, hp.hf_part, hp.hf_dWout,
-                            hp.hf_dbout, nullptr, nullptr, nullptr, hp.hf_accumulate, hp.dloss);
+                            hp.hf_dbout, hp.hf_dbn_w, hp.hf_dbn_b, nullptr, hp.hf_accumulate, hp.dloss);
     return;
   }
   KT_STAMP(0);
@@ -593,9 +593,11 @@ __global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float*
 
   KT_STAMP(1);
   const int ntiles = (M + TR - 1) / TR;
-  for (int tile = blockIdx.x; tile < ntiles; tile += row_blocks) {
-    // ---- row pass: all loads of the wave's RPW rows are issued before the first use
-    float gup[RPW][EPL], z[RPW][EPL], x[RPW][EPL], h[RPW][EPL], gt[RPW], dgt[RPW];
+  // The wave's RPW rows of a tile are loaded into registers in one go (all loads issued before the first use); the
+  // loads of the workgroup's NEXT tile are issued right after the row pass, so they are in flight during the
+  // barrier + MFMA phase of the current one (large chromosomes: several tiles per workgroup).
+  float gup[RPW][EPL], z[RPW][EPL], x[RPW][EPL], h[RPW][EPL], gt[RPW], dgt[RPW];
+  auto load_tile = [&](int tile) {
 #pragma unroll
     for (int t = 0; t < RPW; ++t) {
       const int m = tile * TR + wave + t * NW;
@@ -612,6 +614,9 @@ __global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float*
       gt[t] = ok ? gate[m] : 0.f;
       dgt[t] = (ok && dgate) ? dgate[m] : 0.f;
     }
+  };
+  if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += row_blocks) {
     KT_STAMP(2);
 #pragma unroll
     for (int t = 0; t < RPW; ++t) {
@@ -633,7 +638,8 @@ __global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float*
             if (hp.thresh) dy = dropout_keep(hkey, (uint32_t)(off + e), hp.thresh) ? dy * hp.keep_scale : 0.f;
             const float is = hp.invstd[s * D + c];
             const float xh = (fmaxf(xn, 0.f) - hp.mean[s * D + c]) * is;
-            const float dr = hp.bn_w[c] * is * (dy - hp.bnc[(s * 2 + 0) * D + c] - xh * hp.bnc[(s * 2 + 1) * D + c]);
+            // bnc is for the same upstream d loss as dym (1 when both came from cgcn_head_train): scale alike
+            const float dr = hp.bn_w[c] * is * (dy - hgl * hp.bnc[(s * 2 + 0) * D + c] - xh * (hgl * hp.bnc[(s * 2 + 1) * D + c]));
             gup[t][e] = xn > 0.f ? dr : 0.f;
             if (dxn_store) dxn_store[off + e] = gup[t][e];  // k_bwd_gather reads it back as dL/dXn for the (1-g) dXn term
           }
@@ -663,6 +669,7 @@ __global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float*
         Ut[trow * LD + lane * EPL + e] = du[e];
       }
     }
+    if (tile + row_blocks < ntiles) load_tile(tile + row_blocks);  // prefetch (see above)
     KT_STAMP(3);
     __syncthreads();
     // ---- dW += Ht^T Ut  (K = TR rows)
@@ -1081,22 +1088,31 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   return launch_status();
 }
 
-// Row-tile height of k_bwd_rowlocal.  The kernel is a chain load -> row math -> LDS -> MFMA per tile, one tile in
-// flight per CU, so small graphs take the smallest tile that still gives every tile its own workgroup (more CUs
-// busy, shorter chain); large ones take 64-row tiles and loop.  D = 256 is limited to 32 rows by registers.
+// Row-tile height and workgroup count of k_bwd_rowlocal.  The kernel is a chain load -> row math -> LDS -> MFMA per
+// tile.  Small graphs: the smallest tile that still gives every tile its own workgroup, one per CU (more CUs busy,
+// shorter chain).  Large graphs (more than 64 rows per CU-resident workgroup): 32-row tiles at 122 VGPRs / 36 KB
+// LDS so that TWO workgroups are resident per CU and one's loads overlap the other's MFMA phase, at the price of
+// twice the partials (BWD_LARGE_PARTIALS).  D = 256 is limited to 32 rows by registers.
+#ifndef BWD_LARGE_PARTIALS
+#define BWD_LARGE_PARTIALS 512
+#endif
+static bool bwd_large(int n, int S, int d) { return d == 128 && (long long)n * S > 64LL * BWD_MAX_PARTIALS; }
+
 static int bwd_tile_rows(int n, int S, int d) {
   if (d != 128) return 32;
   const int M = n * S;
   if (M <= 32 * BWD_MAX_PARTIALS) return 32;
   if (M <= 48 * BWD_MAX_PARTIALS) return 48;
-  return BWD_TILE_ROWS;
+  if (!bwd_large(n, S, d)) return BWD_TILE_ROWS;
+  return 32;
 }
 
 static int bwd_partials(int n, int S, int d) {
   const int M = n * S;
   const int tr = bwd_tile_rows(n, S, d);
   const int ntiles = (M + tr - 1) / tr;
-  int P = ntiles < BWD_MAX_PARTIALS ? ntiles : BWD_MAX_PARTIALS;
+  const int cap = bwd_large(n, S, d) ? BWD_LARGE_PARTIALS : BWD_MAX_PARTIALS;
+  int P = ntiles < cap ? ntiles : cap;
   return P < 1 ? 1 : P;
 }
 
@@ -1117,7 +1133,7 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
     return CGCN_ERR_BAD_ARG;
   if ((dXn == nullptr) == (head == nullptr)) return CGCN_ERR_BAD_ARG;  // exactly one source of dL/dXn
   if ((dX && dX == dXn) || misaligned16(dUs) || (dX && misaligned16(dX)) || misaligned16(W)) return CGCN_ERR_BAD_ARG;
-  HeadApply hp = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1.f, 0u, S, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr};
+  HeadApply hp = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1.f, 0u, S, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr, nullptr, nullptr};
   int head_slabs = 0;
   if (head) {
     if (!head->dym || !head->bnc || !head->save_mean || !head->save_invstd || !head->bn_w) return CGCN_ERR_BAD_ARG;
@@ -1127,8 +1143,11 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
     if ((rc = dropout_args(head->dropout_p, head->rng_state, &hks, &hth))) return rc;
     const int CP = head->C <= 128 ? 128 : 256;
     hp = HeadApply{head->dym, head->bnc, head->save_mean, head->save_invstd, head->bn_w, head->rng_state, hks, hth, S,
-                   head->part, head->dW_out, head->db_out, head->n_partials, head->C, CP, head->accumulate, head->dloss};
-    head_slabs = (CP * d + CP) / 64;
+                   head->part, head->dW_out, head->db_out, head->n_partials, head->C, CP, head->accumulate, head->dloss,
+                   head->dbn_w, head->dbn_b};
+    if ((head->dbn_w == nullptr) != (head->dbn_b == nullptr)) return CGCN_ERR_BAD_ARG;
+    // dW_out / db_out slabs, plus the BatchNorm-column slabs when their parameter gradients are still to be summed
+    head_slabs = head->dbn_w ? (CP * d + CP + d + 63) / 64 : (CP * d + CP) / 64;
   }
   if (!workspace || workspace_bytes < cgcn_layer_bwd_workspace_bytes(n, S, d)) return CGCN_ERR_WORKSPACE;
   if (misaligned16(workspace)) return CGCN_ERR_BAD_ARG;

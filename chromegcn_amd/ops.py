@@ -378,20 +378,15 @@ class LastLayerHeadLossFn(torch.autograd.Function):
         if dloss is None:
             return (None,) * 24
         dloss = dloss.contiguous().view(1)
-        # fused mode (dpred = NULL): dym and the partials are already in the workspace cgcn_head_train filled
-        _lib.check(lib.cgcn_head_bwd(_lib.stream_ptr(), n, S, d, C, xn.data_ptr(), bn_w.data_ptr(), bn_b.data_ptr(),
-                                     save_mean.data_ptr(), save_invstd.data_ptr(), w_out.data_ptr(), None,
-                                     dloss.data_ptr(), ctx.dropout_p, _lib.ptr(rng_state), None,
-                                     dw_out.data_ptr(), db_out.data_ptr(), dbn_w.data_ptr(), dbn_b.data_ptr(), 0,
-                                     hws.data_ptr(), hws_bytes), "cgcn_head_bwd")
-        import ctypes
+        # dym, bnc and the partials are already in the workspace cgcn_head_train filled (for d loss = 1); every head
+        # gradient is finished inside cgcn_layer_bwd (cgcn_head_grad.dloss / dbn_w / dbn_b), so no head launch here
         o_dym, o_bnc, o_part = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
         _lib.check(lib.cgcn_head_workspace_layout(n, S, d, C, ctypes.byref(o_dym), ctypes.byref(o_bnc), ctypes.byref(o_part)),
                    "cgcn_head_workspace_layout")
         hg = _lib.HeadGrad(hws.data_ptr() + o_dym.value, hws.data_ptr() + o_bnc.value, save_mean.data_ptr(),
                            save_invstd.data_ptr(), bn_w.data_ptr(), ctx.dropout_p, _lib.ptr(rng_state),
                            hws.data_ptr() + o_part.value, lib.cgcn_head_bwd_partials(n), C, dw_out.data_ptr(),
-                           db_out.data_ptr(), 0, dloss.data_ptr())
+                           db_out.data_ptr(), 0, dloss.data_ptr(), dbn_w.data_ptr(), dbn_b.data_ptr())
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dus = torch.empty_like(x)
         ws_bytes = lib.cgcn_layer_bwd_workspace_bytes(n, S, d)

@@ -48,7 +48,7 @@ extern "C" {
 #define CGCN_ERR_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after a launch      */
 #define CGCN_ERR_WORKSPACE (-4)   /* workspace too small (see cgcn_*_workspace_bytes)    */
 
-#define CGCN_ABI_VERSION 11
+#define CGCN_ABI_VERSION 12
 
 typedef void *cgcn_stream_t; /* hipStream_t */
 
@@ -124,6 +124,8 @@ typedef struct cgcn_head_grad {
   int accumulate;
   const float *dloss;       /* [1] upstream d loss when the workspace came from cgcn_head_train (whose results are for
                                d loss = 1); NULL when it came from cgcn_head_bwd with dpred (already scaled) */
+  float *dbn_w;             /* [d] both set when the workspace came from cgcn_head_train: d(bn weight) / d(bn bias) */
+  float *dbn_b;             /* [d] are then finished here as well (same accumulate flag); NULL after cgcn_head_bwd  */
 } cgcn_head_grad;
 
 /* Bytes of scratch cgcn_layer_bwd needs for (n, S, d).  0 on unsupported shapes. */
@@ -193,9 +195,10 @@ int cgcn_head_fwd(cgcn_stream_t stream, int n, int S, int d, int C, const float 
  * Training-mode head forward fused with the tile-local half of its backward (one pass over X): same outputs as
  * cgcn_head_fwd(training = 1) -- probs, loss, save_mean / save_invstd, running-stat update -- and, left in
  * `workspace` for the backward, dym = d loss / d (mean_s y_s) and the per-workgroup partials of dW_out, db_out and
- * the BatchNorm sums, all for an upstream d loss of 1.  The same workspace must then be handed to cgcn_head_bwd with
- * dpred == NULL and dX == NULL (which only finalises the BatchNorm sums, scaled by dloss) and to cgcn_layer_bwd via
- * cgcn_head_grad (with .dloss set).  d loss / d pred never touches memory.
+ * the BatchNorm sums, all for an upstream d loss of 1, plus bnc (the BatchNorm-backward column means, likewise for
+ * d loss = 1).  The same workspace is then handed to cgcn_layer_bwd via cgcn_head_grad with .dloss, .dbn_w and .dbn_b
+ * set: that call finishes every head gradient.  (cgcn_head_bwd with dpred == NULL and dX == NULL is accepted and
+ * launches nothing.)  d loss / d pred never touches memory.
  * col_stats (may be NULL): the colstats output of the cgcn_layer_fwd call that produced X, with its tile count and
  * rows per tile (cgcn_layer_fwd_colstats_tiles); the head then skips its own first pass over X.
  */

@@ -11,7 +11,7 @@ from tools.kbench import timeit
 
 def main():
     dev = torch.device("cuda"); lib = _lib.load()
-    n, pairs, d, S = 5776, 250000, 128, 2
+    n, pairs, d, S = int(os.environ.get("KS_N", 5776)), 250000, 128, 2
     h = G.normalize_graph("hic", synth.contact_graph(n, pairs, 7, False), n); g = G.upload(h, dev)
     W = torch.randn(d, d, device=dev) / d ** 0.5; wg = torch.randn(d, device=dev) / d ** 0.5
     x = torch.randn(S, n, d, device=dev); z = torch.tanh(torch.randn_like(x)); hh = torch.randn_like(x)
