@@ -262,7 +262,7 @@ def main():
                 "gather_GBps": 4.0 * nnz * 2 * args.d / k_s / 1e9,
                 "mfma_TFLOPs": 2.0 * 2 * n * args.d * args.d / k_s / 1e12}
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the host baseline is reported at N=1 only
             cpu = cpu_baseline(args, n, pairs, seed, args.cpu_steps)
         value = world * n * args.steps / elapsed
         out = {

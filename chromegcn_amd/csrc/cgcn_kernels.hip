@@ -663,17 +663,22 @@ __global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float*
 #pragma unroll
         for (int e = 0; e < EPL; ++e) du[e] = 0.f;
       }
+#ifndef RL_SKIP_MFMA
 #pragma unroll
       for (int e = 0; e < EPL; ++e) {
         Ht[trow * LD + lane * EPL + e] = h[t][e];
         Ut[trow * LD + lane * EPL + e] = du[e];
       }
+#endif
     }
     if (tile + row_blocks < ntiles) load_tile(tile + row_blocks);  // prefetch (see above)
     KT_STAMP(3);
     __syncthreads();
     // ---- dW += Ht^T Ut  (K = TR rows)
     KT_STAMP(4);
+#ifdef RL_SKIP_MFMA
+    if (false)
+#endif
 #pragma unroll
     for (int kk = 0; kk < TR / 4; ++kk) {
       const int k = 4 * kk + q;
@@ -693,6 +698,9 @@ __global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float*
   KT_STAMP(5);
   // ---- write this workgroup's partial
   float* P = part + (size_t)blockIdx.x * PSTRIDE;
+#ifdef RL_SKIP_MFMA
+  if (false)
+#endif
 #pragma unroll
   for (int ib = 0; ib < IBW; ++ib)
 #pragma unroll

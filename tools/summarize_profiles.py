@@ -71,6 +71,19 @@ def main():
             if not k.startswith(("void k_", "k_")):
                 continue
             o.write("%s,%.1f,%s\n" % (k, sum(durs[k]) / len(durs[k]), ",".join("%d" % (sum(vals[k][c]) / max(1, len(vals[k][c]))) for c in names)))
+    vals, durs = counters(os.path.join(root, "mfma"))
+    names = ["SQ_BUSY_CU_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_WAVE_CYCLES"]
+    if vals:
+        with open(os.path.join(out, f"{tag}_pmc_mfma_bench_chr21.csv"), "w") as o:
+            o.write("# rocprofv3 --pmc " + " ".join(names) + " --kernel-trace -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline ; mean per launch.\n")
+            o.write("# mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel duration x 2.4 GHz): fraction of the chip's MFMA issue slots in use\n")
+            o.write("kernel,us," + ",".join(names) + ",mfma_util\n")
+            for k in sorted(vals, key=lambda k: -sum(durs[k])):
+                if not k.startswith(("void k_", "k_")):
+                    continue
+                us = sum(durs[k]) / len(durs[k])
+                mean = {c: sum(vals[k][c]) / max(1, len(vals[k][c])) for c in names}
+                o.write("%s,%.1f,%s,%.3f\n" % (k, us, ",".join("%d" % mean[c] for c in names), mean["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * us * 2400.0)))
     print("summaries in", out, os.listdir(out))
 
 
