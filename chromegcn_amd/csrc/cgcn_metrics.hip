@@ -4,18 +4,34 @@
 // the CPU with one scikit-learn call per label per metric after every split (runner.py:41,45,51 ->
 // utils/evals.py:89-92 -> utils/metrics.py:148-183,238-253): AUROC, area under the precision-recall curve
 // (trapezoid over sklearn's precision_recall_curve points), recall at the first point with FDR <= cutoff,
-// and average precision (mAP).  Here: one segmented radix sort of all (score, label) pairs by descending
-// score (rocPRIM through hipCUB) and a chunked scan of the sorted lists (one wave per 4096-element chunk),
+// and average precision (mAP).  Here: ONE device-wide radix sort (rocPRIM through hipCUB) of 64-bit keys
+// (label | descending score | target) -- every label's list comes out contiguous and sorted and the whole chip
+// works on it (a segmented sort with one long segment per label used a fraction of the chip) -- and a chunked scan
+// of the sorted lists (one wave per 4096-element chunk),
 // treating tied scores as one curve point exactly like sklearn's distinct-threshold curves.  All curve
 // arithmetic is fp64 and summed in a fixed order.
 #include <hipcub/hipcub.hpp>
 
 #include "cgcn_common.hpp"
 
-// [n,C] row-major -> per-label contiguous keys[c][i] (score) and vals[c][i] (1 = positive)
+// Sort key of one (window i, label c) pair: [label c][~ordered(score)][target bit].  ordered() is the usual
+// order-preserving map of IEEE floats to unsigned; complemented so that an ascending sort lists each label's scores in
+// descending order.  -0 is folded onto +0 (sklearn compares scores as numbers).
+__device__ __forceinline__ unsigned long long metric_key(int c, float score, float target) {
+  unsigned u = __float_as_uint(score == 0.f ? 0.f : score);
+  u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;
+  return ((unsigned long long)(unsigned)c << 33) | ((unsigned long long)(~u) << 1) | (target > 0.5f ? 1ull : 0ull);
+}
+__device__ __forceinline__ float metric_key_score(unsigned long long k) {
+  unsigned u = ~(unsigned)(k >> 1);
+  u ^= (u >> 31) ? 0x80000000u : 0xFFFFFFFFu;
+  return __uint_as_float(u);
+}
+
+// [n,C] row-major -> keys[c * n + i], transposed through LDS so that both sides are coalesced
 __global__ __launch_bounds__(256) void k_metrics_pack(long long n, int C, const float* __restrict__ probs,
-                                                      const float* __restrict__ targets, float* __restrict__ keys,
-                                                      unsigned char* __restrict__ vals) {
+                                                      const float* __restrict__ targets,
+                                                      unsigned long long* __restrict__ keys) {
   __shared__ float tp[32][33];
   __shared__ float tt[32][33];
   const long long i0 = (long long)blockIdx.x * 32;
@@ -32,16 +48,18 @@ __global__ __launch_bounds__(256) void k_metrics_pack(long long n, int C, const 
   for (int r = ty; r < 32; r += 8) {
     const int c = c0 + r;
     const long long i = i0 + tx;
-    if (c < C && i < n) {
-      keys[(long long)c * n + i] = tp[tx][r];
-      vals[(long long)c * n + i] = tt[tx][r] > 0.5f ? 1 : 0;
-    }
+    if (c < C && i < n) keys[(long long)c * n + i] = metric_key(c, tp[tx][r], tt[tx][r]);
   }
 }
 
-__global__ void k_metrics_offsets(long long n, int C, int* __restrict__ off) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c <= C) off[c] = (int)((long long)c * n);
+// sorted 64-bit keys -> the score / target arrays the curve kernels read
+__global__ __launch_bounds__(256) void k_metrics_unpack(long long items, const unsigned long long* __restrict__ keys,
+                                                        float* __restrict__ score, unsigned char* __restrict__ val) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= items) return;
+  const unsigned long long k = keys[i];
+  score[i] = metric_key_score(k);
+  val[i] = (unsigned char)(k & 1ull);
 }
 
 __device__ __forceinline__ double wave_sum_d(double v) {
@@ -223,11 +241,15 @@ __global__ __launch_bounds__(64) void k_metrics_final(long long n, int C, int nc
 
 static inline int metric_chunks(long long n) { long long k = (n + METRIC_CHUNK - 1) / METRIC_CHUNK; return k < 1 ? 1 : (int)k; }
 
+static inline int label_bits(int C) {
+  int b = 1;
+  while ((1 << b) < C) ++b;
+  return b;
+}
 static size_t sort_temp_bytes(long long n, int C) {
   size_t bytes = 0;
-  hipcub::DeviceSegmentedRadixSort::SortPairsDescending(nullptr, bytes, (const float*)nullptr, (float*)nullptr,
-                                                        (const unsigned char*)nullptr, (unsigned char*)nullptr,
-                                                        (int)(n * C), C, (const int*)nullptr, (const int*)nullptr);
+  hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                    (int)(n * C), 1, 33 + label_bits(C));
   return bytes;
 }
 static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -238,8 +260,9 @@ size_t cgcn_metrics_workspace_bytes(long long n, int C) {
   if (n < 0 || C < 1 || (double)n * C >= 2147483647.0) return 0;
   const size_t items = (size_t)n * C;
   const size_t nrec = (size_t)C * metric_chunks(n);
-  return 2 * al(items * 4) + 2 * al(items) + al((size_t)(C + 1) * 4) + al(nrec * sizeof(ChunkRec)) + al(nrec * sizeof(ChunkOut)) +
-         al((size_t)C * 8) + al(sort_temp_bytes(n, C)) + 256;
+  // two 64-bit key buffers (the first is reused for the unpacked score / target arrays after the sort)
+  return 2 * al(items * 8) + al(nrec * sizeof(ChunkRec)) + al(nrec * sizeof(ChunkOut)) + al((size_t)C * 8) +
+         al(sort_temp_bytes(n, C)) + 256;
 }
 
 int cgcn_multilabel_metrics(cgcn_stream_t stream, long long n, int C, const float* probs, const float* targets,
@@ -251,11 +274,10 @@ int cgcn_multilabel_metrics(cgcn_stream_t stream, long long n, int C, const floa
   hipStream_t st = (hipStream_t)stream;
   const size_t items = (size_t)n * C;
   char* w = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-  float* keys_in = (float*)w; w += al(items * 4);
-  float* keys_out = (float*)w; w += al(items * 4);
-  unsigned char* vals_in = (unsigned char*)w; w += al(items);
-  unsigned char* vals_out = (unsigned char*)w; w += al(items);
-  int* off = (int*)w; w += al((size_t)(C + 1) * 4);
+  unsigned long long* k_in = (unsigned long long*)w; w += al(items * 8);
+  unsigned long long* k_out = (unsigned long long*)w; w += al(items * 8);
+  float* keys_out = (float*)k_in;                                  // 4 bytes per item of the 8 ...
+  unsigned char* vals_out = (unsigned char*)k_in + ((items * 4 + 15) & ~(size_t)15);  // ... and 1 more: fits in the dead input buffer
   const int nch = metric_chunks(n);
   ChunkRec* rec = (ChunkRec*)w; w += al((size_t)C * nch * sizeof(ChunkRec));
   ChunkOut* outp = (ChunkOut*)w; w += al((size_t)C * nch * sizeof(ChunkOut));
@@ -263,11 +285,11 @@ int cgcn_multilabel_metrics(cgcn_stream_t stream, long long n, int C, const floa
   size_t temp = sort_temp_bytes(n, C);
   if (n > 0) {
     dim3 grid((unsigned)((n + 31) / 32), (unsigned)((C + 31) / 32));
-    hipLaunchKernelGGL(k_metrics_pack, grid, dim3(256), 0, st, n, C, probs, targets, keys_in, vals_in);
-    hipLaunchKernelGGL(k_metrics_offsets, dim3((C + 256) / 256), dim3(256), 0, st, n, C, off);
-    if (hipcub::DeviceSegmentedRadixSort::SortPairsDescending(w, temp, keys_in, keys_out, vals_in, vals_out, (int)items, C, off,
-                                                              off + 1, 0, 32, st) != hipSuccess)
+    hipLaunchKernelGGL(k_metrics_pack, grid, dim3(256), 0, st, n, C, probs, targets, k_in);
+    // bit 0 (the target) does not take part: ties in score are one curve point whatever their order
+    if (hipcub::DeviceRadixSort::SortKeys(w, temp, (const unsigned long long*)k_in, k_out, (int)items, 1, 33 + label_bits(C), st) != hipSuccess)
       return CGCN_ERR_LAUNCH;
+    hipLaunchKernelGGL(k_metrics_unpack, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, (long long)items, k_out, keys_out, vals_out);
   }
   hipLaunchKernelGGL(k_metrics_summary, dim3(nch, C), dim3(64), 0, st, n, nch, keys_out, vals_out, rec);
   hipLaunchKernelGGL(k_metrics_prefix, dim3(C), dim3(64), 0, st, nch, rec, Ptot);
