@@ -36,6 +36,23 @@ def test_metrics_match_oracle(n, C):
         np.testing.assert_allclose(got[k].cpu().numpy(), want[k], rtol=3e-6, atol=3e-7, equal_nan=True, err_msg=k)
 
 
+def test_metrics_order_signed_scores_and_signed_zero():
+    """Scores need not be probabilities: logits (both signs), -0.0 / +0.0 (one threshold for sklearn) and subnormals
+    must rank exactly as numbers do (the sort key is an order-preserving integer image of the float)."""
+    rng = np.random.RandomState(5)
+    n, C = 3000, 5
+    tg = (rng.rand(n, C) < 0.3).astype(np.float32)
+    pr = (rng.randn(n, C) * 3 + tg).astype(np.float32)
+    pr[::7, 0] = 0.0
+    pr[3::7, 0] = -0.0
+    pr[::5, 1] = np.float32(1e-42) * rng.randint(-3, 4, size=pr[::5, 1].shape).astype(np.float32)  # subnormals of both signs
+    pr[:, 2] = -np.abs(pr[:, 2])       # all negative
+    want = O.multilabel_metrics_np(tg.astype(np.float64), pr)
+    got = M.multilabel_metrics(torch.from_numpy(pr).to(DEV), torch.from_numpy(tg).to(DEV))
+    for k in ("auroc", "aupr", "recall_at_fdr", "average_precision"):
+        np.testing.assert_allclose(got[k].cpu().numpy(), want[k], rtol=3e-6, atol=3e-7, equal_nan=True, err_msg=k)
+
+
 def test_compute_metrics_keys_and_aggregation(golden):
     z = golden("g5_metrics.npz")
     out = M.compute_metrics(torch.from_numpy(z["preds"]), torch.from_numpy(z["targets"]), 1.25, None, 0.5)
