@@ -1,0 +1,96 @@
+"""Error behaviour of the C ABI (include/chromegcn.h): every entry point returns a negative code instead of
+launching on bad input, names it through cgcn_strerror, and treats empty inputs as a no-op."""
+import ctypes
+
+import pytest
+import torch
+
+from chromegcn_amd import _lib, graph as G, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+OK, BAD_ARG, UNSUPPORTED, LAUNCH, WORKSPACE = 0, -1, -2, -3, -4
+
+
+@pytest.fixture(scope="module")
+def env():
+    lib = _lib.load()
+    n, S, d = 70, 2, 128
+    g = G.upload(G.normalize_graph("hic", synth.contact_graph(n, 300, 3), n), DEV)
+    t = lambda *shape: torch.randn(*shape, device=DEV)
+    return dict(lib=lib, n=n, S=S, d=d, g=g, x=t(S, n, d), y=t(S, n, d), W=t(d, d), b=t(d), wg=t(d), cg=t(1),
+                gate=t(S, n), z=t(S, n, d), h=t(S, n, d))
+
+
+def fwd(e, **over):
+    a = dict(e); a.update(over)
+    P, g = _lib.ptr, a["g"]
+    return a["lib"].cgcn_layer_fwd(_lib.stream_ptr(), a["n"], a["S"], a["d"], P(g.rowptr), P(g.col), None, P(g.row_scale),
+                                   a.get("xptr", P(a["x"])), P(a["W"]), P(a["b"]), P(a["wg"]), P(a["cg"]), a.get("yptr", P(a["y"])),
+                                   P(a["z"]), P(a["h"]), P(a["gate"]), a.get("p", 0.0), None, 0, None, None)
+
+
+def test_strerror_names_every_code(env):
+    lib = env["lib"]
+    msgs = {c: lib.cgcn_strerror(c).decode() for c in (OK, BAD_ARG, UNSUPPORTED, LAUNCH, WORKSPACE, -99)}
+    assert len(set(msgs.values())) == 6 and all(msgs.values())
+    assert lib.cgcn_abi_version() == _lib.ABI_VERSION
+
+
+def test_layer_fwd_rejects_bad_input_without_launching(env):
+    assert fwd(env) == OK
+    before = env["y"].clone()
+    assert fwd(env, d=64) == UNSUPPORTED                      # d not in {128, 256}
+    assert fwd(env, S=3) == UNSUPPORTED
+    assert fwd(env, n=-1) == BAD_ARG
+    assert fwd(env, xptr=None) == BAD_ARG                     # null feature pointer
+    assert fwd(env, yptr=_lib.ptr(env["x"])) == BAD_ARG       # output aliases the input
+    assert fwd(env, xptr=_lib.ptr(env["x"]) + 4) == BAD_ARG   # not 16-byte aligned
+    assert fwd(env, p=0.3) == BAD_ARG                         # dropout without an rng state
+    assert fwd(env, n=0) == OK                                # empty chromosome: nothing to do
+    torch.cuda.synchronize()
+    assert torch.equal(env["y"], before)
+
+
+def test_workspaces_are_checked(env):
+    lib, n, S, d, g = env["lib"], env["n"], env["S"], env["d"], env["g"]
+    P = _lib.ptr
+    need = lib.cgcn_layer_bwd_workspace_bytes(n, S, d)
+    assert need > 0 and lib.cgcn_layer_bwd_workspace_bytes(n, S, 100) == 0
+    ws = torch.empty(need, dtype=torch.uint8, device=DEV)
+    dx, dus = torch.empty_like(env["x"]), torch.empty_like(env["x"])
+    dW, db, dwg, dcg = torch.empty(d, d, device=DEV), torch.empty(d, device=DEV), torch.empty(d, device=DEV), torch.empty(1, device=DEV)
+
+    def bwd(ws_bytes, dxn=env["y"], wsp=P(ws)):
+        return lib.cgcn_layer_bwd(_lib.stream_ptr(), n, S, d, P(g.rowptr_t), P(g.col_t), None, P(g.row_scale), P(env["x"]), P(env["z"]),
+                                  P(env["h"]), P(env["gate"]), P(env["W"]), P(env["wg"]), _lib.ptr(dxn), None, P(dx), P(dus), P(dW), P(db),
+                                  P(dwg), P(dcg), 0, 0.0, None, 0, None, wsp, ws_bytes, None)
+    assert bwd(need) == OK
+    assert bwd(need - 1) == WORKSPACE
+    assert bwd(need, wsp=None) == WORKSPACE
+    assert bwd(need, dxn=None) == BAD_ARG                     # neither dXn nor a head state: no source of the gradient
+    C = 11
+    assert lib.cgcn_head_workspace_bytes(n, S, d, C) > 0
+    assert lib.cgcn_head_workspace_bytes(n, S, d, 0) == 0 and lib.cgcn_head_workspace_bytes(n, S, d, 257) == 0
+    assert lib.cgcn_metrics_workspace_bytes(10, 0) == 0 and lib.cgcn_metrics_workspace_bytes(10, 3) > 0
+    rows = ctypes.c_int(0)
+    assert lib.cgcn_layer_fwd_colstats_tiles(n, S, d, ctypes.byref(rows)) == (n + rows.value - 1) // rows.value
+    assert lib.cgcn_layer_fwd_colstats_tiles(n, S, 64, ctypes.byref(rows)) == 0
+
+
+def test_sgd_and_spmm_argument_checks(env):
+    lib = env["lib"]
+    P = _lib.ptr
+    p, g_, m = torch.zeros(8, device=DEV), torch.ones(8, device=DEV), torch.zeros(8, device=DEV)
+    assert lib.cgcn_sgd_step(_lib.stream_ptr(), 8, P(p), P(g_), P(m), 0.1, 0.9, 0.0, 0, 1.0, None) == OK
+    assert lib.cgcn_sgd_step(_lib.stream_ptr(), 8, P(p), P(g_), None, 0.1, 0.9, 0.0, 0, 1.0, None) == BAD_ARG   # momentum without a buffer
+    assert lib.cgcn_sgd_step(_lib.stream_ptr(), 8, P(p), P(g_), None, 0.1, 0.0, 0.0, 1, 1.0, None) == BAD_ARG   # nesterov without momentum
+    assert lib.cgcn_sgd_step(_lib.stream_ptr(), -1, P(p), P(g_), P(m), 0.1, 0.9, 0.0, 0, 1.0, None) == UNSUPPORTED
+    assert lib.cgcn_sgd_step(_lib.stream_ptr(), 0, None, None, None, 0.1, 0.0, 0.0, 0, 1.0, None) == OK
+    torch.cuda.synchronize()
+    assert torch.allclose(p, torch.full((8,), -0.1, device=DEV))
+    g = env["g"]
+    y = torch.empty_like(env["x"])
+    assert lib.cgcn_spmm(_lib.stream_ptr(), env["n"], env["n"], env["S"], env["d"], P(g.rowptr), P(g.col), None, P(g.row_scale), P(env["x"]), P(y)) == OK
+    assert lib.cgcn_spmm(_lib.stream_ptr(), env["n"], env["n"], env["S"], env["d"], None, P(g.col), None, P(g.row_scale), P(env["x"]), P(y)) == BAD_ARG
+    assert lib.cgcn_spmm(_lib.stream_ptr(), env["n"], env["n"], env["S"], 96, P(g.rowptr), P(g.col), None, P(g.row_scale), P(env["x"]), P(y)) == UNSUPPORTED
