@@ -19,6 +19,12 @@
 //                          accumulated in registers), column sums for db_out and the BatchNorm backward
 //   k_head_bwd_finalize    deterministic second stage: dW_out, db_out, d(bn weight), d(bn bias), BN constants
 //   k_head_bn_bwd_apply<D> dX = bn_w invstd (dy - mean(dy) - xhat mean(dy xhat)) [x > 0]
+// Training path of the stage engine (cgcn_head_train; 3 launches, none in the backward):
+//   k_head_bn_finalize     on the per-tile statistics the last cgcn_layer_fwd emitted (colstats)
+//   k_head_fused<D,CBMAX>  k_head_fwd + the tile-local half of k_head_bwd in one pass: d loss / d pred lives only
+//                          in LDS; leaves dym and the per-workgroup partial sums in the workspace
+//   k_head_train_finish    loss sum + BatchNorm-backward column means; every parameter sum of the head is then
+//                          finished by extra workgroups of the layer backward (head_finalize_slab, cgcn_common.hpp)
 #include "cgcn_common.hpp"
 
 #define HEAD_STAT_BLOCKS 128
