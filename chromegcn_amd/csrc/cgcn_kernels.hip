@@ -36,8 +36,14 @@ struct Geo {
 // add.  The code is branch-free inside a 64-neighbour chunk: a ragged tail re-reads the row's last valid
 // neighbour (an L1 hit) and adds a selected zero, so it never degenerates into a serial
 // load-wait-add chain.  GATHER_DB = 1 additionally double-buffers the batches.
-#ifndef GU
-#define GU 8
+// Batch depth (GU wave-loads in flight per wave) is a property of the payload and of where the rows come from,
+// measured on MI355X (whole chr21-like step, ms): the sweet spot is about 2 KiB in flight per wave with as many
+// resident waves as the registers then allow (66 instead of 86 VGPRs: three instead of two workgroups per CU, so
+// 722 tiles run as ONE round):  S*D = 256 floats: GU 1 / 2 / 3 / 8 = .249 / .225 / .229 / .236;  S*D = 512
+// (d = 256, L = 4): GU 1 / 2 / 3 / 8 = .887 / 1.04 / 1.08 / 1.13.  When the feature table is much larger than the
+// L2s (chr1-like, 30 MB) the longer miss latency wants one more load in flight: GU 2 / 3 / 8 = .670 / .647 / .668.
+#ifndef GU_OVERRIDE
+#define GU_OVERRIDE 0  // tuning: force one depth everywhere
 #endif
 // Z and H are written for the backward only.  Non-temporal stores for them (NT_SAVED=1) were measured neutral
 // for the kernel (34.3 vs 34.5 us) and slightly negative for the whole step, so plain stores are the default.
@@ -57,10 +63,11 @@ struct Geo {
 #ifndef GATHER_DB
 #define GATHER_DB 0
 #endif
-template <int S, int D, bool HAS_VAL>
+template <int S, int D, bool HAS_VAL, bool DEEP>
 struct Gather {
   using G = Geo<S, D>;
   static constexpr int NV = G::NV;
+  static constexpr int GU = GU_OVERRIDE ? GU_OVERRIDE : (NV == 2 ? 1 : (DEEP ? 3 : 2));
   static constexpr int NPL = G::HALF ? 2 : 1;   // neighbours per wave-load
   static constexpr unsigned ROWB = D * 4;       // bytes per (strand,node) row
 
@@ -103,13 +110,14 @@ struct Gather {
 };
 
 // accumulate neighbours k0..k1 of one row into acc (no initialisation, no half-wave fold)
-template <int S, int D, bool HAS_VAL>
+template <int S, int D, bool HAS_VAL, bool DEEP>
 __device__ __forceinline__ void gather_range(const int* __restrict__ col, const float* __restrict__ val,
                                              int k0, int k1, const char* __restrict__ Xb,
                                              const unsigned (&lane_off)[Geo<S, D>::NV], f32x4 (&acc)[Geo<S, D>::NV],
                                              int lane) {
-  using GA = Gather<S, D, HAS_VAL>;
+  using GA = Gather<S, D, HAS_VAL, DEEP>;
   constexpr int NV = GA::NV;
+  constexpr int GU = GA::GU;
   for (int kb = k0; kb < k1; kb += WAVE) {
     const int cnt = min(WAVE, k1 - kb);
     int myc = 0;
@@ -150,14 +158,14 @@ __device__ __forceinline__ void gather_fold(int lane, f32x4 (&acc)[Geo<S, D>::NV
   }
 }
 
-template <int S, int D, bool HAS_VAL>
+template <int S, int D, bool HAS_VAL, bool DEEP>
 __device__ __forceinline__ void gather_node(const int* __restrict__ col, const float* __restrict__ val,
                                             int k0, int k1, const char* __restrict__ Xb,
                                             const unsigned (&lane_off)[Geo<S, D>::NV], f32x4 (&acc)[Geo<S, D>::NV],
                                             int lane) {
 #pragma unroll
   for (int v = 0; v < Geo<S, D>::NV; ++v) acc[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  gather_range<S, D, HAS_VAL>(col, val, k0, k1, Xb, lane_off, acc, lane);
+  gather_range<S, D, HAS_VAL, DEEP>(col, val, k0, k1, Xb, lane_off, acc, lane);
   gather_fold<S, D>(lane, acc);
 }
 
@@ -168,7 +176,7 @@ __device__ __forceinline__ void gather_node(const int* __restrict__ col, const f
 #ifndef LONG_ROW
 #define LONG_ROW 512
 #endif
-template <int S, int D, bool HAS_VAL, int R, int NW, int LD>
+template <int S, int D, bool HAS_VAL, bool DEEP, int R, int NW, int LD>
 __device__ __forceinline__ void gather_tile(int n, int node0, const int* __restrict__ rowptr,
                                             const int* __restrict__ col, const float* __restrict__ val,
                                             const float* __restrict__ rs, const char* __restrict__ Xb,
@@ -188,7 +196,7 @@ __device__ __forceinline__ void gather_tile(int n, int node0, const int* __restr
       const int k0 = rowptr[i], k1 = rowptr[i + 1];
       is_long = (k1 - k0) > LONG_ROW;
       if (!is_long) {
-        gather_range<S, D, HAS_VAL>(col, val, k0, k1, Xb, lane_off, acc, lane);
+        gather_range<S, D, HAS_VAL, DEEP>(col, val, k0, k1, Xb, lane_off, acc, lane);
         gather_fold<S, D>(lane, acc);
         const float sc = rs ? rs[i] : 1.f;
 #pragma unroll
@@ -215,7 +223,7 @@ __device__ __forceinline__ void gather_tile(int n, int node0, const int* __restr
 #pragma unroll
     for (int v = 0; v < NV; ++v) acc[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int kb = k0 + WAVE * wave; kb < k1; kb += WAVE * NW)
-      gather_range<S, D, HAS_VAL>(col, val, kb, min(kb + WAVE, k1), Xb, lane_off, acc, lane);
+      gather_range<S, D, HAS_VAL, DEEP>(col, val, kb, min(kb + WAVE, k1), Xb, lane_off, acc, lane);
     gather_fold<S, D>(lane, acc);
     if (!G::HALF || lane < 32) {
 #pragma unroll
@@ -241,7 +249,7 @@ __device__ __forceinline__ void gather_tile(int n, int node0, const int* __restr
 // ------------------------------------------------------------------------------------------
 // k_spmm: one wave per output node, grid-stride over nodes.
 // ------------------------------------------------------------------------------------------
-template <int S, int D, bool HAS_VAL>
+template <int S, int D, bool HAS_VAL, bool DEEP>
 __global__ __launch_bounds__(256) void k_spmm(int n_rows, int n_cols, const int* __restrict__ rowptr,
                                               const int* __restrict__ col, const float* __restrict__ val,
                                               const float* __restrict__ rs, const float* __restrict__ X,
@@ -257,7 +265,7 @@ __global__ __launch_bounds__(256) void k_spmm(int n_rows, int n_cols, const int*
   for (int i = wave; i < n_rows; i += nwaves) {
     const int k0 = rowptr[i], k1 = rowptr[i + 1];
     f32x4 acc[G::NV];
-    gather_node<S, D, HAS_VAL>(col, val, k0, k1, (const char*)X, lane_off, acc, lane);
+    gather_node<S, D, HAS_VAL, DEEP>(col, val, k0, k1, (const char*)X, lane_off, acc, lane);
     const float sc = rs ? rs[i] : 1.f;
     if (!G::HALF || lane < 32) {
 #pragma unroll
@@ -389,7 +397,7 @@ extern "C" int cgcn_debug_kt_stamps(unsigned long long* out) {
 #define KT_STAMP(i)
 #endif
 
-template <int S, int D, int MB, bool HAS_VAL, bool FROM_CACHE>
+template <int S, int D, int MB, bool HAS_VAL, bool FROM_CACHE, bool DEEP>
 __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) FWD_OCC void k_layer_fwd(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
                                                      const float* __restrict__ val, const float* __restrict__ rs,
                                                      const float* __restrict__ X, const float* __restrict__ W,
@@ -442,7 +450,7 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) FWD_OCC void
       }
     }
   } else {
-    gather_tile<S, D, HAS_VAL, R, NW, LD>(n, node0, rowptr, col, val, rs, (const char*)X, lane_off, T, Hout, LR, wave, lane);
+    gather_tile<S, D, HAS_VAL, DEEP, R, NW, LD>(n, node0, rowptr, col, val, rs, (const char*)X, lane_off, T, Hout, LR, wave, lane);
   }
   KT_STAMP(10);
   // prefetch the residual rows this wave will mix in phase 3 (latency hides behind the MFMA phase)
@@ -795,7 +803,7 @@ __global__ __launch_bounds__(256) void k_reduce_partials(int P, int D, const flo
 // k_bwd_gather: dX = mask * ((1-g) dXn + (Ahat^T dUs) W^T), same skeleton as the forward.
 // mask: the dropout the PREVIOUS layer applied to this layer's input (stream_id of that layer).
 // ------------------------------------------------------------------------------------------
-template <int S, int D, int MB, bool HAS_VAL>
+template <int S, int D, int MB, bool HAS_VAL, bool DEEP>
 __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) void k_bwd_gather(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
                                                       const float* __restrict__ val, const float* __restrict__ dUs,
                                                       const float* __restrict__ W, const float* dXn,
@@ -835,7 +843,7 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) void k_bwd_g
 #pragma unroll
   for (int v = 0; v < G::NV; ++v) lane_off[v] = ((unsigned)G::strand(v, lane) * (unsigned)n * D + G::column(v, lane)) * 4u;
 
-  gather_tile<S, D, HAS_VAL, R, NW, LD>(n, node0, rowptr, col, val, nullptr, (const char*)dUs, lane_off, T, nullptr, LR, wave, lane);
+  gather_tile<S, D, HAS_VAL, DEEP, R, NW, LD>(n, node0, rowptr, col, val, nullptr, (const char*)dUs, lane_off, T, nullptr, LR, wave, lane);
   // prefetch (1-g) dXn for the rows this wave finishes
   float res[RPW][EPL];
 #pragma unroll
@@ -984,6 +992,12 @@ static int check_shape(int n, int S, int d) {
     else { if (hasval_) { CALL(2, 256, true); } else { CALL(2, 256, false); } }  \
   } while (0)
 
+// Deeper gather batches when the gathered table is much larger than the L2s (see Gather::GU).
+#ifndef DEEP_TABLE_BYTES
+#define DEEP_TABLE_BYTES (12u << 20)
+#endif
+static inline bool pick_deep(int n, int S, int d) { return (double)n * S * d * 4.0 > (double)DEEP_TABLE_BYTES; }
+
 // Tile height of the gather kernels: 32 MFMA rows (MB = 2) when that still gives >= 4 workgroups per CU,
 // otherwise 16 rows (MB = 1) so small chromosomes fill the 256 CUs.
 static inline int pick_mb(int n, int S) {
@@ -1043,8 +1057,12 @@ int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d, const 
   if (misaligned16(X) || misaligned16(Y)) return CGCN_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int blocks = (n_rows + 3) / 4 < 4096 ? (n_rows + 3) / 4 : 4096;
-#define CALL(S_, D_, V_) \
-  hipLaunchKernelGGL((k_spmm<S_, D_, V_>), dim3(blocks), dim3(256), 0, st, n_rows, n_cols, rowptr, col, val, row_scale, X, Y)
+  const bool deep = pick_deep(n_cols, S, d);
+#define CALL(S_, D_, V_)                                                                                                  \
+  do {                                                                                                                    \
+    if (deep) hipLaunchKernelGGL((k_spmm<S_, D_, V_, true>), dim3(blocks), dim3(256), 0, st, n_rows, n_cols, rowptr, col, val, row_scale, X, Y); \
+    else hipLaunchKernelGGL((k_spmm<S_, D_, V_, false>), dim3(blocks), dim3(256), 0, st, n_rows, n_cols, rowptr, col, val, row_scale, X, Y); \
+  } while (0)
   DISPATCH_SDV(S, d, val != nullptr, CALL);
 #undef CALL
   return launch_status();
@@ -1075,24 +1093,24 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   const int mb = pick_mb(n, S);
   const int tn = 16 * mb / S;
   const int blocks = (n + tn - 1) / tn;
-#define CALL(S_, D_, V_)                                                                                            \
-  do {                                                                                                              \
-    const dim3 blk((D_ == 128 && CBW128 == 2) ? 256 : 512);                                                         \
-    if (mb == 2 && H_in)                                                                                            \
-      hipLaunchKernelGGL((k_layer_fwd<S_, D_, 2, V_, true>), dim3(blocks), blk, 0, st, n, rowptr, col, val, row_scale, \
-                         X, W, b, wg, cg, Xn, Z, H, gate, ks, th, rng_state, stream_id, H_in, colstats);                    \
-    else if (mb == 2)                                                                                               \
-      hipLaunchKernelGGL((k_layer_fwd<S_, D_, 2, V_, false>), dim3(blocks), blk, 0, st, n, rowptr, col, val, row_scale, \
-                         X, W, b, wg, cg, Xn, Z, H, gate, ks, th, rng_state, stream_id, H_in, colstats);                    \
-    else if (H_in)                                                                                                  \
-      hipLaunchKernelGGL((k_layer_fwd<S_, D_, 1, V_, true>), dim3(blocks), blk, 0, st, n, rowptr, col, val, row_scale, \
-                         X, W, b, wg, cg, Xn, Z, H, gate, ks, th, rng_state, stream_id, H_in, colstats);                    \
-    else                                                                                                            \
-      hipLaunchKernelGGL((k_layer_fwd<S_, D_, 1, V_, false>), dim3(blocks), blk, 0, st, n, rowptr, col, val, row_scale, \
-                         X, W, b, wg, cg, Xn, Z, H, gate, ks, th, rng_state, stream_id, H_in, colstats);                    \
+  const bool deep = pick_deep(n, S, d);
+#define FWD(S_, D_, MB_, V_, C_, DP_)                                                                                 \
+  hipLaunchKernelGGL((k_layer_fwd<S_, D_, MB_, V_, C_, DP_>), dim3(blocks), blk, 0, st, n, rowptr, col, val, row_scale, \
+                     X, W, b, wg, cg, Xn, Z, H, gate, ks, th, rng_state, stream_id, H_in, colstats)
+#define CALL(S_, D_, V_)                                                                                              \
+  do {                                                                                                                \
+    const dim3 blk((D_ == 128 && CBW128 == 2) ? 256 : 512);                                                           \
+    if (H_in) { /* no gather: depth irrelevant */                                                                     \
+      if (mb == 2) FWD(S_, D_, 2, V_, true, false); else FWD(S_, D_, 1, V_, true, false);                             \
+    } else if (deep) {                                                                                                \
+      if (mb == 2) FWD(S_, D_, 2, V_, false, true); else FWD(S_, D_, 1, V_, false, true);                             \
+    } else {                                                                                                          \
+      if (mb == 2) FWD(S_, D_, 2, V_, false, false); else FWD(S_, D_, 1, V_, false, false);                           \
+    }                                                                                                                 \
   } while (0)
   DISPATCH_SDV(S, d, val != nullptr, CALL);
 #undef CALL
+#undef FWD
   return launch_status();
 }
 
@@ -1206,19 +1224,19 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   const int tn = 16 * mb / S;
   const int blocks = (n + tn - 1) / tn;
   if (head) dXn = dX;  // k_bwd_rowlocal left dL/dXn there; each thread reads its elements before overwriting them
+  const bool deep = pick_deep(n, S, d);
+#define BG(S_, D_, MB_, V_, DP_)                                                                                     \
+  hipLaunchKernelGGL((k_bwd_gather<S_, D_, MB_, V_, DP_>), dim3(blocks + (fuse_reduce ? slabs : 0)),                 \
+                     dim3((D_ == 128 && CBW128 == 2) ? 256 : 512), 0, st, n, rowptr_t, col_t, val_t, dUs, W, dXn,   \
+                     gate, dX, ks, th, rng_state, in_stream_id, blocks, P, part, dW, db, dwg, dcg, accumulate)
 #define CALL(S_, D_, V_)                                                                                             \
   do {                                                                                                               \
-    if (mb == 2)                                                                                                     \
-      hipLaunchKernelGGL((k_bwd_gather<S_, D_, 2, V_>), dim3(blocks + (fuse_reduce ? slabs : 0)),                    \
-                         dim3((D_ == 128 && CBW128 == 2) ? 256 : 512), 0, st, n, rowptr_t, col_t, val_t, dUs,       \
-                         W, dXn, gate, dX, ks, th, rng_state, in_stream_id, blocks, P, part, dW, db, dwg, dcg, accumulate); \
-    else                                                                                                             \
-      hipLaunchKernelGGL((k_bwd_gather<S_, D_, 1, V_>), dim3(blocks + (fuse_reduce ? slabs : 0)),                    \
-                         dim3((D_ == 128 && CBW128 == 2) ? 256 : 512), 0, st, n, rowptr_t, col_t, val_t, dUs,       \
-                         W, dXn, gate, dX, ks, th, rng_state, in_stream_id, blocks, P, part, dW, db, dwg, dcg, accumulate); \
+    if (deep) { if (mb == 2) BG(S_, D_, 2, V_, true); else BG(S_, D_, 1, V_, true); }                                \
+    else { if (mb == 2) BG(S_, D_, 2, V_, false); else BG(S_, D_, 1, V_, false); }                                   \
   } while (0)
   DISPATCH_SDV(S, d, val_t != nullptr, CALL);
 #undef CALL
+#undef BG
   if ((rc = launch_status())) return rc;
   if (rs_stream != st && hipStreamWaitEvent(st, ev_join, 0) != hipSuccess) return CGCN_ERR_LAUNCH;  // join
   return CGCN_OK;

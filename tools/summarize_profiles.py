@@ -54,7 +54,7 @@ def main():
                 v = vals[k][cname]
                 o.write("%s,%s,%d,%.1f\n" % (k, cname, len(v), sum(v) / len(v)))
                 per.setdefault(k, {})[cname] = sum(v) / len(v)
-    key = [k for k in per if k.startswith("void k_layer_fwd<2; 128; 1; false; false>")]
+    key = [k for k in per if k.startswith("void k_layer_fwd<2; 128; 1; false; false")]
     if key and "FETCH_SIZE" in per[key[0]] and "WRITE_SIZE" in per[key[0]]:
         fs, ws = per[key[0]]["FETCH_SIZE"], per[key[0]]["WRITE_SIZE"]
         traffic = {"chr21_d128": (2 * fs + ws) * 1024,
