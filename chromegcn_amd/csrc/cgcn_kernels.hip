@@ -42,6 +42,7 @@ struct Geo {
 // 722 tiles run as ONE round):  S*D = 256 floats: GU 1 / 2 / 3 / 8 = .249 / .225 / .229 / .236;  S*D = 512
 // (d = 256, L = 4): GU 1 / 2 / 3 / 8 = .887 / 1.04 / 1.08 / 1.13.  When the feature table is much larger than the
 // L2s (chr1-like, 30 MB) the longer miss latency wants one more load in flight: GU 2 / 3 / 8 = .670 / .647 / .668.
+// S*D = 128 (one strand, two neighbours per wave-load): layer forward 26.5 / 25.4 / 27.1 us at GU 3 / 4 / 6.
 #ifndef GU_OVERRIDE
 #define GU_OVERRIDE 0  // tuning: force one depth everywhere
 #endif
@@ -67,7 +68,7 @@ template <int S, int D, bool HAS_VAL, bool DEEP>
 struct Gather {
   using G = Geo<S, D>;
   static constexpr int NV = G::NV;
-  static constexpr int GU = GU_OVERRIDE ? GU_OVERRIDE : (NV == 2 ? 1 : (DEEP ? 3 : 2));
+  static constexpr int GU = GU_OVERRIDE ? GU_OVERRIDE : (G::HALF ? 4 : (NV == 2 ? 1 : (DEEP ? 3 : 2)));
   static constexpr int NPL = G::HALF ? 2 : 1;   // neighbours per wave-load
   static constexpr unsigned ROWB = D * 4;       // bytes per (strand,node) row
 
