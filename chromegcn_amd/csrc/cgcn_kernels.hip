@@ -1058,7 +1058,7 @@ int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d, const 
   if (misaligned16(X) || misaligned16(Y)) return CGCN_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int blocks = (n_rows + 3) / 4 < 4096 ? (n_rows + 3) / 4 : 4096;
-  const bool deep = pick_deep(n_cols, S, d);
+  const bool deep = false;  // measured: the bare SpMM never gains from the deeper batches (chr10-like 48.7 vs 55.8 us)
 #define CALL(S_, D_, V_)                                                                                                  \
   do {                                                                                                                    \
     if (deep) hipLaunchKernelGGL((k_spmm<S_, D_, V_, true>), dim3(blocks), dim3(256), 0, st, n_rows, n_cols, rowptr, col, val, row_scale, X, Y); \
