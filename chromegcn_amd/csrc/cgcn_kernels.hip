@@ -378,8 +378,10 @@ __device__ __forceinline__ void tile_mfma(const float* __restrict__ T, const flo
 //   phase 2  U = H W on the matrix cores; the residual rows of X are prefetched meanwhile
 //   phase 3  Z = tanh(U + b) -> LDS -> row-wise gate (wave reduction), mix, optional dropout, stores
 // ------------------------------------------------------------------------------------------
+// 8 waves per SIMD (<= 64 VGPRs; the 16-row variants need 62-66 as it is): four workgroups per CU resident.
+// Measured with it: chr10-like layer forward 73.4 -> 68.9 us, chr1-like 92.5 -> 87.3 us, chr21-like unchanged.
 #ifndef FWD_OCC
-#define FWD_OCC
+#define FWD_OCC __attribute__((amdgpu_waves_per_eu(8, 8)))
 #endif
 #ifdef KT_TIMING  // tuning build only (tools/khead.py --stamps-rowlocal): phase timestamps of a few workgroups
 __device__ unsigned long long kt_stamps[8 * 16];
@@ -999,15 +1001,11 @@ static int check_shape(int n, int S, int d) {
 #endif
 static inline bool pick_deep(int n, int S, int d) { return (double)n * S * d * 4.0 > (double)DEEP_TABLE_BYTES; }
 
-// Tile height of the gather kernels: 32 MFMA rows (MB = 2) when that still gives >= 4 workgroups per CU,
-// otherwise 16 rows (MB = 1) so small chromosomes fill the 256 CUs.
-static inline int pick_mb(int n, int S) {
-  const int tn2 = 32 / S;
-#ifndef MB2_MIN_TILES
-#define MB2_MIN_TILES 1024
-#endif
-  return ((n + tn2 - 1) / tn2 >= MB2_MIN_TILES) ? 2 : 1;
-}
+// Tile height of the gather kernels: 16 MFMA rows (MB = 1: 8 nodes x 2 strands, or 16 nodes of one strand) at every
+// size.  A 32-row variant (the MB template parameter) existed for large chromosomes; with the shallow gather batches
+// it is slower even at 30 k nodes (layer forward 102.7 vs 92.5 us: more, smaller workgroups pack the CUs better),
+// so it is no longer instantiated.
+static inline int pick_mb(int, int) { return 1; }
 
 // Events for fork/join edges between the main and the auxiliary stream.  A small pool reused round-robin;
 // never destroyed (an event may still be referenced by a captured graph).  This is the only state the
@@ -1101,13 +1099,9 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
 #define CALL(S_, D_, V_)                                                                                              \
   do {                                                                                                                \
     const dim3 blk((D_ == 128 && CBW128 == 2) ? 256 : 512);                                                           \
-    if (H_in) { /* no gather: depth irrelevant */                                                                     \
-      if (mb == 2) FWD(S_, D_, 2, V_, true, false); else FWD(S_, D_, 1, V_, true, false);                             \
-    } else if (deep) {                                                                                                \
-      if (mb == 2) FWD(S_, D_, 2, V_, false, true); else FWD(S_, D_, 1, V_, false, true);                             \
-    } else {                                                                                                          \
-      if (mb == 2) FWD(S_, D_, 2, V_, false, false); else FWD(S_, D_, 1, V_, false, false);                           \
-    }                                                                                                                 \
+    if (H_in) FWD(S_, D_, 1, V_, true, false); /* no gather: depth irrelevant */                                      \
+    else if (deep) FWD(S_, D_, 1, V_, false, true);                                                                   \
+    else FWD(S_, D_, 1, V_, false, false);                                                                            \
   } while (0)
   DISPATCH_SDV(S, d, val != nullptr, CALL);
 #undef CALL
@@ -1232,8 +1226,8 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
                      gate, dX, ks, th, rng_state, in_stream_id, blocks, P, part, dW, db, dwg, dcg, accumulate)
 #define CALL(S_, D_, V_)                                                                                             \
   do {                                                                                                               \
-    if (deep) { if (mb == 2) BG(S_, D_, 2, V_, true); else BG(S_, D_, 1, V_, true); }                                \
-    else { if (mb == 2) BG(S_, D_, 2, V_, false); else BG(S_, D_, 1, V_, false); }                                   \
+    if (deep) BG(S_, D_, 1, V_, true);                                                                               \
+    else BG(S_, D_, 1, V_, false);                                                                                   \
   } while (0)
   DISPATCH_SDV(S, d, val_t != nullptr, CALL);
 #undef CALL
