@@ -378,10 +378,14 @@ __device__ __forceinline__ void tile_mfma(const float* __restrict__ T, const flo
 //   phase 2  U = H W on the matrix cores; the residual rows of X are prefetched meanwhile
 //   phase 3  Z = tanh(U + b) -> LDS -> row-wise gate (wave reduction), mix, optional dropout, stores
 // ------------------------------------------------------------------------------------------
-// 8 waves per SIMD (<= 64 VGPRs; the 16-row variants need 62-66 as it is): four workgroups per CU resident.
-// Measured with it: chr10-like layer forward 73.4 -> 68.9 us, chr1-like 92.5 -> 87.3 us, chr21-like unchanged.
+// 8 waves per SIMD (<= 64 VGPRs; the two-strand 16-row variants need 62-66 as it is): four workgroups per CU
+// resident.  Measured with it: chr10-like layer forward 73.4 -> 68.9 us, chr1-like 92.5 -> 87.3 us, chr21-like
+// unchanged.  Not for the single-strand geometry (deeper batches, more registers: 25.4 us free vs 29.2 us forced).
+#ifndef FWD_WAVES_PER_SIMD
+#define FWD_WAVES_PER_SIMD(S_, D_) (((S_) * (D_) == 128) ? 1 : 8)
+#endif
 #ifndef FWD_OCC
-#define FWD_OCC __attribute__((amdgpu_waves_per_eu(8, 8)))
+#define FWD_OCC
 #endif
 #ifdef KT_TIMING  // tuning build only (tools/khead.py --stamps-rowlocal): phase timestamps of a few workgroups
 __device__ unsigned long long kt_stamps[8 * 16];
@@ -401,7 +405,7 @@ extern "C" int cgcn_debug_kt_stamps(unsigned long long* out) {
 #endif
 
 template <int S, int D, int MB, bool HAS_VAL, bool FROM_CACHE, bool DEEP>
-__global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) FWD_OCC void k_layer_fwd(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
+__global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512, FWD_WAVES_PER_SIMD(S, D)) FWD_OCC void k_layer_fwd(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
                                                      const float* __restrict__ val, const float* __restrict__ rs,
                                                      const float* __restrict__ X, const float* __restrict__ W,
                                                      const float* __restrict__ bias, const float* __restrict__ wg,
