@@ -6,6 +6,7 @@
 #include "chromegcn.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define WAVE 64
 #define TILE_NODES 16   // nodes per workgroup tile in the gather kernels
@@ -164,6 +165,31 @@ __device__ __forceinline__ void head_finalize_slab(int slab, int P, int n, int S
       }
     }
   }
+}
+
+// Row accesses of EPL = D/64 consecutive floats per lane.  Through a plain float* the compiler may only assume 4-byte
+// alignment and emits one global_load_dword per element (256 B per wave-instruction); every such pointer in this
+// library is 16-byte aligned at a multiple of EPL floats, so say so: one 8- or 16-byte access per lane.
+template <int N> struct RowVec;
+template <> struct RowVec<2> { typedef f32x2 T; };
+template <> struct RowVec<4> { typedef f32x4 T; };
+template <int N>
+__device__ __forceinline__ void ld_row(float (&dst)[N], const float* __restrict__ p) {
+  const typename RowVec<N>::T v = *(const typename RowVec<N>::T*)p;
+#pragma unroll
+  for (int e = 0; e < N; ++e) dst[e] = v[e];
+}
+template <int N>
+__device__ __forceinline__ void st_row(float* __restrict__ p, const float (&src)[N]) {
+  typename RowVec<N>::T v;
+#pragma unroll
+  for (int e = 0; e < N; ++e) v[e] = src[e];
+  *(typename RowVec<N>::T*)p = v;
+}
+template <int N>
+__device__ __forceinline__ void zero_row(float (&dst)[N]) {
+#pragma unroll
+  for (int e = 0; e < N; ++e) dst[e] = 0.f;
 }
 
 static inline bool misaligned16(const void* p) { return ((uintptr_t)p & 15u) != 0; }

@@ -263,10 +263,10 @@ __global__ __launch_bounds__(512) void k_head_fwd(int n, int S, int C, const flo
   for (int t = 0; t < RPW; ++t) {
     const int i = node0 + wave + t * NW;
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int e = 0; e < EPL; ++e)
-        xv[t][s][e] = (i < n && s < S) ? X[((size_t)s * n + i) * D + lane * EPL + e] : 0.f;
+    for (int s = 0; s < 2; ++s) {
+      if (i < n && s < S) ld_row<EPL>(xv[t][s], &X[((size_t)s * n + i) * D + lane * EPL]);
+      else zero_row<EPL>(xv[t][s]);
+    }
   }
   float mu[2][EPL], is[2][EPL], gw[EPL], gb[EPL];
 #pragma unroll
@@ -469,10 +469,10 @@ __global__ __launch_bounds__(512) void k_head_bwd(int n, int S, int C, const flo
     for (int t = 0; t < RPW; ++t) {
       const int i = node0 + wave + t * NW;
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int e = 0; e < EPL; ++e)
-          xv[t][s][e] = (i < n && s < S) ? X[((size_t)s * n + i) * D + lane * EPL + e] : 0.f;
+      for (int s = 0; s < 2; ++s) {
+        if (i < n && s < S) ld_row<EPL>(xv[t][s], &X[((size_t)s * n + i) * D + lane * EPL]);
+        else zero_row<EPL>(xv[t][s]);
+      }
     }
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
@@ -577,11 +577,14 @@ __global__ __launch_bounds__(512) void k_head_bwd(int n, int S, int C, const flo
     for (int t = 0; t < RPW; ++t) {
       const int rr = wave + t * NW;
       const int i = node0 + rr;
+      float gv[EPL];
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) gv[e] = i < n ? Yt[rr * LDY + lane * EPL + e] : 0.f;
+      if (i < n) st_row<EPL>(&dym[(size_t)i * D + lane * EPL], gv);
 #pragma unroll
       for (int e = 0; e < EPL; ++e) {
         const int c = lane * EPL + e;
-        const float g = i < n ? Yt[rr * LDY + c] : 0.f;
-        if (i < n) dym[(size_t)i * D + c] = g;
+        const float g = gv[e];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           if (s < S) {
@@ -730,10 +733,10 @@ __global__ __launch_bounds__(512) void k_head_fused(int n, int S, int C, const f
     for (int t = 0; t < RPW; ++t) {
       const int i = node0 + wave + t * NW;
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int e = 0; e < EPL; ++e)
-          xv[t][s][e] = (i < n && s < S) ? X[((size_t)s * n + i) * D + lane * EPL + e] : 0.f;
+      for (int s = 0; s < 2; ++s) {
+        if (i < n && s < S) ld_row<EPL>(xv[t][s], &X[((size_t)s * n + i) * D + lane * EPL]);
+        else zero_row<EPL>(xv[t][s]);
+      }
     }
     float tgv[NCBW][2][4], bjv[NCBW];
 #pragma unroll
@@ -901,11 +904,14 @@ __global__ __launch_bounds__(512) void k_head_fused(int n, int S, int C, const f
     for (int t = 0; t < RPW; ++t) {
       const int rr = wave + t * NW;
       const int i = node0 + rr;
+      float gv[EPL];
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) gv[e] = i < n ? Yt[rr * LDY + lane * EPL + e] : 0.f;
+      if (i < n) st_row<EPL>(&dym[(size_t)i * D + lane * EPL], gv);
 #pragma unroll
       for (int e = 0; e < EPL; ++e) {
         const int c = lane * EPL + e;
-        const float g = i < n ? Yt[rr * LDY + c] : 0.f;
-        if (i < n) dym[(size_t)i * D + c] = g;
+        const float g = gv[e];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           if (s < S) {

@@ -466,9 +466,8 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512, FWD_WAVES_PE
   for (int t = 0; t < RPW; ++t) {
     const int m = wave + t * NW;
     const int i = node0 + (m % R);
-#pragma unroll
-    for (int e = 0; e < EPL; ++e)
-      xres[t][e] = (m < ROWS && i < n) ? X[((size_t)(m / R) * n + i) * D + lane * EPL + e] : 0.f;
+    if (m < ROWS && i < n) ld_row<EPL>(xres[t], &X[((size_t)(m / R) * n + i) * D + lane * EPL]);
+    else zero_row<EPL>(xres[t]);
   }
   __syncthreads();
 
@@ -517,14 +516,15 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512, FWD_WAVES_PE
     }
     dot = wave_sum(dot);
     const float g = sigmoidf_(dot + c0);
+    float xo[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
-      float xo = (1.f - g) * xres[t][e] + g * z[e];
-      if (thresh) xo = dropout_keep(key, (uint32_t)(g_off + e), thresh) ? xo * keep_scale : 0.f;
-      Xn[g_off + e] = xo;
-      if (Zout) NT_STORE1(&Zout[g_off + e], z[e]);
-      if (colstats) T[m * LD + lane * EPL + e] = fmaxf(xo, 0.f);  // own row, already consumed above
+      xo[e] = (1.f - g) * xres[t][e] + g * z[e];
+      if (thresh) xo[e] = dropout_keep(key, (uint32_t)(g_off + e), thresh) ? xo[e] * keep_scale : 0.f;
+      if (colstats) T[m * LD + lane * EPL + e] = fmaxf(xo[e], 0.f);  // own row, already consumed above
     }
+    st_row<EPL>(&Xn[g_off], xo);
+    if (Zout) st_row<EPL>(&Zout[g_off], z);
     if (lane == 0) gate[(size_t)s * n + i] = g;
   }
   // ---- optional: first stage of the classifier head's BatchNorm statistics (k_head_colstats' job) while the tile
@@ -618,13 +618,16 @@ __global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float*
       const int m = tile * TR + wave + t * NW;
       const bool ok = m < M;
       const size_t off = (size_t)m * D + lane * EPL;
-#pragma unroll
-      for (int e = 0; e < EPL; ++e) {
-        z[t][e] = ok ? Z[off + e] : 0.f;
-        x[t][e] = ok ? X[off + e] : 0.f;
-        h[t][e] = ok ? H[off + e] : 0.f;
-        if (hp.dym) gup[t][e] = ok ? hp.dym[(size_t)(m % n) * D + lane * EPL + e] : 0.f;
-        else gup[t][e] = ok ? dXn[off + e] : 0.f;
+      if (ok) {
+        ld_row<EPL>(z[t], &Z[off]);
+        ld_row<EPL>(x[t], &X[off]);
+        ld_row<EPL>(h[t], &H[off]);
+        ld_row<EPL>(gup[t], hp.dym ? &hp.dym[(size_t)(m % n) * D + lane * EPL] : &dXn[off]);
+      } else {
+        zero_row<EPL>(z[t]);
+        zero_row<EPL>(x[t]);
+        zero_row<EPL>(h[t]);
+        zero_row<EPL>(gup[t]);
       }
       gt[t] = ok ? gate[m] : 0.f;
       dgt[t] = (ok && dgate) ? dgate[m] : 0.f;
@@ -645,19 +648,23 @@ __global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float*
           // dL/dXn of the last layer from the head's backward state (see HeadApply)
           const int s = m / n;
           const float invS = 1.f / (float)hp.S;
+          float is[EPL], mu[EPL], bw_[EPL], c0[EPL], c1[EPL];
+          ld_row<EPL>(is, &hp.invstd[s * D + lane * EPL]);
+          ld_row<EPL>(mu, &hp.mean[s * D + lane * EPL]);
+          ld_row<EPL>(bw_, &hp.bn_w[lane * EPL]);
+          ld_row<EPL>(c0, &hp.bnc[(s * 2 + 0) * D + lane * EPL]);
+          ld_row<EPL>(c1, &hp.bnc[(s * 2 + 1) * D + lane * EPL]);
 #pragma unroll
           for (int e = 0; e < EPL; ++e) {
-            const int c = lane * EPL + e;
             const float xn = (1.f - g) * x[t][e] + g * z[t][e];
             float dy = gup[t][e] * invS * hgl;
             if (hp.thresh) dy = dropout_keep(hkey, (uint32_t)(off + e), hp.thresh) ? dy * hp.keep_scale : 0.f;
-            const float is = hp.invstd[s * D + c];
-            const float xh = (fmaxf(xn, 0.f) - hp.mean[s * D + c]) * is;
+            const float xh = (fmaxf(xn, 0.f) - mu[e]) * is[e];
             // bnc is for the same upstream d loss as dym (1 when both came from cgcn_head_train): scale alike
-            const float dr = hp.bn_w[c] * is * (dy - hgl * hp.bnc[(s * 2 + 0) * D + c] - xh * (hgl * hp.bnc[(s * 2 + 1) * D + c]));
+            const float dr = bw_[e] * is[e] * (dy - hgl * c0[e] - xh * (hgl * c1[e]));
             gup[t][e] = xn > 0.f ? dr : 0.f;
-            if (dxn_store) dxn_store[off + e] = gup[t][e];  // k_bwd_gather reads it back as dL/dXn for the (1-g) dXn term
           }
+          if (dxn_store) st_row<EPL>(&dxn_store[off], gup[t]);  // k_bwd_gather reads it back as dL/dXn for the (1-g) dXn term
         }
         float dg = 0.f;
 #pragma unroll
@@ -665,14 +672,16 @@ __global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float*
         dg = wave_sum(dg) + dgt[t];
         const float gamma = g * (1.f - g) * dg;
         const float sc = rs ? rs[m % n] : 1.f;
+        float dus[EPL];
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
           const float dz = g * gup[t][e] + gamma * wgl[e];
           du[e] = dz * (1.f - z[t][e] * z[t][e]);
           db_acc[e] += du[e];
           dwg_acc[e] += gamma * z[t][e];
-          dUs[off + e] = du[e] * sc;
+          dus[e] = du[e] * sc;
         }
+        st_row<EPL>(&dUs[off], dus);
         dcg_acc += gamma;
       } else {
 #pragma unroll
@@ -860,8 +869,10 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) void k_bwd_g
     const bool ok = m < ROWS && i < n;
     const size_t row = (size_t)(m / R) * n + i;
     const float og = ok ? 1.f - gate[row] : 0.f;
+    if (ok) ld_row<EPL>(res[t], &dXn[row * D + lane * EPL]);
+    else zero_row<EPL>(res[t]);
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) res[t][e] = ok ? og * dXn[row * D + lane * EPL + e] : 0.f;
+    for (int e = 0; e < EPL; ++e) res[t][e] *= og;
   }
   __syncthreads();
 
@@ -889,12 +900,13 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) void k_bwd_g
     const int i = node0 + rr;
     if (m >= ROWS || i >= n) continue;
     const size_t g_off = ((size_t)s * n + i) * D + lane * EPL;
+    float o[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
-      float o = res[t][e] + T[m * LD + lane * EPL + e];
-      if (thresh) o = dropout_keep(key, (uint32_t)(g_off + e), thresh) ? o * keep_scale : 0.f;
-      dX[g_off + e] = o;
+      o[e] = res[t][e] + T[m * LD + lane * EPL + e];
+      if (thresh) o[e] = dropout_keep(key, (uint32_t)(g_off + e), thresh) ? o[e] * keep_scale : 0.f;
     }
+    st_row<EPL>(&dX[g_off], o);
   }
 }
 
@@ -1158,6 +1170,7 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
     return CGCN_ERR_BAD_ARG;
   if ((dXn == nullptr) == (head == nullptr)) return CGCN_ERR_BAD_ARG;  // exactly one source of dL/dXn
   if ((dX && dX == dXn) || misaligned16(dUs) || (dX && misaligned16(dX)) || misaligned16(W)) return CGCN_ERR_BAD_ARG;
+  if (misaligned16(X) || misaligned16(Z) || misaligned16(H) || (dXn && misaligned16(dXn))) return CGCN_ERR_BAD_ARG;  // vector row accesses
   HeadApply hp = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1.f, 0u, S, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr, nullptr, nullptr};
   int head_slabs = 0;
   if (head) {
