@@ -1106,7 +1106,7 @@ int cgcn_head_fwd(cgcn_stream_t stream, int n, int S, int d, int C, const float*
   const bool drop = training && dropout_p > 0.f;
   if (drop && (!rng_state || dropout_p >= 1.f)) return CGCN_ERR_BAD_ARG;
   if (workspace_bytes < cgcn_head_workspace_bytes(n, S, d, C)) return CGCN_ERR_WORKSPACE;
-  if (misaligned16(Wout) || misaligned16(workspace)) return CGCN_ERR_BAD_ARG;
+  if (misaligned16(Wout) || misaligned16(workspace) || misaligned16(X)) return CGCN_ERR_BAD_ARG;  // vector row accesses
   hipStream_t st = (hipStream_t)stream;
   float* w_stats = (float*)workspace;
   float* w_loss = w_stats + align4(ws_stats(S, d));

@@ -22,6 +22,13 @@ def _require_cuda(t: torch.Tensor, name: str):
         raise RuntimeError("chromegcn_amd: %s must be float32, got %s" % (name, t.dtype))
 
 
+def _dense(t: torch.Tensor) -> torch.Tensor:
+    """contiguous and 16-byte aligned (the kernels use 8/16-byte row accesses): a view that starts in the middle of
+    another tensor's storage is copied once instead of being rejected by the C ABI"""
+    t = t.contiguous()
+    return t.clone() if t.data_ptr() % 16 else t
+
+
 def _check_feat(x: torch.Tensor, g: ChromGraph, name="x"):
     _require_cuda(x, name)
     if x.dim() != 3 or x.shape[0] not in (1, 2) or x.shape[2] not in SUPPORTED_D:
@@ -36,7 +43,7 @@ class SpmmFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, graph: ChromGraph):
         _check_feat(x, graph)
-        x = x.contiguous()
+        x = _dense(x)
         S, n, d = x.shape
         y = torch.empty_like(x)
         lib = _lib.load()
@@ -48,7 +55,7 @@ class SpmmFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         g = ctx.graph
-        dy = dy.contiguous()
+        dy = _dense(dy)
         S, n, d = dy.shape
         # A^T dY = Ahat^T (diag(row_scale) dY)
         if g.row_scale is not None:
@@ -68,7 +75,7 @@ def sddmm(a, b, graph: ChromGraph, transposed=False):
     """out[k] = sum_s <a[s,i,:], b[s,col[k],:]> on the graph's pattern (cgcn_sddmm).  No autograd."""
     _check_feat(a, graph, "a")
     _check_feat(b, graph, "b")
-    a, b = a.contiguous(), b.contiguous()
+    a, b = _dense(a), _dense(b)
     S, n, d = a.shape
     rowptr, col = (graph.rowptr_t, graph.col_t) if transposed else (graph.rowptr, graph.col)
     out = torch.empty(col.shape[0], device=a.device, dtype=torch.float32)
@@ -123,11 +130,11 @@ class GatedLayerFn(torch.autograd.Function):
         _check_feat(x, graph)
         for t, nm in ((weight, "weight"), (bias, "bias"), (gate_w, "gate weight"), (gate_b, "gate bias")):
             _require_cuda(t, nm)
-        x = x.contiguous()
+        x = _dense(x)
         S, n, d = x.shape
         if tuple(weight.shape) != (d, d):
             raise RuntimeError("chromegcn_amd: fused layer needs a square [d,d] weight, got %s" % (tuple(weight.shape),))
-        weight = weight.contiguous()
+        weight = _dense(weight)
         bias = bias.contiguous()
         wg = gate_w.contiguous().view(-1)
         cg = gate_b.contiguous().view(-1)
@@ -164,7 +171,7 @@ class GatedLayerFn(torch.autograd.Function):
         S, n, d = x.shape
         if dxn is None and dgate is None:
             return (None,) * 12
-        dxn = torch.zeros_like(x) if dxn is None else dxn.contiguous()
+        dxn = torch.zeros_like(x) if dxn is None else _dense(dxn)
         dgate = None if dgate is None else dgate.contiguous()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None  # None: skip the gather over Ahat^T
         dus = torch.empty_like(x)
@@ -212,13 +219,13 @@ class HeadLossFn(torch.autograd.Function):
             _require_cuda(t, nm)
         if momentum is None:
             raise RuntimeError("chromegcn_amd: BatchNorm momentum=None (cumulative average) is not supported by the fused head")
-        x = x.contiguous()
+        x = _dense(x)
         S, n, d = x.shape
         C = w_out.shape[0]
         target = target.contiguous()
         if tuple(target.shape) != (n, C):
             raise RuntimeError("chromegcn_amd: target must be [n, C] = [%d, %d], got %s" % (n, C, tuple(target.shape)))
-        bn_w, bn_b, w_out, b_out = bn_w.contiguous(), bn_b.contiguous(), w_out.contiguous(), b_out.contiguous()
+        bn_w, bn_b, w_out, b_out = _dense(bn_w), _dense(bn_b), _dense(w_out), b_out.contiguous()
         lib = _lib.load()
         ws_bytes = lib.cgcn_head_workspace_bytes(n, S, d, C)
         if ws_bytes == 0:
@@ -288,15 +295,15 @@ class LastLayerHeadLossFn(torch.autograd.Function):
             _require_cuda(t, nm)
         if momentum is None:
             raise RuntimeError("chromegcn_amd: BatchNorm momentum=None (cumulative average) is not supported by the fused head")
-        x = x.contiguous()
+        x = _dense(x)
         S, n, d = x.shape
         C = w_out.shape[0]
         target = target.contiguous()
         if tuple(weight.shape) != (d, d) or tuple(target.shape) != (n, C):
             raise RuntimeError("chromegcn_amd: bad shapes for the fused last layer + head")
-        weight, bias = weight.contiguous(), bias.contiguous()
+        weight, bias = _dense(weight), bias.contiguous()
         wg, cg = gate_w.contiguous().view(-1), gate_b.contiguous().view(-1)
-        bn_w, bn_b, w_out, b_out = bn_w.contiguous(), bn_b.contiguous(), w_out.contiguous(), b_out.contiguous()
+        bn_w, bn_b, w_out, b_out = _dense(bn_w), _dense(bn_b), _dense(w_out), b_out.contiguous()
         need_bwd = training and any(ctx.needs_input_grad[:9])
         lib = _lib.load()
         xn = torch.empty_like(x)

@@ -267,3 +267,20 @@ def test_bad_shapes_are_rejected():
         ops.spmm(torch.randn(1, 8, 100, device=DEV), g)
     with pytest.raises(RuntimeError):
         ops.spmm(torch.randn(1, 9, 128, device=DEV), g)
+
+
+def test_views_at_odd_storage_offsets_are_accepted():
+    """A contiguous view that starts 4 bytes into another tensor's storage is not 16-byte aligned; the kernels'
+    vector row accesses need that alignment, so the Python layer copies such inputs once (the raw C ABI rejects them)."""
+    n, d = 97, 128
+    g = G.upload(G.normalize_graph("hic", O.random_symmetric_graph(n, 300, 2), n), DEV)
+    base = torch.randn(n * d + 1, device=DEV)
+    x_off = base[1:].view(1, n, d)
+    assert x_off.data_ptr() % 16 != 0 and x_off.is_contiguous()
+    x_ok = x_off.clone()
+    torch.testing.assert_close(ops.spmm(x_off, g), ops.spmm(x_ok, g), rtol=0, atol=0)
+    w = torch.randn(d, d, device=DEV) / d ** 0.5
+    b, wg, cg = torch.zeros(d, device=DEV), torch.randn(1, d, device=DEV) / d ** 0.5, torch.zeros(1, device=DEV)
+    y1, _ = ops.gated_layer(x_off, w, b, wg, cg, g)
+    y2, _ = ops.gated_layer(x_ok, w, b, wg, cg, g)
+    torch.testing.assert_close(y1, y2, rtol=0, atol=0)
