@@ -1047,16 +1047,13 @@ static inline int head_stat_blocks(int n, int* rows_per_blk) {
   int nb = (n + rpb - 1) / rpb;
   return nb < 1 ? 1 : nb;
 }
-// Workgroups (= partials) of k_head_fused / k_head_bwd: one 32-node tile each up to HEAD_MAX_PARTIALS (one per CU).
-// Larger chromosomes take twice as many, two resident per CU (108 VGPRs, 37 KB LDS), so that one workgroup's loads
-// overlap the other's MFMA phases instead of a longer serial walk over tiles.
-#ifndef HEAD_LARGE_PARTIALS
-#define HEAD_LARGE_PARTIALS 512
-#endif
+// Workgroups (= partials) of k_head_fused / k_head_bwd: one 32-node tile each up to HEAD_MAX_PARTIALS (one per CU),
+// persistent beyond.  Measured alternatives: twice as many workgroups for large chromosomes (the kernel needs 206
+// VGPRs, so they do not co-reside: 81 vs 75 us at chr1 size); 16-node tiles for small ones (more, shorter chains but
+// twice the partials: chr21 step 0.234 vs 0.221 ms).
 static inline int head_bwd_partials(int n) {
   int t = (n + HEADB_TILE - 1) / HEADB_TILE;
-  const int cap = t > 2 * HEAD_MAX_PARTIALS ? HEAD_LARGE_PARTIALS : HEAD_MAX_PARTIALS;
-  if (t > cap) t = cap;
+  if (t > HEAD_MAX_PARTIALS) t = HEAD_MAX_PARTIALS;
   return t < 1 ? 1 : t;
 }
 // workspace regions (floats), in this order
