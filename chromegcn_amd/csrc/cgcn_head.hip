@@ -725,31 +725,58 @@ __global__ __launch_bounds__(512) void k_head_fused(int n, int S, int C, const f
   }
 
   const int ntiles = (n + TR - 1) / TR;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // All global loads of a tile -- this wave's X rows, the targets / bias of this lane's logits -- are issued together.
+  // Workgroups that walk several tiles (large chromosomes) issue the NEXT tile's loads right after the current tile's
+  // operands are in LDS, so they are in flight during the three MFMA phases; the current tile keeps its copy.
+  constexpr bool PF = (CBMAX == 8);  // the 256-label variant has no registers to spare for a second tile
+  float xv[RPW][2][EPL], xv_n[PF ? RPW : 1][2][EPL];
+  float tgv[NCBW][2][4], tgv_n[PF ? NCBW : 1][2][4], bjv[NCBW];
+#pragma unroll
+  for (int cbi = 0; cbi < NCBW; ++cbi) {
+    const int j = (wave + NW * cbi) * 16 + r;
+    bjv[cbi] = j < C ? bout[j] : 0.f;
+  }
+  auto load_tile = [&](int tile, auto& xd, auto& td) {
     const int node0 = tile * TR;
-    // ---- all global loads of the tile first: this wave's X rows, the targets / bias of this lane's logits
-    float xv[RPW][2][EPL];
 #pragma unroll
     for (int t = 0; t < RPW; ++t) {
       const int i = node0 + wave + t * NW;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        if (i < n && s < S) ld_row<EPL>(xv[t][s], &X[((size_t)s * n + i) * D + lane * EPL]);
-        else zero_row<EPL>(xv[t][s]);
+        if (i < n && s < S) ld_row<EPL>(xd[t][s], &X[((size_t)s * n + i) * D + lane * EPL]);
+        else zero_row<EPL>(xd[t][s]);
       }
     }
-    float tgv[NCBW][2][4], bjv[NCBW];
 #pragma unroll
     for (int cbi = 0; cbi < NCBW; ++cbi) {
       const int j = (wave + NW * cbi) * 16 + r;
-      bjv[cbi] = j < C ? bout[j] : 0.f;
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int i = node0 + mb * 16 + q * 4 + e;
-          tgv[cbi][mb][e] = (i < n && j < C) ? target[(size_t)i * C + j] : 0.f;
+          td[cbi][mb][e] = (i < n && j < C) ? target[(size_t)i * C + j] : 0.f;
         }
+    }
+  };
+  if (PF && (int)blockIdx.x < ntiles) load_tile(blockIdx.x, xv_n, tgv_n);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int node0 = tile * TR;
+    if (PF) {
+#pragma unroll
+      for (int t = 0; t < RPW; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) xv[t][s][e] = xv_n[PF ? t : 0][s][e];
+#pragma unroll
+      for (int cbi = 0; cbi < NCBW; ++cbi)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) tgv[cbi][mb][e] = tgv_n[PF ? cbi : 0][mb][e];
+    } else {
+      load_tile(tile, xv, tgv);
     }
     HF_STAMP(3);
     // ---- ym rows -> Yt
@@ -773,6 +800,7 @@ __global__ __launch_bounds__(512) void k_head_fused(int n, int S, int C, const f
         Yt[rr * LDY + lane * EPL + e] = ym * invS;
       }
     }
+    if (PF && tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x, xv_n, tgv_n);  // prefetch (see above)
     __syncthreads();
     HF_STAMP(4);
     // ---- pred = ym W_out^T  (M = 32 rows, K = D permuted, N = this wave's label block(s))
