@@ -432,8 +432,7 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512, FWD_WAVES_PE
   const int node0 = xcd_contiguous(blockIdx.x, gridDim.x) * R;
 
   KT_STAMP(8);
-  float bw[CBW][D / 4];
-  if (PRE) load_wfrag<D, CBW, false>(W, wave, lane, bw);
+  float bw[CBW][D / 4];  // W fragments: loaded after the gather (below)
 
   unsigned lane_off[G::NV];
 #pragma unroll
@@ -459,6 +458,10 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512, FWD_WAVES_PE
   } else {
     gather_tile<S, D, HAS_VAL, DEEP, R, NW, LD>(n, node0, rowptr, col, val, rs, (const char*)X, lane_off, T, Hout, LR, wave, lane);
   }
+  // W fragments -> registers once the gather's loads are issued: in front of it they delay the first neighbour rows
+  // (vector loads return in order) and hold 32 registers through the gather loop; here they land during the barrier
+  // and the residual prefetch (measured: -0.3 ... -1.5 % per step, every workload)
+  if (PRE) load_wfrag<D, CBW, false>(W, wave, lane, bw);
   KT_STAMP(10);
   // prefetch the residual rows this wave will mix in phase 3 (latency hides behind the MFMA phase)
   float xres[RPW][EPL];
@@ -853,7 +856,7 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) void k_bwd_g
   const int node0 = xcd_contiguous(blockIdx.x, gather_blocks) * R;
 
   float bw[CBW][D / 4];
-  if (PRE) load_wfrag<D, CBW, true>(W, wave, lane, bw);
+  if (PRE) load_wfrag<D, CBW, true>(W, wave, lane, bw);  // 8 16-byte loads: in front of the gather (behind it: no gain)
 
   unsigned lane_off[G::NV];
 #pragma unroll
