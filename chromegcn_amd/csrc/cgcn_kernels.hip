@@ -472,6 +472,14 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512, FWD_WAVES_PE
     if (m < ROWS && i < n) ld_row<EPL>(xres[t], &X[((size_t)(m / R) * n + i) * D + lane * EPL]);
     else zero_row<EPL>(xres[t]);
   }
+  // the epilogue's small operands too (bias of this lane's columns, gate weights): their latency would otherwise sit
+  // between the MFMA phase and the tanh
+  float bjv[CBW], wgl[EPL];
+#pragma unroll
+  for (int cb = 0; cb < CBW; ++cb) bjv[cb] = bias[wave * (16 * CBW) + cb * 16 + (lane & 15)];
+  ld_row<EPL>(wgl, &wg[lane * EPL]);
+  const float c0 = cg[0];
+  const uint32_t key = thresh ? dropout_key(rng_state, stream_id) : 0u;
   __syncthreads();
 
   KT_STAMP(11);
@@ -487,18 +495,13 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512, FWD_WAVES_PE
 #pragma unroll
     for (int cb = 0; cb < CBW; ++cb) {
       const int j = wave * (16 * CBW) + cb * 16 + r;
-      const float bj = bias[j];
+      const float bj = bjv[cb];
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int e = 0; e < 4; ++e) T[(mb * 16 + q * 4 + e) * LD + j] = tanhf(acc[mb][cb][e] + bj);
     }
   }
-  float wgl[EPL];
-#pragma unroll
-  for (int e = 0; e < EPL; ++e) wgl[e] = wg[lane * EPL + e];
-  const float c0 = cg[0];
-  const uint32_t key = thresh ? dropout_key(rng_state, stream_id) : 0u;
   __syncthreads();
 
   KT_STAMP(13);
