@@ -1,3 +1,6 @@
+#!/bin/bash
+# A/B of library variants on one GPU box (tuning tool): AB_VARIANTS="name ..." bash tools/ab.sh compares the in-tree
+# build (base) with variants/libcgcn_<name>.so on five workloads (chr21, config1, hic-like, chr1, d=256 L=4), twice.
 run() { python bench.py "$@" --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.4f' % d['ms_per_step'], end=' ')"; }
 for rep in 1 2; do
 for v in base ${AB_VARIANTS}; do
