@@ -1,16 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py -- GCN windows/sec of the 2-layer gated GCN train step (BASELINE.json metric).
+"""bench.py -- GCN windows/sec of the 2-layer gated GCN over the whole GM12878-shaped Hi-C genome
+(BASELINE.json metric), in the REFERENCE's semantics.
 
-One "step" = the reference's per-chromosome train step (finetune.py:38-49): both strands forward,
-BCE-with-logits, backward (incl. d/d features, finetune.py:33-34), SGD(momentum .9, wd 1e-6) step,
-dropout 0.2 -- on one synthetic chromosome per rank, inputs already resident in HBM.
-N = 1: BASELINE.json configs[1] stand-in, "chr21-like" (n = 5776 windows, 250k contact pairs, d = 128,
-L = 2, C = 103).  N > 1 (weak scaling): every rank owns its own chr21-like
-chromosome, and each step ends with one all-reduce of the flat gradient buffer (RCCL).
+One "step" = one training epoch of the GCN stage (finetune.py:29-53 over every chromosome of the train split,
+data/create_data.py:40-45): for each of the 16 train chromosomes, in dict order, both strands forward,
+BCE-with-logits, backward INCLUDING d loss / d features (finetune.py:33-34), one SGD(momentum .9, wd 1e-6) step,
+dropout 0.2 -- every one of the four sparse aggregations redone every step (nothing cached across steps except the
+normalised CSR and the device-resident inputs).  The epoch returns what finetune.py:67 returns (all predictions in
+chromosome order, targets, summed loss) -- predictions stay in HBM; one host sync per epoch (the loss).
+`value` = (sum of train windows) x steps / wall time.  Graphs: SURVEY.md 8(d) config 3 (22 synthetic chromosomes,
+N_c = round(0.12 hg19_len_c / 1 kb), 250 000 contact pairs each, seed = chromosome number; uniform generator).
 
-    python bench.py --gpus 1 --steps 50 --warmup 10
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+N = 1: all 16 train chromosomes on one GPU (they fit: < 3 GB resident).
+N > 1: STRONG scaling of the same epoch: chromosomes sharded across ranks by GCNStage.run_split / dist.plan_shards
+(LPT), one step group = one chromosome per rank + ONE all-reduce of the flat gradient buffer (RCCL) + the same
+optimizer step everywhere; predictions gathered once at the end of the epoch.  (k ranks => 16/k optimizer steps
+per epoch instead of 16: the documented semantics change of data-parallel chromosomes)
+
+    python bench.py                                   # N = 1, genome, 30 epochs
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+    python bench.py --workload chr21|chr1|config1     # one chromosome per rank (weak scaling), secondary lines
+    python bench.py --workload e2e                    # config 5: Expecto-shaped encoder -> hand-off -> GCN stage
 """
 import argparse
 import json
@@ -24,6 +35,7 @@ sys.path.insert(0, ROOT)
 # multi-process GPU work on this pool needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle otherwise); harmless at N=1
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -33,23 +45,33 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="chr21", choices=["chr21", "config1", "chr1"])
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 30 epochs / 50 single-chromosome steps)")
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="genome", choices=["genome", "chr21", "config1", "chr1", "e2e"])
     ap.add_argument("--hic-like", action="store_true", help="distance-decay contact generator instead of uniform")
     ap.add_argument("--d", type=int, default=128)
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--dropout", type=float, default=0.2)
     ap.add_argument("--no-hip-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=8)
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (profiling runs)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the host baseline sample")
     ap.add_argument("--backend", default=os.environ.get("CGCN_DIST_BACKEND", "nccl"),
                     help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU functional tests)")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses cuda:0")
+    ap.add_argument("--e2e-windows", type=int, default=4096, help="e2e: windows per chromosome pushed through the encoder")
     return ap.parse_args()
 
 
-def workload_shape(name):
+# ------------------------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------------------------
+def genome_train_names():
+    from chromegcn_amd import synth
+    return [c for c in synth.HG19_LEN if synth.split_of(c) == "train"]
+
+
+def single_shape(name):
     from chromegcn_amd import synth
     if name == "chr21":
         return "chr21", synth.chrom_nodes("chr21"), synth.PAIRS_PER_CHROM
@@ -58,18 +80,18 @@ def workload_shape(name):
     return "cfg1", 5000, 125000
 
 
-def layer_fwd_bytes(n, nnz, S, d, training=True):
-    """Algorithmic HBM bytes of ONE fused-layer forward launch ('k_layer_fwd'):
-    CSR (rowptr + col) + 1/deg + X read + params + Xn write + gate write (+ Z, H saved when training)."""
-    b = 4 * (n + 1) + 4 * nnz + 4 * n + S * 4 * n * d + (4 * d * d + 8 * d + 4) + S * 4 * n * d + S * 4 * n
-    if training:
-        b += 2 * S * 4 * n * d
-    return b
+def layer_fwd_bytes(n, nnz, S, d):
+    """Algorithmic HBM bytes of ONE fused-layer forward launch in training, SURVEY.md 8(d): CSR (rowptr + col) +
+    1/deg + X read + parameters + X' write + gate write + the saved Z.  (The kernel also writes H = A X for the
+    weight gradient -- a by-product of the (A X) W re-association that 8(d) does not list, so it is NOT counted.)"""
+    return 4 * (n + 1) + 4 * nnz + 4 * n + S * 4 * n * d + (4 * d * d + 8 * d + 4) + S * 4 * n * d + S * 4 * n + S * 4 * n * d
 
 
-def time_dominant_kernel(stage, name, reps):
-    """Average duration of the dominant kernel (k_layer_fwd, training variant, both strands) measured
-    with HIP events on the stream it is launched on (torch's current stream)."""
+def time_layer_fwd(stage, name, reps, dropout_p):
+    """Average duration of k_layer_fwd (training variant, both strands) on one chromosome, measured with HIP events
+    on the stream the library launches on (torch's current stream), in the two forms a train step uses: layer 1
+    (inter-layer dropout with the run's p and RNG state) and layer 2 (BatchNorm column statistics for the head)."""
+    import ctypes
     from chromegcn_amd import _lib
     c = stage.chroms[name]
     m = stage.model
@@ -78,65 +100,49 @@ def time_dominant_kernel(stage, name, reps):
     xn, z, h = torch.empty_like(c.x), torch.empty_like(c.x), torch.empty_like(c.x)
     gate = torch.empty(S, n, device=c.x.device)
     lib = _lib.load()
-    w, b = m.GC1.weight.detach(), m.GC1.bias.detach()
-    wg, cg = m.W1.weight.detach().view(-1), m.W1.bias.detach()
+    rng = m._rng_state
+    rows = ctypes.c_int(0)
+    tiles = lib.cgcn_layer_fwd_colstats_tiles(n, S, d, ctypes.byref(rows))
+    colstats = torch.empty((tiles, S, d, 2), device=c.x.device)
 
-    def launch():
+    def launch(layer):
+        gc, wk = getattr(m, "GC%d" % layer), getattr(m, "W%d" % layer)
+        last = layer == m.n_layers
         _lib.check(lib.cgcn_layer_fwd(_lib.stream_ptr(), n, S, d, _lib.ptr(g.rowptr), _lib.ptr(g.col), _lib.ptr(g.val),
-                                      _lib.ptr(g.row_scale), c.x.data_ptr(), w.data_ptr(), b.data_ptr(), wg.data_ptr(),
-                                      cg.data_ptr(), xn.data_ptr(), z.data_ptr(), h.data_ptr(), gate.data_ptr(), 0.0, None, 0, None, None), "fwd")
-    for _ in range(5):
-        launch()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        launch()
-    e1.record()
-    e1.synchronize()
-    return e0.elapsed_time(e1) / reps * 1e-3  # seconds
+                                      _lib.ptr(g.row_scale), c.x.data_ptr(), gc.weight.data_ptr(), gc.bias.data_ptr(),
+                                      wk.weight.data_ptr(), wk.bias.data_ptr(), xn.data_ptr(), z.data_ptr(),
+                                      h.data_ptr(), gate.data_ptr(), 0.0 if last else float(dropout_p),
+                                      None if (last or dropout_p <= 0) else _lib.ptr(rng), layer, None,
+                                      colstats.data_ptr() if last else None), "fwd")
+    out = []
+    for layer in (1, m.n_layers):
+        for _ in range(3):
+            launch(layer)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            launch(layer)
+        e1.record()
+        e1.synchronize()
+        out.append(e0.elapsed_time(e1) / reps * 1e-3)
+    return out  # seconds: [layer 1 form, last-layer form]
 
 
-def cpu_baseline(args, n, pairs, seed, steps):
-    """The oracle (torch-CPU restatement of the reference ops) timed on this box's host cores on the
-    same workload: a bounded sample of `steps` train steps."""
-    from oracle import chromegcn_oracle as O  # cpu_baseline leg: the oracle is the thing timed here, nowhere else
-    from chromegcn_amd import synth
-    ncpu = os.cpu_count() or 1
-    feats = synth.chrom_features(n, args.d, synth.N_LABELS, 1000 + seed)
-    hic = synth.contact_graph(n, pairs, seed, args.hic_like)
-    torch.manual_seed(0)
-    model = O.GatedGCNOracle(args.d, synth.N_LABELS, args.dropout, args.layers)
-    opt = O.make_sgd(model, 0.25)
-    data = {"c": feats}
-    cache = {}
+def stored_traffic(key):
+    """HBM bytes per launch from the PMC passes of an earlier profiling run (profiles/traffic.json; FETCH_SIZE doubled
+    per MI355X_MICROARCH.md + WRITE_SIZE).  A stored, offline value: the bench line says so and names the tag."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        t = json.load(open(tpath))
+    except Exception:
+        return None, None
+    ent = t.get(key)
+    if isinstance(ent, dict):
+        return ent.get("bytes_per_launch"), ent.get("tag")
+    return ent, t.get("_tag")
 
-    def one(cached=True):
-        t0 = time.perf_counter()
-        O.finetune_epoch(model, data, {"c": hic}, opt, "train", "hic", adj_cache=cache if cached else None)
-        return time.perf_counter() - t0
 
-    # torch's CPU spmm does not scale to every core of a big host (256 threads measured 20x slower than
-    # 8-32): pick the thread count that is fastest on this box, so the baseline is the CPU's best case.
-    best = None
-    for th in sorted({t for t in (4, 8, 16, 32, 64, ncpu) if t <= ncpu}):
-        torch.set_num_threads(th)
-        one()  # warm-up at this thread count (the first call also builds the cached adjacency)
-        dt = min(one(), one())
-        if best is None or dt < best[1]:
-            best = (th, dt)
-        if dt > 4.0 * best[1] or dt > 8.0:
-            break
-    cores = best[0]
-    torch.set_num_threads(cores)
-    one()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        one()
-    t_cached = (time.perf_counter() - t0) / steps
-    t0 = time.perf_counter()
-    for _ in range(max(1, steps // 4)):
-        one(cached=False)  # reference behaviour: process_graph every chromosome every epoch (finetune.py:36)
-    t_full = (time.perf_counter() - t0) / max(1, steps // 4)
+def host_info():
     cpu_model = platform.processor() or ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -146,13 +152,58 @@ def cpu_baseline(args, n, pairs, seed, steps):
                     break
     except OSError:
         pass
-    return {"value": n / t_cached, "unit": "windows/s", "cores": cores, "kind": "port",
-            "sample": "%d train steps (f+r fwd, BCE, bwd, SGD) on the same %d-window chromosome, adjacency cached; "
-                      "oracle = torch-CPU restatement of the reference ops" % (steps, n),
-            "s_per_step": t_cached, "with_process_graph_windows_per_s": n / t_full, "host_cpus": ncpu,
-            "cpu_model": cpu_model, "torch": torch.__version__}
+    return cpu_model
 
 
+def cpu_baseline(args, chroms, budget_s):
+    """The oracle (torch-CPU restatement of the reference ops, finetune.py:29-53) timed on this box's host cores on a
+    BOUNDED sample of the same workload: train steps on the sample's chromosomes, adjacency cached (the reference
+    re-normalises it every chromosome every epoch, finetune.py:36 -- reported separately)."""
+    from oracle import chromegcn_oracle as O  # cpu_baseline leg: the oracle is the thing timed here, nowhere else
+    from chromegcn_amd import synth
+    ncpu = os.cpu_count() or 1
+    data, graphs = {}, {}
+    for nm, n, pairs, seed in chroms:
+        data[nm] = synth.chrom_features(n, args.d, synth.N_LABELS, 1000 + seed)
+        graphs[nm] = synth.contact_graph(n, pairs, seed, args.hic_like)
+    n_sample = sum(c[1] for c in chroms)
+    torch.manual_seed(0)
+    model = O.GatedGCNOracle(args.d, synth.N_LABELS, args.dropout, args.layers)
+    opt = O.make_sgd(model, 0.25)
+    cache = {}
+
+    def one(cached=True):
+        t0 = time.perf_counter()
+        O.finetune_epoch(model, data, graphs, opt, "train", "hic", adj_cache=cache if cached else None)
+        return time.perf_counter() - t0
+
+    # torch's CPU spmm does not scale to every core of a big host (256 threads measured 20x slower than 8-32): pick
+    # the thread count that is fastest on this box, so the baseline is the CPU's best case.
+    best = None
+    for th in sorted({t for t in (4, 8, 16, 32, 64, ncpu) if t <= ncpu}):
+        torch.set_num_threads(th)
+        one()  # warm-up at this thread count (the first call also builds the cached adjacency)
+        dt = one()
+        if best is None or dt < best[1]:
+            best = (th, dt)
+        if dt > 4.0 * best[1] or dt > budget_s / 3:
+            break
+    cores = best[0]
+    torch.set_num_threads(cores)
+    reps = max(2, min(20, int(budget_s / max(best[1], 1e-3))))
+    ts = [one() for _ in range(reps)]
+    t_cached = float(np.median(ts))
+    t_full = one(cached=False)  # reference behaviour: process_graph every chromosome every epoch (finetune.py:36)
+    return {"value": n_sample / t_cached, "unit": "windows/s", "cores": cores, "kind": "port",
+            "sample": "%d passes over %s (%d windows; f+r fwd, BCE, bwd incl. d/dx, SGD step per chromosome), "
+                      "adjacency cached; oracle = torch-CPU restatement of the reference ops; median" %
+                      (reps, "+".join(c[0] for c in chroms), n_sample),
+            "s_per_pass": t_cached, "p10_s": float(np.percentile(ts, 10)), "p90_s": float(np.percentile(ts, 90)),
+            "with_process_graph_windows_per_s": n_sample / t_full, "host_cpus": ncpu,
+            "cpu_model": host_info(), "torch": torch.__version__}
+
+
+# ------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -171,119 +222,188 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
     assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    if args.workload == "e2e":
+        from chromegcn_amd import e2e
+        out = e2e.bench(args, dev, world, rank)
+        if rank == 0:
+            print(json.dumps(out))
+            sys.stdout.flush()
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return out
 
     import chromegcn_amd as C
     from chromegcn_amd import synth
     from chromegcn_amd.finetune import GCNStage
 
-    cname, n, pairs = workload_shape(args.workload)
-    seed = synth.chrom_seed(cname) if cname.startswith("chr") else 0
-    seed += 100 * rank  # every rank owns a different chromosome of the same shape
-    feats = synth.chrom_features(n, args.d, synth.N_LABELS, 1000 + seed)
-    hic = synth.contact_graph(n, pairs, seed, args.hic_like)
+    genome = args.workload == "genome"
+    steps = args.steps if args.steps is not None else (30 if genome else 50)
+    warmup = args.warmup if args.warmup is not None else (5 if genome else 10)
 
     torch.manual_seed(0)  # identical initial parameters on every rank
     model = C.ChromeGCN(args.d, args.d, synth.N_LABELS, args.dropout, True, args.layers).to(dev)
     opt = torch.optim.SGD(model.parameters(), lr=0.25, momentum=0.9, weight_decay=1e-6)  # README.md:45 flags
-    # Headline configuration: EVERY step redoes all four sparse aggregations, like the reference.  (The engine's
-    # default additionally caches A X of the first layer, which is loop invariant because the node features are
-    # fixed -- measured separately below and reported as an extra field, never as `value`.)
+    # Reference semantics: EVERY step redoes all four sparse aggregations and produces d loss / d features, like the
+    # reference.  (The engine's defaults cache A X of the first layer -- loop invariant, the features are fixed -- and
+    # skip the unobservable input gradient; measured separately below, never as `value`.)
     stage = GCNStage(model, opt, "hic", dev, hip_graphs=not args.no_hip_graph, input_grad=True,
                      group=dist.group.WORLD if world > 1 else None, cache_input_aggregation=False)
-    name = "%s_r%d" % (cname, rank)
-    stage.add_chromosome(name, feats, hic)
-    nnz = stage.chroms[name].graph.nnz
 
-    def step():
-        if world > 1:
-            return stage.train_group(name, world)
-        return stage.train_step(name)
+    if genome:
+        names = genome_train_names()
+        shapes = []
+        for nm in names:  # every rank holds every chromosome's inputs (a few GB of 288): the shard plan picks who runs what
+            feats, hic = synth.synthetic_chromosome(nm, d=args.d, hic_like=args.hic_like)
+            stage.add_chromosome(nm, feats, hic)
+            shapes.append((nm, stage.chroms[nm].n, stage.chroms[nm].graph.nnz))
+        windows = sum(s[1] for s in shapes)
+
+        def step():
+            return stage.run_split("train", names, to_cpu=False)
+    else:
+        cname, n, pairs = single_shape(args.workload)
+        seed = (synth.chrom_seed(cname) if cname.startswith("chr") else 0) + 100 * rank  # a different chromosome per rank
+        feats = synth.chrom_features(n, args.d, synth.N_LABELS, 1000 + seed)
+        hic = synth.contact_graph(n, pairs, seed, args.hic_like)
+        name = "%s_r%d" % (cname, rank)
+        stage.add_chromosome(name, feats, hic)
+        names = [name]
+        shapes = [(name, n, stage.chroms[name].graph.nnz)]
+        windows = n * world
+
+        def step():
+            if world > 1:
+                return stage.train_group(name, world)
+            return stage.train_step(name)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 1)):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, _, _ = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    final_loss = float(loss.item())
+    def timed(fn, k):
+        """k steps bracketed by barrier + synchronize; also the per-step host times (genome: every epoch ends with
+        its own loss sync, so these are true per-epoch times)"""
+        fence()
+        per = []
+        t0 = time.perf_counter()
+        for _ in range(k):
+            s0 = time.perf_counter()
+            r = fn()
+            per.append(time.perf_counter() - s0)
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, per, r
 
-    # inference (eval-mode forward of both strands), reported alongside
-    for _ in range(3):
-        stage.eval_step(name)
-    fence()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        stage.eval_step(name)
-    fence()
-    eval_elapsed = time.perf_counter() - t1
+    for _ in range(max(warmup, 1)):
+        step()
+    elapsed, per, last = timed(step, steps)
+    final_loss = float(last[2]) if genome else float(last[0].item())
 
-    # extra: the engine's default configuration -- first-layer aggregation cached, and no gradient w.r.t. the input
-    # features (finetune.py:33-34 asks for it but nothing can observe it)
-    stage.cache_input_aggregation = True
-    stage.input_grad = False
-    stage._drop_graphs()
-    for _ in range(max(args.warmup, 1)):
-        step()
-    fence()
-    t2 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    cached_elapsed = time.perf_counter() - t2
-    if world > 1:
-        t = torch.tensor([cached_elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        cached_elapsed = float(t.item())
+    extras = {}
+    if not args.no_extras:
+        # inference: eval-mode forward of both strands over the same chromosomes
+        if genome:
+            def ev():
+                return stage.run_split("valid", names, to_cpu=False)
+        else:
+            def ev():
+                return stage.eval_step(names[0])
+        for _ in range(2):
+            ev()
+        ev_el, _, _ = timed(ev, max(steps // 2, 3))
+        extras["inference_windows_per_s"] = windows * max(steps // 2, 3) / ev_el
+        # the engine's default configuration: first-layer aggregation cached, no gradient w.r.t. the input features
+        # (finetune.py:33-34 asks for it but nothing can observe it)
+        stage.cache_input_aggregation = True
+        stage.input_grad = False
+        stage._drop_graphs()
+        for _ in range(max(warmup, 1)):
+            step()
+        d_el, _, _ = timed(step, steps)
+        extras["engine_default_windows_per_s"] = windows * steps / d_el
+        extras["engine_default_note"] = ("cached first-layer aggregation (loop invariant) + no d loss / d features; "
+                                         "not the headline")
+        stage.cache_input_aggregation = False
+        stage.input_grad = True
+        stage._drop_graphs()
 
     out = None
     if rank == 0:
-        k_s = time_dominant_kernel(stage, name, 200)
-        alg = layer_fwd_bytes(n, nnz, 2, args.d, True)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("%s_d%d" % (args.workload, args.d))
-            except Exception:
-                traffic = None
-        roof = {"bound": "hbm", "kernel": "k_layer_fwd<S=2,D=%d,MB=1,HAS_VAL=false,FROM_CACHE=false> (training variant: writes Z,H)" % args.d,
-                "achieved": alg / k_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": alg / k_s / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": alg, "avg_kernel_us": k_s * 1e6,
-                "gather_GBps": 4.0 * nnz * 2 * args.d / k_s / 1e9,
-                "mfma_TFLOPs": 2.0 * 2 * n * args.d * args.d / k_s / 1e12}
+        # ---- roofline of the dominant kernel (k_layer_fwd: largest share of the epoch), measured live
+        reps = 30 if genome else 200
+        tot_t = tot_b = tot_g = tot_f = 0.0
+        per_chrom = {}
+        for nm, n, nnz in shapes:
+            if nm not in stage.chroms:
+                continue
+            t1, t2 = time_layer_fwd(stage, nm, reps, args.dropout)
+            b = layer_fwd_bytes(n, nnz, 2, args.d)
+            tot_t += t1 + t2
+            tot_b += 2 * b
+            tot_g += 2 * 4.0 * nnz * 2 * args.d
+            tot_f += 2 * 2.0 * 2 * n * args.d * args.d
+            per_chrom[nm] = {"n": n, "nnz": nnz, "us_layer1": t1 * 1e6, "us_last": t2 * 1e6, "GBps": b / ((t1 + t2) / 2) / 1e9}
+        wl_key = ("genome" if genome else args.workload) + ("_hic" if args.hic_like else "") + "_d%d" % args.d
+        traffic, ttag = stored_traffic(wl_key)
+        nl = 2 * len(per_chrom)
+        roof = {"bound": "hbm",
+                "kernel": "k_layer_fwd<S=2,D=%d> training variant (writes Z, H; layer 1 with dropout, last layer with "
+                          "BatchNorm column statistics), average over the %d launches of one %s" %
+                          (args.d, nl, "train epoch" if genome else "train step"),
+                "achieved": tot_b / tot_t / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": tot_b / tot_t / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
+                "traffic_source": None if traffic is None else "stored profile value (profiles/traffic.json, tag %s), not measured in this run" % ttag,
+                "algorithmic_bytes_per_launch": tot_b / nl, "avg_kernel_us": tot_t / nl * 1e6,
+                "bytes_formula": "SURVEY 8(d): 4(n+1)+4nnz+4n + S*4nd (X) + 4d^2+8d+4 + S*4nd (X') + S*4n (gate) + S*4nd (Z); H not counted",
+                "gather_GBps": tot_g / tot_t / 1e9, "mfma_TFLOPs": tot_f / tot_t / 1e12,
+                "per_chromosome": per_chrom if genome else None}
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # the host baseline is reported at N=1 only
-            cpu = cpu_baseline(args, n, pairs, seed, args.cpu_steps)
-        value = world * n * args.steps / elapsed
+            if genome:  # bounded sample of the same genome: its smallest, a middle and its largest train chromosome
+                by_n = sorted(shapes, key=lambda s: s[1])
+                pick = [by_n[0], by_n[len(by_n) // 2], by_n[-1]]
+                sample = [(nm, n, synth.PAIRS_PER_CHROM, synth.chrom_seed(nm)) for nm, n, _ in pick]
+            else:
+                sample = [(names[0], shapes[0][1], single_shape(args.workload)[2],
+                           (synth.chrom_seed(single_shape(args.workload)[0]) if args.workload != "config1" else 0))]
+            cpu = cpu_baseline(args, sample, args.cpu_seconds)
+        per_ms = np.array(per) * 1e3
+        if genome:
+            wl = ("synthetic GM12878-shaped genome (SURVEY 8d config 3): %d train chromosomes, %d windows, 250000 contact "
+                  "pairs each (nnz(A+I) %d..%d), d=%d, L=%d, C=%d, dropout=%.2f, SGD lr .25 m .9 wd 1e-6; step = one train "
+                  "epoch in reference semantics: per chromosome f+r fwd, BCE, bwd incl. d/dx, optimizer step; all four "
+                  "aggregations every step%s" %
+                  (len(names), windows, min(s[2] for s in shapes), max(s[2] for s in shapes), args.d, args.layers,
+                   synth.N_LABELS, args.dropout,
+                   "; chromosomes sharded over %d ranks (LPT), one flat-gradient all-reduce per step group (RCCL)" % world if world > 1 else ""))
+        else:
+            wl = ("%s-like synthetic Hi-C chromosome per rank: n=%d windows, %d contact pairs (nnz(A+I)=%d), d=%d, L=%d, "
+                  "C=%d, dropout=%.2f, SGD lr .25 m .9 wd 1e-6; train step = f+r fwd, BCE, bwd incl. d/dx, optimizer step%s"
+                  % (args.workload, shapes[0][1], single_shape(args.workload)[2], shapes[0][2], args.d, args.layers,
+                     synth.N_LABELS, args.dropout, "; grad all-reduce over RCCL" if world > 1 else ""))
         out = {
-            "metric": "GCN windows/sec (2-layer, d_model=128) train step", "value": value, "unit": "windows/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s-like synthetic Hi-C chromosome per rank: n=%d windows, %d contact pairs "
-                                   "(nnz(A+I)=%d), d=%d, L=%d, C=%d, dropout=%.2f, SGD lr .25 m .9 wd 1e-6; "
-                                   "train step = f+r fwd, BCE, bwd incl. d/dx, optimizer step%s"
-                                   % (args.workload, n, pairs, nnz, args.d, args.layers, synth.N_LABELS, args.dropout,
-                                      "; grad all-reduce over RCCL" if world > 1 else ""),
-                       "generator": "hic_like" if args.hic_like else "uniform",
-                       "hip_graph": not args.no_hip_graph, "parallelism": "chromosome-per-rank x%d" % world},
-            "roofline": roof, "cpu_baseline": cpu,
-            "inference_windows_per_s": world * n * args.steps / eval_elapsed,
-            "engine_default_windows_per_s": world * n * args.steps / cached_elapsed,
-            "engine_default_note": "cached first-layer aggregation (loop invariant) + no d loss/d features; not the headline",
-            "final_loss": final_loss,
+            "metric": "GCN windows/sec (2-layer, d_model=128) on GM12878 Hi-C graph" if genome else
+                      "GCN windows/sec (2-layer, d_model=128) train step, one chromosome",
+            "value": windows * steps / elapsed, "unit": "windows/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+            "higher_is_better": True, "scaling": "strong" if genome else "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": wl, "generator": "hic_like" if args.hic_like else "uniform",
+                       "hip_graph": not args.no_hip_graph,
+                       "parallelism": ("chromosomes sharded over %d rank(s)" % world) if genome else "chromosome-per-rank x%d" % world},
+            "step_ms": {"median": float(np.median(per_ms)), "p10": float(np.percentile(per_ms, 10)),
+                        "p90": float(np.percentile(per_ms, 90)), "n": len(per),
+                        "note": "per-step host time on rank 0" + (" (each epoch ends with its own loss sync)" if genome else " (launch only: steps are asynchronous)")},
+            "value_at_median": windows / (float(np.median(per_ms)) * 1e-3) if genome else None,
+            "roofline": roof, "cpu_baseline": cpu, "final_loss": final_loss,
         }
+        out.update(extras)
         print(json.dumps(out))
         sys.stdout.flush()
     if world > 1:

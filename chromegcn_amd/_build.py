@@ -1,5 +1,14 @@
-"""Builds libchromegcn_hip.so (gfx950 only) in-tree with hipcc.  Called by __graft_entry__.build()
-and lazily by chromegcn_amd._lib when the library is missing and hipcc is available."""
+"""Builds libchromegcn_hip.so (gfx950 only) in-tree with hipcc.
+
+Building is always an explicit act: `python -m chromegcn_amd._build`, `__graft_entry__.build()`, or the test
+session's start-up hook (tests/conftest.py, before anything touches the GPU).  `chromegcn_amd._lib.load()` never
+shells out to the compiler: a process that has initialised the GPU (or runs under a profiler's preload) must not
+spawn hipcc, and N ranks of one job must not race to write the same file.
+
+Staleness is decided by CONTENT, not by mtime: the build writes the hash of every source, header and flag next to
+the library (`libchromegcn_hip.so.srchash`); a snapshot copied to another box keeps matching whatever the copy did
+to the timestamps."""
+import hashlib
 import os
 import shutil
 import subprocess
@@ -10,6 +19,8 @@ SRC = [os.path.join(PKG, "csrc", "cgcn_kernels.hip"), os.path.join(PKG, "csrc", 
        os.path.join(PKG, "csrc", "cgcn_graph.hip"), os.path.join(PKG, "csrc", "cgcn_metrics.hip")]
 HDR = [os.path.join(ROOT, "include", "chromegcn.h"), os.path.join(PKG, "csrc", "cgcn_common.hpp")]
 LIB = os.path.join(PKG, "libchromegcn_hip.so")
+HASH = LIB + ".srchash"
+BASE_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared"]
 
 
 def hipcc_path():
@@ -19,27 +30,54 @@ def hipcc_path():
     return None
 
 
-def is_stale():
-    if not os.path.exists(LIB):
+def _extra_flags():
+    return os.environ.get("CGCN_EXTRA_FLAGS", "").split()  # tuning experiments only (tools/)
+
+
+def source_hash(extra=None) -> str:
+    h = hashlib.sha256()
+    h.update(" ".join(BASE_FLAGS + (list(extra) if extra is not None else [])).encode())
+    for f in SRC + HDR:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def is_stale() -> bool:
+    """True when the in-tree library is missing or was built from other sources than the ones in the tree."""
+    if not os.path.exists(LIB) or not os.path.exists(HASH):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(f) > t for f in SRC + HDR if os.path.exists(f))
+    try:
+        with open(HASH) as f:
+            return f.read().strip() != source_hash([])
+    except OSError:
+        return True
 
 
 def build_library(force=False, verbose=False, out=None):
-    if out is None and not force and not is_stale():
+    extra = _extra_flags()
+    if out is None and not force and not is_stale() and not extra:
         return LIB
     hipcc = hipcc_path()
     if hipcc is None:
         raise RuntimeError("chromegcn_amd: hipcc not found; cannot build libchromegcn_hip.so")
-    extra = os.environ.get("CGCN_EXTRA_FLAGS", "").split()  # tuning experiments only (tools/)
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-           "-I" + os.path.join(ROOT, "include")] + extra + SRC + ["-o", (out or LIB) + ".tmp"]
+    target = out or LIB
+    tmp = "%s.tmp.%d" % (target, os.getpid())  # per-process temporary: concurrent builders never share a file
+    cmd = [hipcc] + BASE_FLAGS + ["-I" + os.path.join(ROOT, "include")] + extra + SRC + ["-o", tmp]
     if verbose:
         print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
-    os.replace((out or LIB) + ".tmp", out or LIB)
-    return out or LIB
+    try:
+        subprocess.run(cmd, check=True)
+        os.replace(tmp, target)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+    if out is None:
+        with open(HASH + ".tmp.%d" % os.getpid(), "w") as f:
+            f.write(source_hash([]) + "\n")  # extra (tuning) flags do not make the tree "stale"
+        os.replace(HASH + ".tmp.%d" % os.getpid(), HASH)
+    return target
 
 
 if __name__ == "__main__":

@@ -52,18 +52,24 @@ def exported_symbols():
     return sorted(_SIGNATURES)
 
 
-def load(build_if_missing=True):
-    """Load (once) and return the ctypes handle.  Raises ChromeGCNLibraryError if unavailable."""
+def load(build_if_missing=False):
+    """Load (once) and return the ctypes handle.  Raises ChromeGCNLibraryError if the library is missing or was
+    built from different sources than the tree holds.  Never compiles: building is explicit
+    (`python -m chromegcn_amd._build` / `__graft_entry__.build()`), because this may run in a process that has
+    already initialised the GPU, under a profiler, or as one of N ranks (chromegcn_amd/_build.py).
+    `build_if_missing` is accepted for old callers and ignored."""
     global _lib
     if _lib is not None:
         return _lib
     path = os.environ.get("CHROMEGCN_LIB") or _build.LIB  # override: tuning experiments load a variant build
-    if path == _build.LIB and build_if_missing and _build.is_stale() and _build.hipcc_path() is not None:
-        _build.build_library()
     if not os.path.exists(path):
         raise ChromeGCNLibraryError(
-            "chromegcn_amd: %s is missing and could not be built (run __graft_entry__.build()). "
-            "There is no CPU/torch fallback for the HIP path." % path)
+            "chromegcn_amd: %s is missing -- build it first: python -m chromegcn_amd._build (or "
+            "__graft_entry__.build()).  There is no CPU/torch fallback for the HIP path." % path)
+    if path == _build.LIB and _build.is_stale():
+        raise ChromeGCNLibraryError(
+            "chromegcn_amd: %s is stale (sources changed since it was built) -- rebuild: "
+            "python -m chromegcn_amd._build" % path)
     lib = ctypes.CDLL(path)
     for name, (res, args) in _SIGNATURES.items():
         try:

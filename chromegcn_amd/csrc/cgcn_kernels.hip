@@ -279,6 +279,54 @@ __global__ __launch_bounds__(256) void k_spmm(int n_rows, int n_cols, const int*
 }
 
 // ------------------------------------------------------------------------------------------
+// k_spmm_any: the same aggregation for ANY feature width d that is a multiple of 4 (d <= 4096) -- the
+// GraphConvolution drop-in accepts arbitrary in/out widths (models/SubLayers.py:8-12), only the fused gated
+// layer is specialised to d = 128 / 256.  One wave per (strand, node) row; lane l owns the float4 column
+// groups l, l + 64, ...; column indices are broadcast with v_readlane, four neighbour rows are in flight per wave.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_spmm_any(int n_rows, int n_cols, int S, int d, const int* __restrict__ rowptr,
+                                                  const int* __restrict__ col, const float* __restrict__ val,
+                                                  const float* __restrict__ rs, const float* __restrict__ X,
+                                                  float* __restrict__ Y) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int d4 = d >> 2;
+  for (int row = wave; row < S * n_rows; row += nwaves) {
+    const int s = row / n_rows, i = row - s * n_rows;
+    const float* Xs = X + (size_t)s * n_cols * d;
+    const int k0 = rowptr[i], k1 = rowptr[i + 1];
+    const float sc = rs ? rs[i] : 1.f;
+    for (int c4b = 0; c4b < d4; c4b += WAVE) {   // every lane stays in the loop (the index broadcast needs all 64)
+      const int c4 = c4b + lane;
+      const bool on = c4 < d4;
+      const int c4c = on ? c4 : 0;                // lanes past the row's end re-read column group 0 and drop it
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int kb = k0; kb < k1; kb += WAVE) {
+        const int cnt = min(WAVE, k1 - kb);
+        const int myc = lane < cnt ? col[kb + lane] : 0;
+        const float myv = (val && lane < cnt) ? val[kb + lane] : 1.f;
+        for (int j = 0; j < cnt; j += 4) {
+          f32x4 t[4];
+          float w[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int idx = min(j + u, cnt - 1);
+            const int cj = rl_i(myc, idx);
+            w[u] = rl_f(myv, idx);
+            t[u] = *(const f32x4*)&Xs[(size_t)cj * d + c4c * 4];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (j + u < cnt) acc += w[u] * t[u];
+        }
+      }
+      if (on) *(f32x4*)&Y[((size_t)s * n_rows + i) * d + c4 * 4] = acc * sc;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Shared pieces of the two gather kernels (k_layer_fwd, k_bwd_gather).
 //
 // Tile: TN = 16*MB/S nodes x S strands = 16*MB MFMA rows, staged in LDS as T[row][D+4].
@@ -1062,7 +1110,7 @@ const char* cgcn_strerror(int code) {
   switch (code) {
     case CGCN_OK: return "ok";
     case CGCN_ERR_BAD_ARG: return "bad argument (null pointer, negative size or misaligned buffer)";
-    case CGCN_ERR_UNSUPPORTED: return "unsupported shape (need S in {1,2}, d in {128,256}, S*n*d*4 < 4 GiB)";
+    case CGCN_ERR_UNSUPPORTED: return "unsupported shape (need S in {1,2}; d in {128,256} for the fused kernels, a multiple of 4 <= 4096 for cgcn_spmm; S*n*d*4 < 4 GiB)";
     case CGCN_ERR_LAUNCH: return "HIP kernel launch failed";
     case CGCN_ERR_WORKSPACE: return "workspace too small";
     default: return "unknown chromegcn error";
@@ -1071,12 +1119,21 @@ const char* cgcn_strerror(int code) {
 
 int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d, const int32_t* rowptr, const int32_t* col,
               const float* val, const float* row_scale, const float* X, float* Y) {
-  int rc = check_shape(n_rows > n_cols ? n_rows : n_cols, S, d);
-  if (rc) return rc;
+  const int nmax = n_rows > n_cols ? n_rows : n_cols;
+  if (nmax < 0) return CGCN_ERR_BAD_ARG;
+  // the bare aggregation takes any width that is a multiple of 4 (k_spmm_any); S*D in {128, 256, 512} has tuned kernels
+  if (!(S == 1 || S == 2) || d < 4 || (d & 3) || d > 4096) return CGCN_ERR_UNSUPPORTED;
+  if ((double)nmax * (double)S * (double)d * 4.0 >= 4294967296.0) return CGCN_ERR_UNSUPPORTED;
   if (n_rows == 0) return CGCN_OK;
   if (!rowptr || !col || !X || !Y || X == Y) return CGCN_ERR_BAD_ARG;
   if (misaligned16(X) || misaligned16(Y)) return CGCN_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
+  if (!(d == 128 || d == 256)) {
+    const long long rows = (long long)S * n_rows;
+    const int blocks = (int)((rows + 3) / 4 < 8192 ? (rows + 3) / 4 : 8192);
+    hipLaunchKernelGGL(k_spmm_any, dim3(blocks), dim3(256), 0, st, n_rows, n_cols, S, d, rowptr, col, val, row_scale, X, Y);
+    return launch_status();
+  }
   const int blocks = (n_rows + 3) / 4 < 4096 ? (n_rows + 3) / 4 : 4096;
   const bool deep = false;  // measured: the bare SpMM never gains from the deeper batches (chr10-like 48.7 vs 55.8 us)
 #define CALL(S_, D_, V_)                                                                                                  \

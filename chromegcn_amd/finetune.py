@@ -33,11 +33,24 @@ from .dist import ShardPlan, plan_shards
 
 
 class _Chrom:
-    __slots__ = ("name", "n", "graph", "x", "target", "cost", "h1")
+    __slots__ = ("name", "n", "graph", "x", "target", "cost", "h1", "src_key")
 
-    def __init__(self, name, n, graph, x, target, cost):
+    def __init__(self, name, n, graph, x, target, cost, src_key=None):
         self.name, self.n, self.graph, self.x, self.target, self.cost = name, n, graph, x, target, cost
         self.h1 = {"h": None}  # cached A X of the first layer (features and graph are fixed per chromosome)
+        self.src_key = src_key  # identity + version of the caller's tensors / graph object this was built from
+
+
+def _source_key(feats, hic):
+    """What a cached chromosome was built from: storage address and in-place version of the three feature tensors
+    and the identity (+ nnz) of the Hi-C matrix.  A caller that hands in regenerated features, new targets or
+    another graph under the same chromosome name gets a rebuild instead of stale device copies."""
+    parts = []
+    for k in ("forward", "backward", "target"):
+        t = feats[k]
+        parts.append((t.data_ptr(), t._version, tuple(t.shape)) if torch.is_tensor(t) else id(t))
+    parts.append(None if hic is None else (id(hic), getattr(hic, "nnz", None), getattr(hic, "shape", None)))
+    return tuple(parts)
 
 
 class GCNStage:
@@ -81,6 +94,9 @@ class GCNStage:
         self._one: Optional[torch.Tensor] = None
         self._int_synced: Dict[str, torch.Tensor] = {}
         self._targets_cpu: Dict[tuple, torch.Tensor] = {}
+        self._gather_plans: Dict[tuple, dict] = {}
+        self._targets_dev: Dict[tuple, torch.Tensor] = {}
+        self._arena: Optional[dict] = None
 
     def _drop_graphs(self):
         """forget every captured HIP graph (and the memory pool they shared, which dies with the last of them)"""
@@ -98,20 +114,72 @@ class GCNStage:
         t = feats["target"].to(self.device, torch.float32).contiguous()
         d = x.shape[2]
         cost = float(h.nnz) * d + 3.0 * n * d * d / 16.0
-        self.chroms[name] = _Chrom(name, n, g, x, t, cost)
+        self.chroms[name] = _Chrom(name, n, g, x, t, cost, _source_key(feats, hic))
         self._targets_cpu.clear()
+        self._targets_dev.clear()
+        self._gather_plans.clear()
+        self._arena = None   # the output arena is laid out over the chromosome set: rebuilt (and graphs dropped) lazily
         self._graphs = {k: v for k, v in self._graphs.items() if k[0] != name}
         if not self._graphs:
             self._pool = None
 
     def load(self, chrom_feature_dict, split_adj_dict=None, only: Optional[Iterable[str]] = None):
+        """Upload the chromosomes that are not cached yet.  The reference re-reads everything on every call
+        (finetune.py:20-36); here a chromosome is reused only while the caller's feature tensors (address, in-place
+        version) and graph object are the ones it was built from -- anything else rebuilds it, dropping its cached
+        first-layer aggregation and captured HIP graphs (add_chromosome).  `invalidate()` forces a rebuild."""
         for name in chrom_feature_dict:
             if only is not None and name not in only:
                 continue
-            if name in self.chroms and self.chroms[name].n == chrom_feature_dict[name]["forward"].shape[0]:
-                continue
             hic = None if split_adj_dict is None else split_adj_dict.get(name)
+            cur = self.chroms.get(name)
+            if cur is not None and cur.src_key == _source_key(chrom_feature_dict[name], hic):
+                continue
             self.add_chromosome(name, chrom_feature_dict[name], hic)
+
+    def invalidate(self, name: Optional[str] = None):
+        """forget the device copy of one chromosome (or of all of them) and every HIP graph captured on it"""
+        for nm in ([name] if name is not None else list(self.chroms)):
+            self.chroms.pop(nm, None)
+            self._graphs = {k: v for k, v in self._graphs.items() if k[0] != nm}
+        if not self._graphs:
+            self._pool = None
+        self._targets_cpu.clear()
+        self._targets_dev.clear()
+        self._gather_plans.clear()
+        self._arena = None
+
+    # ------------------------------------------------------------------ output arena
+    def _ensure_arena(self):
+        """One [sum n, C] buffer for the predictions and one [#chromosomes] buffer for the losses of every cached
+        chromosome, in insertion order (= the reference's chromosome iteration order, finetune.py:29).  The fused head
+        writes each chromosome's sigmoid(pred) and mean BCE straight into its slice, so the concatenation of
+        finetune.py:52 and the loss sum of :51 need no per-chromosome copy / add kernels."""
+        if self._arena is not None or not self.chroms:
+            return
+        C = next(iter(self.chroms.values())).target.shape[1]
+        total = sum(c.n for c in self.chroms.values())
+        probs = torch.empty((total, C), device=self.device, dtype=torch.float32)
+        loss = torch.zeros(len(self.chroms), device=self.device, dtype=torch.float32)
+        slots, rows, order = {}, {}, {}
+        off = 0
+        for i, (nm, c) in enumerate(self.chroms.items()):
+            slots[nm] = {"probs": probs[off:off + c.n], "loss": loss[i:i + 1]}
+            rows[nm] = (off, off + c.n)
+            order[nm] = i
+            off += c.n
+        self._arena = {"probs": probs, "loss": loss, "slots": slots, "rows": rows, "order": order}
+        self._drop_graphs()  # captured graphs wrote into the previous arena
+
+    def _arena_span(self, names):
+        """(row0, row1, i0, i1) if `names` is a contiguous run of the arena's chromosome order, else None"""
+        if not names:
+            return None
+        order = self._arena["order"]
+        idx = [order[nm] for nm in names]
+        if idx != list(range(idx[0], idx[0] + len(idx))):
+            return None
+        return self._arena["rows"][names[0]][0], self._arena["rows"][names[-1]][1], idx[0], idx[-1] + 1
 
     # ------------------------------------------------------------------ flat parameter / gradient / momentum arenas
     def _params(self):
@@ -198,14 +266,21 @@ class GCNStage:
 
     # ------------------------------------------------------------------ one chromosome, eager
     def _forward_loss(self, c: _Chrom, x):
+        slot = self._arena["slots"][c.name] if self._arena is not None else None
         if self.fused_head and hasattr(self.model, "forward_loss"):
             loss, probs, _ = self.model.forward_loss(x, c.graph, c.target,   # fused head + loss kernels
-                                                     h1_cache=c.h1 if self.cache_input_aggregation else None)
+                                                     h1_cache=c.h1 if self.cache_input_aggregation else None,
+                                                     out_slots=slot)
             return loss, probs
         logits, _ = self.model.forward_strands(x, c.graph)
         pred = (logits[0] + logits[1]) / 2                                # finetune.py:43
         loss = F.binary_cross_entropy_with_logits(pred, c.target)          # finetune.py:45
-        return loss, torch.sigmoid(pred).detach()                          # finetune.py:52
+        if slot is None:
+            return loss, torch.sigmoid(pred).detach()                      # finetune.py:52
+        with torch.no_grad():
+            torch.sigmoid(pred, out=slot["probs"])
+            slot["loss"].copy_(loss.detach().view(1))
+        return loss, slot["probs"]
 
     def _fwd_bwd(self, c: _Chrom):
         x = c.x.detach().requires_grad_(True) if self.input_grad else c.x  # finetune.py:33-34
@@ -264,22 +339,30 @@ class GCNStage:
                 self._optimizer_step()                                    # finetune.py:49
             return loss, probs, dx
 
-        side = torch.cuda.Stream(device=self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(side):
-            for _ in range(2):  # warm-up: allocator pools, rocBLAS/MIOpen handles, lazy optimizer state
-                body()
-        torch.cuda.current_stream(self.device).wait_stream(side)
-        torch.cuda.synchronize(self.device)
-        self._restore(snap)
-        graph = torch.cuda.CUDAGraph()
-        if self._pool is None:
-            self._pool = torch.cuda.graph_pool_handle()
-        # thread_local: an RCCL watchdog thread polling events while we capture must not invalidate the capture
-        with torch.cuda.graph(graph, pool=self._pool, capture_error_mode="thread_local"):
-            loss, probs, dx = body()
-        self._restore(snap)  # capture launches nothing, but keep state bit-identical regardless
-        self.model.train(was_training)
+        if kind == "train" and not self._fused_sgd:
+            # torch optimizers are not capturable by default (Adam.step raises under capture): callers replay
+            # 'fwdbwd' and step eagerly instead (train_step)
+            raise RuntimeError("only the fused SGD step can be captured; use kind='fwdbwd' + an eager optimizer.step()")
+        try:
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                for _ in range(2):  # warm-up: allocator pools, rocBLAS/MIOpen handles, lazy optimizer state
+                    body()
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            self._restore(snap)
+            graph = torch.cuda.CUDAGraph()
+            if self._pool is None:
+                self._pool = torch.cuda.graph_pool_handle()
+            # thread_local: an RCCL watchdog thread polling events while we capture must not invalidate the capture
+            with torch.cuda.graph(graph, pool=self._pool, capture_error_mode="thread_local"):
+                loss, probs, dx = body()
+        finally:
+            # the warm-up steps mutated parameters / running statistics / optimizer state: whatever happened above,
+            # hand the model back exactly as it came in (capture itself launches nothing)
+            self._restore(snap)
+            self.model.train(was_training)
         return {"graph": graph, "loss": loss, "probs": probs, "dx": dx}
 
     def _replay(self, c: _Chrom, kind: str):
@@ -300,17 +383,21 @@ class GCNStage:
         c = self.chroms[name]
         self.model.train()
         self._ensure_flat_grad()
+        self._ensure_arena()
         if self.world > 1:
             raise RuntimeError("use train_group() when running on more than one rank")
-        if self.hip_graphs:
-            return self._replay(c, "train")
-        loss, probs, dx = self._fwd_bwd(c)
+        if self.hip_graphs and self._fused_sgd:
+            return self._replay(c, "train")          # zero_grad + fwd + bwd + fused SGD: one HIP graph
+        # any other optimizer (Adam is the reference's -optim adam, utils/util_methods.py:20-21): its step() is
+        # not capturable, so the graph ends after the backward and the step runs eagerly on the flat buffers
+        loss, probs, dx = self._replay(c, "fwdbwd") if self.hip_graphs else self._fwd_bwd(c)
         self._optimizer_step()
         return loss, probs, dx
 
     def eval_step(self, name: str):
         c = self.chroms[name]
         self.model.eval()
+        self._ensure_arena()
         if self.hip_graphs:
             loss, probs, _ = self._replay(c, "eval")
             return loss, probs
@@ -322,6 +409,7 @@ class GCNStage:
         in the group, then every rank takes the same optimizer step."""
         self.model.train()
         self._ensure_flat_grad()
+        self._ensure_arena()
         out = (None, None, None)
         if name is not None:
             c = self.chroms[name]
@@ -363,30 +451,34 @@ class GCNStage:
         """(all_preds, all_targets, total_loss) with finetune.py:67's meaning: sigmoid probabilities and
         targets concatenated in chromosome order, total_loss = sum of per-chromosome mean BCE.
         to_cpu=True returns CPU tensors like the reference (finetune.py:52-53 moves every chromosome's
-        predictions to the host); to_cpu=False leaves them on the device for chromegcn_amd.metrics.
-        Multi-rank: every rank returns the full concatenation (CPU)."""
+        predictions to the host); to_cpu=False leaves them on the device for chromegcn_amd.metrics -- the
+        predictions are then a view of the stage's output arena, valid until the next step on this stage.
+        Multi-rank: every rank returns the full concatenation."""
         names = list(self.chroms) if names is None else list(names)
         train = split == "train"
         C = next(iter(self.chroms.values())).target.shape[1] if self.chroms else 0
         if self.world == 1:
-            total_n = sum(self.chroms[nm].n for nm in names)
-            preds_dev = torch.empty((total_n, C), device=self.device, dtype=torch.float32)
-            loss_dev = torch.zeros((), device=self.device, dtype=torch.float32)
-            off = 0
+            self._ensure_arena()
             for nm in names:
-                loss, p, _ = self.train_step(nm) if train else (*self.eval_step(nm), None)
-                loss_dev += loss                      # stays on the device: no per-chromosome sync (finetune.py:51)
-                preds_dev[off:off + p.shape[0]].copy_(p)
-                off += p.shape[0]
+                self.train_step(nm) if train else self.eval_step(nm)   # results land in the arena: nothing to copy or add
+            span = self._arena_span(names)
+            if span is not None:   # the usual case: the split is the stage's chromosomes in order -> views, no copy
+                preds_dev = self._arena["probs"][span[0]:span[1]]
+                loss_dev = self._arena["loss"][span[2]:span[3]].sum()
+            elif names:
+                preds_dev = torch.cat([self._arena["slots"][nm]["probs"] for nm in names], 0)
+                loss_dev = torch.cat([self._arena["slots"][nm]["loss"] for nm in names]).sum()
+            else:
+                preds_dev = torch.empty((0, C), device=self.device)
+                loss_dev = torch.zeros((), device=self.device)
+            total = float(loss_dev.item())            # the one host sync of the split (finetune.py:51 syncs per chromosome)
             if not to_cpu:
-                targets_dev = torch.cat([self.chroms[nm].target for nm in names], 0) if names else torch.empty(0, C, device=self.device)
-                return preds_dev, targets_dev, float(loss_dev.item())
-            total = float(loss_dev.item())
+                return preds_dev, self._split_targets_dev(names, C), total
             preds = preds_dev.cpu()
         else:
-            plan = plan_shards({nm: self.chroms[nm].cost for nm in names}, self.world) if train else \
-                plan_shards({nm: self.chroms[nm].cost for nm in names}, self.world)
-            mine: Dict[str, torch.Tensor] = {}
+            plan = plan_shards({nm: self.chroms[nm].cost for nm in names}, self.world)
+            gp = self._gather_plan(names, plan, C)
+            send = gp["send"]
             loss_sum = torch.zeros((), device=self.device)
             for group in plan.rounds:
                 nm = group[self.rank] if self.rank < len(group) else None
@@ -398,28 +490,63 @@ class GCNStage:
                 else:
                     loss = p = None
                 if nm is not None:
-                    mine[nm] = p.clone()
+                    o = gp["my_offset"][nm]
+                    send[o:o + p.shape[0]].copy_(p)   # straight into this rank's slab of the split-end gather
                     loss_sum += loss
             if train:
                 self.sync_running_stats()
             torch.distributed.all_reduce(loss_sum, group=self.group)
+            # predictions: ONE all-gather at the end of the split (every rank's rows, padded to the largest rank),
+            # then one index_select into the reference's chromosome order -- no per-chromosome collective or host sync
+            if torch.distributed.get_backend(self.group) == "nccl":
+                torch.distributed.all_gather_into_tensor(gp["recv"], send, group=self.group)
+            else:  # gloo (CPU tests, single-GPU functional runs): the list form is the one every backend implements
+                torch.distributed.all_gather(list(gp["recv"].view(self.world, -1, C).unbind(0)), send, group=self.group)
+            preds_dev = gp["recv"].view(-1, C).index_select(0, gp["index"]) if gp["total"] else gp["recv"].view(-1, C)[:0]
             total = float(loss_sum.item())
-            preds = _gather_predictions(mine, names, {nm: self.chroms[nm].n for nm in names}, C, plan, self)
+            if not to_cpu:
+                return preds_dev, self._split_targets_dev(names, C), total
+            preds = preds_dev.cpu()
         key = tuple(names)
         if key not in self._targets_cpu:  # targets never change: one D2H per split, not one per epoch
             self._targets_cpu[key] = torch.cat([self.chroms[nm].target for nm in names], 0).cpu() if names else torch.empty(0, C)
         return preds, self._targets_cpu[key], total
 
+    def _split_targets_dev(self, names, C):
+        key = tuple(names)
+        if key not in self._targets_dev:  # targets never change: concatenated once per split, not once per epoch
+            self._targets_dev[key] = (torch.cat([self.chroms[nm].target for nm in names], 0) if names
+                                      else torch.empty(0, C, device=self.device))
+        return self._targets_dev[key]
 
-def _gather_predictions(mine, names, sizes, C, plan: ShardPlan, stage: GCNStage):
-    """No data-path collective is needed for predictions: each rank broadcasts the rows it produced."""
-    owner = plan.owner
-    parts = []
-    for nm in names:
-        buf = mine[nm] if owner[nm] == stage.rank else torch.empty(sizes[nm], C, device=stage.device)
-        torch.distributed.broadcast(buf, src=owner[nm], group=stage.group)
-        parts.append(buf.cpu())
-    return torch.cat(parts, 0) if parts else torch.empty(0, C)
+    def _gather_plan(self, names, plan: ShardPlan, C: int):
+        """Buffers and the row permutation of the split-end prediction gather, built once per (split, plan):
+        rank r's rows are its chromosomes in `names` order, padded to the largest rank's row count; `index` maps
+        the reference's concatenation order (finetune.py:52, chromosome iteration order) onto the gathered
+        [world * max_rows] rows."""
+        key = (tuple(names), self.world, C)
+        gp = self._gather_plans.get(key)
+        if gp is not None:
+            return gp
+        sizes = {nm: self.chroms[nm].n for nm in names}
+        rows = [0] * self.world
+        offset = {}
+        for nm in names:
+            r = plan.owner[nm]
+            offset[nm] = rows[r]
+            rows[r] += sizes[nm]
+        max_rows = max(rows) if rows else 0
+        idx = []
+        for nm in names:
+            base = plan.owner[nm] * max_rows + offset[nm]
+            idx.append(torch.arange(base, base + sizes[nm], dtype=torch.int64))
+        index = torch.cat(idx) if idx else torch.empty(0, dtype=torch.int64)
+        gp = {"send": torch.zeros((max_rows, C), device=self.device, dtype=torch.float32),
+              "recv": torch.empty((self.world * max_rows, C), device=self.device, dtype=torch.float32),
+              "index": index.to(self.device), "total": int(index.numel()),
+              "my_offset": {nm: offset[nm] for nm in names if plan.owner[nm] == self.rank}}
+        self._gather_plans[key] = gp
+        return gp
 
 
 # ---------------------------------------------------------------------------------------------

@@ -271,7 +271,12 @@ def load_csr_cache(path: str) -> HostCSR:
         col = np.frombuffer(f.read(4 * nnz), dtype="<i4").copy()
         val = np.frombuffer(f.read(4 * nnz), dtype="<f4").copy() if has_val else None
         rs = np.frombuffer(f.read(4 * n), dtype="<f4").copy() if has_scale else None
-    if rowptr.shape[0] != n + 1 or col.shape[0] != nnz or int(rowptr[-1]) != nnz:
+    if rowptr.shape[0] != n + 1 or col.shape[0] != nnz or int(rowptr[-1]) != nnz or (n and int(rowptr[0]) != 0):
+        raise ValueError("%s is truncated or corrupt" % path)
+    # the kernels trust the structure: a bad file must fail here, not read out of bounds on the GPU
+    if np.any(np.diff(rowptr) < 0) or (nnz and (int(col.min()) < 0 or int(col.max()) >= n)):
+        raise ValueError("%s holds an invalid CSR (non-monotonic rowptr or column index out of range)" % path)
+    if (val is not None and val.shape[0] != nnz) or (rs is not None and rs.shape[0] != n):
         raise ValueError("%s is truncated or corrupt" % path)
     return HostCSR(n=n, rowptr=rowptr, col=col, val=val, row_scale=rs, symmetric=bool(sym))
 
@@ -296,20 +301,27 @@ def convert_graph_pickle(pkl_path: str, out_dir: str, adj_type: str = "hic") -> 
 # ----------------------------------------------------------------------------------------------
 # torch sparse tensors from reference-style callers
 # ----------------------------------------------------------------------------------------------
-_coo_cache: Dict[tuple, ChromGraph] = {}
+_coo_cache: Dict[tuple, tuple] = {}
 _COO_CACHE_MAX = 64
 
 
 def graph_from_torch_sparse(adj: torch.Tensor, device=None) -> ChromGraph:
     """Accept the torch sparse COO adjacency a reference caller passes (finetune.py:36 builds it with
-    the reference's process_graph).  Converted once per distinct tensor and cached."""
+    the reference's process_graph).  Converted once per live tensor object and cached (the two strand calls of
+    finetune.py:41-42 share one conversion)."""
     if adj.layout != torch.sparse_coo:
         raise TypeError("expected a torch sparse COO tensor or a ChromGraph")
     idx, vals = adj._indices(), adj._values()
-    key = (idx.data_ptr(), vals.data_ptr(), int(vals.shape[0]), tuple(adj.shape), str(adj.device), idx._version, vals._version)
-    g = _coo_cache.get(key)
-    if g is not None:
-        return g
+    key = (idx.data_ptr(), vals.data_ptr(), int(vals.shape[0]), tuple(adj.shape), str(adj.device))
+    ent = _coo_cache.get(key)
+    if ent is not None:
+        g, ref, ver = ent
+        # a hit only counts while the sparse tensor the entry was built from is still alive and unmodified: reference
+        # callers build a fresh COO per chromosome per epoch (finetune.py:36), and the caching allocator hands the
+        # same addresses out again for a different adjacency of the same size
+        if ref() is adj and ver == (idx._version, vals._version):
+            return g
+        del _coo_cache[key]
     dev = adj.device if device is None else torch.device(device)
     i = idx.detach().cpu().numpy()
     v = vals.detach().cpu().numpy().astype(np.float32)
@@ -317,17 +329,41 @@ def graph_from_torch_sparse(adj: torch.Tensor, device=None) -> ChromGraph:
         raise ValueError("adjacency must be square")
     m = sp.coo_matrix((v, (i[0], i[1])), shape=tuple(adj.shape)).tocsr()
     g = upload(host_csr_from_matrix(m), dev)
+    for k in [k for k, e in _coo_cache.items() if e[1]() is None]:
+        del _coo_cache[k]            # entries whose source tensor died: do not pin their device CSRs
     if len(_coo_cache) >= _COO_CACHE_MAX:
         _coo_cache.pop(next(iter(_coo_cache)))
-    _coo_cache[key] = g
+    import weakref
+    _coo_cache[key] = (g, weakref.ref(adj), (idx._version, vals._version))
     return g
 
 
-def as_graph(adj, device) -> ChromGraph:
+_identity_cache: Dict[tuple, ChromGraph] = {}
+
+
+def identity_graph(n: int, device) -> ChromGraph:
+    """A = I as a device CSR (process_graph 'none', utils/util_methods.py:173-174).  Used for `adj=None`:
+    GraphConvolution.forward then returns X W + b without aggregating (models/SubLayers.py:45-48), which is
+    exactly one gated layer over the identity adjacency."""
+    key = (int(n), str(torch.device(device)))
+    g = _identity_cache.get(key)
+    if g is None:
+        if len(_identity_cache) >= 16:
+            _identity_cache.pop(next(iter(_identity_cache)))
+        g = _identity_cache[key] = upload(normalize_graph("none", None, n), device)
+    return g
+
+
+def as_graph(adj, device, n: Optional[int] = None) -> ChromGraph:
+    """adj: ChromGraph, torch sparse COO (reference callers), or None (= no aggregation; needs n)."""
+    if adj is None:
+        if n is None:
+            raise TypeError("adj=None needs the number of nodes")
+        return identity_graph(n, device)
     if isinstance(adj, ChromGraph):
         if adj.device != torch.device(device) and str(adj.device) != str(device):
             raise RuntimeError("graph is on %s but features are on %s" % (adj.device, device))
         return adj
     if isinstance(adj, torch.Tensor) and adj.layout == torch.sparse_coo:
         return graph_from_torch_sparse(adj, device)
-    raise TypeError("adj must be a ChromGraph or a torch sparse COO tensor, got %r" % type(adj))
+    raise TypeError("adj must be a ChromGraph, a torch sparse COO tensor or None, got %r" % type(adj))

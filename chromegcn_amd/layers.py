@@ -52,12 +52,12 @@ class GraphConvolution(nn.Module):
 
     def forward(self, input, adj, deg=None):
         ops._require_cuda(input, "input")
-        support = torch.mm(input, self.weight)
+        support = torch.mm(input, self.weight)                              # SubLayers.py:43
         if adj is not None:
             g = as_graph(adj, input.device)
-            output = ops.spmm(support.unsqueeze(0), g).squeeze(0)
+            output = ops.spmm(support.unsqueeze(0), g).squeeze(0)           # SubLayers.py:46 (any width % 4 == 0)
         else:
-            output = support
+            output = support                                                # SubLayers.py:48
         return output + self.bias if self.bias is not None else output
 
     def __repr__(self):
@@ -145,7 +145,8 @@ class ChromeGCN(nn.Module):
 
     def forward(self, x_in, adj, deg=None, src_dict=None, return_gate=False):
         ops._require_cuda(x_in, "x_in")
-        graph = as_graph(adj, x_in.device)
+        # adj=None: the reference's GraphConvolution then skips the aggregation (SubLayers.py:45-48), i.e. A = I
+        graph = as_graph(adj, x_in.device, n=x_in.shape[0])
         x, gates = self._gated_stack(x_in.unsqueeze(0), graph, self._step_rng())
         out = self._head(x).squeeze(0)
         gs = [g.view(-1, 1) for g in gates]  # [n,1] like sigmoid(Linear(d,1)(z))
@@ -157,20 +158,21 @@ class ChromeGCN(nn.Module):
         """Both strands of finetune.py:41-42 in one pass over the graph.
         x_fr: [2, n, d] (forward strand, reverse-complement strand).  Returns (logits [2,n,C], gates)."""
         ops._require_cuda(x_fr, "x_fr")
-        graph = as_graph(adj, x_fr.device)
+        graph = as_graph(adj, x_fr.device, n=x_fr.shape[1])
         x, gates = self._gated_stack(x_fr, graph, self._step_rng())
         return self._head(x), gates
 
-    def forward_loss(self, x_fr, adj, target, h1_cache=None):
+    def forward_loss(self, x_fr, adj, target, h1_cache=None, out_slots=None):
         """The whole per-chromosome forward of the GCN stage (finetune.py:41-45,52) in fused kernels:
         gated stack on both strands, then ReLU/BatchNorm/dropout/Linear/strand-mean/BCE.  The last gated
         layer and the head form one autograd node (ops.LastLayerHeadLossFn).
         h1_cache: optional dict holder for H1 = A X of the FIRST layer.  H1 depends on the graph and the input
         features only, not on any weight, so a caller whose features are fixed (GCNStage: they never change
         across epochs) computes it on the first call and streams it afterwards instead of repeating the gather.
+        out_slots: optional {'probs': [n,C], 'loss': [1]} views the head writes its results into (ops._out_slots).
         Returns (loss [], probs [n,C] = sigmoid(pred), gates)."""
         ops._require_cuda(x_fr, "x_fr")
-        graph = as_graph(adj, x_fr.device)
+        graph = as_graph(adj, x_fr.device, n=x_fr.shape[1])
         rng = self._step_rng()
         L = self.n_layers
         x, gates = self._gated_stack(x_fr, graph, rng, upto=L - 1, h1_cache=h1_cache)
@@ -179,5 +181,6 @@ class ChromeGCN(nn.Module):
         loss, probs, g = ops.last_layer_head_loss(
             x, gc, wk, bn, out, graph, target, self.training, p, p if L > 1 else 0.0, rng, L,
             layer_sink=self._sink(gc.weight, gc.bias, wk.weight, wk.bias),
-            head_sink=self._sink(bn.weight, bn.bias, out.weight, out.bias), h_cache=h1_cache if L == 1 else None)
+            head_sink=self._sink(bn.weight, bn.bias, out.weight, out.bias), h_cache=h1_cache if L == 1 else None,
+            out_slots=out_slots)
         return loss, probs, gates + [g]

@@ -29,10 +29,12 @@ def _dense(t: torch.Tensor) -> torch.Tensor:
     return t.clone() if t.data_ptr() % 16 else t
 
 
-def _check_feat(x: torch.Tensor, g: ChromGraph, name="x"):
+def _check_feat(x: torch.Tensor, g: ChromGraph, name="x", any_width=False):
     _require_cuda(x, name)
-    if x.dim() != 3 or x.shape[0] not in (1, 2) or x.shape[2] not in SUPPORTED_D:
-        raise RuntimeError("chromegcn_amd: %s must be [S in {1,2}, n, d in {128,256}], got %s" % (name, tuple(x.shape)))
+    ok_d = (x.dim() == 3 and x.shape[2] % 4 == 0 and 4 <= x.shape[2] <= 4096) if any_width else (x.dim() == 3 and x.shape[2] in SUPPORTED_D)
+    if x.dim() != 3 or x.shape[0] not in (1, 2) or not ok_d:
+        raise RuntimeError("chromegcn_amd: %s must be [S in {1,2}, n, d %s], got %s" %
+                           (name, "a multiple of 4, <= 4096" if any_width else "in {128,256}", tuple(x.shape)))
     if x.shape[1] != g.n:
         raise RuntimeError("chromegcn_amd: %s has %d nodes but the graph has %d" % (name, x.shape[1], g.n))
 
@@ -42,7 +44,7 @@ class SpmmFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, graph: ChromGraph):
-        _check_feat(x, graph)
+        _check_feat(x, graph, any_width=True)
         x = _dense(x)
         S, n, d = x.shape
         y = torch.empty_like(x)
@@ -85,6 +87,10 @@ def sddmm(a, b, graph: ChromGraph, transposed=False):
     return out
 
 
+_EVAL_BWD_MSG = ("chromegcn_amd: backward through the fused classifier head needs train mode (the eval-mode kernel "
+                 "saves nothing for it); call model.train(), or use ChromeGCN.forward / forward_strands, whose "
+                 "torch head differentiates in eval mode like the reference's")
+
 _saliency_tap = None  # set by chromegcn_amd.saliency while it collects per-layer (X, dUs, W)
 
 
@@ -107,6 +113,18 @@ def _store_h_cache(h_cache, h_in, h):
     if h_cache is not None and h is not None:
         h_cache["h"] = h
     return h
+
+
+def _out_slots(out_slots, n, C, device):
+    """(probs [n,C], loss [1]) buffers for the fused head.  out_slots: None, or a holder {'probs': [n,C] view,
+    'loss': [1] view} into caller-owned arenas (GCNStage lays every chromosome's predictions out in one buffer in
+    chromosome order, so a split's concatenated predictions -- finetune.py:52 -- need no copy at all)."""
+    if out_slots is not None:
+        probs, loss = out_slots["probs"], out_slots["loss"]
+        if tuple(probs.shape) != (n, C) or loss.numel() != 1 or not probs.is_contiguous() or probs.device != device:
+            raise RuntimeError("chromegcn_amd: out_slots do not match [n, C] = [%d, %d]" % (n, C))
+        return probs, loss.view(1)
+    return (torch.empty((n, C), device=device, dtype=torch.float32), torch.empty(1, device=device, dtype=torch.float32))
 
 
 def _sink_ok(sink, shapes):
@@ -213,7 +231,7 @@ class HeadLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, bn_w, bn_b, w_out, b_out, target, run_mean, run_var, nbt, momentum, eps, training,
-                dropout_p, rng_state, grad_sink):
+                dropout_p, rng_state, grad_sink, out_slots=None):
         _require_cuda(x, "x")
         for t, nm in ((bn_w, "bn weight"), (bn_b, "bn bias"), (w_out, "out.weight"), (b_out, "out.bias"), (target, "target")):
             _require_cuda(t, nm)
@@ -232,8 +250,8 @@ class HeadLossFn(torch.autograd.Function):
             raise RuntimeError("chromegcn_amd: fused head does not support S=%d n=%d d=%d C=%d" % (S, n, d, C))
         ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8)
         need_bwd = training and any(ctx.needs_input_grad[:5])
-        probs = torch.empty((n, C), device=x.device, dtype=torch.float32)
-        loss = torch.empty(1, device=x.device, dtype=torch.float32)
+        ctx.eval_grad = (not training) and any(ctx.needs_input_grad[:5])
+        probs, loss = _out_slots(out_slots, n, C, x.device)
         dpred = torch.empty((n, C), device=x.device, dtype=torch.float32) if need_bwd else None
         save_mean = torch.empty((S, d), device=x.device, dtype=torch.float32) if training else None
         save_invstd = torch.empty((S, d), device=x.device, dtype=torch.float32) if training else None
@@ -255,6 +273,8 @@ class HeadLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dloss, _dprobs):
+        if ctx.eval_grad:
+            raise RuntimeError(_EVAL_BWD_MSG)
         x, bn_w, bn_b, w_out, dpred, save_mean, save_invstd, rng_state = ctx.saved_tensors
         S, n, d = x.shape
         C = w_out.shape[0]
@@ -276,8 +296,8 @@ class HeadLossFn(torch.autograd.Function):
                                      dw_out.data_ptr(), db_out.data_ptr(), dbn_w.data_ptr(), dbn_b.data_ptr(), 0,
                                      ws.data_ptr(), ws_bytes), "cgcn_head_bwd")
         if ctx.sink is not None:
-            return (dx,) + (None,) * 14
-        return (dx, dbn_w, dbn_b, dw_out, db_out) + (None,) * 10
+            return (dx,) + (None,) * 15
+        return (dx, dbn_w, dbn_b, dw_out, db_out) + (None,) * 11
 
 
 class LastLayerHeadLossFn(torch.autograd.Function):
@@ -288,7 +308,8 @@ class LastLayerHeadLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gate_w, gate_b, bn_w, bn_b, w_out, b_out, graph, target, run_mean, run_var, nbt,
-                momentum, eps, training, dropout_p, dropout_in, rng_state, layer_id, layer_sink, head_sink, h_cache):
+                momentum, eps, training, dropout_p, dropout_in, rng_state, layer_id, layer_sink, head_sink, h_cache,
+                out_slots=None):
         _check_feat(x, graph)
         for t, nm in ((weight, "weight"), (bias, "bias"), (gate_w, "gate weight"), (gate_b, "gate bias"),
                       (bn_w, "bn weight"), (bn_b, "bn bias"), (w_out, "out.weight"), (b_out, "out.bias"), (target, "target")):
@@ -305,6 +326,7 @@ class LastLayerHeadLossFn(torch.autograd.Function):
         wg, cg = gate_w.contiguous().view(-1), gate_b.contiguous().view(-1)
         bn_w, bn_b, w_out, b_out = _dense(bn_w), _dense(bn_b), _dense(w_out), b_out.contiguous()
         need_bwd = training and any(ctx.needs_input_grad[:9])
+        ctx.eval_grad = (not training) and any(ctx.needs_input_grad[:9])
         lib = _lib.load()
         xn = torch.empty_like(x)
         gate = torch.empty((S, n), device=x.device, dtype=torch.float32)
@@ -326,8 +348,7 @@ class LastLayerHeadLossFn(torch.autograd.Function):
         if ws_bytes == 0:
             raise RuntimeError("chromegcn_amd: fused head does not support S=%d n=%d d=%d C=%d" % (S, n, d, C))
         ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8)
-        probs = torch.empty((n, C), device=x.device, dtype=torch.float32)
-        loss = torch.empty(1, device=x.device, dtype=torch.float32)
+        probs, loss = _out_slots(out_slots, n, C, x.device)
         save_mean = torch.empty((S, d), device=x.device, dtype=torch.float32) if training else None
         save_invstd = torch.empty((S, d), device=x.device, dtype=torch.float32) if training else None
         drop = bool(training) and dropout_p > 0
@@ -365,6 +386,8 @@ class LastLayerHeadLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dloss, _dprobs, _dgate):
+        if ctx.eval_grad:
+            raise RuntimeError(_EVAL_BWD_MSG)
         (x, z, h, gate, weight, wg, xn, bn_w, bn_b, w_out, hws, save_mean, save_invstd, rng_state) = ctx.saved_tensors
         g = ctx.graph
         S, n, d = x.shape
@@ -383,7 +406,7 @@ class LastLayerHeadLossFn(torch.autograd.Function):
             dw, db, dwg, dcg = torch.empty_like(weight), torch.empty(d, **f32), torch.empty(d, **f32), torch.empty(1, **f32)
         hws_bytes = hws.numel()
         if dloss is None:
-            return (None,) * 24
+            return (None,) * 25
         dloss = dloss.contiguous().view(1)
         # dym, bnc and the partials are already in the workspace cgcn_head_train filled (for d loss = 1); every head
         # gradient is finished inside cgcn_layer_bwd (cgcn_head_grad.dloss / dbn_w / dbn_b), so no head launch here
@@ -406,21 +429,22 @@ class LastLayerHeadLossFn(torch.autograd.Function):
                                       max(ctx.layer_id - 1, 0), ctypes.byref(hg), ws.data_ptr(), ws_bytes, _lib.aux_stream_ptr()), "cgcn_layer_bwd")
         gl = (None,) * 4 if ctx.layer_sink is not None else (dw, db, dwg.view(ctx.shapes[0]), dcg.view(ctx.shapes[1]))
         gh = (None,) * 4 if ctx.head_sink is not None else (dbn_w, dbn_b, dw_out, db_out)
-        return (dx,) + gl + gh + (None,) * 15
+        return (dx,) + gl + gh + (None,) * 16
 
 
 def last_layer_head_loss(x, gc, wk, bn, out, graph, target, training, dropout_p, dropout_in, rng_state, layer_id,
-                         layer_sink=None, head_sink=None, h_cache=None):
+                         layer_sink=None, head_sink=None, h_cache=None, out_slots=None):
     return LastLayerHeadLossFn.apply(x, gc.weight, gc.bias, wk.weight, wk.bias, bn.weight, bn.bias, out.weight, out.bias,
                                      graph, target, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum,
                                      bn.eps, bool(training), float(dropout_p), float(dropout_in), rng_state, int(layer_id),
-                                     layer_sink, head_sink, h_cache)
+                                     layer_sink, head_sink, h_cache, out_slots)
 
 
-def head_loss(x, bn: torch.nn.BatchNorm1d, out: torch.nn.Linear, target, training, dropout_p, rng_state, grad_sink=None):
+def head_loss(x, bn: torch.nn.BatchNorm1d, out: torch.nn.Linear, target, training, dropout_p, rng_state, grad_sink=None,
+              out_slots=None):
     return HeadLossFn.apply(x, bn.weight, bn.bias, out.weight, out.bias, target, bn.running_mean, bn.running_var,
                             bn.num_batches_tracked, bn.momentum, bn.eps, bool(training), float(dropout_p), rng_state,
-                            grad_sink)
+                            grad_sink, out_slots)
 
 
 def sgd_step(flat_param, flat_grad, flat_mom, lr, momentum, weight_decay, nesterov, rng_state=None, grad_scale=1.0):

@@ -62,6 +62,8 @@ const char *cgcn_strerror(int code);
  * Y[s,i,:] = row_scale[i] * sum_{k in row i} val[k] * X[s, col[k], :]
  * Unfused sparse aggregation.  Replaces torch.spmm(adj, support), models/SubLayers.py:46.
  * X, Y: [S, n_cols, d] and [S, n_rows, d]; X and Y must not alias.
+ * d: any multiple of 4 up to 4096 (GraphConvolution takes arbitrary in/out widths, models/SubLayers.py:8-12);
+ * d = 128 / 256 run tuned kernels.  The fused gated layer below needs d in {128, 256}.
  */
 int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d,
               const int32_t *rowptr, const int32_t *col, const float *val, const float *row_scale,

@@ -221,12 +221,14 @@ def layer_backward_np(a_norm: sp.csr_matrix, x: np.ndarray, w: np.ndarray, wg: n
 # Stage loop (finetune.py:9-67) and its timer (runner.py:10-23)
 # --------------------------------------------------------------------------- #
 def finetune_epoch(model: nn.Module, chrom_feature_dict, split_adj_dict, optimizer, split: str,
-                   adj_type: str = "hic", adj_cache: Optional[dict] = None):
+                   adj_type: str = "hic", adj_cache: Optional[dict] = None, input_grads: Optional[dict] = None):
     """CPU restatement of the reference GCN-stage loop body, finetune.py:29-53, minus the
     hard-coded .cuda() calls (:30-36) that make the original unrunnable without a GPU.
     Returns (all_preds, all_targets, total_loss) exactly like finetune.py:67.
     adj_cache (optional dict) lets a caller hoist process_graph out of the timed loop; the
-    reference recomputes it every chromosome every epoch (finetune.py:36)."""
+    reference recomputes it every chromosome every epoch (finetune.py:36).
+    input_grads (optional dict) receives {chrom: (x_f.grad, x_r.grad)}: finetune.py:33-34 makes the features
+    require grad, but the loop-local tensors die with the iteration; tests need them to check d loss / d features."""
     model.train() if split == "train" else model.eval()  # :10-13
     all_preds = torch.Tensor()
     all_targets = torch.Tensor()
@@ -250,6 +252,8 @@ def finetune_epoch(model: nn.Module, chrom_feature_dict, split_adj_dict, optimiz
         if split == "train":
             loss.backward()  # :48
             optimizer.step()  # :49
+            if input_grads is not None:
+                input_grads[chrom] = (x_f.grad.detach().clone(), x_r.grad.detach().clone())
         total_loss += loss.sum().item()  # :51
         all_preds = torch.cat((all_preds, torch.sigmoid(pred).detach()), 0)  # :52
         all_targets = torch.cat((all_targets, targets.detach().float()), 0)  # :53

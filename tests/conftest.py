@@ -12,6 +12,13 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The library is never compiled implicitly by the product (chromegcn_amd/_build.py).  The test session builds
+    # it here -- explicitly, once, before anything has touched the GPU -- when the tree's sources are newer than
+    # the in-tree .so (content hash, not mtime: the prebuilt library that travels to the GPU box stays valid).
+    if os.environ.get("PYTEST_XDIST_WORKER") is None:
+        from chromegcn_amd import _build
+        if _build.is_stale() and _build.hipcc_path() is not None:
+            _build.build_library()
 
 
 def pytest_collection_modifyitems(config, items):

@@ -93,4 +93,4 @@ def test_sgd_and_spmm_argument_checks(env):
     y = torch.empty_like(env["x"])
     assert lib.cgcn_spmm(_lib.stream_ptr(), env["n"], env["n"], env["S"], env["d"], P(g.rowptr), P(g.col), None, P(g.row_scale), P(env["x"]), P(y)) == OK
     assert lib.cgcn_spmm(_lib.stream_ptr(), env["n"], env["n"], env["S"], env["d"], None, P(g.col), None, P(g.row_scale), P(env["x"]), P(y)) == BAD_ARG
-    assert lib.cgcn_spmm(_lib.stream_ptr(), env["n"], env["n"], env["S"], 96, P(g.rowptr), P(g.col), None, P(g.row_scale), P(env["x"]), P(y)) == UNSUPPORTED
+    assert lib.cgcn_spmm(_lib.stream_ptr(), env["n"], env["n"], env["S"], 98, P(g.rowptr), P(g.col), None, P(g.row_scale), P(env["x"]), P(y)) == UNSUPPORTED

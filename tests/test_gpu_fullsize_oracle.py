@@ -1,0 +1,109 @@
+"""Full-size parity against the ORACLE (not against the build's own kernels): whole train steps of the HIP engine in
+the reference's semantics -- all four aggregations, d loss / d features, SGD -- versus oracle.finetune_epoch on the host,
+at BASELINE.json's shapes:
+
+  config1   n =  5 000, 125 k pairs            (configs[0])
+  chr21     n =  5 776, 250 k pairs            (configs[1]; feature table 5.9 MB: shallow-batch gather kernels)
+  chr1      n = 29 910, 250 k pairs, hic-like  (feature table 30.6 MB: the DEEP = true gather kernels, only reachable
+                                                at this size)
+  both13k   n = 13 000, 'both' adjacency       (explicit-value CSR, table 13.3 MB > 12 MB: HAS_VAL + DEEP kernels)
+
+Checked per step: loss, sigmoid(pred), every parameter gradient, d loss / d features of both strands, the parameters
+after the SGD step, BatchNorm running statistics.  Tolerance: fp32 atol = rtol = 1e-4 (north star) on every tensor,
+AND -- because gradients of a mean-reduced loss are ~1e-6 and pass any absolute 1e-4 -- the scale-relative error
+max|hip - oracle| / max|oracle| <= 1e-4 for every gradient; the measured figures are printed."""
+import numpy as np
+import pytest
+import torch
+
+import chromegcn_amd as C
+from chromegcn_amd import synth
+from chromegcn_amd.finetune import GCNStage
+from oracle import chromegcn_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+D, NC = 128, 103
+CASES = [
+    ("config1", 5000, 125000, False, "hic", 0),
+    ("chr21", synth.chrom_nodes("chr21"), 250000, False, "hic", 21),
+    ("chr1", synth.chrom_nodes("chr1"), 250000, True, "hic", 1),
+    ("both13k", 13000, 60000, True, "both", 7),
+]
+
+
+def _scaled_oracle(seed):
+    torch.manual_seed(seed)
+    orc = O.GatedGCNOracle(D, NC, 0.0, 2)
+    with torch.no_grad():  # the reference init (gain 0.02) leaves tanh / gates in their linear range: scale up
+        orc.GC1.weight.mul_(40)
+        orc.GC2.weight.mul_(40)
+        orc.W1.weight.mul_(3)
+        orc.W2.weight.mul_(3)
+    return orc
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_train_steps_match_oracle_at_full_size(case):
+    name, n, pairs, hic_like, adj_type, seed = case
+    feats = synth.chrom_features(n, D, NC, 1000 + seed)
+    hic = synth.contact_graph(n, pairs, seed, hic_like)
+    orc = _scaled_oracle(seed)
+    model = C.ChromeGCN(D, D, NC, 0.0, True, 2)
+    model.load_state_dict(orc.state_dict())
+    model.to(DEV)
+    opt = torch.optim.SGD(model.parameters(), lr=0.25, momentum=0.9, weight_decay=1e-6)
+    stage = GCNStage(model, opt, adj_type, DEV, hip_graphs=True, input_grad=True, cache_input_aggregation=False)
+    stage.add_chromosome(name, feats, hic)
+    oopt = O.make_sgd(orc, 0.25)
+    cache = {}
+    worst = {}
+    for step in range(2):
+        loss, probs, dx = stage.train_step(name)
+        torch.cuda.synchronize()
+        grads_hip = {k: p.grad.detach().cpu().numpy().copy() for k, p in model.named_parameters()}
+        ig = {}
+        preds, _, tot = O.finetune_epoch(orc, {name: feats}, {name: hic}, oopt, "train", adj_type, adj_cache=cache, input_grads=ig)
+        assert abs(loss.item() - tot) <= 1e-4 + 1e-4 * abs(tot), (step, loss.item(), tot)
+        np.testing.assert_allclose(probs.cpu().numpy(), preds.numpy(), atol=1e-4, rtol=1e-4, err_msg="probs step %d" % step)
+        # d loss / d features, both strands
+        dxo = np.stack([ig[name][0].numpy(), ig[name][1].numpy()])
+        np.testing.assert_allclose(dx.cpu().numpy(), dxo, atol=1e-4, rtol=1e-4)
+        worst["dx"] = max(worst.get("dx", 0.0), _rel(dx.cpu().numpy(), dxo))
+        # every parameter gradient (the oracle's .grad survives its optimizer.step())
+        for k, p in orc.named_parameters():
+            np.testing.assert_allclose(grads_hip[k], p.grad.numpy(), atol=1e-4, rtol=1e-4, err_msg=k)
+            worst["d" + k] = max(worst.get("d" + k, 0.0), _rel(grads_hip[k], p.grad.numpy()))
+        # parameters after the SGD step + BatchNorm running statistics
+        osd = orc.state_dict()
+        for k, v in model.state_dict().items():
+            tol = 1e-5 if "running" in k else 1e-4
+            np.testing.assert_allclose(v.cpu().numpy(), osd[k].numpy(), atol=tol, rtol=tol, err_msg="%s after step %d" % (k, step))
+    print("\n[%s] scale-relative max errors vs oracle:" % name, {k: "%.2e" % v for k, v in sorted(worst.items())})
+    bad = {k: v for k, v in worst.items() if v > 1e-4}
+    assert not bad, "scale-relative gradient error above 1e-4: %s" % bad
+
+
+def test_eval_forward_matches_oracle_at_chr1_size():
+    """inference path (eval-mode BatchNorm, no dropout) through the DEEP gather kernels"""
+    name, n, pairs, hic_like, adj_type, seed = CASES[2]
+    feats = synth.chrom_features(n, D, NC, 1000 + seed)
+    hic = synth.contact_graph(n, pairs, seed, hic_like)
+    orc = _scaled_oracle(seed)
+    with torch.no_grad():
+        orc.batch_norm.running_mean.uniform_(-0.2, 0.2)
+        orc.batch_norm.running_var.uniform_(0.5, 1.5)
+    model = C.ChromeGCN(D, D, NC, 0.0, True, 2)
+    model.load_state_dict(orc.state_dict())
+    model.to(DEV)
+    stage = GCNStage(model, None, adj_type, DEV, hip_graphs=True)
+    stage.add_chromosome(name, feats, hic)
+    loss, probs = stage.eval_step(name)
+    preds, _, tot = O.finetune_epoch(orc, {name: feats}, {name: hic}, None, "valid", adj_type)
+    assert abs(loss.item() - tot) <= 1e-4 + 1e-4 * abs(tot)
+    np.testing.assert_allclose(probs.cpu().numpy(), preds.numpy(), atol=1e-4, rtol=1e-4)

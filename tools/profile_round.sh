@@ -1,17 +1,24 @@
 #!/bin/bash
-# Collects the rocprofv3 evidence for one round on the GPU box (run through gpurun):
-#   tools/profile_round.sh <tag>      e.g. r01f
-# kernel-trace/stats pass and four separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_*, MFMA/LDS), never combined with
-# sys/hip/hsa traces.  Raw output: gpurun_out/<tag>/ ; summaries: gpurun_out/<tag>/summary/ (copy those to profiles/).
+# Collects the rocprofv3 evidence for one workload on the GPU box (run through gpurun):
+#   tools/profile_round.sh <tag> <workload-name> [bench.py args ...]
+#   e.g. tools/profile_round.sh r02 genome
+#        tools/profile_round.sh r02 chr1_hic --workload chr1 --hic-like
+# One kernel-trace/stats pass and four separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_*, MFMA/LDS + L2 hit/miss), never
+# combined with sys/hip/hsa traces.  The program after `--` is python3 itself (no wrapper hop); the library must
+# already be built (chromegcn_amd._lib never compiles).  Raw output: gpurun_out/<tag>_<wl>/ ; summaries:
+# gpurun_out/<tag>_<wl>/summary/ (copy those to profiles/).
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}; WL=${2:-genome}; shift 2 || true
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-O=$R/gpurun_out/$TAG
+O=$R/gpurun_out/${TAG}_${WL}
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 "$R/bench.py" --steps 50 --warmup 5 --no-cpu-baseline > "$O/stats.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/fetch" -- python3 "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$O/fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/write" -- python3 "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$O/write.log" 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d "$O/sq" -- python3 "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$O/sq.log" 2>&1
-rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES --kernel-trace --output-format csv -d "$O/mfma" -- python3 "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$O/mfma.log" 2>&1
-python3 "$R/tools/summarize_profiles.py" "$O" "$TAG"
+B="$R/bench.py --no-cpu-baseline --no-extras $*"
+echo "$B" > "$O/cmd.txt"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 $B --steps 10 --warmup 3 > "$O/stats.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/fetch" -- python3 $B --steps 3 --warmup 1 > "$O/fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/write" -- python3 $B --steps 3 --warmup 1 > "$O/write.log" 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d "$O/sq" -- python3 $B --steps 3 --warmup 1 > "$O/sq.log" 2>&1
+rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES --kernel-trace --output-format csv -d "$O/mfma" -- python3 $B --steps 3 --warmup 1 > "$O/mfma.log" 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d "$O/l2" -- python3 $B --steps 3 --warmup 1 > "$O/l2.log" 2>&1
+python3 "$R/tools/summarize_profiles.py" "$O" "$TAG" "$WL" "$*"

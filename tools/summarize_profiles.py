@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Turns the raw rocprofv3 CSVs of tools/profile_round.sh into the small per-kernel summaries kept under profiles/."""
+"""Turns the raw rocprofv3 CSVs of tools/profile_round.sh into the small per-kernel summaries kept under profiles/:
+    <tag>_<wl>_kernel_stats.csv, <tag>_<wl>_pmc_{fetch_size,write_size,sq,mfma,l2}.csv, and the workload's entry of
+    traffic.json ({"<wl>_d<d>": {"bytes_per_launch", "tag", "fetch_KB", "write_KB", "launches"}})."""
 import csv, glob, json, os, sys
 from collections import defaultdict
 
@@ -30,60 +32,86 @@ def counters(d):
     return vals, durs
 
 
+def is_gather_fwd(k):
+    """the gathering variants of k_layer_fwd<S; D; MB; HAS_VAL; FROM_CACHE; DEEP...> (FROM_CACHE = false)"""
+    if not k.startswith("void k_layer_fwd<"):
+        return False
+    args = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(";")]
+    return len(args) >= 5 and args[4] == "false"
+
+
 def main():
-    root, tag = sys.argv[1], sys.argv[2]
+    root, tag, wl = sys.argv[1], sys.argv[2], sys.argv[3]
+    bargs = sys.argv[4] if len(sys.argv) > 4 else ""
+    d = 256 if "--d 256" in bargs else 128
     out = os.path.join(root, "summary")
     os.makedirs(out, exist_ok=True)
+    cmd = "python3 bench.py --no-cpu-baseline --no-extras %s" % bargs
     f = find(os.path.join(root, "stats"), "*kernel_stats.csv")
     if f:
         rows = list(csv.DictReader(open(f)))
-        with open(os.path.join(out, f"{tag}_kernel_stats_bench_chr21.csv"), "w") as o:
-            o.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline\n")
-            o.write("# (headline train steps + engine-default steps + bench.py's isolated k_layer_fwd launches for the roofline + eval)\n")
+        with open(os.path.join(out, f"{tag}_{wl}_kernel_stats.csv"), "w") as o:
+            o.write("# rocprofv3 --kernel-trace --stats -- %s --steps 10 --warmup 3\n" % cmd)
+            o.write("# (timed steps + bench.py's isolated k_layer_fwd launches for the roofline)\n")
             o.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
             for r in rows:
                 o.write("%s,%s,%s,%s,%s,%s,%s\n" % (short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]))
-    traffic = {}
     per = {}
     for cname, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
         vals, _ = counters(os.path.join(root, sub))
-        with open(os.path.join(out, f"{tag}_pmc_{cname.lower()}_bench_chr21.csv"), "w") as o:
-            o.write(f"# rocprofv3 --pmc {cname} --kernel-trace -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline ; mean per launch, unit KB (x1024 = bytes)\n")
+        with open(os.path.join(out, f"{tag}_{wl}_pmc_{cname.lower()}.csv"), "w") as o:
+            o.write(f"# rocprofv3 --pmc {cname} --kernel-trace -- {cmd} --steps 3 --warmup 1 ; mean per launch, unit KB (x1024 = bytes)\n")
             o.write("kernel,counter,launches,mean_KB\n")
             for k in sorted(vals, key=lambda k: -sum(vals[k][cname])):
                 v = vals[k][cname]
                 o.write("%s,%s,%d,%.1f\n" % (k, cname, len(v), sum(v) / len(v)))
-                per.setdefault(k, {})[cname] = sum(v) / len(v)
-    key = [k for k in per if k.startswith("void k_layer_fwd<2; 128; 1; false; false")]
-    if key and "FETCH_SIZE" in per[key[0]] and "WRITE_SIZE" in per[key[0]]:
-        fs, ws = per[key[0]]["FETCH_SIZE"], per[key[0]]["WRITE_SIZE"]
-        traffic = {"chr21_d128": (2 * fs + ws) * 1024,
-                   "_note": "k_layer_fwd<2,128,1,false,false>: (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes per launch; FETCH_SIZE=%.0f KB WRITE_SIZE=%.0f KB "
-                            "(rocprofv3 --pmc, separate passes, %s kernels). gfx950: FETCH_SIZE reports half the bytes of wide (16 B/lane) reads, hence the "
-                            "factor 2. FETCH_SIZE counts L2->fabric reads and includes Infinity-Cache hits, so this is traffic beyond L2, not HBM-only." % (fs, ws, tag)}
-        json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+                per.setdefault(k, {})[cname] = (sum(v), len(v))
+    fk = [k for k in per if is_gather_fwd(k) and "FETCH_SIZE" in per[k] and "WRITE_SIZE" in per[k]]
+    if fk:
+        fs = sum(per[k]["FETCH_SIZE"][0] for k in fk) / sum(per[k]["FETCH_SIZE"][1] for k in fk)
+        ws = sum(per[k]["WRITE_SIZE"][0] for k in fk) / sum(per[k]["WRITE_SIZE"][1] for k in fk)
+        ent = {"bytes_per_launch": (2 * fs + ws) * 1024, "tag": tag, "fetch_KB": fs, "write_KB": ws,
+               "launches": sum(per[k]["FETCH_SIZE"][1] for k in fk), "kernels": fk}
+        json.dump({"%s_d%d" % (wl, d): ent,
+                   "_note": "gathering k_layer_fwd variants, mean over their launches in one bench run: (2*FETCH_SIZE + WRITE_SIZE)*1024 "
+                            "bytes per launch (rocprofv3 --pmc, separate passes). gfx950: FETCH_SIZE reports half the bytes of wide (16 B/lane) "
+                            "reads, hence the factor 2 (MI355X_MICROARCH.md, HBM). FETCH_SIZE counts L2->fabric reads and includes "
+                            "Infinity-Cache hits: traffic beyond L2, not HBM-only."},
+                  open(os.path.join(out, "traffic_%s.json" % wl), "w"), indent=1)
     vals, durs = counters(os.path.join(root, "sq"))
     names = ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_INSTS_VMEM_RD"]
-    with open(os.path.join(out, f"{tag}_pmc_sq_bench_chr21.csv"), "w") as o:
-        o.write("# rocprofv3 --pmc " + " ".join(names) + " --kernel-trace -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline ; mean per launch; SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* are quad-cycles\n")
-        o.write("kernel,us," + ",".join(names) + "\n")
-        for k in sorted(vals, key=lambda k: -sum(durs[k])):
-            if not k.startswith(("void k_", "k_")):
-                continue
-            o.write("%s,%.1f,%s\n" % (k, sum(durs[k]) / len(durs[k]), ",".join("%d" % (sum(vals[k][c]) / max(1, len(vals[k][c]))) for c in names)))
+    if vals:
+        with open(os.path.join(out, f"{tag}_{wl}_pmc_sq.csv"), "w") as o:
+            o.write("# rocprofv3 --pmc " + " ".join(names) + " --kernel-trace -- %s --steps 3 --warmup 1 ; mean per launch; SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* are quad-cycles\n" % cmd)
+            o.write("kernel,launches,us," + ",".join(names) + "\n")
+            for k in sorted(vals, key=lambda k: -sum(durs[k])):
+                if not k.startswith(("void k_", "k_")):
+                    continue
+                o.write("%s,%d,%.1f,%s\n" % (k, len(durs[k]), sum(durs[k]) / len(durs[k]), ",".join("%d" % (sum(vals[k][c]) / max(1, len(vals[k][c]))) for c in names)))
     vals, durs = counters(os.path.join(root, "mfma"))
     names = ["SQ_BUSY_CU_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_WAVE_CYCLES"]
     if vals:
-        with open(os.path.join(out, f"{tag}_pmc_mfma_bench_chr21.csv"), "w") as o:
-            o.write("# rocprofv3 --pmc " + " ".join(names) + " --kernel-trace -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline ; mean per launch.\n")
+        with open(os.path.join(out, f"{tag}_{wl}_pmc_mfma.csv"), "w") as o:
+            o.write("# rocprofv3 --pmc " + " ".join(names) + " --kernel-trace -- %s --steps 3 --warmup 1 ; mean per launch.\n" % cmd)
             o.write("# mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel duration x 2.4 GHz): fraction of the chip's MFMA issue slots in use\n")
-            o.write("kernel,us," + ",".join(names) + ",mfma_util\n")
+            o.write("kernel,launches,us," + ",".join(names) + ",mfma_util\n")
             for k in sorted(vals, key=lambda k: -sum(durs[k])):
                 if not k.startswith(("void k_", "k_")):
                     continue
                 us = sum(durs[k]) / len(durs[k])
                 mean = {c: sum(vals[k][c]) / max(1, len(vals[k][c])) for c in names}
-                o.write("%s,%.1f,%s,%.3f\n" % (k, us, ",".join("%d" % mean[c] for c in names), mean["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * us * 2400.0)))
+                o.write("%s,%d,%.1f,%s,%.3f\n" % (k, len(durs[k]), us, ",".join("%d" % mean[c] for c in names), mean["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * us * 2400.0)))
+    vals, durs = counters(os.path.join(root, "l2"))
+    if vals:
+        with open(os.path.join(out, f"{tag}_{wl}_pmc_l2.csv"), "w") as o:
+            o.write("# rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace -- %s --steps 3 --warmup 1 ; mean per launch; hit rate = HIT / (HIT + MISS)\n" % cmd)
+            o.write("kernel,launches,us,TCC_HIT_sum,TCC_MISS_sum,l2_hit_rate\n")
+            for k in sorted(vals, key=lambda k: -sum(durs[k])):
+                if not k.startswith(("void k_", "k_")):
+                    continue
+                h = sum(vals[k]["TCC_HIT_sum"]) / max(1, len(vals[k]["TCC_HIT_sum"]))
+                m = sum(vals[k]["TCC_MISS_sum"]) / max(1, len(vals[k]["TCC_MISS_sum"]))
+                o.write("%s,%d,%.1f,%d,%d,%.3f\n" % (k, len(durs[k]), sum(durs[k]) / len(durs[k]), h, m, h / max(1.0, h + m)))
     print("summaries in", out, os.listdir(out))
 
 
