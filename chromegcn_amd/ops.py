@@ -39,38 +39,12 @@ def _check_feat(x: torch.Tensor, g: ChromGraph, name="x", any_width=False):
         raise RuntimeError("chromegcn_amd: %s has %d nodes but the graph has %d" % (name, x.shape[1], g.n))
 
 
-class SpmmFn(torch.autograd.Function):
-    """Y = diag(row_scale) Ahat X  (torch.spmm of models/SubLayers.py:46)."""
-
-    @staticmethod
-    def forward(ctx, x, graph: ChromGraph):
-        _check_feat(x, graph, any_width=True)
-        x = _dense(x)
-        S, n, d = x.shape
-        y = torch.empty_like(x)
-        lib = _lib.load()
-        _lib.check(lib.cgcn_spmm(_lib.stream_ptr(), n, n, S, d, _lib.ptr(graph.rowptr), _lib.ptr(graph.col),
-                                 _lib.ptr(graph.val), _lib.ptr(graph.row_scale), x.data_ptr(), y.data_ptr()), "cgcn_spmm")
-        ctx.graph = graph
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        g = ctx.graph
-        dy = _dense(dy)
-        S, n, d = dy.shape
-        # A^T dY = Ahat^T (diag(row_scale) dY)
-        if g.row_scale is not None:
-            dy = dy * g.row_scale.view(1, n, 1)
-        dx = torch.empty_like(dy)
-        lib = _lib.load()
-        _lib.check(lib.cgcn_spmm(_lib.stream_ptr(), n, n, S, d, _lib.ptr(g.rowptr_t), _lib.ptr(g.col_t),
-                                 _lib.ptr(g.val_t), None, dy.data_ptr(), dx.data_ptr()), "cgcn_spmm(T)")
-        return dx, None
-
-
 def spmm(x, graph):
-    return SpmmFn.apply(x, graph)
+    """registered operator torch.ops.chromegcn.spmm (chromegcn_amd/torch_ops.py) on the graph's CSR tensors"""
+    _check_feat(x, graph, any_width=True)
+    from . import torch_ops  # noqa: F401  (registers the ops)
+    return torch.ops.chromegcn.spmm(x, graph.rowptr, graph.col, graph.val, graph.row_scale, graph.rowptr_t, graph.col_t,
+                                    graph.val_t)
 
 
 def sddmm(a, b, graph: ChromGraph, transposed=False):
@@ -219,6 +193,16 @@ class GatedLayerFn(torch.autograd.Function):
 
 def gated_layer(x, weight, bias, gate_w, gate_b, graph, dropout_out=0.0, dropout_in=0.0, rng_state=None,
                 layer_id=0, grad_sink=None, h_cache=None):
+    """One gated layer -> (X', gate).  Plain callers (ChromeGCN.forward, tests) go through the registered operator
+    torch.ops.chromegcn.gated_layer; the engine's extras (gradient sinks, cached aggregation, the saliency tap) need
+    the autograd node below."""
+    if grad_sink is None and h_cache is None and _saliency_tap is None:
+        _check_feat(x, graph)
+        from . import torch_ops  # noqa: F401
+        xn, gate, _z, _h = torch.ops.chromegcn.gated_layer(
+            x, weight, bias, gate_w, gate_b, graph.rowptr, graph.col, graph.val, graph.row_scale, graph.rowptr_t,
+            graph.col_t, graph.val_t, float(dropout_out), float(dropout_in), rng_state, int(layer_id))
+        return xn, gate
     return GatedLayerFn.apply(x, weight, bias, gate_w, gate_b, graph, float(dropout_out), float(dropout_in),
                               rng_state, int(layer_id), grad_sink, h_cache)
 
@@ -442,6 +426,10 @@ def last_layer_head_loss(x, gc, wk, bn, out, graph, target, training, dropout_p,
 
 def head_loss(x, bn: torch.nn.BatchNorm1d, out: torch.nn.Linear, target, training, dropout_p, rng_state, grad_sink=None,
               out_slots=None):
+    if grad_sink is None and out_slots is None:
+        from . import torch_ops
+        _require_cuda(x, "x")
+        return torch_ops.head_loss_module(x, bn, out, target, training, dropout_p, rng_state)  # torch.ops.chromegcn.head_loss
     return HeadLossFn.apply(x, bn.weight, bn.bias, out.weight, out.bias, target, bn.running_mean, bn.running_var,
                             bn.num_batches_tracked, bn.momentum, bn.eps, bool(training), float(dropout_p), rng_state,
                             grad_sink, out_slots)

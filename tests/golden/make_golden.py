@@ -17,6 +17,10 @@ Entry points exercised (reference file:line):
   G5  utils/metrics.py:148,168,238,25  fdr / aupr / auroc / mean_average_precision per label
   G6  utils/util_methods.py:183-199    save_feats: encoder outputs regrouped per chromosome (the
       chrom_feature_dict_<split>.pt contract between the window encoder and the GCN stage)
+  G7  models/WindowModels.py:9-87 Expecto + models/NonStrandSpecific.py:81-94 strand wrapper: the encoder whose
+      x_feat outputs are the GCN stage's node features (config 5).  The weights (tens of MB) are not recorded:
+      the reference encoder is built under a recorded torch seed, and the fixture holds the tokens, the outputs
+      and a few parameter checksums; the build's own encoder must reproduce them when built under the same seed.
 """
 import json
 import os
@@ -333,6 +337,32 @@ def make_g6():
     np.savez_compressed(os.path.join(HERE, "g6_save_feats.npz"), **out)
 
 
+def make_g7():
+    from models.WindowModels import Expecto  # reference
+    from models.NonStrandSpecific import GraphNonStrandSpecific  # reference
+    seed, L, C, B = 77, 600, 11, 4
+    torch.manual_seed(seed)
+    enc = Expecto(C, L)
+    g = torch.Generator().manual_seed(78)
+    with torch.no_grad():  # non-trivial BatchNorm statistics, drawn AFTER construction from a separate generator
+        for m in enc.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+    enc.eval()
+    tokens = torch.randint(0, 5, (B, L), generator=g)
+    src_dict = {"a": 0, "c": 1, "g": 2, "t": 3, "n": 4}
+    with torch.no_grad():
+        x_f, x_r, y, _, _ = GraphNonStrandSpecific(enc)(tokens, src_dict)
+    sd = enc.state_dict()
+    out = {"meta": np.array(json.dumps(dict(META, seed=seed, bn_seed=78, seq_length=L, nclass=C))),
+           "tokens": tokens.numpy(), "x_f": x_f.numpy(), "x_r": x_r.numpy(), "logits": y.numpy(),
+           "keys": np.array(list(sd.keys())),
+           "param_sums": np.array([float(v.double().sum()) for v in sd.values()]),
+           "param_numel": np.array([v.numel() for v in sd.values()])}
+    np.savez_compressed(os.path.join(HERE, "g7_encoder.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(1)  # fixed reduction order for the recorded values
@@ -340,7 +370,7 @@ if __name__ == "__main__":
         for name in sys.argv[1:]:
             globals()["make_" + name]()
     else:
-        make_g1(); make_g2(); make_g3(); make_g4(); make_g5(); make_g6()
+        make_g1(); make_g2(); make_g3(); make_g4(); make_g5(); make_g6(); make_g7()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

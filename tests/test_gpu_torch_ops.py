@@ -1,0 +1,125 @@
+"""torch.library.opcheck on the registered operators (schema, fake tensors, autograd registration, AOT dispatch) and
+their values against the oracle; ChromeGCN.forward -- which runs through these operators -- is checked against the
+reference's golden vectors in tests/test_gpu_parity.py (G3)."""
+import numpy as np
+import pytest
+import torch
+
+import chromegcn_amd as C
+from chromegcn_amd import graph as G, torch_ops
+from oracle import chromegcn_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _graph(n, pairs, adj="hic", seed=1):
+    a = O.random_symmetric_graph(n, pairs, seed)
+    h = G.normalize_graph(adj, a, n)
+    return h, G.upload(h, DEV)
+
+
+def _csr(g):
+    return g.rowptr, g.col, g.val, g.row_scale, g.rowptr_t, g.col_t, g.val_t
+
+
+@pytest.mark.parametrize("S,d,adj", [(2, 128, "hic"), (1, 256, "both"), (1, 36, "hic")])
+def test_opcheck_spmm(S, d, adj):
+    h, g = _graph(150, 900, adj)
+    x = torch.randn(S, 150, d, device=DEV, requires_grad=True)
+    torch.library.opcheck(torch.ops.chromegcn.spmm.default, (x,) + _csr(g))
+
+
+@pytest.mark.parametrize("S,d,adj,p", [(2, 128, "hic", 0.0), (1, 256, "both", 0.0), (2, 128, "hic", 0.3)])
+def test_opcheck_gated_layer(S, d, adj, p):
+    n = 150
+    h, g = _graph(n, 900, adj)
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.randn(S, n, d, device=DEV, generator=gen, requires_grad=True)
+    W = (torch.randn(d, d, device=DEV, generator=gen) / d ** 0.5).requires_grad_(True)
+    b = (torch.randn(d, device=DEV, generator=gen) * 0.1).requires_grad_(True)
+    wg = (torch.randn(1, d, device=DEV, generator=gen) / d ** 0.5).requires_grad_(True)
+    cg = torch.zeros(1, device=DEV, requires_grad=True)
+    rng = torch.tensor([12345, 7], dtype=torch.int64, device=DEV) if p > 0 else None
+    args = (x, W, b, wg, cg, g.rowptr, g.col, g.val, g.row_scale, g.rowptr_t, g.col_t, g.val_t, p, p, rng, 2)
+    torch.library.opcheck(torch.ops.chromegcn.gated_layer.default, args)
+    xn, gate, z, hh = torch.ops.chromegcn.gated_layer(*args)
+    bargs = (torch.randn_like(xn), torch.randn_like(gate), x.detach(), z, hh, gate, W.detach(), wg.detach(), g.rowptr_t,
+             g.col_t, g.val_t, g.row_scale, p, rng, 2, True)
+    torch.library.opcheck(torch.ops.chromegcn.gated_layer_backward.default, bargs)
+
+
+@pytest.mark.parametrize("training,p", [(True, 0.0), (True, 0.25), (False, 0.0)])
+def test_opcheck_head_loss(training, p):
+    S, n, d, Cn = 2, 200, 128, 13
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    x = torch.randn(S, n, d, device=DEV, generator=gen, requires_grad=training)
+    bw = (1 + 0.1 * torch.randn(d, device=DEV, generator=gen)).requires_grad_(training)
+    bb = (0.1 * torch.randn(d, device=DEV, generator=gen)).requires_grad_(training)
+    Wo = (torch.randn(Cn, d, device=DEV, generator=gen) / d ** 0.5).requires_grad_(training)
+    bo = torch.zeros(Cn, device=DEV, requires_grad=training)
+    tgt = (torch.rand(n, Cn, device=DEV, generator=gen) < 0.1).float()
+    rm, rv = torch.zeros(d, device=DEV), torch.ones(d, device=DEV)
+    rng = torch.tensor([99, 3], dtype=torch.int64, device=DEV) if p > 0 else None
+    args = (x, bw, bb, Wo, bo, tgt, rm, rv, 0.1, 1e-5, training, p, rng)
+    torch.library.opcheck(torch.ops.chromegcn.head_loss.default, args)
+    assert torch.equal(rm, torch.zeros(d, device=DEV)) and torch.equal(rv, torch.ones(d, device=DEV))  # functional
+    if training:
+        loss, probs, sm, si, dp, nrm, nrv = torch.ops.chromegcn.head_loss(*args)
+        bargs = (torch.ones((), device=DEV), x.detach(), bw.detach(), bb.detach(), Wo.detach(), dp, sm, si, p, rng)
+        torch.library.opcheck(torch.ops.chromegcn.head_loss_backward.default, bargs)
+
+
+def test_opcheck_and_values_of_sgd_step():
+    n = 5000
+    p = torch.randn(n, device=DEV); g = torch.randn(n, device=DEV); m = torch.randn(n, device=DEV)
+    rng = torch.tensor([1, 41], dtype=torch.int64, device=DEV)
+    torch.library.opcheck(torch.ops.chromegcn.sgd_step.default, (p.clone(), g, m.clone(), 0.25, 0.9, 1e-6, False, 0.5, rng.clone()))
+    p2, m2 = p.clone(), m.clone()
+    torch.ops.chromegcn.sgd_step(p2, g, m2, 0.25, 0.9, 1e-6, False, 0.5, rng)
+    d = 0.5 * g + 1e-6 * p
+    mm = 0.9 * m + d
+    assert torch.allclose(m2, mm, atol=1e-6) and torch.allclose(p2, p - 0.25 * mm, atol=1e-6) and int(rng[1]) == 42
+
+
+def test_head_loss_module_updates_batchnorm_like_two_forward_calls():
+    """head_loss_module applies the functional operator's returned running statistics: same buffers as the oracle model
+    after its forward + reverse strand calls"""
+    n, d, Cn = 300, 128, 9
+    torch.manual_seed(2)
+    orc = O.GatedGCNOracle(d, Cn, 0.0, 1)
+    x = torch.randn(2, n, d)
+    tgt = (torch.rand(n, Cn) < 0.2).float()
+    orc.train()
+    # the oracle's head on a pre-activation tensor: relu -> BN -> Linear (models/ChromeModels.py:48-51), strand by strand
+    preds = [orc.out(orc.batch_norm(torch.relu(x[s]))) for s in range(2)]
+    want = torch.nn.functional.binary_cross_entropy_with_logits((preds[0] + preds[1]) / 2, tgt)
+    bn = torch.nn.BatchNorm1d(d).to(DEV); out = torch.nn.Linear(d, Cn).to(DEV)
+    out.load_state_dict(orc.out.state_dict())
+    loss, probs = torch_ops.head_loss_module(x.to(DEV), bn, out, tgt.to(DEV), True, 0.0, None)
+    assert abs(loss.item() - want.item()) < 1e-5
+    np.testing.assert_allclose(bn.running_mean.cpu().numpy(), orc.batch_norm.running_mean.numpy(), atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(bn.running_var.cpu().numpy(), orc.batch_norm.running_var.numpy(), atol=1e-5, rtol=1e-5)
+    assert int(bn.num_batches_tracked) == int(orc.batch_norm.num_batches_tracked) == 2
+
+
+def test_compiled_forward_through_the_registered_ops_matches_eager():
+    """torch.compile can trace ChromeGCN's gated stack because every kernel call is a registered operator with a fake
+    implementation (backend='eager': graph capture + functionalisation, no code generation)"""
+    n, d = 257, 128
+    h, g = _graph(n, 1500)
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(2, n, d, device=DEV, generator=gen)
+    W = torch.randn(d, d, device=DEV, generator=gen) / d ** 0.5
+    b = torch.randn(d, device=DEV, generator=gen) * 0.1
+    wg = torch.randn(1, d, device=DEV, generator=gen) / d ** 0.5
+    cg = torch.zeros(1, device=DEV)
+
+    def f(x, W, b, wg, cg):
+        xn, gate, _, _ = torch.ops.chromegcn.gated_layer(x, W, b, wg, cg, g.rowptr, g.col, g.val, g.row_scale, g.rowptr_t,
+                                                         g.col_t, g.val_t, 0.0, 0.0, None, 1)
+        y = torch.ops.chromegcn.spmm(xn, g.rowptr, g.col, g.val, g.row_scale, g.rowptr_t, g.col_t, g.val_t)
+        return y.relu().sum() + gate.mean()
+    want = f(x, W, b, wg, cg)
+    got = torch.compile(f, backend="eager", fullgraph=True)(x, W, b, wg, cg)
+    assert torch.allclose(got, want, rtol=1e-6, atol=1e-6)
