@@ -162,13 +162,12 @@ def _layer_setup(ctx, inputs, output):
     ctx.save_for_backward(x, z, h, gate, weight, gate_w, rowptr_t, col_t, val_t, row_scale, rng_state)
     ctx.dropout_in, ctx.layer_id = float(dropout_in), int(layer_id)
     ctx.gate_w_shape, ctx.gate_b_shape = gate_w.shape, gate_b.shape
+    ctx.mark_non_differentiable(z, h)     # saved activations handed to the backward, not differentiable results
     ctx.set_materialize_grads(False)
 
 
 def _layer_backward(ctx, dxn, dgate, dz, dh):
     x, z, h, gate, weight, gate_w, rowptr_t, col_t, val_t, row_scale, rng_state = ctx.saved_tensors
-    if dz is not None or dh is not None:
-        raise RuntimeError("chromegcn::gated_layer: Z and H are saved activations, not differentiable outputs")
     if dxn is None and dgate is None:
         return (None,) * 16
     if dxn is None:
@@ -271,6 +270,7 @@ def _head_setup(ctx, inputs, output):
     ctx.training = bool(training)
     ctx.dropout_p = float(dropout_p) if training else 0.0
     ctx.save_for_backward(x, bn_w, bn_b, w_out, dpred, save_mean, save_invstd, rng_state)
+    ctx.mark_non_differentiable(probs, save_mean, save_invstd, dpred, _rm, _rv)   # only the loss is differentiable
     ctx.set_materialize_grads(False)
 
 

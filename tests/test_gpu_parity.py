@@ -264,9 +264,14 @@ def test_cpu_inputs_fail_loudly():
 def test_bad_shapes_are_rejected():
     g = C.process_graph("none", None, 8, "c", device=DEV)
     with pytest.raises(RuntimeError):
-        ops.spmm(torch.randn(1, 8, 100, device=DEV), g)
+        ops.spmm(torch.randn(1, 8, 102, device=DEV), g)      # the bare aggregation takes any width % 4 == 0 ...
+    assert torch.allclose(ops.spmm(torch.ones(1, 8, 100, device=DEV), g), torch.ones(1, 8, 100, device=DEV))
     with pytest.raises(RuntimeError):
         ops.spmm(torch.randn(1, 9, 128, device=DEV), g)
+    w = torch.randn(100, 100, device=DEV)
+    with pytest.raises(RuntimeError):                         # ... the fused gated layer only 128 / 256
+        ops.gated_layer(torch.randn(1, 8, 100, device=DEV), w, torch.zeros(100, device=DEV), torch.zeros(1, 100, device=DEV),
+                        torch.zeros(1, device=DEV), g)
 
 
 def test_views_at_odd_storage_offsets_are_accepted():

@@ -44,8 +44,9 @@ def test_opcheck_gated_layer(S, d, adj, p):
     args = (x, W, b, wg, cg, g.rowptr, g.col, g.val, g.row_scale, g.rowptr_t, g.col_t, g.val_t, p, p, rng, 2)
     torch.library.opcheck(torch.ops.chromegcn.gated_layer.default, args)
     xn, gate, z, hh = torch.ops.chromegcn.gated_layer(*args)
-    bargs = (torch.randn_like(xn), torch.randn_like(gate), x.detach(), z, hh, gate, W.detach(), wg.detach(), g.rowptr_t,
-             g.col_t, g.val_t, g.row_scale, p, rng, 2, True)
+    assert xn.requires_grad and gate.requires_grad and not z.requires_grad and not hh.requires_grad
+    bargs = (torch.randn_like(xn).detach(), torch.randn_like(gate).detach(), x.detach(), z, hh, gate.detach(), W.detach(),
+             wg.detach(), g.rowptr_t, g.col_t, g.val_t, g.row_scale, p, rng, 2, True)
     torch.library.opcheck(torch.ops.chromegcn.gated_layer_backward.default, bargs)
 
 
@@ -66,6 +67,7 @@ def test_opcheck_head_loss(training, p):
     assert torch.equal(rm, torch.zeros(d, device=DEV)) and torch.equal(rv, torch.ones(d, device=DEV))  # functional
     if training:
         loss, probs, sm, si, dp, nrm, nrv = torch.ops.chromegcn.head_loss(*args)
+        assert loss.requires_grad and not any(t.requires_grad for t in (probs, sm, si, dp, nrm, nrv))
         bargs = (torch.ones((), device=DEV), x.detach(), bw.detach(), bb.detach(), Wo.detach(), dp, sm, si, p, rng)
         torch.library.opcheck(torch.ops.chromegcn.head_loss_backward.default, bargs)
 
