@@ -86,6 +86,69 @@ __global__ __launch_bounds__(512) void k_gather(int n, const int* __restrict__ r
   }
 }
 
+struct Graph;
+typedef Graph Graph_;
+
+__device__ __forceinline__ int xcd_contiguous(int b, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, xcd = b & 7, idx = b >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+//   window<Q,W> workgroup owns 8Q nodes (wave w: rows w, w+8, ...) and first stages the rows of nodes
+//               [node0 - W, node0 + 8Q + W) in LDS (1 KiB per node, both strands); neighbours inside that window are
+//               read from LDS (ds_read_b128, conflict-free), the others from L2 as before.  XCD-contiguous tile order.
+template <int Q, int W, int GU, bool USE_LDS>
+__global__ __launch_bounds__(512) void k_window(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                const float* __restrict__ rs, const float* __restrict__ X,
+                                                float* __restrict__ H) {
+  constexpr int NR = 8 * Q + 2 * W;
+  extern __shared__ __attribute__((aligned(16))) char win[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int node0 = xcd_contiguous(blockIdx.x, gridDim.x) * 8 * Q;
+  const unsigned lane_off = ((unsigned)(lane >> 5) * (unsigned)n * 128u + (lane & 31) * 4u) * 4u;
+  const char* Xb = (const char*)X;
+  const int lo = max(0, node0 - W), hi = min(n, node0 + 8 * Q + W);
+  if (USE_LDS) {
+    f32x4 t[(NR + 7) / 8];
+#pragma unroll
+    for (int k = 0; k < (NR + 7) / 8; ++k) {
+      const int r = wave + 8 * k;
+      t[k] = *(const f32x4*)(Xb + (size_t)(unsigned)min(lo + r, n - 1) * 512u + lane_off);
+    }
+#pragma unroll
+    for (int k = 0; k < (NR + 7) / 8; ++k) {
+      const int r = wave + 8 * k;
+      if (r < NR) *(f32x4*)(win + r * 1024 + lane * 16) = t[k];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < Q; ++r) {
+    const int i = node0 + wave + 8 * r;
+    if (i >= n) continue;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int k0 = rowptr[i], k1 = rowptr[i + 1];
+    for (int kb = k0; kb < k1; kb += 64) {
+      const int cnt = min(64, k1 - kb);
+      const int myc = lane < cnt ? col[kb + lane] : 0;
+      for (int b = 0; b < cnt; b += GU) {
+        f32x4 t[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+          const int c = rl_i(myc, min(b + u, cnt - 1));
+          if (USE_LDS && c >= lo && c < hi) t[u] = *(const f32x4*)(win + (c - lo) * 1024 + lane * 16);
+          else t[u] = *(const f32x4*)(Xb + (size_t)(unsigned)c * 512u + lane_off);
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u)
+          if (b + u < cnt) acc += t[u];
+      }
+    }
+    *(f32x4*)((char*)H + (size_t)i * 512u + lane_off) = acc * rs[i];
+  }
+}
+
 struct Graph {
   int n, nnz;
   std::vector<int> rowptr, col;
@@ -198,6 +261,57 @@ static void bench_q(const Graph& g, const int* d_rowptr, const int* d_col, const
   CK(hipFree(d_packed));
 }
 
+
+template <int Q, int W, int GU, bool USE_LDS>
+static float run_window(const Graph& g, const int* d_rowptr, const int* d_col, const float* d_rs, const float* d_X, float* d_H, int reps) {
+  const int grid = (g.n + 8 * Q - 1) / (8 * Q);
+  const size_t lds = USE_LDS ? (size_t)(8 * Q + 2 * W) * 1024 : 0;
+  auto kern = k_window<Q, W, GU, USE_LDS>;
+  CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, g.n, d_rowptr, d_col, d_rs, d_X, d_H);
+  CK(hipGetLastError());
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, g.n, d_rowptr, d_col, d_rs, d_X, d_H);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms * 1e3f / reps;
+}
+
+static void bench_window(const Graph& g, const int* d_rowptr, const int* d_col, const float* d_rs, const float* d_X, float* d_H,
+                         const std::vector<float>& h_ref, int reps) {
+  const size_t elems = (size_t)2 * g.n * 128;
+  std::vector<float> h(elems);
+  auto check = [&](const char* what) {
+    CK(hipMemcpy(h.data(), d_H, elems * 4, hipMemcpyDeviceToHost));
+    double md = 0;
+    for (size_t i = 0; i < elems; ++i) md = std::max(md, (double)std::fabs(h[i] - h_ref[i]));
+    if (md != 0.0) printf("   !! %s differs from baseline by %g\n", what, md);
+  };
+  // in-window share of the gathers for the (Q, W) geometries below
+  auto share = [&](int Q, int W) {
+    long long in = 0;
+    for (int i = 0; i < g.n; ++i) {
+      const int node0 = (i / (8 * Q)) * 8 * Q, lo = std::max(0, node0 - W), hi = std::min(g.n, node0 + 8 * Q + W);
+      for (int k = g.rowptr[i]; k < g.rowptr[i + 1]; ++k) in += (g.col[k] >= lo && g.col[k] < hi);
+    }
+    return (double)in / g.nnz;
+  };
+#define WV(Q_, W_, GU_) do { \
+    const float a = run_window<Q_, W_, GU_, false>(g, d_rowptr, d_col, d_rs, d_X, d_H, reps); \
+    const float b = run_window<Q_, W_, GU_, true>(g, d_rowptr, d_col, d_rs, d_X, d_H, reps); check("window"); \
+    printf("  window Q=%d W=%3d (%3d KB LDS, %4.1f%% of gathers in window) GU%d: L2 only %6.1f | LDS window %6.1f us\n", Q_, W_, (8 * Q_ + 2 * W_), 100.0 * share(Q_, W_), GU_, a, b); } while (0)
+  WV(1, 28, 2); WV(1, 28, 4);
+  WV(2, 24, 2); WV(2, 24, 4);
+  WV(4, 16, 2); WV(4, 16, 4);
+  WV(2, 56, 4); WV(4, 48, 4); WV(4, 48, 8);
+#undef WV
+}
+
 int main(int argc, char** argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 50;
   const int sizes[] = {5776, 7563, 9369, 12304, 16264, 20534, 29184};
@@ -226,6 +340,7 @@ int main(int argc, char** argv) {
       bench_q<2>(g, d_rowptr, d_col, d_rs, d_X, d_H, h_ref, reps);
       bench_q<3>(g, d_rowptr, d_col, d_rs, d_X, d_H, h_ref, reps);
       bench_q<4>(g, d_rowptr, d_col, d_rs, d_X, d_H, h_ref, reps);
+      bench_window(g, d_rowptr, d_col, d_rs, d_X, d_H, h_ref, reps);
       CK(hipFree(d_rowptr)); CK(hipFree(d_col)); CK(hipFree(d_rs)); CK(hipFree(d_X)); CK(hipFree(d_H));
     }
   return 0;
