@@ -4,13 +4,14 @@
 // the CPU with one scikit-learn call per label per metric after every split (runner.py:41,45,51 ->
 // utils/evals.py:89-92 -> utils/metrics.py:148-183,238-253): AUROC, area under the precision-recall curve
 // (trapezoid over sklearn's precision_recall_curve points), recall at the first point with FDR <= cutoff,
-// and average precision (mAP).  Here: ONE device-wide radix sort (rocPRIM through hipCUB) of 64-bit keys
+// and average precision (mAP).  Here: ONE device-wide radix sort (rocprim::radix_sort_keys, called directly) of 64-bit keys
 // (label | descending score | target) -- every label's list comes out contiguous and sorted and the whole chip
 // works on it (a segmented sort with one long segment per label used a fraction of the chip) -- and a chunked scan
 // of the sorted lists (one wave per 4096-element chunk),
 // treating tied scores as one curve point exactly like sklearn's distinct-threshold curves.  All curve
 // arithmetic is fp64 and summed in a fixed order.
-#include <hipcub/hipcub.hpp>
+#include <cstring>  // rocprim 4.x headers use memset without including it
+#include <rocprim/rocprim.hpp>
 
 #include "cgcn_common.hpp"
 
@@ -248,8 +249,8 @@ static inline int label_bits(int C) {
 }
 static size_t sort_temp_bytes(long long n, int C) {
   size_t bytes = 0;
-  hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                                    (int)(n * C), 1, 33 + label_bits(C));
+  (void)rocprim::radix_sort_keys(nullptr, bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                  (size_t)(n * C), 1u, (unsigned)(33 + label_bits(C)));
   return bytes;
 }
 static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -287,7 +288,7 @@ int cgcn_multilabel_metrics(cgcn_stream_t stream, long long n, int C, const floa
     dim3 grid((unsigned)((n + 31) / 32), (unsigned)((C + 31) / 32));
     hipLaunchKernelGGL(k_metrics_pack, grid, dim3(256), 0, st, n, C, probs, targets, k_in);
     // bit 0 (the target) does not take part: ties in score are one curve point whatever their order
-    if (hipcub::DeviceRadixSort::SortKeys(w, temp, (const unsigned long long*)k_in, k_out, (int)items, 1, 33 + label_bits(C), st) != hipSuccess)
+    if (rocprim::radix_sort_keys((void*)w, temp, (const unsigned long long*)k_in, k_out, items, 1u, (unsigned)(33 + label_bits(C)), st) != hipSuccess)
       return CGCN_ERR_LAUNCH;
     hipLaunchKernelGGL(k_metrics_unpack, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, (long long)items, k_out, keys_out, vals_out);
   }
