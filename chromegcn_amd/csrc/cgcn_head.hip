@@ -650,8 +650,11 @@ __device__ unsigned long long hf_stamps[8 * 16];
 #define HF_STAMP(i)
 #endif
 
+#ifndef HF_LOWREG
+#define HF_LOWREG 0   // experiment: no register-resident W_out fragments / no tile prefetch, <= 128 VGPRs, two workgroups per CU
+#endif
 template <int D, int CBMAX>
-__global__ __launch_bounds__(512) void k_head_fused(int n, int S, int C, const float* __restrict__ X,
+__global__ __launch_bounds__(512, HF_LOWREG ? 4 : 1) void k_head_fused(int n, int S, int C, const float* __restrict__ X,
                                                     const float* __restrict__ bn_w, const float* __restrict__ bn_b,
                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                                     const float* __restrict__ Wout, const float* __restrict__ bout,
@@ -665,7 +668,7 @@ __global__ __launch_bounds__(512) void k_head_fused(int n, int S, int C, const f
   constexpr int LDY = D + 16;
   constexpr int JBW = D / 128;
   constexpr int PS = CP * D + CP + 2 * 2 * D;
-  constexpr bool PRE = (D == 128);
+  constexpr bool PRE = (D == 128) && !HF_LOWREG;
   __shared__ __attribute__((aligned(16))) float Pt[TR * LDP];
   __shared__ __attribute__((aligned(16))) float Yt[TR * LDY];
   __shared__ float lsum[NW];
@@ -728,7 +731,7 @@ __global__ __launch_bounds__(512) void k_head_fused(int n, int S, int C, const f
   // All global loads of a tile -- this wave's X rows, the targets / bias of this lane's logits -- are issued together.
   // Workgroups that walk several tiles (large chromosomes) issue the NEXT tile's loads right after the current tile's
   // operands are in LDS, so they are in flight during the three MFMA phases; the current tile keeps its copy.
-  constexpr bool PF = (CBMAX == 8);  // the 256-label variant has no registers to spare for a second tile
+  constexpr bool PF = (CBMAX == 8) && !HF_LOWREG;  // the 256-label variant has no registers to spare for a second tile
   float xv[RPW][2][EPL], xv_n[PF ? RPW : 1][2][EPL];
   float tgv[NCBW][2][4], tgv_n[PF ? NCBW : 1][2][4], bjv[NCBW];
 #pragma unroll

@@ -92,7 +92,6 @@ class GCNStage:
         self._fused_sgd = False
         self._captured_lr = None
         self._one: Optional[torch.Tensor] = None
-        self._int_synced: Dict[str, torch.Tensor] = {}
         self._targets_cpu: Dict[tuple, torch.Tensor] = {}
         self._gather_plans: Dict[tuple, dict] = {}
         self._targets_dev: Dict[tuple, torch.Tensor] = {}
@@ -421,30 +420,34 @@ class GCNStage:
         self._optimizer_step(1.0 / group_size if group_size > 1 else 1.0)
         return out
 
-    def sync_running_stats(self):
-        """BatchNorm running statistics see different chromosomes on different ranks; average them so
-        every rank evaluates with the same model (deliberate deviation)."""
+    def sync_running_stats(self, extra: Optional[torch.Tensor] = None, calls_total: int = 0, calls_mine: int = 0):
+        """BatchNorm running statistics see different chromosomes on different ranks; average them so every rank
+        evaluates with the same model (deliberate deviation).  ONE all-reduce: the floating-point buffers
+        and `extra` (values to be SUMMED over ranks, e.g. the split's loss) travel in the same flat tensor.
+        Integer counters (num_batches_tracked) need no collective: every rank knows how many BatchNorm calls the
+        whole step plan makes (`calls_total`) and how many of them it made itself (`calls_mine`).
+        Returns the summed `extra` (or None)."""
         if self.world <= 1:
-            return
+            return extra
         bufs = [b for k, b in self.model.named_buffers() if b.dtype.is_floating_point]
-        if bufs:
-            flat = torch.cat([b.reshape(-1) for b in bufs])
-            torch.distributed.all_reduce(flat, group=self.group)
-            flat.div_(self.world)
-            off = 0
-            for b in bufs:
-                b.copy_(flat[off:off + b.numel()].view_as(b))
-                off += b.numel()
-        # integer counters (num_batches_tracked): every rank ends with the total number of BatchNorm
-        # calls made by all ranks, which is what one sequential process would have counted
-        for k, b in self.model.named_buffers():
-            if not b.dtype.is_floating_point:
-                prev = self._int_synced.get(k)
-                prev = torch.zeros_like(b) if prev is None else prev
-                delta = (b - prev).clone()
-                torch.distributed.all_reduce(delta, group=self.group)
-                b.copy_(prev + delta)
-                self._int_synced[k] = b.clone()
+        parts = [b.reshape(-1).float() for b in bufs]
+        n_stat = sum(p.numel() for p in parts)
+        if extra is not None:
+            parts.append(extra.reshape(-1).float() * self.world)   # undo the mean below: extras are sums
+        if not parts:
+            return extra
+        flat = torch.cat(parts)
+        torch.distributed.all_reduce(flat, group=self.group)
+        flat.div_(self.world)
+        off = 0
+        for b in bufs:
+            b.copy_(flat[off:off + b.numel()].view_as(b))
+            off += b.numel()
+        if calls_total:
+            for k, b in self.model.named_buffers():
+                if not b.dtype.is_floating_point:
+                    b += int(calls_total - calls_mine)   # the calls the other ranks made
+        return flat[n_stat:].view_as(extra) if extra is not None else None
 
     # ------------------------------------------------------------------ a whole split
     def run_split(self, split: str, names: Optional[Sequence[str]] = None, to_cpu: bool = True):
@@ -478,9 +481,10 @@ class GCNStage:
         else:
             plan = plan_shards({nm: self.chroms[nm].cost for nm in names}, self.world)
             gp = self._gather_plan(names, plan, C)
-            send = gp["send"]
+            nccl = torch.distributed.get_backend(self.group) == "nccl"
             loss_sum = torch.zeros((), device=self.device)
-            for group in plan.rounds:
+            pending = []
+            for r, group in enumerate(plan.rounds):
                 nm = group[self.rank] if self.rank < len(group) else None
                 k = sum(1 for g in group if g is not None)
                 if train:
@@ -489,20 +493,27 @@ class GCNStage:
                     loss, p = self.eval_step(nm)
                 else:
                     loss = p = None
+                send, recv = gp["send"][r], gp["recv"][r]
                 if nm is not None:
-                    o = gp["my_offset"][nm]
-                    send[o:o + p.shape[0]].copy_(p)   # straight into this rank's slab of the split-end gather
+                    send[:p.shape[0]].copy_(p)            # this rank's slab of the round's gather
                     loss_sum += loss
-            if train:
-                self.sync_running_stats()
-            torch.distributed.all_reduce(loss_sum, group=self.group)
-            # predictions: ONE all-gather at the end of the split (every rank's rows, padded to the largest rank),
-            # then one index_select into the reference's chromosome order -- no per-chromosome collective or host sync
-            if torch.distributed.get_backend(self.group) == "nccl":
-                torch.distributed.all_gather_into_tensor(gp["recv"], send, group=self.group)
-            else:  # gloo (CPU tests, single-GPU functional runs): the list form is the one every backend implements
-                torch.distributed.all_gather(list(gp["recv"].view(self.world, -1, C).unbind(0)), send, group=self.group)
-            preds_dev = gp["recv"].view(-1, C).index_select(0, gp["index"]) if gp["total"] else gp["recv"].view(-1, C)[:0]
+                # predictions of this round: ONE all-gather, issued asynchronously so that it travels (xGMI) while
+                # the next round computes; the split waits for all of them once, at the end
+                if nccl:
+                    pending.append(torch.distributed.all_gather_into_tensor(recv, send, group=self.group, async_op=True))
+                else:  # gloo (CPU tests, single-GPU functional runs): the list form is the one every backend implements
+                    pending.append(torch.distributed.all_gather(list(recv.view(self.world, -1, C).unbind(0)), send,
+                                                                group=self.group, async_op=True))
+            mine = sum(1 for nm in names if plan.owner[nm] == self.rank)
+            S = next(iter(self.chroms.values())).x.shape[0] if self.chroms else 0
+            if train:   # running statistics + the loss in one all-reduce; counters without communication
+                loss_sum = self.sync_running_stats(loss_sum, calls_total=S * len(names), calls_mine=S * mine)
+            else:
+                torch.distributed.all_reduce(loss_sum, group=self.group)
+            for w in pending:
+                w.wait()
+            # one index_select puts the gathered rows into the reference's chromosome order (finetune.py:52)
+            preds_dev = gp["recv_all"].index_select(0, gp["index"]) if gp["total"] else gp["recv_all"][:0]
             total = float(loss_sum.item())
             if not to_cpu:
                 return preds_dev, self._split_targets_dev(names, C), total
@@ -520,31 +531,31 @@ class GCNStage:
         return self._targets_dev[key]
 
     def _gather_plan(self, names, plan: ShardPlan, C: int):
-        """Buffers and the row permutation of the split-end prediction gather, built once per (split, plan):
-        rank r's rows are its chromosomes in `names` order, padded to the largest rank's row count; `index` maps
-        the reference's concatenation order (finetune.py:52, chromosome iteration order) onto the gathered
-        [world * max_rows] rows."""
+        """Buffers and the row permutation of the prediction gathers, built once per (split, plan).  Round r of the
+        plan gathers [world, max_r, C] rows (max_r = the round's largest chromosome; every rank sends one padded slab);
+        the rounds' receive buffers are consecutive slices of ONE allocation, and `index` maps the reference's
+        concatenation order (finetune.py:52, chromosome iteration order) onto its rows."""
         key = (tuple(names), self.world, C)
         gp = self._gather_plans.get(key)
         if gp is not None:
             return gp
         sizes = {nm: self.chroms[nm].n for nm in names}
-        rows = [0] * self.world
-        offset = {}
-        for nm in names:
-            r = plan.owner[nm]
-            offset[nm] = rows[r]
-            rows[r] += sizes[nm]
-        max_rows = max(rows) if rows else 0
-        idx = []
-        for nm in names:
-            base = plan.owner[nm] * max_rows + offset[nm]
-            idx.append(torch.arange(base, base + sizes[nm], dtype=torch.int64))
+        max_r = [max([sizes[g] for g in group if g is not None] + [0]) for group in plan.rounds]
+        base_r, tot = [], 0
+        for m in max_r:
+            base_r.append(tot)
+            tot += self.world * m
+        recv_all = torch.empty((tot, C), device=self.device, dtype=torch.float32)
+        where = {}
+        for r, group in enumerate(plan.rounds):
+            for rank, g in enumerate(group):
+                if g is not None:
+                    where[g] = base_r[r] + rank * max_r[r]
+        idx = [torch.arange(where[nm], where[nm] + sizes[nm], dtype=torch.int64) for nm in names]
         index = torch.cat(idx) if idx else torch.empty(0, dtype=torch.int64)
-        gp = {"send": torch.zeros((max_rows, C), device=self.device, dtype=torch.float32),
-              "recv": torch.empty((self.world * max_rows, C), device=self.device, dtype=torch.float32),
-              "index": index.to(self.device), "total": int(index.numel()),
-              "my_offset": {nm: offset[nm] for nm in names if plan.owner[nm] == self.rank}}
+        gp = {"send": [torch.zeros((m, C), device=self.device, dtype=torch.float32) for m in max_r],
+              "recv": [recv_all[base_r[r]:base_r[r] + self.world * max_r[r]] for r in range(len(max_r))],
+              "recv_all": recv_all, "index": index.to(self.device), "total": int(index.numel())}
         self._gather_plans[key] = gp
         return gp
 
