@@ -19,11 +19,18 @@ pytestmark = pytest.mark.gpu
 D, NC = 128, 23
 SIZES = {"chr2": 900, "chr4": 610, "chr5": 1200, "chr6": 750, "chr7": 330}
 EPOCHS = 2
+GENOME = False   # set by the genome-scale test (module globals travel to the spawned children through the args)
 
 
-def make_data():
+def make_data(genome=False):
     from chromegcn_amd import synth
     feats, graphs = {}, {}
+    if genome:  # BASELINE.json configs[2]: the 16 train chromosomes of the synthetic GM12878-shaped genome, full size
+        for c in synth.HG19_LEN:
+            if synth.split_of(c) == "train":
+                f, g = synth.synthetic_chromosome(c, d=D, n_labels=NC)
+                feats[c], graphs[c] = f, g
+        return feats, graphs
     for i, (c, n) in enumerate(SIZES.items()):
         feats[c] = synth.chrom_features(n, D, NC, 50 + i, positive_rate=0.2)
         graphs[c] = synth.contact_graph(n, 6 * n, 60 + i)
@@ -40,7 +47,7 @@ def make_model(dev):
     return m.to(dev)
 
 
-def worker(rank, world, port, q):
+def worker(rank, world, port, q, genome=False, epochs=EPOCHS):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -48,30 +55,35 @@ def worker(rank, world, port, q):
     from chromegcn_amd.finetune import GCNStage
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    feats, graphs = make_data()
+    feats, graphs = make_data(genome)
+    rows = sum(f["forward"].shape[0] for f in feats.values())
     m = make_model("cuda:0")
     opt = torch.optim.SGD(m.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-6)
     stage = GCNStage(m, opt, "hic", "cuda:0", hip_graphs=True, input_grad=True, group=dist.group.WORLD,
                      cache_input_aggregation=False)
     stage.load(feats, graphs)
     tot = []
-    for _ in range(EPOCHS):
+    for _ in range(epochs):
         preds, targets, t = stage.run_split("train")
         tot.append(t)
-        assert preds.shape == (sum(SIZES.values()), NC) and targets.shape == preds.shape
+        assert preds.shape == (rows, NC) and targets.shape == preds.shape
     pd, td, tv = stage.run_split("valid", to_cpu=False)          # device-resident gather path
-    assert pd.is_cuda and pd.shape == (sum(SIZES.values()), NC)
-    q.put((rank, {k: v.cpu().numpy() for k, v in m.state_dict().items()}, tot, preds.numpy(), pd.cpu().numpy(), tv))
+    assert pd.is_cuda and pd.shape == (rows, NC)
+    if genome:   # 243 k x 23 predictions: send checksums and a strided sample instead of everything
+        preds, pdc = preds[::97].contiguous(), pd[::97].cpu()
+    else:
+        pdc = pd.cpu()
+    q.put((rank, {k: v.cpu().numpy() for k, v in m.state_dict().items()}, tot, preds.numpy(), pdc.numpy(), tv))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def emulate(world):
+def emulate(world, genome=False, epochs=EPOCHS):
     """single process, same GPU, same kernels: per step group, run fwd+bwd of each member eagerly, average the flat
     gradient buffers, take one fused optimizer step"""
     from chromegcn_amd.dist import plan_shards
     from chromegcn_amd.finetune import GCNStage
-    feats, graphs = make_data()
+    feats, graphs = make_data(genome)
     m = make_model("cuda")
     opt = torch.optim.SGD(m.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-6)
     stage = GCNStage(m, opt, "hic", "cuda", hip_graphs=False, input_grad=True, cache_input_aggregation=False)
@@ -79,7 +91,7 @@ def emulate(world):
     plan = plan_shards({c: stage.chroms[c].cost for c in feats}, world)
     m.train()
     tot = []
-    for _ in range(EPOCHS):
+    for _ in range(epochs):
         t = 0.0
         for group in plan.rounds:
             names = [g for g in group if g is not None]
@@ -93,6 +105,8 @@ def emulate(world):
             stage._optimizer_step(1.0 / len(names))
         tot.append(t)
     preds, _, ev = stage.run_split("valid")
+    if genome:
+        preds = preds[::97].contiguous()
     return {k: v.cpu().numpy() for k, v in m.state_dict().items()}, tot, preds.numpy(), ev, plan
 
 
@@ -101,22 +115,29 @@ def free_port():
     return p
 
 
-@pytest.mark.timeout(900)
-def test_two_ranks_on_one_gpu_match_the_gradient_averaging_emulation():
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("genome", [False, True], ids=["five_small_chromosomes", "full_size_train_genome_configs2"])
+def test_two_ranks_on_one_gpu_match_the_gradient_averaging_emulation(genome):
+    """genome=True is BASELINE.json configs[2]'s code path at full size -- the 16 train chromosomes (242 908 windows,
+    250 000 contact pairs each) sharded by plan_shards -- on the two ranks one GPU can host (8 ranks need the node)."""
     import torch.multiprocessing as mp
     world = 2
+    epochs = 1 if genome else EPOCHS
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, q, genome, epochs)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=600) for _ in range(world)]
+    results = [q.get(timeout=900) for _ in range(world)]
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    ref_sd, ref_tot, ref_preds, ref_ev, plan = emulate(world)
-    assert len(plan.rounds) == 3 and all(any(g is None for g in r) is (i == 2) for i, r in enumerate(plan.rounds))
+    ref_sd, ref_tot, ref_preds, ref_ev, plan = emulate(world, genome, epochs)
+    if genome:
+        assert len(plan.rounds) == 8 and all(g is not None for r in plan.rounds for g in r)
+    else:
+        assert len(plan.rounds) == 3 and all(any(g is None for g in r) is (i == 2) for i, r in enumerate(plan.rounds))
     results.sort(key=lambda r: r[0])
     for rank, sd, tot, preds, preds_dev, ev in results:
         np.testing.assert_allclose(tot, ref_tot, rtol=1e-4, atol=1e-5)
@@ -125,6 +146,8 @@ def test_two_ranks_on_one_gpu_match_the_gradient_averaging_emulation():
                 continue  # per-rank BatchNorm statistics are averaged across ranks (documented deviation)
             np.testing.assert_allclose(sd[k], ref_sd[k], rtol=1e-4, atol=1e-4, err_msg=k)
         np.testing.assert_array_equal(preds_dev.shape, ref_preds.shape)
+        # (evaluation predictions are not compared with the emulation: they depend on the BatchNorm running statistics,
+        #  which the multi-rank run averages across ranks -- the documented deviation; rank 0 == rank 1 is checked below)
     # both ranks hold identical models (incl. the averaged BatchNorm buffers) and identical full predictions
     for k in results[0][1]:
         np.testing.assert_array_equal(results[0][1][k], results[1][1][k], err_msg=k)

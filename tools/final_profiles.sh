@@ -1,0 +1,23 @@
+set -u
+T=$1
+mkdir -p gpurun_out/$T
+python -m pytest tests -m gpu -q > gpurun_out/$T/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/$T/pytest.log; tail -3 gpurun_out/$T/pytest.log
+python bench.py > gpurun_out/$T/bench_genome.json 2> gpurun_out/$T/bench_genome.err
+python bench.py --hic-like --no-cpu-baseline > gpurun_out/$T/bench_genome_hic.json 2>/dev/null
+for w in chr21 chr1 config1; do python bench.py --workload $w --no-cpu-baseline > gpurun_out/$T/bench_$w.json 2>/dev/null; python bench.py --workload $w --hic-like --no-cpu-baseline > gpurun_out/$T/bench_${w}_hic.json 2>/dev/null; done
+python bench.py --workload chr21 --d 256 --layers 4 --no-cpu-baseline > gpurun_out/$T/bench_chr21_d256L4.json 2>/dev/null
+python bench.py --workload e2e > gpurun_out/$T/bench_e2e.json 2>/dev/null
+bash tools/profile_round.sh $T genome
+bash tools/profile_round.sh $T genome_hic --hic-like
+bash tools/profile_round.sh $T chr21 --workload chr21
+bash tools/profile_round.sh $T chr21_hic --workload chr21 --hic-like
+bash tools/profile_round.sh $T chr1 --workload chr1
+bash tools/profile_round.sh $T chr1_hic --workload chr1 --hic-like
+bash tools/profile_round.sh $T chr21_d256L4 --workload chr21 --d 256 --layers 4
+for f in gpurun_out/$T/bench_*.json; do python - "$f" <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(sys.argv[1].split('/')[-1], round(d['ms_per_step'],4), 'ms', round(d['value']/1e6,2), 'M win/s')
+except Exception as e: print(sys.argv[1], 'ERR', e)
+PY
+done
