@@ -1,7 +1,7 @@
 set -u
 T=$1
 mkdir -p gpurun_out/$T
-python -m pytest tests -m gpu -q > gpurun_out/$T/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/$T/pytest.log; tail -3 gpurun_out/$T/pytest.log
+if [ -z "${SKIP_TESTS:-}" ]; then python -m pytest tests -m gpu -q > gpurun_out/$T/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/$T/pytest.log; tail -3 gpurun_out/$T/pytest.log; fi
 python bench.py > gpurun_out/$T/bench_genome.json 2> gpurun_out/$T/bench_genome.err
 python bench.py --hic-like --no-cpu-baseline > gpurun_out/$T/bench_genome_hic.json 2>/dev/null
 for w in chr21 chr1 config1; do python bench.py --workload $w --no-cpu-baseline > gpurun_out/$T/bench_$w.json 2>/dev/null; python bench.py --workload $w --hic-like --no-cpu-baseline > gpurun_out/$T/bench_${w}_hic.json 2>/dev/null; done

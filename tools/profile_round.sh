@@ -22,3 +22,5 @@ rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_
 rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES --kernel-trace --output-format csv -d "$O/mfma" -- python3 $B --steps 3 --warmup 1 > "$O/mfma.log" 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d "$O/l2" -- python3 $B --steps 3 --warmup 1 > "$O/l2.log" 2>&1
 python3 "$R/tools/summarize_profiles.py" "$O" "$TAG" "$WL" "$*"
+# the raw per-dispatch CSVs are tens of MB per pass; gpurun merges at most 64 MiB back: keep the summaries and logs only
+rm -rf "$O/stats" "$O/fetch" "$O/write" "$O/sq" "$O/mfma" "$O/l2"
