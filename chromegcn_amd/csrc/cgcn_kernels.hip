@@ -13,6 +13,8 @@
 //
 // Reference semantics: models/SubLayers.py:42-52, models/ChromeModels.py:34-46 (forward);
 // SURVEY.md Appendix A (backward).
+#include <atomic>
+
 #include "cgcn_common.hpp"
 
 // Geometry of one node's payload (S strands x D features) over a 64-lane wave of float4 loads.
@@ -1081,15 +1083,18 @@ static inline int pick_mb(int, int) { return 1; }
 // never destroyed (an event may still be referenced by a captured graph).  This is the only state the
 // library keeps, and it holds no caller memory.
 static hipEvent_t pooled_event() {
-  static hipEvent_t pool[64];
-  static unsigned next = 0;
-  static bool init = false;
-  if (!init) {
-    for (auto& e : pool)
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
-    init = true;
-  }
-  return pool[(next++) & 63];
+  // thread-safe: the pool is created once (C++11 static initialisation), the cursor is atomic.  Only reached when the
+  // caller passes an auxiliary stream (opt-in, CHROMEGCN_AUX_STREAM); the default path creates no events at all.
+  struct Pool {
+    hipEvent_t ev[64];
+    Pool() {
+      for (auto& e : ev)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+    }
+  };
+  static Pool pool;
+  static std::atomic<unsigned> next{0};
+  return pool.ev[next.fetch_add(1u, std::memory_order_relaxed) & 63u];
 }
 
 static int dropout_args(float p, const unsigned long long* rng_state, float* keep_scale, uint32_t* thresh) {

@@ -88,6 +88,27 @@ def test_binary_csr_cache_roundtrip(tmp_path):
         G.load_csr_cache(str(tmp_path / "bad.cgcsr"))
 
 
+def test_binary_csr_cache_rejects_invalid_structure(tmp_path):
+    """the kernels trust the CSR: a corrupted cache file must fail in load_csr_cache, not read out of bounds on the GPU"""
+    import dataclasses
+    h = G.normalize_graph("hic", O.random_symmetric_graph(30, 60, 3), 30)
+    bad_col = h.col.copy(); bad_col[5] = 30                      # column index == n
+    neg_col = h.col.copy(); neg_col[0] = -1
+    bad_ptr = h.rowptr.copy(); bad_ptr[3], bad_ptr[4] = bad_ptr[4] + 2, bad_ptr[3]   # non-monotonic
+    for i, broken in enumerate([dataclasses.replace(h, col=bad_col), dataclasses.replace(h, col=neg_col),
+                                dataclasses.replace(h, rowptr=bad_ptr)]):
+        p = str(tmp_path / ("broken%d.cgcsr" % i))
+        G.save_csr_cache(p, broken)
+        with pytest.raises(ValueError):
+            G.load_csr_cache(p)
+    p = str(tmp_path / "short.cgcsr")
+    G.save_csr_cache(p, h)
+    data = open(p, "rb").read()
+    open(p, "wb").write(data[:-20])                               # truncated file
+    with pytest.raises(ValueError):
+        G.load_csr_cache(p)
+
+
 def test_convert_graph_pickle(tmp_path):
     """the reference's on-disk graph contract (data/7create_graph_new.py:197-202) -> flat per-chromosome files"""
     import pickle
