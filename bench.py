@@ -53,8 +53,6 @@ def parse():
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--dropout", type=float, default=0.2)
     ap.add_argument("--no-hip-graph", action="store_true")
-    ap.add_argument("--prefetch", action="store_true",
-                    help="software-pipeline the next chromosome's first-layer aggregation on a side branch of each step's HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the host baseline sample")
@@ -250,8 +248,7 @@ def main():
     # reference.  (The engine's defaults cache A X of the first layer -- loop invariant, the features are fixed -- and
     # skip the unobservable input gradient; measured separately below, never as `value`.)
     stage = GCNStage(model, opt, "hic", dev, hip_graphs=not args.no_hip_graph, input_grad=True,
-                     group=dist.group.WORLD if world > 1 else None, cache_input_aggregation=False,
-                     prefetch_input_aggregation=args.prefetch)
+                     group=dist.group.WORLD if world > 1 else None, cache_input_aggregation=False)
 
     if genome:
         names = genome_train_names()

@@ -66,16 +66,8 @@ class GCNStage:
     group      : torch.distributed process group (None = single process)"""
 
     def __init__(self, model, optimizer=None, adj_type: str = "hic", device="cuda", hip_graphs: bool = True,
-                 input_grad: bool = False, group=None, fused_head: bool = True, cache_input_aggregation: bool = True,
-                 prefetch_input_aggregation: bool = False):
+                 input_grad: bool = False, group=None, fused_head: bool = True, cache_input_aggregation: bool = True):
         self.model = model
-        # Software pipelining across chromosomes (single rank, captured train steps): the first layer's aggregation
-        # A X0 of the NEXT chromosome does not depend on any parameter (op order (A X) W), so chromosome c's HIP graph
-        # recomputes it for chromosome c+1 on a side branch, concurrently with c's latency-bound head / row-local
-        # kernels; c+1's first layer then streams it.  Every aggregation is still recomputed every epoch -- nothing is
-        # carried over from earlier epochs -- it is only scheduled earlier.
-        self.prefetch_input_aggregation = bool(prefetch_input_aggregation)
-        self._side = None
         self.fused_head = fused_head
         # A X of the first layer is loop invariant across steps and epochs (like the normalised CSR): compute it once
         # per chromosome and stream it afterwards.  False = redo that gather every step, as the reference does.
@@ -275,10 +267,8 @@ class GCNStage:
     def _forward_loss(self, c: _Chrom, x):
         slot = self._arena["slots"][c.name] if self._arena is not None else None
         if self.fused_head and hasattr(self.model, "forward_loss"):
-            use_h1 = self.cache_input_aggregation or (self.prefetch_input_aggregation and self.model.training
-                                                      and c.h1.get("h") is not None)
             loss, probs, _ = self.model.forward_loss(x, c.graph, c.target,   # fused head + loss kernels
-                                                     h1_cache=c.h1 if use_h1 else None,
+                                                     h1_cache=c.h1 if self.cache_input_aggregation else None,
                                                      out_slots=slot)
             return loss, probs
         logits, _ = self.model.forward_strands(x, c.graph)
@@ -333,37 +323,19 @@ class GCNStage:
             return None
         return tuple((g.get("lr"), g.get("momentum"), g.get("weight_decay"), g.get("nesterov")) for g in self.optimizer.param_groups)
 
-    def _prefetch_aggregation(self, nxt: _Chrom):
-        """H1(next) = A X0(next) into next's persistent buffer, on the side stream (forked from / joined to the current
-        stream by the caller)"""
-        from . import ops
-        if nxt.h1.get("h") is None:
-            nxt.h1["h"] = torch.empty_like(nxt.x)
-        ops.spmm_into(nxt.x, nxt.graph, nxt.h1["h"])
-
-    def _capture(self, c: _Chrom, kind: str, nxt: Optional[_Chrom] = None):
-        """kind: 'train' (zero_grad+fwd+bwd+step), 'fwdbwd' (no optimizer step: multi-rank), 'eval'.
-        nxt: chromosome whose first-layer aggregation this step recomputes on a side branch (prefetch)."""
+    def _capture(self, c: _Chrom, kind: str):
+        """kind: 'train' (zero_grad+fwd+bwd+step), 'fwdbwd' (no optimizer step: multi-rank), 'eval'."""
         was_training = self.model.training
         self.model.train(kind != "eval")
         snap = self._snapshot()
-        if nxt is not None and self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
 
         def body():
             if kind == "eval":
                 loss, probs = self._eval(c)
                 return loss, probs, None
-            if nxt is not None:                                           # fork: side branch runs beside the whole step
-                cur = torch.cuda.current_stream(self.device)
-                self._side.wait_stream(cur)
-                with torch.cuda.stream(self._side):
-                    self._prefetch_aggregation(nxt)
             loss, probs, dx = self._fwd_bwd(c)
             if kind == "train":
                 self._optimizer_step()                                    # finetune.py:49
-            if nxt is not None:
-                torch.cuda.current_stream(self.device).wait_stream(self._side)   # join
             return loss, probs, dx
 
         if kind == "train" and not self._fused_sgd:
@@ -392,22 +364,21 @@ class GCNStage:
             self.model.train(was_training)
         return {"graph": graph, "loss": loss, "probs": probs, "dx": dx}
 
-    def _replay(self, c: _Chrom, kind: str, nxt: Optional[_Chrom] = None):
+    def _replay(self, c: _Chrom, kind: str):
         if self._captured_lr != self._lr_signature():
             self._drop_graphs()  # the learning rate is baked into the captured optimizer kernels
             self._captured_lr = self._lr_signature()
-        key = (c.name, kind) if nxt is None else (c.name, kind, nxt.name)
+        key = (c.name, kind)
         ent = self._graphs.get(key)
         if ent is None:
-            ent = self._graphs[key] = self._capture(c, kind, nxt)
+            ent = self._graphs[key] = self._capture(c, kind)
         ent["graph"].replay()
         return ent["loss"], ent["probs"], ent["dx"]
 
     # ------------------------------------------------------------------ public steps
-    def train_step(self, name: str, next_name: Optional[str] = None):
+    def train_step(self, name: str):
         """One reference train step on one chromosome (finetune.py:38-49).  Returns device tensors
-        (loss [], probs [n,C], dx [2,n,d] or None); valid until the next step.
-        next_name (prefetch_input_aggregation only): the chromosome that will be stepped next."""
+        (loss [], probs [n,C], dx [2,n,d] or None); valid until the next step."""
         c = self.chroms[name]
         self.model.train()
         self._ensure_flat_grad()
@@ -415,14 +386,7 @@ class GCNStage:
         if self.world > 1:
             raise RuntimeError("use train_group() when running on more than one rank")
         if self.hip_graphs and self._fused_sgd:
-            nxt = None
-            if self.prefetch_input_aggregation and not self.cache_input_aggregation and next_name is not None:
-                nxt = self.chroms[next_name]
-                if nxt is c:                         # a one-chromosome split has nothing to pipeline with
-                    nxt, c.h1["h"] = None, None
-                elif c.h1.get("h") is None:          # first step ever: nobody has prefetched for this chromosome yet
-                    self._prefetch_aggregation(c)
-            return self._replay(c, "train", nxt)     # zero_grad + fwd + bwd + fused SGD: one HIP graph
+            return self._replay(c, "train")          # zero_grad + fwd + bwd + fused SGD: one HIP graph
         # any other optimizer (Adam is the reference's -optim adam, utils/util_methods.py:20-21): its step() is
         # not capturable, so the graph ends after the backward and the step runs eagerly on the flat buffers
         loss, probs, dx = self._replay(c, "fwdbwd") if self.hip_graphs else self._fwd_bwd(c)
@@ -498,8 +462,8 @@ class GCNStage:
         C = next(iter(self.chroms.values())).target.shape[1] if self.chroms else 0
         if self.world == 1:
             self._ensure_arena()
-            for i, nm in enumerate(names):   # results land in the arena: nothing to copy or add
-                self.train_step(nm, names[(i + 1) % len(names)]) if train else self.eval_step(nm)
+            for nm in names:
+                self.train_step(nm) if train else self.eval_step(nm)   # results land in the arena: nothing to copy or add
             span = self._arena_span(names)
             if span is not None:   # the usual case: the split is the stage's chromosomes in order -> views, no copy
                 preds_dev = self._arena["probs"][span[0]:span[1]]

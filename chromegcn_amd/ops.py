@@ -47,20 +47,6 @@ def spmm(x, graph):
                                     graph.val_t)
 
 
-def spmm_into(x, graph: ChromGraph, out):
-    """Y = diag(row_scale) Ahat X written into a caller-owned buffer (no autograd, no allocation): the engine's
-    prefetch of the next chromosome's first-layer aggregation on a side stream (finetune.GCNStage)."""
-    _check_feat(x, graph, any_width=True)
-    if out.shape != x.shape or not out.is_contiguous() or out.data_ptr() == x.data_ptr():
-        raise RuntimeError("chromegcn_amd: spmm_into needs a distinct contiguous output of the input's shape")
-    x = _dense(x)
-    S, n, d = x.shape
-    lib = _lib.load()
-    _lib.check(lib.cgcn_spmm(_lib.stream_ptr(), n, n, S, d, _lib.ptr(graph.rowptr), _lib.ptr(graph.col), _lib.ptr(graph.val),
-                             _lib.ptr(graph.row_scale), x.data_ptr(), out.data_ptr()), "cgcn_spmm")
-    return out
-
-
 def sddmm(a, b, graph: ChromGraph, transposed=False):
     """out[k] = sum_s <a[s,i,:], b[s,col[k],:]> on the graph's pattern (cgcn_sddmm).  No autograd."""
     _check_feat(a, graph, "a")
