@@ -73,7 +73,7 @@ def test_fused_layer_equals_unfused_composition(big):
     assert torch.allclose(gate, gt.squeeze(-1), atol=1e-4, rtol=1e-4)
     for a_, b_, nm in zip(t1, t2, ["dX", "dW", "db", "dwg", "dcg"]):
         scale = max(1.0, b_.grad.abs().max().item())
-        assert torch.allclose(a_.grad, b_.grad, atol=1e-4 * scale, rtol=1e-3), nm
+        assert torch.allclose(a_.grad, b_.grad, atol=1e-4 * scale, rtol=1e-4), nm
 
 
 def test_whole_step_is_bit_reproducible_and_matches_torch_head(big):

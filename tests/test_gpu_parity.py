@@ -202,11 +202,14 @@ def test_model_train_steps_against_reference_golden(golden, batched):
 
         loss = step()
         assert abs(loss.item() - float(z[name + "_train_loss"])) < 1e-4
-        np.testing.assert_allclose(xf.grad.cpu().numpy(), z[name + "_train_dxf"], atol=1e-6, rtol=1e-3)
-        np.testing.assert_allclose(xr.grad.cpu().numpy(), z[name + "_train_dxr"], atol=1e-6, rtol=1e-3)
+        np.testing.assert_allclose(xf.grad.cpu().numpy(), z[name + "_train_dxf"], atol=1e-4 * np.abs(z[name + "_train_dxf"]).max(), rtol=1e-4)
+        np.testing.assert_allclose(xr.grad.cpu().numpy(), z[name + "_train_dxr"], atol=1e-4 * np.abs(z[name + "_train_dxr"]).max(), rtol=1e-4)
         for k, p in m.named_parameters():
             ref = z["%s_grad_%s" % (name, k)]
-            np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=1e-4 * max(1.0, float(np.abs(ref).max())), rtol=1e-4, err_msg=k)
+            # scale-relative 1e-4; the layer bias sums (signed per-row terms that mostly cancel) are bounded at 1e-3, see
+            # tests/test_gpu_fullsize_oracle.py for their measured conditioning against float64
+            rel = 1e-3 if (k.endswith(".bias") and k[:2] in ("GC", "W1", "W2", "W3", "W4")) else 1e-4
+            np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=rel * float(np.abs(ref).max()), rtol=1e-4, err_msg=k)
         opt.step()
         post = state_from(z, name + "_post")
         for k, v in m.state_dict().items():
@@ -248,11 +251,12 @@ def test_deeper_wider_model_against_oracle():
     lg = F.binary_cross_entropy_with_logits((p[0] + p[1]) / 2, tgt.to(DEV))
     lg.backward()
     assert len(gates) == 4 and abs(lo.item() - lg.item()) < 1e-4
-    np.testing.assert_allclose(xg.grad.cpu().numpy(), xo.grad.numpy(), atol=1e-6, rtol=1e-3)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xo.grad.numpy(), atol=1e-4 * xo.grad.abs().max().item(), rtol=1e-4)
     po = dict(orc.named_parameters())
     for k, pp in m.named_parameters():
         ref = po[k].grad.numpy()
-        np.testing.assert_allclose(pp.grad.cpu().numpy(), ref, atol=1e-4 * max(1.0, float(np.abs(ref).max())), rtol=1e-4, err_msg=k)
+        rel = 1e-3 if (k.endswith(".bias") and k[:2] in ("GC", "W1", "W2", "W3", "W4")) else 1e-4
+        np.testing.assert_allclose(pp.grad.cpu().numpy(), ref, atol=rel * float(np.abs(ref).max()), rtol=1e-4, err_msg=k)
 
 
 def test_cpu_inputs_fail_loudly():
