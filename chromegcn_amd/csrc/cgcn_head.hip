@@ -176,7 +176,10 @@ __global__ __launch_bounds__(1024) void k_head_bn_finalize(int n, int S, int D, 
 static void launch_bn_finalize(hipStream_t st, int n, int S, int d, int nblk, int rpb, const float* part, float momentum,
                                float eps, float* run_mean, float* run_var, long long* nbt, float* save_mean,
                                float* save_invstd) {
-  if (nblk > 2048)  // measured at 722 partials: 16 columns x 64 slices (2 load batches) 9.6 us, 4 x 256 (1 batch) 11 us
+#ifndef BNFIN_WIDE_FROM
+#define BNFIN_WIDE_FROM 2048
+#endif
+  if (nblk > BNFIN_WIDE_FROM)  // measured at 722 partials: 16 columns x 64 slices (2 load batches) 9.6 us, 4 x 256 (1 batch) 11 us
     hipLaunchKernelGGL(k_head_bn_finalize<4>, dim3((S * d + 3) / 4), dim3(1024), 0, st, n, S, d, nblk, rpb, part, momentum, eps,
                        run_mean, run_var, nbt, save_mean, save_invstd);
   else

@@ -82,7 +82,9 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 //                      the curve point preceding it; total positives
 //   k_metrics_chunks   per chunk: the trapezoid / step sums of its own curve points (fp64) + R@FDR candidate
 //   k_metrics_final    per label: fixed-order sum over chunks  => deterministic
+#ifndef METRIC_CHUNK
 #define METRIC_CHUNK 4096
+#endif
 
 struct ChunkRec {      // written by k_metrics_summary, completed by k_metrics_prefix
   double pos;          // positives in the chunk

@@ -97,6 +97,37 @@ __device__ __forceinline__ int xcd_contiguous(int b, int nblk) {
 //   window<Q,W> workgroup owns 8Q nodes (wave w: rows w, w+8, ...) and first stages the rows of nodes
 //               [node0 - W, node0 + 8Q + W) in LDS (1 KiB per node, both strands); neighbours inside that window are
 //               read from LDS (ds_read_b128, conflict-free), the others from L2 as before.  XCD-contiguous tile order.
+// ILV: node-major feature layout [n][2][128] (one contiguous 1 KiB segment per neighbour) instead of the strand-major
+// [2][n][128] (two 512-B segments n*512 B apart)
+template <int GU, bool ILV>
+__global__ __launch_bounds__(512) void k_layout(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                const float* __restrict__ rs, const float* __restrict__ X,
+                                                float* __restrict__ H) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int node0 = xcd_contiguous(blockIdx.x, gridDim.x) * 8;
+  const unsigned lane_off = ILV ? (unsigned)lane * 16u : ((unsigned)(lane >> 5) * (unsigned)n * 128u + (lane & 31) * 4u) * 4u;
+  const unsigned row_b = ILV ? 1024u : 512u;
+  const char* Xb = (const char*)X;
+  const int i = node0 + wave;
+  if (i >= n) return;
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int k0 = rowptr[i], k1 = rowptr[i + 1];
+  for (int kb = k0; kb < k1; kb += 64) {
+    const int cnt = min(64, k1 - kb);
+    const int myc = lane < cnt ? col[kb + lane] : 0;
+    for (int b = 0; b < cnt; b += GU) {
+      f32x4 t[GU];
+#pragma unroll
+      for (int u = 0; u < GU; ++u) t[u] = *(const f32x4*)(Xb + (size_t)(unsigned)rl_i(myc, min(b + u, cnt - 1)) * row_b + lane_off);
+#pragma unroll
+      for (int u = 0; u < GU; ++u)
+        if (b + u < cnt) acc += t[u];
+    }
+  }
+  *(f32x4*)((char*)H + (size_t)i * row_b + lane_off) = acc * rs[i];
+}
+
 template <int Q, int W, int GU, bool USE_LDS>
 __global__ __launch_bounds__(512) void k_window(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
                                                 const float* __restrict__ rs, const float* __restrict__ X,
@@ -282,6 +313,22 @@ static float run_window(const Graph& g, const int* d_rowptr, const int* d_col, c
   return ms * 1e3f / reps;
 }
 
+template <int GU, bool ILV>
+static float run_layout(const Graph& g, const int* d_rowptr, const int* d_col, const float* d_rs, const float* d_X, float* d_H, int reps) {
+  const int grid = (g.n + 7) / 8;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k_layout<GU, ILV>), dim3(grid), dim3(512), 0, 0, g.n, d_rowptr, d_col, d_rs, d_X, d_H);
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k_layout<GU, ILV>), dim3(grid), dim3(512), 0, 0, g.n, d_rowptr, d_col, d_rs, d_X, d_H);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms * 1e3f / reps;
+}
+
 static void bench_window(const Graph& g, const int* d_rowptr, const int* d_col, const float* d_rs, const float* d_X, float* d_H,
                          const std::vector<float>& h_ref, int reps) {
   const size_t elems = (size_t)2 * g.n * 128;
@@ -336,11 +383,17 @@ int main(int argc, char** argv) {
       CK(hipMemcpy(d_X, X.data(), X.size() * 4, hipMemcpyHostToDevice));
       printf("%s n=%d nnz=%d table=%.1f MB\n", hic ? "hic-like" : "uniform", n, g.nnz, X.size() * 4 / 1e6);
       std::vector<float> h_ref;
-      bench_q<1>(g, d_rowptr, d_col, d_rs, d_X, d_H, h_ref, reps);
-      bench_q<2>(g, d_rowptr, d_col, d_rs, d_X, d_H, h_ref, reps);
-      bench_q<3>(g, d_rowptr, d_col, d_rs, d_X, d_H, h_ref, reps);
-      bench_q<4>(g, d_rowptr, d_col, d_rs, d_X, d_H, h_ref, reps);
-      bench_window(g, d_rowptr, d_col, d_rs, d_X, d_H, h_ref, reps);
+      if (getenv("SG_LAYOUT_ONLY")) {
+        printf("  layout: strand-major GU2 %6.1f GU3 %6.1f | node-major (1 KiB contiguous) GU2 %6.1f GU3 %6.1f us\n",
+               run_layout<2, false>(g, d_rowptr, d_col, d_rs, d_X, d_H, reps), run_layout<3, false>(g, d_rowptr, d_col, d_rs, d_X, d_H, reps),
+               run_layout<2, true>(g, d_rowptr, d_col, d_rs, d_X, d_H, reps), run_layout<3, true>(g, d_rowptr, d_col, d_rs, d_X, d_H, reps));
+      } else {
+        bench_q<1>(g, d_rowptr, d_col, d_rs, d_X, d_H, h_ref, reps);
+        bench_q<2>(g, d_rowptr, d_col, d_rs, d_X, d_H, h_ref, reps);
+        bench_q<3>(g, d_rowptr, d_col, d_rs, d_X, d_H, h_ref, reps);
+        bench_q<4>(g, d_rowptr, d_col, d_rs, d_X, d_H, h_ref, reps);
+        bench_window(g, d_rowptr, d_col, d_rs, d_X, d_H, h_ref, reps);
+      }
       CK(hipFree(d_rowptr)); CK(hipFree(d_col)); CK(hipFree(d_rs)); CK(hipFree(d_X)); CK(hipFree(d_H));
     }
   return 0;
