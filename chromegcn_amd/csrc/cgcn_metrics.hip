@@ -201,9 +201,9 @@ __global__ __launch_bounds__(64) void k_metrics_chunks(long long n, int nch, con
       d_aupr = (rec_ - pr) * (prec + pp) * 0.5;
       d_ap = (rec_ - pr) * prec;
     }
-    s_auc += wave_sum_d(d_auc);
-    s_aupr += wave_sum_d(d_aupr);
-    s_ap += wave_sum_d(d_ap);
+    s_auc += d_auc;    // per-lane partial sums, folded across the wave ONCE after the loop (fixed order: deterministic);
+    s_aupr += d_aupr;  // three fp64 wave reductions per 64 elements were a third of this kernel's instructions
+    s_ap += d_ap;
     const bool q = end && (1.0 - prec) <= fdr_cutoff;
     const unsigned long long bal = __ballot(q);
     if (bal) {
@@ -218,6 +218,9 @@ __global__ __launch_bounds__(64) void k_metrics_chunks(long long n, int nch, con
     }
     carry_tp = __shfl(tp, WAVE - 1, WAVE);
   }
+  s_auc = wave_sum_d(s_auc);
+  s_aupr = wave_sum_d(s_aupr);
+  s_ap = wave_sum_d(s_ap);
   if (lane == 0) {
     ChunkOut& o = outp[(size_t)c * nch + ch];
     o.auc = s_auc; o.aupr = s_aupr; o.ap = s_ap; o.rfdr = r_fdr; o.has_fdr = has_fdr;
