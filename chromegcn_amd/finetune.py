@@ -445,7 +445,7 @@ class GCNStage:
             off += b.numel()
         if calls_total:
             for k, b in self.model.named_buffers():
-                if not b.dtype.is_floating_point:
+                if k.endswith("num_batches_tracked"):    # (not the dropout RNG state, which is an integer buffer too)
                     b += int(calls_total - calls_mine)   # the calls the other ranks made
         return flat[n_stat:].view_as(extra) if extra is not None else None
 

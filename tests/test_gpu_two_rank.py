@@ -73,7 +73,8 @@ def worker(rank, world, port, q, genome=False, epochs=EPOCHS):
         preds, pdc = preds[::97].contiguous(), pd[::97].cpu()
     else:
         pdc = pd.cpu()
-    q.put((rank, {k: v.cpu().numpy() for k, v in m.state_dict().items()}, tot, preds.numpy(), pdc.numpy(), tv))
+    q.put((rank, {k: v.cpu().numpy() for k, v in m.state_dict().items()}, tot, preds.numpy(), pdc.numpy(), tv,
+           m._rng_state.cpu().numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -139,7 +140,9 @@ def test_two_ranks_on_one_gpu_match_the_gradient_averaging_emulation(genome):
     else:
         assert len(plan.rounds) == 3 and all(any(g is None for g in r) is (i == 2) for i, r in enumerate(plan.rounds))
     results.sort(key=lambda r: r[0])
-    for rank, sd, tot, preds, preds_dev, ev in results:
+    for rank, sd, tot, preds, preds_dev, ev, rng in results:
+        # dropout RNG state: the seed is untouched by the statistics sync, the step counter advanced once per step group
+        assert int(rng[0]) == 0x5DEECE66D and int(rng[1]) == len(plan.rounds) * epochs, rng
         np.testing.assert_allclose(tot, ref_tot, rtol=1e-4, atol=1e-5)
         for k in ref_sd:
             if "running" in k or "num_batches" in k:
