@@ -1,3 +1,8 @@
+#!/bin/bash
+# A/B of library variants on one GPU box (tuning tool): AB_VARIANTS="name ..." bash tools/ab.sh compares the in-tree
+# build (base) with variants/libcgcn_<name>.so (built with CGCN_EXTRA_FLAGS=... python -c "from chromegcn_amd import
+# _build; _build.build_library(out='variants/libcgcn_<name>.so')") on the genome epoch, a chr21-like and a chr1-like
+# train step, twice, interleaved.  Prints ms per step.
 run() { python bench.py --no-cpu-baseline --no-extras --steps 20 "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.4f' % d['ms_per_step'], end=' ')"; }
 for rep in 1 2; do
 for v in base ${AB_VARIANTS}; do
