@@ -7,6 +7,8 @@ at BASELINE.json's shapes:
   chr1      n = 29 910, 250 k pairs, hic-like  (feature table 30.6 MB: the DEEP = true gather kernels, only reachable
                                                 at this size)
   both13k   n = 13 000, 'both' adjacency       (explicit-value CSR, table 13.3 MB > 12 MB: HAS_VAL + DEEP kernels)
+  k562      n =  5 776, d = 256, L = 4         (configs[3]; beyond the reference -- its constructor builds 1 or 2 layers --
+                                                so the oracle is the restatement rule "repeat models/ChromeModels.py:42-46")
 
 Checked per step: loss, sigmoid(pred), every parameter gradient, d loss / d features of both strands, the parameters
 after the SGD step, BatchNorm running statistics.  Tolerance: fp32 atol = rtol = 1e-4 (north star) on every tensor
@@ -29,22 +31,22 @@ from oracle import chromegcn_oracle as O
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 D, NC = 128, 103
-CASES = [
-    ("config1", 5000, 125000, False, "hic", 0),
-    ("chr21", synth.chrom_nodes("chr21"), 250000, False, "hic", 21),
-    ("chr1", synth.chrom_nodes("chr1"), 250000, True, "hic", 1),
-    ("both13k", 13000, 60000, True, "both", 7),
+CASES = [   # name, n, pairs, hic_like, adj_type, seed, d, layers
+    ("config1", 5000, 125000, False, "hic", 0, 128, 2),
+    ("chr21", synth.chrom_nodes("chr21"), 250000, False, "hic", 21, 128, 2),
+    ("chr1", synth.chrom_nodes("chr1"), 250000, True, "hic", 1, 128, 2),
+    ("both13k", 13000, 60000, True, "both", 7, 128, 2),
+    ("k562_d256_L4", synth.chrom_nodes("chr21"), 250000, False, "hic", 33, 256, 4),
 ]
 
 
-def _scaled_oracle(seed):
+def _scaled_oracle(seed, d=D, layers=2):
     torch.manual_seed(seed)
-    orc = O.GatedGCNOracle(D, NC, 0.0, 2)
+    orc = O.GatedGCNOracle(d, NC, 0.0, layers)
     with torch.no_grad():  # the reference init (gain 0.02) leaves tanh / gates in their linear range: scale up
-        orc.GC1.weight.mul_(40)
-        orc.GC2.weight.mul_(40)
-        orc.W1.weight.mul_(3)
-        orc.W2.weight.mul_(3)
+        for k in range(1, layers + 1):
+            getattr(orc, "GC%d" % k).weight.mul_(40 * (128.0 / d) ** 0.5)
+            getattr(orc, "W%d" % k).weight.mul_(3)
     return orc
 
 
@@ -55,11 +57,11 @@ def _rel(a, b):
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_train_steps_match_oracle_at_full_size(case):
-    name, n, pairs, hic_like, adj_type, seed = case
-    feats = synth.chrom_features(n, D, NC, 1000 + seed)
+    name, n, pairs, hic_like, adj_type, seed, d, layers = case
+    feats = synth.chrom_features(n, d, NC, 1000 + seed)
     hic = synth.contact_graph(n, pairs, seed, hic_like)
-    orc = _scaled_oracle(seed)
-    model = C.ChromeGCN(D, D, NC, 0.0, True, 2)
+    orc = _scaled_oracle(seed, d, layers)
+    model = C.ChromeGCN(d, d, NC, 0.0, True, layers)
     model.load_state_dict(orc.state_dict())
     model.to(DEV)
     opt = torch.optim.SGD(model.parameters(), lr=0.25, momentum=0.9, weight_decay=1e-6)
@@ -112,7 +114,7 @@ def test_train_steps_match_oracle_at_full_size(case):
 
 def test_eval_forward_matches_oracle_at_chr1_size():
     """inference path (eval-mode BatchNorm, no dropout) through the DEEP gather kernels"""
-    name, n, pairs, hic_like, adj_type, seed = CASES[2]
+    name, n, pairs, hic_like, adj_type, seed, _d, _layers = CASES[2]
     feats = synth.chrom_features(n, D, NC, 1000 + seed)
     hic = synth.contact_graph(n, pairs, seed, hic_like)
     orc = _scaled_oracle(seed)
