@@ -128,6 +128,63 @@ __global__ __launch_bounds__(512) void k_layout(int n, const int* __restrict__ r
   *(f32x4*)((char*)H + (size_t)i * row_b + lane_off) = acc * rs[i];
 }
 
+// Premise test for "the last-arriving wave runs the tile's dense phase alone": the bare gather followed by a simulated
+// dense phase of `ticks` (100 MHz) --  MODE 1: all 8 waves of the workgroup sit through it (today's structure: barrier,
+// MFMA, epilogue);  MODE 2: the waves count their arrival in LDS, seven exit at once (their wave slots can take new
+// workgroups), the last one sits through 1.6 x ticks alone.
+template <int GU, int MODE>
+__global__ __launch_bounds__(512) void k_tail(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                              const float* __restrict__ rs, const float* __restrict__ X,
+                                              float* __restrict__ H, int ticks) {
+  __shared__ int arrived;
+  __shared__ __attribute__((aligned(16))) float T[16 * 132];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (MODE == 2 && threadIdx.x == 0) arrived = 0;
+  if (MODE == 2) __syncthreads();
+  const int node0 = xcd_contiguous(blockIdx.x, gridDim.x) * 8;
+  const unsigned lane_off = ((unsigned)(lane >> 5) * (unsigned)n * 128u + (lane & 31) * 4u) * 4u;
+  const char* Xb = (const char*)X;
+  const int i = node0 + wave;
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (i < n) {
+    const int k0 = rowptr[i], k1 = rowptr[i + 1];
+    for (int kb = k0; kb < k1; kb += 64) {
+      const int cnt = min(64, k1 - kb);
+      const int myc = lane < cnt ? col[kb + lane] : 0;
+      for (int b = 0; b < cnt; b += GU) {
+        f32x4 t[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) t[u] = *(const f32x4*)(Xb + (size_t)(unsigned)rl_i(myc, min(b + u, cnt - 1)) * 512u + lane_off);
+#pragma unroll
+        for (int u = 0; u < GU; ++u)
+          if (b + u < cnt) acc += t[u];
+      }
+    }
+    *(f32x4*)((char*)H + (size_t)i * 512u + lane_off) = acc * rs[i];
+  }
+  *(f32x4*)&T[((lane >> 5) * 8 + wave) * 132 + (lane & 31) * 4] = acc;
+  if (MODE == 0) return;
+  unsigned long long t0;
+  if (MODE == 1) {
+    __syncthreads();
+    t0 = wall_clock64();
+    while ((long long)(wall_clock64() - t0) < ticks) __builtin_amdgcn_s_sleep(4);
+  } else {
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): my tile row is in LDS before I count myself in
+    int old = 0;
+    if (lane == 0) old = atomicAdd(&arrived, 1);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old != 7) return;                // seven waves leave; their slots are free for the next workgroup
+    t0 = wall_clock64();
+    while ((long long)(wall_clock64() - t0) < (ticks * 8) / 5) __builtin_amdgcn_s_sleep(4);
+  }
+  if (T[lane] == 123456.f) H[0] = 0.f;   // keep T alive
+}
+
+template <int GU, int MODE>
+static float run_tail(const Graph_& g, const int* d_rowptr, const int* d_col, const float* d_rs, const float* d_X, float* d_H, int ticks, int reps);
+
 template <int Q, int W, int GU, bool USE_LDS>
 __global__ __launch_bounds__(512) void k_window(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
                                                 const float* __restrict__ rs, const float* __restrict__ X,
@@ -329,6 +386,22 @@ static float run_layout(const Graph& g, const int* d_rowptr, const int* d_col, c
   return ms * 1e3f / reps;
 }
 
+template <int GU, int MODE>
+static float run_tail(const Graph& g, const int* d_rowptr, const int* d_col, const float* d_rs, const float* d_X, float* d_H, int ticks, int reps) {
+  const int grid = (g.n + 7) / 8;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k_tail<GU, MODE>), dim3(grid), dim3(512), 0, 0, g.n, d_rowptr, d_col, d_rs, d_X, d_H, ticks);
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k_tail<GU, MODE>), dim3(grid), dim3(512), 0, 0, g.n, d_rowptr, d_col, d_rs, d_X, d_H, ticks);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms * 1e3f / reps;
+}
+
 static void bench_window(const Graph& g, const int* d_rowptr, const int* d_col, const float* d_rs, const float* d_X, float* d_H,
                          const std::vector<float>& h_ref, int reps) {
   const size_t elems = (size_t)2 * g.n * 128;
@@ -383,7 +456,11 @@ int main(int argc, char** argv) {
       CK(hipMemcpy(d_X, X.data(), X.size() * 4, hipMemcpyHostToDevice));
       printf("%s n=%d nnz=%d table=%.1f MB\n", hic ? "hic-like" : "uniform", n, g.nnz, X.size() * 4 / 1e6);
       std::vector<float> h_ref;
-      if (getenv("SG_LAYOUT_ONLY")) {
+      if (getenv("SG_TAIL_ONLY")) {
+        printf("  dense phase 5.5 us: gather only %6.1f | all 8 waves wait %6.1f | 7 exit, last waits 8.8 us %6.1f us\n",
+               run_tail<2, 0>(g, d_rowptr, d_col, d_rs, d_X, d_H, 550, reps), run_tail<2, 1>(g, d_rowptr, d_col, d_rs, d_X, d_H, 550, reps),
+               run_tail<2, 2>(g, d_rowptr, d_col, d_rs, d_X, d_H, 550, reps));
+      } else if (getenv("SG_LAYOUT_ONLY")) {
         printf("  layout: strand-major GU2 %6.1f GU3 %6.1f | node-major (1 KiB contiguous) GU2 %6.1f GU3 %6.1f us\n",
                run_layout<2, false>(g, d_rowptr, d_col, d_rs, d_X, d_H, reps), run_layout<3, false>(g, d_rowptr, d_col, d_rs, d_X, d_H, reps),
                run_layout<2, true>(g, d_rowptr, d_col, d_rs, d_X, d_H, reps), run_layout<3, true>(g, d_rowptr, d_col, d_rs, d_X, d_H, reps));
