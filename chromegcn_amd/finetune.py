@@ -49,7 +49,12 @@ def _source_key(feats, hic):
     for k in ("forward", "backward", "target"):
         t = feats[k]
         parts.append((t.data_ptr(), t._version, tuple(t.shape)) if torch.is_tensor(t) else id(t))
-    parts.append(None if hic is None else (id(hic), getattr(hic, "nnz", None), getattr(hic, "shape", None)))
+    if hic is None:
+        parts.append(None)
+    else:   # identity alone can be recycled after garbage collection: add the size and the index buffers' addresses
+        ptrs = tuple(getattr(hic, a).__array_interface__["data"][0] for a in ("indptr", "indices")
+                     if hasattr(getattr(hic, a, None), "__array_interface__"))
+        parts.append((id(hic), getattr(hic, "nnz", None), getattr(hic, "shape", None), ptrs))
     return tuple(parts)
 
 
