@@ -24,7 +24,7 @@ _SIGNATURES = {
     "cgcn_layer_fwd": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 13 + [_c_float, _c_vp, _c_uint, _c_vp, _c_vp]),
     "cgcn_layer_fwd_colstats_tiles": (_c_int, [_c_int, _c_int, _c_int, _c_vp]),
     "cgcn_layer_bwd_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
-    "cgcn_layer_bwd": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 18 + [_c_int, _c_float, _c_vp, _c_uint, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "cgcn_layer_bwd": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 18 + [_c_int, _c_float, _c_vp, _c_uint, _c_vp, _c_vp, _c_sz, _c_vp, _c_vp]),
     "cgcn_head_workspace_bytes": (_c_sz, [_c_int] * 4),
     "cgcn_head_workspace_layout": (_c_int, [_c_int] * 4 + [ctypes.POINTER(_c_sz)] * 3),
     "cgcn_head_bwd_partials": (_c_int, [_c_int]),
@@ -40,7 +40,7 @@ _SIGNATURES = {
     "cgcn_multilabel_metrics": (_c_int, [_c_vp, ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_float, _c_vp, _c_vp, _c_sz]),
     "cgcn_sgd_step": (_c_int, [_c_vp, ctypes.c_longlong, _c_vp, _c_vp, _c_vp, _c_float, _c_float, _c_float, _c_int, _c_float, _c_vp]),
 }
-ABI_VERSION = 12
+ABI_VERSION = 13
 _lib = None
 
 
@@ -97,6 +97,13 @@ class HeadGrad(ctypes.Structure):
                 ("dropout_p", _c_float), ("rng_state", _c_vp), ("part", _c_vp), ("n_partials", _c_int), ("C", _c_int),
                 ("dW_out", _c_vp), ("db_out", _c_vp), ("accumulate", _c_int), ("dloss", _c_vp), ("dbn_w", _c_vp),
                 ("dbn_b", _c_vp)]
+
+
+class SgdFuse(ctypes.Structure):
+    """mirror of cgcn_sgd_fuse (include/chromegcn.h)"""
+    _fields_ = [("param", _c_vp), ("grad", _c_vp), ("momentum_buf", _c_vp), ("count", ctypes.c_longlong),
+                ("lr", _c_float), ("momentum", _c_float), ("weight_decay", _c_float), ("grad_scale", _c_float),
+                ("nesterov", _c_int), ("rng_state", _c_vp)]
 
 
 def ptr(t):

@@ -623,12 +623,21 @@ __global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float*
                                                       const float* __restrict__ H, const float* __restrict__ wg,
                                                       const float* __restrict__ rs, float* __restrict__ dUs,
                                                       float* __restrict__ part, HeadApply hp,
-                                                      float* __restrict__ dxn_store, int row_blocks) {
+                                                      float* __restrict__ dxn_store, int row_blocks, int head_slabs,
+                                                      const float* __restrict__ Wsrc, float* __restrict__ Wsnap) {
   constexpr int NW = 8;
   // extra workgroups past the row tiles: the head's deferred dW_out / db_out second stage (independent work,
-  // fused "horizontally" so it costs no launch of its own)
+  // fused "horizontally" so it costs no launch of its own) and, when the optimizer step is fused into the gather
+  // launch that follows (cgcn_sgd_fuse), a snapshot of W: that launch multiplies by the OLD weight while its extra
+  // workgroups already write the new one
   if ((int)blockIdx.x >= row_blocks) {
-    head_finalize_slab<512>(blockIdx.x - row_blocks, hp.hf_P, n, hp.S, D, hp.hf_C, hp.hf_CP, hp.hf_part, hp.hf_dWout,
+    const int extra = (int)blockIdx.x - row_blocks;
+    if (extra >= head_slabs) {
+      const int i4 = (extra - head_slabs) * (int)blockDim.x + (int)threadIdx.x;
+      if (i4 < D * D / 4) ((f32x4*)Wsnap)[i4] = ((const f32x4*)Wsrc)[i4];
+      return;
+    }
+    head_finalize_slab<512>(extra, hp.hf_P, n, hp.S, D, hp.hf_C, hp.hf_CP, hp.hf_part, hp.hf_dWout,
                             hp.hf_dbout, hp.hf_dbn_w, hp.hf_dbn_b, nullptr, hp.hf_accumulate, hp.dloss);
     return;
   }
@@ -810,12 +819,34 @@ __global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float*
   KT_STAMP(7);
 }
 
+// Fused optimizer step (cgcn_sgd_fuse): torch.optim.SGD on the flat arenas, element `idx`, given its final gradient g.
+struct SgdFuse {
+  float* param;          // nullptr = no fusion
+  const float* grad;
+  float* mom;
+  int count;
+  float lr, mu, wd, grad_scale;
+  int nesterov;
+  unsigned long long* rng_state;
+};
+__device__ __forceinline__ void sgd_apply(const SgdFuse& sg, int idx, float g) {
+  const float pi = sg.param[idx];
+  const float d = g * sg.grad_scale + sg.wd * pi;
+  float upd = d;
+  if (sg.mom) {
+    const float b = sg.mu * sg.mom[idx] + d;
+    sg.mom[idx] = b;
+    upd = sg.nesterov ? d + sg.mu * b : b;
+  }
+  sg.param[idx] = pi - sg.lr * upd;
+}
+
 // One 64-element slab of the second-stage sum, computed by a workgroup of NT threads (NT/64 partial slices).
 // Used by k_reduce_partials and, fused "horizontally", by the extra workgroups at the end of k_bwd_gather's grid.
 template <int NT>
 __device__ __forceinline__ void reduce_slab(int slab, int P, int D, const float* __restrict__ part,
                                             float* __restrict__ dW, float* __restrict__ db, float* __restrict__ dwg,
-                                            float* __restrict__ dcg, int accumulate) {
+                                            float* __restrict__ dcg, int accumulate, const SgdFuse& sg) {
   constexpr int NS = NT / 64;
   const int PSTRIDE = D * D + 2 * D + 4;
   const int total = D * D + 2 * D + 1;
@@ -860,6 +891,7 @@ __device__ __forceinline__ void reduce_slab(int slab, int P, int D, const float*
     else if (e < D * D + 2 * D) dst = dwg + (e - D * D - D);
     else dst = dcg;
     *dst = accumulate ? (*dst + s) : s;
+    if (sg.param) sgd_apply(sg, (int)(dst - sg.grad), s);   // this element's gradient is final: step it right here
   }
 }
 
@@ -868,7 +900,7 @@ __global__ __launch_bounds__(256) void k_reduce_partials(int P, int D, const flo
                                                          float* __restrict__ dW, float* __restrict__ db,
                                                          float* __restrict__ dwg, float* __restrict__ dcg,
                                                          int accumulate) {
-  reduce_slab<256>(blockIdx.x, P, D, part, dW, db, dwg, dcg, accumulate);
+  reduce_slab<256>(blockIdx.x, P, D, part, dW, db, dwg, dcg, accumulate, SgdFuse{nullptr, nullptr, nullptr, 0, 0.f, 0.f, 0.f, 1.f, 0, nullptr});
 }
 
 // ------------------------------------------------------------------------------------------
@@ -885,7 +917,7 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) void k_bwd_g
                                                       uint32_t stream_id, int gather_blocks, int P,
                                                       const float* __restrict__ part, float* __restrict__ dW,
                                                       float* __restrict__ db, float* __restrict__ dwg,
-                                                      float* __restrict__ dcg, int accumulate) {
+                                                      float* __restrict__ dcg, int accumulate, SgdFuse sg, int reduce_slabs) {
   using G = Geo<S, D>;
   constexpr int ROWS = 16 * MB;
   constexpr int R = ROWS / S;
@@ -898,7 +930,20 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) void k_bwd_g
   // Horizontal fusion: the workgroups past the gather tiles do the (independent) second-stage sum of the
   // row-local kernel's partials, so that reduction costs no launch of its own and overlaps the gather's tail.
   if ((int)blockIdx.x >= gather_blocks) {
-    reduce_slab<NW * 64>(blockIdx.x - gather_blocks, P, D, part, dW, db, dwg, dcg, accumulate);
+    const int extra = (int)blockIdx.x - gather_blocks;
+    if (extra < reduce_slabs) {
+      reduce_slab<NW * 64>(extra, P, D, part, dW, db, dwg, dcg, accumulate, sg);
+      return;
+    }
+    // fused optimizer step (cgcn_sgd_fuse) for every arena element whose gradient an EARLIER launch finished: all but
+    // this layer's own dW / db / dwg / dcg, which the slabs above step as they finish them
+    const int i = (extra - reduce_slabs) * (int)blockDim.x + (int)threadIdx.x;
+    if (i == 0 && sg.rng_state) sg.rng_state[1] += 1ull;
+    if (i < sg.count) {
+      const float* gp = sg.grad + i;
+      const bool mine = (gp >= dW && gp < dW + D * D) || (gp >= db && gp < db + D) || (gp >= dwg && gp < dwg + D) || gp == dcg;
+      if (!mine) sgd_apply(sg, i, *gp);
+    }
     return;
   }
   __shared__ __attribute__((aligned(16))) float T[ROWS * LD];
@@ -1223,7 +1268,8 @@ static int bwd_partials(int n, int S, int d) {
 
 size_t cgcn_layer_bwd_workspace_bytes(int n, int S, int d) {
   if (check_shape(n, S, d) != CGCN_OK) return 0;
-  return (size_t)bwd_partials(n, S, d) * ((size_t)d * d + 2 * d + 4) * sizeof(float);
+  // partial blocks of the row-local kernel + one d x d snapshot of W (cgcn_sgd_fuse)
+  return ((size_t)bwd_partials(n, S, d) * ((size_t)d * d + 2 * d + 4) + (size_t)d * d) * sizeof(float);
 }
 
 int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* rowptr_t, const int32_t* col_t,
@@ -1231,11 +1277,24 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
                    const float* gate, const float* W, const float* wg, const float* dXn, const float* dgate, float* dX,
                    float* dUs, float* dW, float* db, float* dwg, float* dcg, int accumulate, float in_dropout_p,
                    const unsigned long long* rng_state, unsigned int in_stream_id, const cgcn_head_grad* head,
-                   void* workspace, size_t workspace_bytes, cgcn_stream_t aux_stream) {
+                   void* workspace, size_t workspace_bytes, cgcn_stream_t aux_stream, const cgcn_sgd_fuse* sgd) {
   int rc = check_shape(n, S, d);
   if (rc) return rc;
   if (!rowptr_t || !col_t || !X || !Z || !H || !gate || !W || !wg || !dUs || !dW || !db || !dwg || !dcg)
     return CGCN_ERR_BAD_ARG;
+  SgdFuse sg = {nullptr, nullptr, nullptr, 0, 0.f, 0.f, 0.f, 1.f, 0, nullptr};
+  if (sgd) {
+    // only the gather launch can carry the step: it must exist, overwrite its sums, and run on the main stream
+    if (!dX || n == 0 || accumulate || aux_stream) return CGCN_ERR_BAD_ARG;
+    if (!sgd->param || !sgd->grad || sgd->count <= 0 || sgd->count > 2147483647LL) return CGCN_ERR_BAD_ARG;
+    if ((sgd->momentum != 0.f) != (sgd->momentum_buf != nullptr) || (sgd->nesterov && sgd->momentum == 0.f)) return CGCN_ERR_BAD_ARG;
+    const float* g0 = sgd->grad;
+    const float* g1 = sgd->grad + sgd->count;
+    if (!(dW >= g0 && dW + (size_t)d * d <= g1 && db >= g0 && db + d <= g1 && dwg >= g0 && dwg + d <= g1 && dcg >= g0 && dcg < g1))
+      return CGCN_ERR_BAD_ARG;  // the layer's gradient outputs must live inside the flat gradient arena
+    sg = SgdFuse{sgd->param, sgd->grad, sgd->momentum_buf, (int)sgd->count, sgd->lr, sgd->momentum, sgd->weight_decay,
+                 sgd->grad_scale, sgd->nesterov, sgd->rng_state};
+  }
   if ((dXn == nullptr) == (head == nullptr)) return CGCN_ERR_BAD_ARG;  // exactly one source of dL/dXn
   if ((dX && dX == dXn) || misaligned16(dUs) || (dX && misaligned16(dX)) || misaligned16(W)) return CGCN_ERR_BAD_ARG;
   if (misaligned16(X) || misaligned16(Z) || misaligned16(H) || (dXn && misaligned16(dXn))) return CGCN_ERR_BAD_ARG;  // vector row accesses
@@ -1263,17 +1322,19 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   hipStream_t st = (hipStream_t)stream;
   const int P = bwd_partials(n, S, d);
   float* part = (float*)workspace;
+  float* Wsnap = part + (size_t)P * ((size_t)d * d + 2 * d + 4);   // 16-byte aligned: the partial stride is a multiple of 4
+  const int copy_blocks = sg.param ? (d * d / 4 + 511) / 512 : 0;
   const int M = n * S;
   if (d == 128)
     switch (bwd_tile_rows(n, S, d)) {
-#define RL(TR_) hipLaunchKernelGGL((k_bwd_rowlocal<128, TR_>), dim3(P + head_slabs), dim3(512), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dUs, part, hp, dX, P)
+#define RL(TR_) hipLaunchKernelGGL((k_bwd_rowlocal<128, TR_>), dim3(P + head_slabs + copy_blocks), dim3(512), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dUs, part, hp, dX, P, head_slabs, W, Wsnap)
       case 32: RL(32); break;
       case 48: RL(48); break;
       default: RL(BWD_TILE_ROWS); break;
 #undef RL
     }
   else
-    hipLaunchKernelGGL((k_bwd_rowlocal<256, 32>), dim3(P + head_slabs), dim3(512), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dUs, part, hp, dX, P);
+    hipLaunchKernelGGL((k_bwd_rowlocal<256, 32>), dim3(P + head_slabs + copy_blocks), dim3(512), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dUs, part, hp, dX, P, head_slabs, W, Wsnap);
   if ((rc = launch_status())) return rc;
   // The reduction of the per-tile partials and the gather kernel are independent: with an auxiliary stream
   // they run side by side (fork after k_bwd_rowlocal, join before returning; both edges are events, so the
@@ -1304,11 +1365,15 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   const int tn = 16 * mb / S;
   const int blocks = (n + tn - 1) / tn;
   if (head) dXn = dX;  // k_bwd_rowlocal left dL/dXn there; each thread reads its elements before overwriting them
+  if (sg.param) W = Wsnap;  // the fused step rewrites W inside the gather launch: multiply by the snapshot taken above
   const bool deep = pick_deep(n, S, d);
+  const int gthreads = (d == 128 && CBW128 == 2) ? 256 : 512;
+  const int sgd_blocks = sg.param ? (sg.count + gthreads - 1) / gthreads : 0;
 #define BG(S_, D_, MB_, V_, DP_)                                                                                     \
-  hipLaunchKernelGGL((k_bwd_gather<S_, D_, MB_, V_, DP_>), dim3(blocks + (fuse_reduce ? slabs : 0)),                 \
+  hipLaunchKernelGGL((k_bwd_gather<S_, D_, MB_, V_, DP_>), dim3(blocks + (fuse_reduce ? slabs : 0) + sgd_blocks),    \
                      dim3((D_ == 128 && CBW128 == 2) ? 256 : 512), 0, st, n, rowptr_t, col_t, val_t, dUs, W, dXn,   \
-                     gate, dX, ks, th, rng_state, in_stream_id, blocks, P, part, dW, db, dwg, dcg, accumulate)
+                     gate, dX, ks, th, rng_state, in_stream_id, blocks, P, part, dW, db, dwg, dcg, accumulate, sg,  \
+                     fuse_reduce ? slabs : 0)
 #define CALL(S_, D_, V_)                                                                                             \
   do {                                                                                                               \
     if (deep) BG(S_, D_, 1, V_, true);                                                                               \

@@ -286,6 +286,28 @@ class GCNStage:
             slot["loss"].copy_(loss.detach().view(1))
         return loss, slot["probs"]
 
+    def _fwd_bwd_step(self, c: _Chrom):
+        """forward + backward + optimizer step of one chromosome (finetune.py:38-49).  With the fused SGD and the
+        gradient w.r.t. the features requested, the step rides in the last backward launch (cgcn_sgd_fuse: the first
+        layer's gather kernel carries it in extra workgroups) instead of being a launch of its own."""
+        from . import ops
+        fuse = (self._fused_sgd and self.input_grad and getattr(self.model, "_grad_sink", False)
+                and getattr(self.model, "n_layers", 0) >= 1)
+        if fuse:
+            g = self.optimizer.param_groups[0]
+            ops._sgd_fuse = {"param": self._flat_param, "grad": self._flat_grad, "mom": self._flat_mom, "lr": g["lr"],
+                             "momentum": g.get("momentum", 0), "weight_decay": g.get("weight_decay", 0),
+                             "nesterov": g.get("nesterov", False), "grad_scale": 1.0, "done": False,
+                             "rng_state": self.model._rng_state if getattr(self.model, "_rng_managed", False) else None}
+        try:
+            out = self._fwd_bwd(c)
+            done = bool(fuse and ops._sgd_fuse["done"])
+        finally:
+            ops._sgd_fuse = None
+        if not done:
+            self._optimizer_step()                                         # finetune.py:49
+        return out
+
     def _fwd_bwd(self, c: _Chrom):
         x = c.x.detach().requires_grad_(True) if self.input_grad else c.x  # finetune.py:33-34
         if not getattr(self.model, "_grad_sink", False):
@@ -304,6 +326,9 @@ class GCNStage:
     # ------------------------------------------------------------------ HIP-graph capture
     def _snapshot(self):
         st = {"model": {k: v.clone() for k, v in self.model.state_dict().items()}}
+        rng = getattr(self.model, "_rng_state", None)   # non-persistent buffer (not in the state_dict): the dropout
+        if torch.is_tensor(rng):                        # step counter must not remember the warm-up steps either
+            st["rng"] = rng.clone()
         if self.optimizer is not None:
             st["opt"] = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in s.items()}
                          for s in (self.optimizer.state.get(p, {}) for p in self._params())]
@@ -313,6 +338,8 @@ class GCNStage:
         with torch.no_grad():
             for k, v in self.model.state_dict().items():
                 v.copy_(st["model"][k])
+            if "rng" in st:
+                self.model._rng_state.copy_(st["rng"])
             if self.optimizer is not None:
                 for p, saved in zip(self._params(), st["opt"]):
                     cur = self.optimizer.state.get(p, {})
@@ -338,10 +365,9 @@ class GCNStage:
             if kind == "eval":
                 loss, probs = self._eval(c)
                 return loss, probs, None
-            loss, probs, dx = self._fwd_bwd(c)
             if kind == "train":
-                self._optimizer_step()                                    # finetune.py:49
-            return loss, probs, dx
+                return self._fwd_bwd_step(c)
+            return self._fwd_bwd(c)
 
         if kind == "train" and not self._fused_sgd:
             # torch optimizers are not capturable by default (Adam.step raises under capture): callers replay
@@ -390,8 +416,8 @@ class GCNStage:
         self._ensure_arena()
         if self.world > 1:
             raise RuntimeError("use train_group() when running on more than one rank")
-        if self.hip_graphs and self._fused_sgd:
-            return self._replay(c, "train")          # zero_grad + fwd + bwd + fused SGD: one HIP graph
+        if self._fused_sgd:                          # zero_grad + fwd + bwd + fused SGD: one HIP graph (or the same, eagerly)
+            return self._replay(c, "train") if self.hip_graphs else self._fwd_bwd_step(c)
         # any other optimizer (Adam is the reference's -optim adam, utils/util_methods.py:20-21): its step() is
         # not capturable, so the graph ends after the backward and the step runs eagerly on the flat buffers
         loss, probs, dx = self._replay(c, "fwdbwd") if self.hip_graphs else self._fwd_bwd(c)

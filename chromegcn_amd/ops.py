@@ -67,6 +67,27 @@ _EVAL_BWD_MSG = ("chromegcn_amd: backward through the fused classifier head need
 
 _saliency_tap = None  # set by chromegcn_amd.saliency while it collects per-layer (X, dUs, W)
 
+# Set by the stage engine around one train step (finetune.GCNStage): the flat parameter / gradient / momentum arenas and
+# the SGD hyper-parameters.  The FIRST layer's backward -- the last launch of the step -- then carries the optimizer step
+# in extra workgroups of its gather launch (cgcn_sgd_fuse) and marks the request done; anything it cannot fuse (no
+# gradient w.r.t. the input requested, no sinks) is left for cgcn_sgd_step.
+_sgd_fuse = None
+
+
+def _sgd_fuse_arg(layer_id, dx, sink):
+    """ctypes reference to a cgcn_sgd_fuse for this cgcn_layer_bwd call, or None (plus the struct to keep alive)"""
+    rq = _sgd_fuse
+    if rq is None or rq.get("done") or layer_id != 1 or dx is None or sink is None or _lib.aux_stream_ptr() is not None:
+        return None, None
+    fg = rq["grad"]
+    lo, hi = fg.data_ptr(), fg.data_ptr() + 4 * fg.numel()
+    if not all(lo <= t.data_ptr() and t.data_ptr() + 4 * t.numel() <= hi for t in sink):
+        return None, None
+    sg = _lib.SgdFuse(rq["param"].data_ptr(), fg.data_ptr(), _lib.ptr(rq["mom"]), fg.numel(), float(rq["lr"]),
+                      float(rq["momentum"]), float(rq["weight_decay"]), float(rq["grad_scale"]), 1 if rq["nesterov"] else 0,
+                      _lib.ptr(rq["rng_state"]))
+    return ctypes.byref(sg), sg
+
 
 def _resolve_h_cache(h_cache, x, need_bwd):
     """h_cache: None, or a dict holder {'h': tensor-or-None} for H = A X of a layer whose input never changes
@@ -177,13 +198,17 @@ class GatedLayerFn(torch.autograd.Function):
         lib = _lib.load()
         ws_bytes = lib.cgcn_layer_bwd_workspace_bytes(n, S, d)
         ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8)
+        sg_ref, sg_keep = _sgd_fuse_arg(ctx.layer_id, dx, ctx.sink)
         _lib.check(lib.cgcn_layer_bwd(_lib.stream_ptr(), n, S, d, _lib.ptr(g.rowptr_t), _lib.ptr(g.col_t),
                                       _lib.ptr(g.val_t), _lib.ptr(g.row_scale), x.data_ptr(), z.data_ptr(),
                                       h.data_ptr(), gate.data_ptr(), weight.data_ptr(), wg.data_ptr(),
                                       dxn.data_ptr(), _lib.ptr(dgate), _lib.ptr(dx), dus.data_ptr(), dw.data_ptr(),
                                       db.data_ptr(), dwg.data_ptr(), dcg.data_ptr(), 0, ctx.dropout_in,
-                                      _lib.ptr(rng_state), max(ctx.layer_id - 1, 0), None, ws.data_ptr(), ws_bytes, _lib.aux_stream_ptr()),
+                                      _lib.ptr(rng_state), max(ctx.layer_id - 1, 0), None, ws.data_ptr(), ws_bytes,
+                                      _lib.aux_stream_ptr(), sg_ref),
                    "cgcn_layer_bwd")
+        if sg_ref is not None:
+            _sgd_fuse["done"] = True
         if _saliency_tap is not None:
             _saliency_tap.append((x, dus, weight, g))  # dus = diag(row_scale) dL/dU of this layer
         if ctx.sink is not None:
@@ -405,12 +430,17 @@ class LastLayerHeadLossFn(torch.autograd.Function):
         dus = torch.empty_like(x)
         ws_bytes = lib.cgcn_layer_bwd_workspace_bytes(n, S, d)
         ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        # a one-layer model: this IS the first layer's backward, i.e. the last launch of the step
+        sg_ref, sg_keep = _sgd_fuse_arg(ctx.layer_id, dx, ctx.layer_sink if ctx.head_sink is not None else None)
         _lib.check(lib.cgcn_layer_bwd(_lib.stream_ptr(), n, S, d, _lib.ptr(g.rowptr_t), _lib.ptr(g.col_t),
                                       _lib.ptr(g.val_t), _lib.ptr(g.row_scale), x.data_ptr(), z.data_ptr(),
                                       h.data_ptr(), gate.data_ptr(), weight.data_ptr(), wg.data_ptr(),
                                       None, None, _lib.ptr(dx), dus.data_ptr(), dw.data_ptr(), db.data_ptr(),
                                       dwg.data_ptr(), dcg.data_ptr(), 0, ctx.dropout_in, _lib.ptr(rng_state),
-                                      max(ctx.layer_id - 1, 0), ctypes.byref(hg), ws.data_ptr(), ws_bytes, _lib.aux_stream_ptr()), "cgcn_layer_bwd")
+                                      max(ctx.layer_id - 1, 0), ctypes.byref(hg), ws.data_ptr(), ws_bytes,
+                                      _lib.aux_stream_ptr(), sg_ref), "cgcn_layer_bwd")
+        if sg_ref is not None:
+            _sgd_fuse["done"] = True
         gl = (None,) * 4 if ctx.layer_sink is not None else (dw, db, dwg.view(ctx.shapes[0]), dcg.view(ctx.shapes[1]))
         gh = (None,) * 4 if ctx.head_sink is not None else (dbn_w, dbn_b, dw_out, db_out)
         return (dx,) + gl + gh + (None,) * 16

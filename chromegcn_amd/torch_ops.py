@@ -144,7 +144,7 @@ def gated_layer_backward(dxn: Tensor, dgate: Optional[Tensor], x: Tensor, z: Ten
                                   wg.data_ptr(), dxn.data_ptr(), _P(None if dgate is None else dgate.contiguous()),
                                   dx.data_ptr() if need_dx else None, dus.data_ptr(), dw.data_ptr(), db.data_ptr(),
                                   dwg.data_ptr(), dcg.data_ptr(), 0, float(dropout_in), _P(rng_state) if dropout_in > 0 else None,
-                                  max(int(layer_id) - 1, 0), None, ws.data_ptr(), ws_bytes, None), "cgcn_layer_bwd")
+                                  max(int(layer_id) - 1, 0), None, ws.data_ptr(), ws_bytes, None, None), "cgcn_layer_bwd")
     return dx, dw, db, dwg, dcg, dus
 
 

@@ -48,7 +48,7 @@ extern "C" {
 #define CGCN_ERR_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after a launch      */
 #define CGCN_ERR_WORKSPACE (-4)   /* workspace too small (see cgcn_*_workspace_bytes)    */
 
-#define CGCN_ABI_VERSION 12
+#define CGCN_ABI_VERSION 13
 
 typedef void *cgcn_stream_t; /* hipStream_t */
 
@@ -130,6 +130,26 @@ typedef struct cgcn_head_grad {
   float *dbn_b;             /* [d] are then finished here as well (same accumulate flag); NULL after cgcn_head_bwd  */
 } cgcn_head_grad;
 
+/*
+ * Optional: the optimizer step of utils/util_methods.py:14-19's SGD (optimizer.step(), finetune.py:49) fused into
+ * the LAST cgcn_layer_bwd call of a train step -- the first layer's backward with dX != NULL, whose gather launch
+ * carries the second stage of this layer's parameter sums in extra workgroups anyway.  Those workgroups then apply
+ * the update to the elements they have just finished, and further extra workgroups update every other element of
+ * the flat arenas (their gradients were finished by earlier launches of the step): no cgcn_sgd_step launch.
+ * param / grad / momentum_buf: flat fp32 arenas of `count` elements in which every parameter, its gradient and its
+ * momentum buffer sit at the SAME offset; dW, db, dwg, dcg of this call must point into `grad`.  Semantics and the
+ * rng_state counter advance are those of cgcn_sgd_step.  Needs dX != NULL, accumulate == 0, aux_stream == NULL.
+ */
+typedef struct cgcn_sgd_fuse {
+  float *param;
+  const float *grad;
+  float *momentum_buf;      /* NULL iff momentum == 0 */
+  long long count;
+  float lr, momentum, weight_decay, grad_scale;
+  int nesterov;
+  unsigned long long *rng_state;   /* may be NULL */
+} cgcn_sgd_fuse;
+
 /* Bytes of scratch cgcn_layer_bwd needs for (n, S, d).  0 on unsupported shapes. */
 size_t cgcn_layer_bwd_workspace_bytes(int n, int S, int d);
 
@@ -151,6 +171,7 @@ size_t cgcn_layer_bwd_workspace_bytes(int n, int S, int d);
  * Exactly one of dXn and head must be non-NULL (head: see cgcn_head_grad).
  * aux_stream (may be NULL): a second stream on which the partial-sum reduction runs concurrently with the
  * gather kernel; forked from and joined back into `stream` with events inside this call.
+ * sgd (may be NULL): see cgcn_sgd_fuse.
  */
 int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d,
                    const int32_t *rowptr_t, const int32_t *col_t, const float *val_t, const float *row_scale,
@@ -160,7 +181,8 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d,
                    float *dX, float *dUs, float *dW, float *db, float *dwg, float *dcg,
                    int accumulate, float in_dropout_p, const unsigned long long *rng_state,
                    unsigned int in_stream_id, const cgcn_head_grad *head,
-                   void *workspace, size_t workspace_bytes, cgcn_stream_t aux_stream);
+                   void *workspace, size_t workspace_bytes, cgcn_stream_t aux_stream,
+                   const cgcn_sgd_fuse *sgd);
 
 /* Bytes of scratch cgcn_head_fwd / cgcn_head_bwd need for (n, S, d, C).  0 on unsupported shapes. */
 size_t cgcn_head_workspace_bytes(int n, int S, int d, int C);

@@ -64,7 +64,7 @@ def test_workspaces_are_checked(env):
     def bwd(ws_bytes, dxn=env["y"], wsp=P(ws)):
         return lib.cgcn_layer_bwd(_lib.stream_ptr(), n, S, d, P(g.rowptr_t), P(g.col_t), None, P(g.row_scale), P(env["x"]), P(env["z"]),
                                   P(env["h"]), P(env["gate"]), P(env["W"]), P(env["wg"]), _lib.ptr(dxn), None, P(dx), P(dus), P(dW), P(db),
-                                  P(dwg), P(dcg), 0, 0.0, None, 0, None, wsp, ws_bytes, None)
+                                  P(dwg), P(dcg), 0, 0.0, None, 0, None, wsp, ws_bytes, None, None)
     assert bwd(need) == OK
     assert bwd(need - 1) == WORKSPACE
     assert bwd(need, wsp=None) == WORKSPACE
