@@ -895,12 +895,30 @@ __device__ __forceinline__ void reduce_slab(int slab, int P, int D, const float*
   }
 }
 
-// Second stage: out[e] (+)= sum_p part[p][e], fixed order => deterministic.
+// Extra workgroups of a launch that carries the optimizer step (cgcn_sgd_fuse): every arena element whose gradient an
+// EARLIER launch finished, i.e. all but this layer's own dW / db / dwg / dcg (the reduce slabs step those as they finish).
+__device__ __forceinline__ void sgd_other_elements(const SgdFuse& sg, int block, int D, const float* dW, const float* db,
+                                                   const float* dwg, const float* dcg) {
+  const int i = block * (int)blockDim.x + (int)threadIdx.x;
+  if (i == 0 && sg.rng_state) sg.rng_state[1] += 1ull;
+  if (i < sg.count) {
+    const float* gp = sg.grad + i;
+    const bool mine = (gp >= dW && gp < dW + D * D) || (gp >= db && gp < db + D) || (gp >= dwg && gp < dwg + D) || gp == dcg;
+    if (!mine) sgd_apply(sg, i, *gp);
+  }
+}
+
+// Second stage: out[e] (+)= sum_p part[p][e], fixed order => deterministic.  (Stand-alone form: the first layer's
+// backward when nobody wants d loss / d features, so there is no gather launch to ride in.)
 __global__ __launch_bounds__(256) void k_reduce_partials(int P, int D, const float* __restrict__ part,
                                                          float* __restrict__ dW, float* __restrict__ db,
                                                          float* __restrict__ dwg, float* __restrict__ dcg,
-                                                         int accumulate) {
-  reduce_slab<256>(blockIdx.x, P, D, part, dW, db, dwg, dcg, accumulate, SgdFuse{nullptr, nullptr, nullptr, 0, 0.f, 0.f, 0.f, 1.f, 0, nullptr});
+                                                         int accumulate, SgdFuse sg, int reduce_slabs) {
+  if ((int)blockIdx.x >= reduce_slabs) {
+    sgd_other_elements(sg, (int)blockIdx.x - reduce_slabs, D, dW, db, dwg, dcg);
+    return;
+  }
+  reduce_slab<256>(blockIdx.x, P, D, part, dW, db, dwg, dcg, accumulate, sg);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -937,13 +955,7 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) void k_bwd_g
     }
     // fused optimizer step (cgcn_sgd_fuse) for every arena element whose gradient an EARLIER launch finished: all but
     // this layer's own dW / db / dwg / dcg, which the slabs above step as they finish them
-    const int i = (extra - reduce_slabs) * (int)blockDim.x + (int)threadIdx.x;
-    if (i == 0 && sg.rng_state) sg.rng_state[1] += 1ull;
-    if (i < sg.count) {
-      const float* gp = sg.grad + i;
-      const bool mine = (gp >= dW && gp < dW + D * D) || (gp >= db && gp < db + D) || (gp >= dwg && gp < dwg + D) || gp == dcg;
-      if (!mine) sgd_apply(sg, i, *gp);
-    }
+    sgd_other_elements(sg, extra - reduce_slabs, D, dW, db, dwg, dcg);
     return;
   }
   __shared__ __attribute__((aligned(16))) float T[ROWS * LD];
@@ -1284,8 +1296,8 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
     return CGCN_ERR_BAD_ARG;
   SgdFuse sg = {nullptr, nullptr, nullptr, 0, 0.f, 0.f, 0.f, 1.f, 0, nullptr};
   if (sgd) {
-    // only the gather launch can carry the step: it must exist, overwrite its sums, and run on the main stream
-    if (!dX || n == 0 || accumulate || aux_stream) return CGCN_ERR_BAD_ARG;
+    // the launch that finishes this layer's sums carries the step: it must overwrite them and run on the main stream
+    if (n == 0 || accumulate || aux_stream) return CGCN_ERR_BAD_ARG;
     if (!sgd->param || !sgd->grad || sgd->count <= 0 || sgd->count > 2147483647LL) return CGCN_ERR_BAD_ARG;
     if ((sgd->momentum != 0.f) != (sgd->momentum_buf != nullptr) || (sgd->nesterov && sgd->momentum == 0.f)) return CGCN_ERR_BAD_ARG;
     const float* g0 = sgd->grad;
@@ -1323,7 +1335,7 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   const int P = bwd_partials(n, S, d);
   float* part = (float*)workspace;
   float* Wsnap = part + (size_t)P * ((size_t)d * d + 2 * d + 4);   // 16-byte aligned: the partial stride is a multiple of 4
-  const int copy_blocks = sg.param ? (d * d / 4 + 511) / 512 : 0;
+  const int copy_blocks = (sg.param && dX) ? (d * d / 4 + 511) / 512 : 0;   // the W snapshot is for the gather launch only
   const int M = n * S;
   if (d == 128)
     switch (bwd_tile_rows(n, S, d)) {
@@ -1353,7 +1365,9 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   // default: the sum rides at the end of the gather launch; no gather when the caller does not want dX
   const bool fuse_reduce = (rs_stream == st) && n > 0 && dX != nullptr;
   if (!fuse_reduce) {
-    hipLaunchKernelGGL(k_reduce_partials, dim3(slabs), dim3(256), 0, rs_stream, P, d, part, dW, db, dwg, dcg, accumulate);
+    const int sgd_blocks_r = sg.param ? (sg.count + 255) / 256 : 0;   // no gather launch: the step rides here instead
+    hipLaunchKernelGGL(k_reduce_partials, dim3(slabs + sgd_blocks_r), dim3(256), 0, rs_stream, P, d, part, dW, db, dwg, dcg,
+                       accumulate, sg, slabs);
     if ((rc = launch_status())) return rc;
     if (rs_stream != st && hipEventRecord(ev_join, rs_stream) != hipSuccess) return CGCN_ERR_LAUNCH;
   }

@@ -287,12 +287,12 @@ class GCNStage:
         return loss, slot["probs"]
 
     def _fwd_bwd_step(self, c: _Chrom):
-        """forward + backward + optimizer step of one chromosome (finetune.py:38-49).  With the fused SGD and the
-        gradient w.r.t. the features requested, the step rides in the last backward launch (cgcn_sgd_fuse: the first
-        layer's gather kernel carries it in extra workgroups) instead of being a launch of its own."""
+        """forward + backward + optimizer step of one chromosome (finetune.py:38-49).  With the fused SGD the step
+        rides in the last backward launch (cgcn_sgd_fuse: the first layer's gather kernel -- or, when nobody wants
+        d loss / d features, its partial-sum launch -- carries it in extra workgroups) instead of being a launch of
+        its own."""
         from . import ops
-        fuse = (self._fused_sgd and self.input_grad and getattr(self.model, "_grad_sink", False)
-                and getattr(self.model, "n_layers", 0) >= 1)
+        fuse = self._fused_sgd and getattr(self.model, "_grad_sink", False) and getattr(self.model, "n_layers", 0) >= 1
         if fuse:
             g = self.optimizer.param_groups[0]
             ops._sgd_fuse = {"param": self._flat_param, "grad": self._flat_grad, "mom": self._flat_mom, "lr": g["lr"],

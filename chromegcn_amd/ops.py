@@ -69,15 +69,15 @@ _saliency_tap = None  # set by chromegcn_amd.saliency while it collects per-laye
 
 # Set by the stage engine around one train step (finetune.GCNStage): the flat parameter / gradient / momentum arenas and
 # the SGD hyper-parameters.  The FIRST layer's backward -- the last launch of the step -- then carries the optimizer step
-# in extra workgroups of its gather launch (cgcn_sgd_fuse) and marks the request done; anything it cannot fuse (no
-# gradient w.r.t. the input requested, no sinks) is left for cgcn_sgd_step.
+# in extra workgroups of its gather (or, without an input gradient, its partial-sum) launch (cgcn_sgd_fuse) and marks
+# the request done; anything it cannot fuse (gradients not in the flat arena) is left for cgcn_sgd_step.
 _sgd_fuse = None
 
 
 def _sgd_fuse_arg(layer_id, dx, sink):
     """ctypes reference to a cgcn_sgd_fuse for this cgcn_layer_bwd call, or None (plus the struct to keep alive)"""
     rq = _sgd_fuse
-    if rq is None or rq.get("done") or layer_id != 1 or dx is None or sink is None or _lib.aux_stream_ptr() is not None:
+    if rq is None or rq.get("done") or layer_id != 1 or sink is None or _lib.aux_stream_ptr() is not None:
         return None, None
     fg = rq["grad"]
     lo, hi = fg.data_ptr(), fg.data_ptr() + 4 * fg.numel()

@@ -132,13 +132,13 @@ typedef struct cgcn_head_grad {
 
 /*
  * Optional: the optimizer step of utils/util_methods.py:14-19's SGD (optimizer.step(), finetune.py:49) fused into
- * the LAST cgcn_layer_bwd call of a train step -- the first layer's backward with dX != NULL, whose gather launch
- * carries the second stage of this layer's parameter sums in extra workgroups anyway.  Those workgroups then apply
+ * the LAST cgcn_layer_bwd call of a train step -- the first layer's backward, whose gather launch (dX != NULL) or
+ * partial-sum launch (dX == NULL) finishes this layer's parameter sums in slab workgroups.  Those workgroups then apply
  * the update to the elements they have just finished, and further extra workgroups update every other element of
  * the flat arenas (their gradients were finished by earlier launches of the step): no cgcn_sgd_step launch.
  * param / grad / momentum_buf: flat fp32 arenas of `count` elements in which every parameter, its gradient and its
  * momentum buffer sit at the SAME offset; dW, db, dwg, dcg of this call must point into `grad`.  Semantics and the
- * rng_state counter advance are those of cgcn_sgd_step.  Needs dX != NULL, accumulate == 0, aux_stream == NULL.
+ * rng_state counter advance are those of cgcn_sgd_step.  Needs n > 0, accumulate == 0, aux_stream == NULL.
  */
 typedef struct cgcn_sgd_fuse {
   float *param;

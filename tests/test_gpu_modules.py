@@ -179,14 +179,15 @@ def test_capture_failure_leaves_the_model_as_it_was():
     st._ensure_flat_grad()
     st._ensure_arena()
     calls = {"n": 0}
-    orig = st._optimizer_step
+    orig = st._fwd_bwd
 
     def boom(*a, **k):
+        out = orig(*a, **k)          # the step itself runs (and mutates the model: the optimizer step rides in it) ...
         calls["n"] += 1
-        if calls["n"] >= 3:          # two warm-up steps pass (mutating the model), the capture step fails
+        if calls["n"] >= 3:          # ... twice as warm-up; the third call, under capture, fails
             raise RuntimeError("boom")
-        return orig(*a, **k)
-    st._optimizer_step = boom
+        return out
+    st._fwd_bwd = boom
     with pytest.raises(RuntimeError):
         st.train_step("c")
     torch.cuda.synchronize()

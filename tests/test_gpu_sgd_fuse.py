@@ -17,8 +17,9 @@ DEV = "cuda"
 P = _lib.ptr
 
 
+@pytest.mark.parametrize("want_dx", [True, False], ids=["gather_launch", "partial_sum_launch"])
 @pytest.mark.parametrize("n,d,momentum,nesterov", [(777, 128, 0.9, False), (12000, 128, 0.9, True), (300, 256, 0.0, False)])
-def test_fused_step_equals_separate_step_bitwise(n, d, momentum, nesterov):
+def test_fused_step_equals_separate_step_bitwise(n, d, momentum, nesterov, want_dx):
     lib = _lib.load()
     S = 2
     g = G.upload(G.normalize_graph("hic", synth.contact_graph(n, 6 * n, 3), n), DEV)
@@ -43,7 +44,7 @@ def test_fused_step_equals_separate_step_bitwise(n, d, momentum, nesterov):
         sg = _lib.SgdFuse(param.data_ptr(), grad.data_ptr(), mom.data_ptr() if momentum else None, total, lr, momentum, wd, gs,
                           1 if nesterov else 0, rng.data_ptr())
         rc = lib.cgcn_layer_bwd(_lib.stream_ptr(), n, S, d, P(g.rowptr_t), P(g.col_t), None, P(g.row_scale), P(x), P(z), P(h),
-                                P(gate), W.data_ptr(), wg.data_ptr(), P(dxn), None, P(dx), P(dus),
+                                P(gate), W.data_ptr(), wg.data_ptr(), P(dxn), None, P(dx) if want_dx else None, P(dus),
                                 grad[off_W:].data_ptr(), grad[off_b:].data_ptr(), grad[off_wg:].data_ptr(), grad[off_cg:].data_ptr(),
                                 0, 0.0, None, 0, None, P(ws), ws_bytes, None, ctypes.byref(sg) if fused else None)
         assert rc == 0
@@ -51,7 +52,7 @@ def test_fused_step_equals_separate_step_bitwise(n, d, momentum, nesterov):
             assert lib.cgcn_sgd_step(_lib.stream_ptr(), total, P(param), P(grad), P(mom) if momentum else None, lr, momentum, wd,
                                      1 if nesterov else 0, gs, P(rng)) == 0
         torch.cuda.synchronize()
-        return param, grad, mom, rng, dx
+        return param, grad, mom, rng, (dx if want_dx else dus)
     a, b = run(True), run(False)
     for name, ta, tb in zip(("param", "grad", "momentum", "rng", "dX"), a, b):
         assert torch.equal(ta, tb), name
@@ -77,7 +78,7 @@ def test_fuse_request_is_validated():
                                   arena_g[16384:].data_ptr(), arena_g[16600:].data_ptr(), arena_g[16800:].data_ptr(), accumulate,
                                   0.0, None, 0, None, P(ws), ws_bytes, None, ctypes.byref(sgd) if sgd is not None else None)
     assert call(P(dx), arena_g.data_ptr()) == 0
-    assert call(None, arena_g.data_ptr()) == -1                      # no gather launch to carry the step
+    assert call(None, arena_g.data_ptr()) == 0                       # no gather launch: the partial-sum launch carries the step
     assert call(P(dx), elsewhere.data_ptr()) == -1                   # dW outside the gradient arena
     assert call(P(dx), arena_g.data_ptr(), accumulate=1) == -1       # the step needs final (overwritten) sums
     bad = _lib.SgdFuse(arena_p.data_ptr(), arena_g.data_ptr(), None, 20000, 0.1, 0.9, 0.0, 1.0, 0, None)
@@ -85,10 +86,10 @@ def test_fuse_request_is_validated():
     torch.cuda.synchronize()
 
 
-def test_engine_fuses_the_step_and_matches_the_unfused_engine():
-    """GCNStage with d loss / d features requested (reference semantics) takes the fused path; without it the first
-    layer has no gather launch and cgcn_sgd_step runs: same parameters either way (to fp32 rounding: the two paths sum
-    the first layer's partial blocks with 512- and 256-thread second stages, i.e. in different orders), and the oracle's."""
+def test_engine_fuses_the_step_with_and_without_input_gradient():
+    """GCNStage with d loss / d features requested (reference semantics) carries the step in the first layer's gather
+    launch, without it in that layer's partial-sum launch: same parameters either way (to fp32 rounding: the two launches
+    sum the partial blocks with 512- and 256-thread second stages, i.e. in different orders), and the oracle's."""
     n, d, c = 900, 128, 13
     feats = synth.chrom_features(n, d, c, 5)
     hic = synth.contact_graph(n, 7000, 5)
