@@ -68,10 +68,13 @@ class GCNStage:
                  resulting x.grad is unobservable there (the tensors are loop-local and finetune returns only
                  predictions, targets and the loss), so the default skips that last gather; train_step returns
                  dx = None then
-    group      : torch.distributed process group (None = single process)"""
+    group      : torch.distributed process group (None = single process)
+    force_collectives : take the multi-rank path (shard plan, all-reduce, prediction gathers) even when the group has
+                 one rank -- the only way to drive the engine's RCCL calls on a single-GPU box"""
 
     def __init__(self, model, optimizer=None, adj_type: str = "hic", device="cuda", hip_graphs: bool = True,
-                 input_grad: bool = False, group=None, fused_head: bool = True, cache_input_aggregation: bool = True):
+                 input_grad: bool = False, group=None, fused_head: bool = True, cache_input_aggregation: bool = True,
+                 force_collectives: bool = False):
         self.model = model
         self.fused_head = fused_head
         # A X of the first layer is loop invariant across steps and epochs (like the normalised CSR): compute it once
@@ -88,6 +91,9 @@ class GCNStage:
             self.rank = torch.distributed.get_rank(group)
         else:
             self.world, self.rank = 1, 0
+        if force_collectives and not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            raise RuntimeError("force_collectives needs an initialised torch.distributed process group")
+        self.multi = self.world > 1 or bool(force_collectives)
         self.chroms: Dict[str, _Chrom] = {}
         self._graphs: Dict[tuple, dict] = {}
         self._pool = None
@@ -414,7 +420,7 @@ class GCNStage:
         self.model.train()
         self._ensure_flat_grad()
         self._ensure_arena()
-        if self.world > 1:
+        if self.multi:
             raise RuntimeError("use train_group() when running on more than one rank")
         if self._fused_sgd:                          # zero_grad + fwd + bwd + fused SGD: one HIP graph (or the same, eagerly)
             return self._replay(c, "train") if self.hip_graphs else self._fwd_bwd_step(c)
@@ -446,7 +452,7 @@ class GCNStage:
             out = self._replay(c, "fwdbwd") if self.hip_graphs else self._fwd_bwd(c)
         else:
             self._flat_grad.zero_()
-        if self.world > 1:
+        if self.multi:
             torch.distributed.all_reduce(self._flat_grad, op=torch.distributed.ReduceOp.SUM, group=self.group)
         self._optimizer_step(1.0 / group_size if group_size > 1 else 1.0)
         return out
@@ -458,7 +464,7 @@ class GCNStage:
         Integer counters (num_batches_tracked) need no collective: every rank knows how many BatchNorm calls the
         whole step plan makes (`calls_total`) and how many of them it made itself (`calls_mine`).
         Returns the summed `extra` (or None)."""
-        if self.world <= 1:
+        if not self.multi:
             return extra
         bufs = [b for k, b in self.model.named_buffers() if b.dtype.is_floating_point]
         parts = [b.reshape(-1).float() for b in bufs]
@@ -491,7 +497,7 @@ class GCNStage:
         names = list(self.chroms) if names is None else list(names)
         train = split == "train"
         C = next(iter(self.chroms.values())).target.shape[1] if self.chroms else 0
-        if self.world == 1:
+        if not self.multi:
             self._ensure_arena()
             for nm in names:
                 self.train_step(nm) if train else self.eval_step(nm)   # results land in the arena: nothing to copy or add
