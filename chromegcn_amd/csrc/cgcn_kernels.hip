@@ -611,49 +611,62 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512, FWD_WAVES_PE
 }
 
 // ------------------------------------------------------------------------------------------
-// k_bwd_rowlocal: everything in the layer backward that is local to a (strand,node) row, plus
-// dW = H^T dU on MFMA.  Persistent: each workgroup walks row tiles and keeps its D x D slice of
+// k_bwd_rowlocal: everything in the layer backward that is local to a (strand,node) row, plus the two dense
+// products on MFMA:  dW = H^T dU  and  dHs = diag(row_scale) dU W^T  (dL/dH, pre-scaled: the operand of the gather
+// over Ahat^T that follows in k_bwd_sliced).  Persistent: each workgroup walks row tiles and keeps its D x D slice of
 // dW in accumulators, then writes one partial.  Rows are the flattened [S*n] axis.
 //   partial layout per workgroup: [D*D dW][D db][D dwg][1 dcg][3 pad]
+// D = 128: one workgroup of 16 waves per CU.  All 16 do the row pass (TR/16 rows each); in the MFMA phase waves 0-7
+// own 16 rows of dW each (8 accumulator blocks) and waves 8-15 own 16 output columns of dHs each, their W^T fragments
+// resident in the SAME 32 registers the other half uses as accumulators (R below): 64 KB of accumulators + 64 KB of
+// weights per workgroup in 32 registers per thread, which is what lets 16 waves (<= 128 VGPRs) live on one CU.
+// D = 256: 8 waves, every wave owns 32 rows of dW (128 accumulator registers) and 32 columns of dHs, whose W^T
+// operand is read from L2 in the loop.
 // ------------------------------------------------------------------------------------------
+// LDS row stride of the two tiles = D + RL_LD_PAD floats.  Ht / Ut are read column-wise (dW = Ht^T Ut: lanes (q, r)
+// read row 4kk+q, column c0+r: conflict-free in a half-wave when the stride is 16 mod 32) and Ut also row-wise with
+// ds_read_b128 (dHs = Ut W^T); measured: 4 / 12 / 16 / 20 make no difference to the step.
+#ifndef RL_LD_PAD
+#define RL_LD_PAD 16
+#endif
 template <int D, int TR>
-__global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float* __restrict__ dXn,
+__global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, int n, const float* __restrict__ dXn,
                                                       const float* __restrict__ Z, const float* __restrict__ X,
                                                       const float* __restrict__ gate, const float* __restrict__ dgate,
                                                       const float* __restrict__ H, const float* __restrict__ wg,
-                                                      const float* __restrict__ rs, float* __restrict__ dUs,
+                                                      const float* __restrict__ rs, float* __restrict__ dHs,
                                                       float* __restrict__ part, HeadApply hp,
                                                       float* __restrict__ dxn_store, int row_blocks, int head_slabs,
-                                                      const float* __restrict__ Wsrc, float* __restrict__ Wsnap) {
-  constexpr int NW = 8;
+                                                      const float* __restrict__ W) {
+  constexpr bool SPLIT = (D == 128);  // role-split MFMA phase (see above)
+  constexpr int NW = SPLIT ? 16 : 8;
   // extra workgroups past the row tiles: the head's deferred dW_out / db_out second stage (independent work,
-  // fused "horizontally" so it costs no launch of its own) and, when the optimizer step is fused into the gather
-  // launch that follows (cgcn_sgd_fuse), a snapshot of W: that launch multiplies by the OLD weight while its extra
-  // workgroups already write the new one
+  // fused "horizontally" so it costs no launch of its own)
   if ((int)blockIdx.x >= row_blocks) {
     const int extra = (int)blockIdx.x - row_blocks;
-    if (extra >= head_slabs) {
-      const int i4 = (extra - head_slabs) * (int)blockDim.x + (int)threadIdx.x;
-      if (i4 < D * D / 4) ((f32x4*)Wsnap)[i4] = ((const f32x4*)Wsrc)[i4];
-      return;
-    }
-    head_finalize_slab<512>(extra, hp.hf_P, n, hp.S, D, hp.hf_C, hp.hf_CP, hp.hf_part, hp.hf_dWout,
-                            hp.hf_dbout, hp.hf_dbn_w, hp.hf_dbn_b, nullptr, hp.hf_accumulate, hp.dloss);
+    head_finalize_slab<NW * 64>(extra, hp.hf_P, n, hp.S, D, hp.hf_C, hp.hf_CP, hp.hf_part, hp.hf_dWout,
+                                hp.hf_dbout, hp.hf_dbn_w, hp.hf_dbn_b, nullptr, hp.hf_accumulate, hp.dloss);
     return;
   }
   KT_STAMP(0);
-  constexpr int IBW = D / 128;        // 16-row blocks of dW owned by one wave (i index)
-  constexpr int LD = D + 16;          // stride = 16 (mod 32): conflict-free transposed ds_read_b32
+  constexpr int IBW = SPLIT ? 1 : D / 128;  // 16-row blocks of dW / 16-column blocks of dHs owned by one wave
+  constexpr int LD = D + RL_LD_PAD;
   constexpr int EPL = D / 64;
   constexpr int JB = D / 16;
+  constexpr int MB = TR / 16;
   constexpr int RPW = TR / NW;        // rows per wave per tile
   constexpr int PSTRIDE = D * D + 2 * D + 4;
+  static_assert(TR % NW == 0 && TR % 16 == 0, "tile rows");
   __shared__ __attribute__((aligned(16))) float Ht[TR * LD];
   __shared__ __attribute__((aligned(16))) float Ut[TR * LD];
+  __shared__ float Sc[TR];            // row_scale of the tile's rows (0 past the end)
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, q = lane >> 4;
+  const bool dw_wave = !SPLIT || wave < 8;
+  const bool dh_wave = dHs && (!SPLIT || wave >= 8);
+  const int own = SPLIT ? (wave & 7) : wave;  // first 16-row block of dW / 16-column block of dHs of this wave: own * IBW
 
   float wgl[EPL], db_acc[EPL], dwg_acc[EPL];
   float dcg_acc = 0.f;
@@ -663,11 +676,17 @@ __global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float*
     db_acc[e] = 0.f;
     dwg_acc[e] = 0.f;
   }
-  f32x4 acc[IBW][JB];
+  // R: dW accumulators acc[ib][jb] of a dW wave; with SPLIT, the W^T fragments of a dHs wave instead:
+  // R[0][t][u] = W[(16 * own + r) * D + 16 t + 4 q + u]  (B operand of k-step (t, u), as load_wfrag<.., true>)
+  f32x4 R[IBW][JB];
 #pragma unroll
   for (int ib = 0; ib < IBW; ++ib)
 #pragma unroll
-    for (int jb = 0; jb < JB; ++jb) acc[ib][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int jb = 0; jb < JB; ++jb) R[ib][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (SPLIT && dh_wave) {
+#pragma unroll
+    for (int t = 0; t < JB; ++t) R[0][t] = *(const f32x4*)&W[(size_t)(16 * own + r) * D + 16 * t + 4 * q];
+  }
   const uint32_t hkey = (hp.dym && hp.thresh) ? dropout_key(hp.rng_state, HEAD_STREAM_ID) : 0u;
   const float hgl = (hp.dym && hp.dloss) ? hp.dloss[0] : 1.f;
 
@@ -675,7 +694,7 @@ __global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float*
   const int ntiles = (M + TR - 1) / TR;
   // The wave's RPW rows of a tile are loaded into registers in one go (all loads issued before the first use); the
   // loads of the workgroup's NEXT tile are issued right after the row pass, so they are in flight during the
-  // barrier + MFMA phase of the current one (large chromosomes: several tiles per workgroup).
+  // barrier + MFMA phase of the current one.
   float gup[RPW][EPL], z[RPW][EPL], x[RPW][EPL], h[RPW][EPL], gt[RPW], dgt[RPW];
   auto load_tile = [&](int tile) {
 #pragma unroll
@@ -729,28 +748,26 @@ __global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float*
             const float dr = bw_[e] * is[e] * (dy - hgl * c0[e] - xh * (hgl * c1[e]));
             gup[t][e] = xn > 0.f ? dr : 0.f;
           }
-          if (dxn_store) st_row<EPL>(&dxn_store[off], gup[t]);  // k_bwd_gather reads it back as dL/dXn for the (1-g) dXn term
+          if (dxn_store) st_row<EPL>(&dxn_store[off], gup[t]);  // k_bwd_sliced reads it back as dL/dXn for the (1-g) dXn term
         }
         float dg = 0.f;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) dg += gup[t][e] * (z[t][e] - x[t][e]);
         dg = wave_sum(dg) + dgt[t];
         const float gamma = g * (1.f - g) * dg;
-        const float sc = rs ? rs[m % n] : 1.f;
-        float dus[EPL];
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
           const float dz = g * gup[t][e] + gamma * wgl[e];
           du[e] = dz * (1.f - z[t][e] * z[t][e]);
           db_acc[e] += du[e];
           dwg_acc[e] += gamma * z[t][e];
-          dus[e] = du[e] * sc;
         }
-        st_row<EPL>(&dUs[off], dus);
         dcg_acc += gamma;
+        if (lane == 0) Sc[trow] = rs ? rs[m % n] : 1.f;
       } else {
 #pragma unroll
         for (int e = 0; e < EPL; ++e) du[e] = 0.f;
+        if (lane == 0) Sc[trow] = 0.f;
       }
 #ifndef RL_SKIP_MFMA
 #pragma unroll
@@ -763,47 +780,91 @@ __global__ __launch_bounds__(512) void k_bwd_rowlocal(int M, int n, const float*
     if (tile + row_blocks < ntiles) load_tile(tile + row_blocks);  // prefetch (see above)
     KT_STAMP(3);
     __syncthreads();
-    // ---- dW += Ht^T Ut  (K = TR rows)
     KT_STAMP(4);
-#ifdef RL_SKIP_MFMA
-    if (false)
-#endif
+#ifndef RL_SKIP_MFMA
+    // ---- dW += Ht^T Ut  (K = TR rows)
+    if (dw_wave) {
 #pragma unroll
-    for (int kk = 0; kk < TR / 4; ++kk) {
-      const int k = 4 * kk + q;
-      float a[IBW];
+      for (int kk = 0; kk < TR / 4; ++kk) {
+        const int k = 4 * kk + q;
+        float a[IBW];
 #pragma unroll
-      for (int ib = 0; ib < IBW; ++ib) a[ib] = Ht[k * LD + (IBW * wave + ib) * 16 + r];
+        for (int ib = 0; ib < IBW; ++ib) a[ib] = Ht[k * LD + (IBW * own + ib) * 16 + r];
 #pragma unroll
-      for (int jb = 0; jb < JB; ++jb) {
-        const float b = Ut[k * LD + jb * 16 + r];
+        for (int jb = 0; jb < JB; ++jb) {
+          const float b = Ut[k * LD + jb * 16 + r];
 #pragma unroll
-        for (int ib = 0; ib < IBW; ++ib) acc[ib][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ib], b, acc[ib][jb], 0, 0, 0);
+          for (int ib = 0; ib < IBW; ++ib) R[ib][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ib], b, R[ib][jb], 0, 0, 0);
+        }
       }
     }
+    // ---- dHs = diag(row_scale) Ut W^T: this wave's 16*IBW output columns, straight from the accumulators
+    // (64-byte row segments; the other column blocks of the same rows are written by the neighbouring waves)
+    if (dh_wave) {
+      constexpr int MBG = SPLIT ? MB : 1;   // row blocks in flight (independent accumulation chains); registers at D = 256
+#pragma unroll 1
+      for (int mb0 = 0; mb0 < MB; mb0 += MBG) {
+        f32x4 hacc[MBG][IBW];
+#pragma unroll
+        for (int mb = 0; mb < MBG; ++mb)
+#pragma unroll
+          for (int ib = 0; ib < IBW; ++ib) hacc[mb][ib] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll(SPLIT ? JB : 2)
+        for (int t = 0; t < JB; ++t) {
+          f32x4 a[MBG], b[IBW];
+#pragma unroll
+          for (int mb = 0; mb < MBG; ++mb) a[mb] = *(const f32x4*)&Ut[((mb0 + mb) * 16 + r) * LD + 16 * t + 4 * q];
+#pragma unroll
+          for (int ib = 0; ib < IBW; ++ib)
+            b[ib] = SPLIT ? R[0][t] : *(const f32x4*)&W[(size_t)((IBW * own + ib) * 16 + r) * D + 16 * t + 4 * q];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int mb = 0; mb < MBG; ++mb)
+#pragma unroll
+              for (int ib = 0; ib < IBW; ++ib)
+                hacc[mb][ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb][u], b[ib][u], hacc[mb][ib], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mb = 0; mb < MBG; ++mb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int trow = (mb0 + mb) * 16 + q * 4 + e;
+            const int m = tile * TR + trow;
+            const float sc = Sc[trow];
+            if (m < M) {
+#pragma unroll
+              for (int ib = 0; ib < IBW; ++ib) dHs[(size_t)m * D + (IBW * own + ib) * 16 + r] = hacc[mb][ib][e] * sc;
+            }
+          }
+      }
+    }
+#endif
     __syncthreads();
   }
 
   KT_STAMP(5);
   // ---- write this workgroup's partial
   float* P = part + (size_t)blockIdx.x * PSTRIDE;
-#ifdef RL_SKIP_MFMA
-  if (false)
+#ifndef RL_SKIP_MFMA
+  if (dw_wave) {
+#pragma unroll
+    for (int ib = 0; ib < IBW; ++ib)
+#pragma unroll
+      for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = (IBW * own + ib) * 16 + q * 4 + e;
+          const int j = jb * 16 + r;
+          P[i * D + j] = R[ib][jb][e];
+        }
+  }
 #endif
-#pragma unroll
-  for (int ib = 0; ib < IBW; ++ib)
-#pragma unroll
-    for (int jb = 0; jb < JB; ++jb)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int i = (IBW * wave + ib) * 16 + q * 4 + e;
-        const int j = jb * 16 + r;
-        P[i * D + j] = acc[ib][jb][e];
-      }
   KT_STAMP(6);
   // column sums: combine the NW waves through LDS in a fixed order
   float* red = Ht;  // [NW][2*D + 1]
   constexpr int RS = 2 * D + 1;
+  static_assert(NW * RS <= TR * LD, "column-sum staging fits the H tile");
 #pragma unroll
   for (int e = 0; e < EPL; ++e) {
     red[wave * RS + lane * EPL + e] = db_acc[e];
@@ -922,35 +983,130 @@ __global__ __launch_bounds__(256) void k_reduce_partials(int P, int D, const flo
 }
 
 // ------------------------------------------------------------------------------------------
-// k_bwd_gather: dX = mask * ((1-g) dXn + (Ahat^T dUs) W^T), same skeleton as the forward.
+// Feature-sliced aggregation (the standalone gathers: k_aggregate_sliced, k_bwd_sliced).
+//
+// One node's payload is S*D*4 bytes (1 KiB at S = 2, D = 128), a chromosome's table 6..30 MB: several times an XCD's
+// 4 MiB L2, so a gather of whole rows misses L2 about half the time and runs at the fabric / Infinity-Cache rate
+// (measured: 7.9 TB/s at n = 29 k against 20 TB/s at n = 5.8 k, tools/micro/sliced_gather.hip).  Here the table is cut
+// into S*D/32 column slices of one 128-byte line per node -- (strand s, features 32q .. 32q+31) -- and workgroup b
+// aggregates slice b % NSL for 64 rows: workgroups are dealt round-robin over the 8 XCDs, so every XCD (every private
+// L2) only ever touches its own slice(s), n * 128 B = 0.7..3.7 MB: L2 resident after the first touch.  The column
+// indices are re-read once per slice (2 MB x 8), which is the price.
+//   one wave = 8 rows x 8 lanes; a lane holds 16 B of its row's slice; an 8-lane group walks its own row's
+//   neighbour list 8 at a time: one coalesced 32-byte load of column indices (+ values), broadcast inside the
+//   group with ds_swizzle, 8 line loads in flight per group (64 per wave), summed in list order.
+//   Waves that own a row longer than SLICED_HUB neighbours (Hi-C hubs) switch to a cooperative walk: the 8 groups
+//   share each of the wave's rows (64 neighbours per step) and are summed in a fixed butterfly order, so one hub
+//   costs len/8 instead of len serial steps and the result stays bit-reproducible.
+// ------------------------------------------------------------------------------------------
+#ifndef SLICED_HUB
+#define SLICED_HUB 192
+#endif
+// lane (8*group + U) of every 8-lane group: ds_swizzle bit-mask mode, lane' = (lane & 0x18) | U inside each 32
+template <int U>
+__device__ __forceinline__ int group8_bcast(int v) { return __builtin_amdgcn_ds_swizzle(v, 0x18 | (U << 5)); }
+
+template <int U, bool HAS_VAL>
+struct SlicedIssue {
+  static __device__ __forceinline__ void run(f32x4 (&t)[8], float (&w)[8], int myc, float myv, const char* __restrict__ Xb,
+                                             unsigned rowb) {
+    SlicedIssue<U - 1, HAS_VAL>::run(t, w, myc, myv, Xb, rowb);
+    t[U - 1] = *(const f32x4*)(Xb + (size_t)(unsigned)group8_bcast<U - 1>(myc) * rowb);
+    if (HAS_VAL) w[U - 1] = __int_as_float(group8_bcast<U - 1>(__float_as_int(myv)));
+  }
+};
+template <bool HAS_VAL>
+struct SlicedIssue<0, HAS_VAL> {
+  static __device__ __forceinline__ void run(f32x4 (&)[8], float (&)[8], int, float, const char* __restrict__, unsigned) {}
+};
+
+// neighbours k, k + step, ... of [k0, k1) in chunks of 8 (k0 already offset by the caller for the cooperative walk);
+// Xb = this lane's 16 bytes of row 0 of its slice, rowb = bytes per (strand, node) row
+template <bool HAS_VAL>
+__device__ __forceinline__ f32x4 sliced_walk(const int* __restrict__ col, const float* __restrict__ val, int k0, int k1,
+                                             int step, const char* __restrict__ Xb, unsigned rowb, int j) {
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int k = k0; k < k1; k += step) {
+    const int kk = min(k + j, k1 - 1);   // ragged tail: re-read the last neighbour (an L1 hit), add a selected zero
+    const int myc = col[kk];
+    const float myv = HAS_VAL ? val[kk] : 0.f;
+    f32x4 t[8];
+    float w[8];
+    SlicedIssue<8, HAS_VAL>::run(t, w, myc, myv, Xb, rowb);
+    const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const f32x4 x = HAS_VAL ? w[u] * t[u] : t[u];
+      acc += (k + u < k1) ? x : zero;
+    }
+  }
+  return acc;
+}
+
+// sum over the neighbours of this lane's group's row (k0, k1: that row's range; equal inside a group)
+template <bool HAS_VAL>
+__device__ __forceinline__ f32x4 sliced_row_sum(const int* __restrict__ col, const float* __restrict__ val, int k0, int k1,
+                                                const char* __restrict__ Xb, unsigned rowb, int lane) {
+  const int g = lane >> 3, j = lane & 7;
+  if (!__any(k1 - k0 > SLICED_HUB)) return sliced_walk<HAS_VAL>(col, val, k0, k1, 8, Xb, rowb, j);
+  f32x4 mine = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int rr = 0; rr < 8; ++rr) {   // wave-uniform: every group helps with row rr of the wave
+    const int a0 = __shfl(k0, rr * 8, WAVE), a1 = __shfl(k1, rr * 8, WAVE);
+    f32x4 acc = sliced_walk<HAS_VAL>(col, val, a0 + g * 8, a1, 64, Xb, rowb, j);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc[e] += __shfl_xor(acc[e], 8, WAVE);
+      acc[e] += __shfl_xor(acc[e], 16, WAVE);
+      acc[e] += __shfl_xor(acc[e], 32, WAVE);
+    }
+    if (g == rr) mine = acc;
+  }
+  return mine;
+}
+
+// H = diag(rs) Ahat X, [S, n, D] -> [S, n, D]  (grid: NSL * ceil(n / 64) workgroups of 512)
+template <int S, int D, bool HAS_VAL>
+__global__ __launch_bounds__(512) void k_aggregate_sliced(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                          const float* __restrict__ val, const float* __restrict__ rs,
+                                                          const float* __restrict__ X, float* __restrict__ H) {
+  constexpr int NSL = S * D / 32, QPR = D / 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slice = blockIdx.x % NSL, tile = blockIdx.x / NSL;
+  const int i = tile * 64 + wave * 8 + (lane >> 3);
+  const size_t lane_el = (size_t)(slice / QPR) * n * D + (slice % QPR) * 32 + (lane & 7) * 4;
+  int k0 = 0, k1 = 0;
+  float sc = 0.f;
+  if (i < n) {
+    k0 = rowptr[i];
+    k1 = rowptr[i + 1];
+    sc = rs ? rs[i] : 1.f;
+  }
+  const f32x4 acc = sliced_row_sum<HAS_VAL>(col, val, k0, k1, (const char*)(X + lane_el), D * 4u, lane);
+  if (i < n) *(f32x4*)&H[lane_el + (size_t)i * D] = acc * sc;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_bwd_sliced: dX = mask * ((1-g) dXn + Ahat^T dHs), dHs = diag(rs) dU W^T from k_bwd_rowlocal: the aggregation over
+// the transposed adjacency with an element-wise epilogue, feature-sliced (above).
 // mask: the dropout the PREVIOUS layer applied to this layer's input (stream_id of that layer).
 // ------------------------------------------------------------------------------------------
-template <int S, int D, int MB, bool HAS_VAL, bool DEEP>
-__global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) void k_bwd_gather(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
-                                                      const float* __restrict__ val, const float* __restrict__ dUs,
-                                                      const float* __restrict__ W, const float* dXn,
-                                                      const float* __restrict__ gate, float* dX,
-                                                      float keep_scale, uint32_t thresh,
-                                                      const unsigned long long* __restrict__ rng_state,
-                                                      uint32_t stream_id, int gather_blocks, int P,
-                                                      const float* __restrict__ part, float* __restrict__ dW,
-                                                      float* __restrict__ db, float* __restrict__ dwg,
-                                                      float* __restrict__ dcg, int accumulate, SgdFuse sg, int reduce_slabs) {
-  using G = Geo<S, D>;
-  constexpr int ROWS = 16 * MB;
-  constexpr int R = ROWS / S;
-  constexpr int CBW = (D == 128) ? CBW128 : 2;
-  constexpr int NW = D / (16 * CBW);
-  constexpr int LD = D + 4;
-  constexpr int EPL = D / 64;
-  constexpr int RPW = (ROWS + NW - 1) / NW;
-  constexpr bool PRE = (D == 128);
+template <int S, int D, bool HAS_VAL>
+__global__ __launch_bounds__(512) void k_bwd_sliced(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                    const float* __restrict__ val, const float* __restrict__ dHs,
+                                                    const float* dXn, const float* __restrict__ gate, float* dX,
+                                                    float keep_scale, uint32_t thresh,
+                                                    const unsigned long long* __restrict__ rng_state,
+                                                    uint32_t stream_id, int gather_blocks, int P,
+                                                    const float* __restrict__ part, float* __restrict__ dW,
+                                                    float* __restrict__ db, float* __restrict__ dwg,
+                                                    float* __restrict__ dcg, int accumulate, SgdFuse sg, int reduce_slabs) {
   // Horizontal fusion: the workgroups past the gather tiles do the (independent) second-stage sum of the
   // row-local kernel's partials, so that reduction costs no launch of its own and overlaps the gather's tail.
   if ((int)blockIdx.x >= gather_blocks) {
     const int extra = (int)blockIdx.x - gather_blocks;
     if (extra < reduce_slabs) {
-      reduce_slab<NW * 64>(extra, P, D, part, dW, db, dwg, dcg, accumulate, sg);
+      reduce_slab<512>(extra, P, D, part, dW, db, dwg, dcg, accumulate, sg);
       return;
     }
     // fused optimizer step (cgcn_sgd_fuse) for every arena element whose gradient an EARLIER launch finished: all but
@@ -958,69 +1114,29 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512) void k_bwd_g
     sgd_other_elements(sg, extra - reduce_slabs, D, dW, db, dwg, dcg);
     return;
   }
-  __shared__ __attribute__((aligned(16))) float T[ROWS * LD];
-  __shared__ __attribute__((aligned(16))) float LR[NW * S * D];  // hub-row partial sums (gather_tile)
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int node0 = xcd_contiguous(blockIdx.x, gather_blocks) * R;
-
-  float bw[CBW][D / 4];
-  if (PRE) load_wfrag<D, CBW, true>(W, wave, lane, bw);  // 8 16-byte loads: in front of the gather (behind it: no gain)
-
-  unsigned lane_off[G::NV];
-#pragma unroll
-  for (int v = 0; v < G::NV; ++v) lane_off[v] = ((unsigned)G::strand(v, lane) * (unsigned)n * D + G::column(v, lane)) * 4u;
-
-  gather_tile<S, D, HAS_VAL, DEEP, R, NW, LD>(n, node0, rowptr, col, val, nullptr, (const char*)dUs, lane_off, T, nullptr, LR, wave, lane);
-  // prefetch (1-g) dXn for the rows this wave finishes
-  float res[RPW][EPL];
-#pragma unroll
-  for (int t = 0; t < RPW; ++t) {
-    const int m = wave + t * NW;
-    const int i = node0 + (m % R);
-    const bool ok = m < ROWS && i < n;
-    const size_t row = (size_t)(m / R) * n + i;
-    const float og = ok ? 1.f - gate[row] : 0.f;
-    if (ok) ld_row<EPL>(res[t], &dXn[row * D + lane * EPL]);
-    else zero_row<EPL>(res[t]);
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) res[t][e] *= og;
+  constexpr int NSL = S * D / 32, QPR = D / 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slice = blockIdx.x % NSL, tile = blockIdx.x / NSL;
+  const int s = slice / QPR;
+  const int i = tile * 64 + wave * 8 + (lane >> 3);
+  const size_t lane_el = (size_t)s * n * D + (slice % QPR) * 32 + (lane & 7) * 4;
+  int k0 = 0, k1 = 0;
+  f32x4 res = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (i < n) {   // the (1-g) dXn term first: its loads are in flight during the walk
+    k0 = rowptr[i];
+    k1 = rowptr[i + 1];
+    res = *(const f32x4*)&dXn[lane_el + (size_t)i * D] * (1.f - gate[(size_t)s * n + i]);
   }
-  __syncthreads();
-
-  f32x4 acc[MB][CBW];
-  tile_mfma<MB, D, CBW, LD, true, PRE>(T, W, bw, wave, lane, acc);
-  __syncthreads();
-  {
-    const int r = lane & 15, q = lane >> 4;
+  const f32x4 acc = sliced_row_sum<HAS_VAL>(col, val, k0, k1, (const char*)(dHs + lane_el), D * 4u, lane);
+  if (i >= n) return;
+  const size_t g_off = lane_el + (size_t)i * D;
+  f32x4 o = res + acc;
+  if (thresh) {
+    const uint32_t key = dropout_key(rng_state, stream_id);
 #pragma unroll
-    for (int cb = 0; cb < CBW; ++cb) {
-      const int j = wave * (16 * CBW) + cb * 16 + r;
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) T[(mb * 16 + q * 4 + e) * LD + j] = acc[mb][cb][e];
-    }
+    for (int e = 0; e < 4; ++e) o[e] = dropout_keep(key, (uint32_t)(g_off + e), thresh) ? o[e] * keep_scale : 0.f;
   }
-  const uint32_t key = thresh ? dropout_key(rng_state, stream_id) : 0u;
-  __syncthreads();
-
-#pragma unroll
-  for (int t = 0; t < RPW; ++t) {
-    const int m = wave + t * NW;
-    const int s = m / R, rr = m % R;
-    const int i = node0 + rr;
-    if (m >= ROWS || i >= n) continue;
-    const size_t g_off = ((size_t)s * n + i) * D + lane * EPL;
-    float o[EPL];
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-      o[e] = res[t][e] + T[m * LD + lane * EPL + e];
-      if (thresh) o[e] = dropout_keep(key, (uint32_t)(g_off + e), thresh) ? o[e] * keep_scale : 0.f;
-    }
-    st_row<EPL>(&dX[g_off], o);
-  }
+  *(f32x4*)&dX[g_off] = o;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1250,50 +1366,44 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   return launch_status();
 }
 
-// Row-tile height and workgroup count of k_bwd_rowlocal.  The kernel is a chain load -> row math -> LDS -> MFMA per
-// tile.  Small graphs: the smallest tile that still gives every tile its own workgroup, one per CU (more CUs busy,
-// shorter chain).  Large graphs (more than 64 rows per CU-resident workgroup): 32-row tiles at 122 VGPRs / 36 KB
-// LDS so that TWO workgroups are resident per CU and one's loads overlap the other's MFMA phase, at the price of
-// twice the partials (BWD_LARGE_PARTIALS).  D = 256 is limited to 32 rows by registers.
-#ifndef BWD_LARGE_PARTIALS
-#define BWD_LARGE_PARTIALS 512
+// Row-tile height and workgroup count of k_bwd_rowlocal: one persistent workgroup per CU at most (BWD_MAX_PARTIALS;
+// 16 waves at d = 128), the smallest tile that still gives every tile its own workgroup on small graphs (more CUs busy,
+// shorter load -> row math -> LDS -> MFMA chain), BWD_TILE_ROWS on large ones.  D = 256 is limited to 32 rows by registers.
+#ifndef BWD_MID_ROWS
+#define BWD_MID_ROWS 48
 #endif
-static bool bwd_large(int n, int S, int d) { return d == 128 && (long long)n * S > 64LL * BWD_MAX_PARTIALS; }
-
 static int bwd_tile_rows(int n, int S, int d) {
   if (d != 128) return 32;
   const int M = n * S;
   if (M <= 32 * BWD_MAX_PARTIALS) return 32;
-  if (M <= 48 * BWD_MAX_PARTIALS) return 48;
-  if (!bwd_large(n, S, d)) return BWD_TILE_ROWS;
-  return 32;
+  if (M <= 48 * BWD_MAX_PARTIALS) return BWD_MID_ROWS;
+  return BWD_TILE_ROWS;
 }
 
 static int bwd_partials(int n, int S, int d) {
   const int M = n * S;
   const int tr = bwd_tile_rows(n, S, d);
   const int ntiles = (M + tr - 1) / tr;
-  const int cap = bwd_large(n, S, d) ? BWD_LARGE_PARTIALS : BWD_MAX_PARTIALS;
-  int P = ntiles < cap ? ntiles : cap;
+  int P = ntiles < BWD_MAX_PARTIALS ? ntiles : BWD_MAX_PARTIALS;
   return P < 1 ? 1 : P;
 }
 
 size_t cgcn_layer_bwd_workspace_bytes(int n, int S, int d) {
   if (check_shape(n, S, d) != CGCN_OK) return 0;
-  // partial blocks of the row-local kernel + one d x d snapshot of W (cgcn_sgd_fuse)
-  return ((size_t)bwd_partials(n, S, d) * ((size_t)d * d + 2 * d + 4) + (size_t)d * d) * sizeof(float);
+  // partial blocks of the row-local kernel
+  return (size_t)bwd_partials(n, S, d) * ((size_t)d * d + 2 * d + 4) * sizeof(float);
 }
 
 int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* rowptr_t, const int32_t* col_t,
                    const float* val_t, const float* row_scale, const float* X, const float* Z, const float* H,
                    const float* gate, const float* W, const float* wg, const float* dXn, const float* dgate, float* dX,
-                   float* dUs, float* dW, float* db, float* dwg, float* dcg, int accumulate, float in_dropout_p,
+                   float* dHs, float* dW, float* db, float* dwg, float* dcg, int accumulate, float in_dropout_p,
                    const unsigned long long* rng_state, unsigned int in_stream_id, const cgcn_head_grad* head,
                    void* workspace, size_t workspace_bytes, cgcn_stream_t aux_stream, const cgcn_sgd_fuse* sgd) {
   int rc = check_shape(n, S, d);
   if (rc) return rc;
-  if (!rowptr_t || !col_t || !X || !Z || !H || !gate || !W || !wg || !dUs || !dW || !db || !dwg || !dcg)
-    return CGCN_ERR_BAD_ARG;
+  if (!rowptr_t || !col_t || !X || !Z || !H || !gate || !W || !wg || !dW || !db || !dwg || !dcg) return CGCN_ERR_BAD_ARG;
+  if (dX && !dHs) return CGCN_ERR_BAD_ARG;  // the gather's operand; without dX it is optional (NULL: not computed)
   SgdFuse sg = {nullptr, nullptr, nullptr, 0, 0.f, 0.f, 0.f, 1.f, 0, nullptr};
   if (sgd) {
     // the launch that finishes this layer's sums carries the step: it must overwrite them and run on the main stream
@@ -1308,7 +1418,7 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
                  sgd->grad_scale, sgd->nesterov, sgd->rng_state};
   }
   if ((dXn == nullptr) == (head == nullptr)) return CGCN_ERR_BAD_ARG;  // exactly one source of dL/dXn
-  if ((dX && dX == dXn) || misaligned16(dUs) || (dX && misaligned16(dX)) || misaligned16(W)) return CGCN_ERR_BAD_ARG;
+  if ((dX && dX == dXn) || (dHs && (misaligned16(dHs) || dHs == dX)) || (dX && misaligned16(dX)) || misaligned16(W)) return CGCN_ERR_BAD_ARG;
   if (misaligned16(X) || misaligned16(Z) || misaligned16(H) || (dXn && misaligned16(dXn))) return CGCN_ERR_BAD_ARG;  // vector row accesses
   HeadApply hp = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1.f, 0u, S, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr, nullptr, nullptr};
   int head_slabs = 0;
@@ -1334,19 +1444,17 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   hipStream_t st = (hipStream_t)stream;
   const int P = bwd_partials(n, S, d);
   float* part = (float*)workspace;
-  float* Wsnap = part + (size_t)P * ((size_t)d * d + 2 * d + 4);   // 16-byte aligned: the partial stride is a multiple of 4
-  const int copy_blocks = (sg.param && dX) ? (d * d / 4 + 511) / 512 : 0;   // the W snapshot is for the gather launch only
   const int M = n * S;
-  if (d == 128)
-    switch (bwd_tile_rows(n, S, d)) {
-#define RL(TR_) hipLaunchKernelGGL((k_bwd_rowlocal<128, TR_>), dim3(P + head_slabs + copy_blocks), dim3(512), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dUs, part, hp, dX, P, head_slabs, W, Wsnap)
-      case 32: RL(32); break;
-      case 48: RL(48); break;
-      default: RL(BWD_TILE_ROWS); break;
+  if (d == 128) {
+#define RL(TR_) hipLaunchKernelGGL((k_bwd_rowlocal<128, TR_>), dim3(P + head_slabs), dim3(1024), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, P, head_slabs, W)
+    const int tr = bwd_tile_rows(n, S, d);
+    if (tr == 32) RL(32);
+    else if (tr == 48) RL(48);
+    else RL(64);
 #undef RL
-    }
+  }
   else
-    hipLaunchKernelGGL((k_bwd_rowlocal<256, 32>), dim3(P + head_slabs + copy_blocks), dim3(512), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dUs, part, hp, dX, P, head_slabs, W, Wsnap);
+    hipLaunchKernelGGL((k_bwd_rowlocal<256, 32>), dim3(P + head_slabs), dim3(512), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, P, head_slabs, W);
   if ((rc = launch_status())) return rc;
   // The reduction of the per-tile partials and the gather kernel are independent: with an auxiliary stream
   // they run side by side (fork after k_bwd_rowlocal, join before returning; both edges are events, so the
@@ -1375,27 +1483,15 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
     if (rs_stream != st && hipStreamWaitEvent(st, ev_join, 0) != hipSuccess) return CGCN_ERR_LAUNCH;
     return CGCN_OK;  // parameter gradients only (the input is a leaf nobody differentiates)
   }
-  const int mb = pick_mb(n, S);
-  const int tn = 16 * mb / S;
-  const int blocks = (n + tn - 1) / tn;
+  const int blocks = (S * d / 32) * ((n + 63) / 64);   // slices x 64-row tiles (k_bwd_sliced)
   if (head) dXn = dX;  // k_bwd_rowlocal left dL/dXn there; each thread reads its elements before overwriting them
-  if (sg.param) W = Wsnap;  // the fused step rewrites W inside the gather launch: multiply by the snapshot taken above
-  const bool deep = pick_deep(n, S, d);
-  const int gthreads = (d == 128 && CBW128 == 2) ? 256 : 512;
-  const int sgd_blocks = sg.param ? (sg.count + gthreads - 1) / gthreads : 0;
-#define BG(S_, D_, MB_, V_, DP_)                                                                                     \
-  hipLaunchKernelGGL((k_bwd_gather<S_, D_, MB_, V_, DP_>), dim3(blocks + (fuse_reduce ? slabs : 0) + sgd_blocks),    \
-                     dim3((D_ == 128 && CBW128 == 2) ? 256 : 512), 0, st, n, rowptr_t, col_t, val_t, dUs, W, dXn,   \
-                     gate, dX, ks, th, rng_state, in_stream_id, blocks, P, part, dW, db, dwg, dcg, accumulate, sg,  \
-                     fuse_reduce ? slabs : 0)
+  const int sgd_blocks = sg.param ? (sg.count + 511) / 512 : 0;
 #define CALL(S_, D_, V_)                                                                                             \
-  do {                                                                                                               \
-    if (deep) BG(S_, D_, 1, V_, true);                                                                               \
-    else BG(S_, D_, 1, V_, false);                                                                                   \
-  } while (0)
+  hipLaunchKernelGGL((k_bwd_sliced<S_, D_, V_>), dim3(blocks + (fuse_reduce ? slabs : 0) + sgd_blocks), dim3(512), 0, \
+                     st, n, rowptr_t, col_t, val_t, dHs, dXn, gate, dX, ks, th, rng_state, in_stream_id, blocks, P,  \
+                     part, dW, db, dwg, dcg, accumulate, sg, fuse_reduce ? slabs : 0)
   DISPATCH_SDV(S, d, val_t != nullptr, CALL);
 #undef CALL
-#undef BG
   if ((rc = launch_status())) return rc;
   if (rs_stream != st && hipStreamWaitEvent(st, ev_join, 0) != hipSuccess) return CGCN_ERR_LAUNCH;  // join
   return CGCN_OK;

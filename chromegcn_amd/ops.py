@@ -65,7 +65,7 @@ _EVAL_BWD_MSG = ("chromegcn_amd: backward through the fused classifier head need
                  "saves nothing for it); call model.train(), or use ChromeGCN.forward / forward_strands, whose "
                  "torch head differentiates in eval mode like the reference's")
 
-_saliency_tap = None  # set by chromegcn_amd.saliency while it collects per-layer (X, dUs, W)
+_saliency_tap = None  # set by chromegcn_amd.saliency while it collects per-layer (X, dHs)
 
 # Set by the stage engine around one train step (finetune.GCNStage): the flat parameter / gradient / momentum arenas and
 # the SGD hyper-parameters.  The FIRST layer's backward -- the last launch of the step -- then carries the optimizer step
@@ -187,7 +187,8 @@ class GatedLayerFn(torch.autograd.Function):
         dxn = torch.zeros_like(x) if dxn is None else _dense(dxn)
         dgate = None if dgate is None else dgate.contiguous()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None  # None: skip the gather over Ahat^T
-        dus = torch.empty_like(x)
+        # dHs = diag(row_scale) dL/dU W^T: the gather's operand (and the saliency SDDMM's); not computed when unused
+        dhs = torch.empty_like(x) if (dx is not None or _saliency_tap is not None) else None
         if ctx.sink is not None:
             dw, db, dwg, dcg = ctx.sink
         else:
@@ -202,7 +203,7 @@ class GatedLayerFn(torch.autograd.Function):
         _lib.check(lib.cgcn_layer_bwd(_lib.stream_ptr(), n, S, d, _lib.ptr(g.rowptr_t), _lib.ptr(g.col_t),
                                       _lib.ptr(g.val_t), _lib.ptr(g.row_scale), x.data_ptr(), z.data_ptr(),
                                       h.data_ptr(), gate.data_ptr(), weight.data_ptr(), wg.data_ptr(),
-                                      dxn.data_ptr(), _lib.ptr(dgate), _lib.ptr(dx), dus.data_ptr(), dw.data_ptr(),
+                                      dxn.data_ptr(), _lib.ptr(dgate), _lib.ptr(dx), _lib.ptr(dhs), dw.data_ptr(),
                                       db.data_ptr(), dwg.data_ptr(), dcg.data_ptr(), 0, ctx.dropout_in,
                                       _lib.ptr(rng_state), max(ctx.layer_id - 1, 0), None, ws.data_ptr(), ws_bytes,
                                       _lib.aux_stream_ptr(), sg_ref),
@@ -210,7 +211,7 @@ class GatedLayerFn(torch.autograd.Function):
         if sg_ref is not None:
             _sgd_fuse["done"] = True
         if _saliency_tap is not None:
-            _saliency_tap.append((x, dus, weight, g))  # dus = diag(row_scale) dL/dU of this layer
+            _saliency_tap.append((x, dhs, g))
         if ctx.sink is not None:
             return (dx, None, None, None, None) + (None,) * 7
         return (dx, dw, db, dwg.view(ctx.gate_w_shape), dcg.view(ctx.gate_b_shape)) + (None,) * 7
@@ -427,7 +428,7 @@ class LastLayerHeadLossFn(torch.autograd.Function):
                            hws.data_ptr() + o_part.value, lib.cgcn_head_bwd_partials(n), C, dw_out.data_ptr(),
                            db_out.data_ptr(), 0, dloss.data_ptr(), dbn_w.data_ptr(), dbn_b.data_ptr())
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dus = torch.empty_like(x)
+        dhs = torch.empty_like(x) if dx is not None else None
         ws_bytes = lib.cgcn_layer_bwd_workspace_bytes(n, S, d)
         ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
         # a one-layer model: this IS the first layer's backward, i.e. the last launch of the step
@@ -435,7 +436,7 @@ class LastLayerHeadLossFn(torch.autograd.Function):
         _lib.check(lib.cgcn_layer_bwd(_lib.stream_ptr(), n, S, d, _lib.ptr(g.rowptr_t), _lib.ptr(g.col_t),
                                       _lib.ptr(g.val_t), _lib.ptr(g.row_scale), x.data_ptr(), z.data_ptr(),
                                       h.data_ptr(), gate.data_ptr(), weight.data_ptr(), wg.data_ptr(),
-                                      None, None, _lib.ptr(dx), dus.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                      None, None, _lib.ptr(dx), _lib.ptr(dhs), dw.data_ptr(), db.data_ptr(),
                                       dwg.data_ptr(), dcg.data_ptr(), 0, ctx.dropout_in, _lib.ptr(rng_state),
                                       max(ctx.layer_id - 1, 0), ctypes.byref(hg), ws.data_ptr(), ws_bytes,
                                       _lib.aux_stream_ptr(), sg_ref), "cgcn_layer_bwd")

@@ -3,7 +3,7 @@
 The reference computes it by making the adjacency a DENSE n x n tensor with requires_grad on the CPU
 (scripts/visualize.py:29-49): adj_grad = |adj * d sum(sigmoid(pred) * targets) / d adj|, then a row-sum and a
 row-max normalisation.  Entries outside the pattern have adj = 0 and drop out of the product, so only
-    dL/dA_ij = sum over layers and strands of < dL/dU_i , (X W)_j >      for stored (i, j)
+    dL/dA_ij = sum over layers and strands of < dL/dU_i , (X W)_j > = < dL/dU_i W^T , X_j >      for stored (i, j)
 is needed: one SDDMM per layer (cgcn_sddmm) instead of an O(n^2) gradient (3.6 GB at n = 30k)."""
 from __future__ import annotations
 
@@ -28,11 +28,11 @@ def adjacency_saliency(model, x_f: torch.Tensor, x_r: torch.Tensor, adj, targets
         torch.sigmoid(pred).backward(gradient=targets)           # visualize.py:40,47
     finally:
         ops._saliency_tap = None
-    # dL/dA_ij (A = diag(rs) Ahat) = <dU_i, (XW)_j>;  a_ij * dL/dA_ij = ahat_ij * <rs_i dU_i, (XW)_j> = ahat_ij * <dUs_i, Q_j>
+    # dL/dA_ij (A = diag(rs) Ahat) = <dU_i, (XW)_j>;  a_ij * dL/dA_ij = ahat_ij * <rs_i dU_i W^T, X_j> = ahat_ij * <dHs_i, X_j>
+    # with dHs = diag(rs) dL/dU W^T, which the layer backward leaves behind (cgcn_layer_bwd)
     total = torch.zeros(graph.col.shape[0], device=x.device)
-    for (xin, dus, w, g) in tap:
-        q = torch.matmul(xin, w)                                  # S = X W of models/SubLayers.py:43
-        total += ops.sddmm(dus, q, graph)
+    for (xin, dhs, g) in tap:
+        total += ops.sddmm(dhs, xin, graph)
     if graph.val is not None:
         total = total * graph.val
     sal = total.abs()                                             # visualize.py:49  |adj * adj.grad|

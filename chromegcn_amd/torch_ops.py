@@ -125,15 +125,15 @@ def gated_layer_backward(dxn: Tensor, dgate: Optional[Tensor], x: Tensor, z: Ten
                          weight: Tensor, gate_w: Tensor, rowptr_t: Tensor, col_t: Tensor, val_t: Optional[Tensor],
                          row_scale: Optional[Tensor], dropout_in: float, rng_state: Optional[Tensor], layer_id: int,
                          need_dx: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor, Tensor]:
-    """(dX, dW, db, dgate_w, dgate_b, dUs) given dL/dX' and (optionally) dL/dgate.  need_dx = False skips the gather
-    over Ahat^T (dX comes back empty).  dUs = diag(row_scale) dL/dU (the saliency SDDMM's operand)."""
+    """(dX, dW, db, dgate_w, dgate_b, dHs) given dL/dX' and (optionally) dL/dgate.  need_dx = False skips the gather
+    over Ahat^T (dX comes back empty).  dHs = diag(row_scale) dL/dU W^T (the gather's and the saliency SDDMM's operand)."""
     dxn = _dense(dxn)
     x, z, h, weight = _dense(x), _dense(z), _dense(h), _dense(weight)
     S, n, d = x.shape
     dev = x.device
     f32 = dict(device=dev, dtype=torch.float32)
     dx = torch.empty_like(x) if need_dx else torch.empty(0, **f32)
-    dus = torch.empty_like(x)
+    dhs = torch.empty_like(x)
     dw, db, dwg, dcg = torch.empty_like(weight), torch.empty(d, **f32), torch.empty(d, **f32), torch.empty(1, **f32)
     lib = _lib.load()
     ws_bytes = lib.cgcn_layer_bwd_workspace_bytes(n, S, d)
@@ -142,10 +142,10 @@ def gated_layer_backward(dxn: Tensor, dgate: Optional[Tensor], x: Tensor, z: Ten
     _lib.check(lib.cgcn_layer_bwd(_lib.stream_ptr(), n, S, d, _P(rowptr_t), _P(col_t), _P(val_t), _P(row_scale),
                                   x.data_ptr(), z.data_ptr(), h.data_ptr(), gate.contiguous().data_ptr(), weight.data_ptr(),
                                   wg.data_ptr(), dxn.data_ptr(), _P(None if dgate is None else dgate.contiguous()),
-                                  dx.data_ptr() if need_dx else None, dus.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                  dx.data_ptr() if need_dx else None, dhs.data_ptr(), dw.data_ptr(), db.data_ptr(),
                                   dwg.data_ptr(), dcg.data_ptr(), 0, float(dropout_in), _P(rng_state) if dropout_in > 0 else None,
                                   max(int(layer_id) - 1, 0), None, ws.data_ptr(), ws_bytes, None, None), "cgcn_layer_bwd")
-    return dx, dw, db, dwg, dcg, dus
+    return dx, dw, db, dwg, dcg, dhs
 
 
 @gated_layer_backward.register_fake

@@ -1,0 +1,44 @@
+"""Phase timestamps of k_bwd_rowlocal (tuning tool).  Needs a -DKT_TIMING build loaded through CHROMEGCN_LIB:
+  CGCN_EXTRA_FLAGS="-DKT_TIMING" python -c "from chromegcn_amd import _build; _build.build_library(out='variants/libcgcn_kt.so')"
+  CHROMEGCN_LIB=$PWD/variants/libcgcn_kt.so python tools/kt_rowlocal.py [chromosome]
+Stamps (100 MHz wall clock) of workgroups 0, 32, ... 224 of the LAST rowlocal launch of a train step (first layer's
+backward): 0 entry, 1 setup done, 2 top of the last tile, 3 its row pass done, 4 past the barrier, 5 loop done (MFMA +
+barrier), 6 partial written, 7 column sums written."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import chromegcn_amd as C
+from chromegcn_amd import synth
+from chromegcn_amd.finetune import GCNStage
+
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else "chr10"
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    model = C.ChromeGCN(128, 128, synth.N_LABELS, 0.2, True, 2).to(dev)
+    opt = torch.optim.SGD(model.parameters(), lr=0.25, momentum=0.9, weight_decay=1e-6)
+    stage = GCNStage(model, opt, "hic", dev, hip_graphs=False, input_grad=True, cache_input_aggregation=False)
+    feats, hic = synth.synthetic_chromosome(name, d=128)
+    stage.add_chromosome(name, feats, hic)
+    for _ in range(5):
+        stage.train_step(name)
+    torch.cuda.synchronize()
+    raw = ctypes.CDLL(os.environ["CHROMEGCN_LIB"])
+    buf = np.zeros(8 * 16, dtype=np.uint64)
+    assert raw.cgcn_debug_kt_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+    t = buf.reshape(8, 16).astype(np.int64)
+    t0 = t[:, 0].min()
+    print(name, "n =", stage.chroms[name].n)
+    for b in range(8):
+        print("wg %3d start+%.2fus" % (b * 32, (t[b, 0] - t0) / 100.0), " setup %.2f | to last tile %.2f | row pass %.2f | barrier %.2f | mfma+barrier %.2f | partial %.2f | colsums %.2f | total %.2f"
+              % (tuple((t[b, i + 1] - t[b, i]) / 100.0 for i in range(7)) + ((t[b, 7] - t[b, 0]) / 100.0,)))
+
+
+if __name__ == "__main__":
+    main()
