@@ -11,7 +11,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define WAVE 64
 #define TILE_NODES 16   // nodes per workgroup tile in the gather kernels
 #ifndef BWD_TILE_ROWS
-#define BWD_TILE_ROWS 64  // rows per tile of k_bwd_rowlocal on large graphs (32, 48 or 64)
+#define BWD_TILE_ROWS 32  // rows per tile of k_bwd_rowlocal on large graphs (32, 48 or 64)
 #endif
 #ifndef BWD_MAX_PARTIALS
 #define BWD_MAX_PARTIALS 256

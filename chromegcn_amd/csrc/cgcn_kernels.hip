@@ -454,7 +454,7 @@ extern "C" int cgcn_debug_kt_stamps(unsigned long long* out) {
 #define KT_STAMP(i)
 #endif
 
-template <int S, int D, int MB, bool HAS_VAL, bool FROM_CACHE, bool DEEP>
+template <int S, int D, int MB, bool HAS_VAL, bool DEEP>
 __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512, FWD_WAVES_PER_SIMD(S, D)) FWD_OCC void k_layer_fwd(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
                                                      const float* __restrict__ val, const float* __restrict__ rs,
                                                      const float* __restrict__ X, const float* __restrict__ W,
@@ -463,8 +463,7 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512, FWD_WAVES_PE
                                                      float* __restrict__ Zout, float* __restrict__ Hout,
                                                      float* __restrict__ gate, float keep_scale, uint32_t thresh,
                                                      const unsigned long long* __restrict__ rng_state,
-                                                     uint32_t stream_id, const float* __restrict__ Hin,
-                                                     float* __restrict__ colstats) {
+                                                     uint32_t stream_id, float* __restrict__ colstats) {
   using G = Geo<S, D>;
   constexpr int ROWS = 16 * MB;      // MFMA rows in the tile
   constexpr int R = ROWS / S;        // nodes in the tile
@@ -489,25 +488,8 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512, FWD_WAVES_PE
   for (int v = 0; v < G::NV; ++v) lane_off[v] = ((unsigned)G::strand(v, lane) * (unsigned)n * D + G::column(v, lane)) * 4u;
 
   KT_STAMP(9);
-  // ---- phase 1 (FROM_CACHE is a template parameter so that profiles list the two variants separately)
-  if (FROM_CACHE) {
-    // the aggregation was computed before (it does not depend on the weights: the engine caches A X of the
-    // first layer, whose input features never change): stream the rows in instead of gathering
-    for (int rr = wave; rr < R; rr += NW) {
-      const int i = node0 + rr;
-      if (!G::HALF || lane < 32) {
-#pragma unroll
-        for (int v = 0; v < G::NV; ++v) {
-          const int s = G::strand(v, lane), c = G::column(v, lane);
-          f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (i < n) t = *(const f32x4*)&Hin[((size_t)s * n + i) * D + c];
-          *(f32x4*)&T[(s * R + rr) * LD + c] = t;
-        }
-      }
-    }
-  } else {
-    gather_tile<S, D, HAS_VAL, DEEP, R, NW, LD>(n, node0, rowptr, col, val, rs, (const char*)X, lane_off, T, Hout, LR, wave, lane);
-  }
+  // ---- phase 1
+  gather_tile<S, D, HAS_VAL, DEEP, R, NW, LD>(n, node0, rowptr, col, val, rs, (const char*)X, lane_off, T, Hout, LR, wave, lane);
   // W fragments -> registers once the gather's loads are issued: in front of it they delay the first neighbour rows
   // (vector loads return in order) and hold 32 registers through the gather loop; here they land during the barrier
   // and the residual prefetch (measured: -0.3 ... -1.5 % per step, every workload)
@@ -608,6 +590,161 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512, FWD_WAVES_PE
     }
   }
   KT_STAMP(14);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_layer_dense: the row-local half of the layer forward for an aggregation H that is already in memory (the split
+// path: k_aggregate_sliced wrote it; or the engine's cached A X of the first layer): U = H W + b on MFMA, tanh, gate,
+// mix, optional dropout and BatchNorm column statistics -- phases 2 and 3 of k_layer_fwd.  Persistent: a workgroup
+// walks node tiles (R nodes x S strands = 16 MB rows) with its W fragments resident in registers (D = 128), so W is
+// read once per workgroup instead of once per tile, and several workgroups per CU overlap each other's load, MFMA
+// and store phases.  Streams H and X in, Xn, Z and the gate out.
+// ------------------------------------------------------------------------------------------
+#ifndef DENSE_WAVES_PER_SIMD
+#define DENSE_WAVES_PER_SIMD 4
+#endif
+template <int S, int D, int MB>
+__global__ __launch_bounds__(512, DENSE_WAVES_PER_SIMD) void k_layer_dense(int n, int ntiles, const float* __restrict__ Hin,
+                                                    const float* __restrict__ X, const float* __restrict__ W,
+                                                    const float* __restrict__ bias, const float* __restrict__ wg,
+                                                    const float* __restrict__ cg, float* __restrict__ Xn,
+                                                    float* __restrict__ Zout, float* __restrict__ gate,
+                                                    float keep_scale, uint32_t thresh,
+                                                    const unsigned long long* __restrict__ rng_state,
+                                                    uint32_t stream_id, float* __restrict__ colstats) {
+  constexpr int ROWS = 16 * MB;      // MFMA rows in the tile
+  constexpr int R = ROWS / S;        // nodes in the tile
+  constexpr int CBW = (D == 128) ? 1 : 2;  // 16-wide output column blocks per wave
+  constexpr int NW = 8;
+  constexpr int LD = D + 4;          // LDS row stride (floats); keeps 16-byte alignment
+  constexpr int EPL = D / 64;        // floats per lane in the row-wise passes
+  constexpr int RPW = ROWS / NW;     // rows per wave
+  constexpr bool PRE = (D == 128);
+  static_assert(D / (16 * CBW) == NW && ROWS % NW == 0, "geometry");
+  __shared__ __attribute__((aligned(16))) float T[ROWS * LD];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  KT_STAMP(8);
+  float bw[CBW][D / 4];
+  if (PRE) load_wfrag<D, CBW, false>(W, wave, lane, bw);
+  float bjv[CBW], wgl[EPL];
+#pragma unroll
+  for (int cb = 0; cb < CBW; ++cb) bjv[cb] = bias[wave * (16 * CBW) + cb * 16 + (lane & 15)];
+  ld_row<EPL>(wgl, &wg[lane * EPL]);
+  const float c0 = cg[0];
+  const uint32_t key = thresh ? dropout_key(rng_state, stream_id) : 0u;
+
+  // rows of the tile this wave streams in / finishes: m = wave + t * NW  ->  (strand m / R, node node0 + m % R).
+  // Both input streams run one whole tile ahead: the loads of tile t+1 are issued at the top of tile t, so every
+  // resident workgroup keeps a full tile of reads in flight through its MFMA, tanh and store phases.
+  float hrow[RPW][EPL], xres[RPW][EPL], xnext[RPW][EPL];
+  auto load_rows = [&](float (&dst)[RPW][EPL], const float* __restrict__ src, int tile) {
+#pragma unroll
+    for (int t = 0; t < RPW; ++t) {
+      const int m = wave + t * NW;
+      const int i = tile * R + (m % R);
+      if (i < n) ld_row<EPL>(dst[t], &src[((size_t)(m / R) * n + i) * D + lane * EPL]);
+      else zero_row<EPL>(dst[t]);
+    }
+  };
+  if ((int)blockIdx.x < ntiles) {
+    load_rows(hrow, Hin, blockIdx.x);
+    load_rows(xnext, X, blockIdx.x);
+  }
+  KT_STAMP(9);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int node0 = tile * R;
+    KT_STAMP(10);
+#pragma unroll
+    for (int t = 0; t < RPW; ++t) {
+      st_row<EPL>(&T[(wave + t * NW) * LD + lane * EPL], hrow[t]);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) xres[t][e] = xnext[t][e];
+    }
+    if (tile + (int)gridDim.x < ntiles) {
+      load_rows(hrow, Hin, tile + gridDim.x);
+      load_rows(xnext, X, tile + gridDim.x);
+    }
+    __syncthreads();
+    KT_STAMP(11);
+    // ---- U = H W
+    f32x4 acc[MB][CBW];
+    tile_mfma<MB, D, CBW, LD, false, PRE>(T, W, bw, wave, lane, acc);
+    __syncthreads();  // every wave is done reading T as the A operand
+    KT_STAMP(12);
+    // ---- Z = tanh(U + b) back into the tile
+    {
+      const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+      for (int cb = 0; cb < CBW; ++cb) {
+        const int j = wave * (16 * CBW) + cb * 16 + r;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) T[(mb * 16 + q * 4 + e) * LD + j] = tanhf(acc[mb][cb][e] + bjv[cb]);
+      }
+    }
+    __syncthreads();
+    KT_STAMP(13);
+    // ---- row-wise gate + residual mix, coalesced stores
+#pragma unroll
+    for (int t = 0; t < RPW; ++t) {
+      const int m = wave + t * NW;
+      const int s = m / R, rr = m % R;
+      const int i = node0 + rr;
+      if (i >= n) continue;  // wave-uniform
+      float z[EPL];
+      float dot = 0.f;
+      const size_t g_off = ((size_t)s * n + i) * D + lane * EPL;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        z[e] = T[m * LD + lane * EPL + e];
+        dot += z[e] * wgl[e];
+      }
+      dot = wave_sum(dot);
+      const float g = sigmoidf_(dot + c0);
+      float xo[EPL];
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        xo[e] = (1.f - g) * xres[t][e] + g * z[e];
+        if (thresh) xo[e] = dropout_keep(key, (uint32_t)(g_off + e), thresh) ? xo[e] * keep_scale : 0.f;
+        if (colstats) T[m * LD + lane * EPL + e] = fmaxf(xo[e], 0.f);  // own row, already consumed above
+      }
+      st_row<EPL>(&Xn[g_off], xo);
+      if (Zout) st_row<EPL>(&Zout[g_off], z);
+      if (lane == 0) gate[(size_t)s * n + i] = g;
+    }
+    KT_STAMP(14);
+    // ---- optional: first stage of the classifier head's BatchNorm statistics while the tile is on chip: per
+    // (strand, column) the exact two-pass (mean, M2) of relu(Xn) over this tile's nodes
+    if (colstats) {   // statistic tiles are 16 / S nodes (cgcn_layer_fwd_colstats_tiles), MB of them per tile here
+      __syncthreads();
+      constexpr int CR = 16 / S;
+      for (int idx = threadIdx.x; idx < MB * S * D; idx += blockDim.x) {
+        const int sub = idx / (S * D), sc = idx % (S * D);
+        const int s = sc / D, c = sc % D;
+        const int cnt = min(CR, n - (node0 + sub * CR));
+        if (cnt <= 0) continue;
+        const float inv = 1.f / (float)cnt;
+        float v[CR];
+        float sum = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < CR; ++rr) {
+          v[rr] = T[(s * R + sub * CR + rr) * LD + c];
+          sum += rr < cnt ? v[rr] : 0.f;
+        }
+        const float mean = sum * inv;
+        float m2 = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < CR; ++rr) m2 += rr < cnt ? (v[rr] - mean) * (v[rr] - mean) : 0.f;
+        float* out = colstats + ((size_t)(tile * MB + sub) * S * D + sc) * 2;
+        out[0] = mean;
+        out[1] = m2;
+      }
+    }
+    __syncthreads();  // T is rewritten by the next tile
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1324,6 +1461,19 @@ int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d, const 
   return launch_status();
 }
 
+// the split forward (see cgcn_layer_fwd): tables from this size on; workgroups and tile height of k_layer_dense
+#ifndef FWD_SPLIT_TABLE_BYTES
+#define FWD_SPLIT_TABLE_BYTES (8u << 20)
+#endif
+#ifndef DENSE_MAX_BLOCKS
+#define DENSE_MAX_BLOCKS (256 * (DENSE_WAVES_PER_SIMD / 2))   // exactly the workgroups resident at once: one round
+#endif
+#ifndef DENSE_MB
+#define DENSE_MB 1
+#endif
+static std::atomic<long long> g_fwd_split_bytes{(long long)FWD_SPLIT_TABLE_BYTES};
+void cgcn_debug_set_fwd_split_bytes(long long bytes) { g_fwd_split_bytes.store(bytes < 0 ? (long long)FWD_SPLIT_TABLE_BYTES : bytes); }
+
 int cgcn_layer_fwd_colstats_tiles(int n, int S, int d, int* rows_per_tile) {
   if (check_shape(n, S, d) != CGCN_OK || n == 0) return 0;
   const int tn = 16 * pick_mb(n, S) / S;
@@ -1346,19 +1496,42 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   uint32_t th;
   if ((rc = dropout_args(dropout_p, rng_state, &ks, &th))) return rc;
   hipStream_t st = (hipStream_t)stream;
+  // Three routes.  H_in given: the row-local kernel alone.  Training (H is wanted anyway) on a table that does not
+  // fit the L2s: feature-sliced aggregation into H, then the row-local kernel on it.  Otherwise the fused kernel.
+  const bool split = !H_in && H && (double)n * S * d * 4.0 >= (double)g_fwd_split_bytes.load();
+  if (split) {
+    const int gblocks = (S * d / 32) * ((n + 63) / 64);
+#define CALL(S_, D_, V_) \
+    hipLaunchKernelGGL((k_aggregate_sliced<S_, D_, V_>), dim3(gblocks), dim3(512), 0, st, n, rowptr, col, val, row_scale, X, H)
+    DISPATCH_SDV(S, d, val != nullptr, CALL);
+#undef CALL
+    if ((rc = launch_status())) return rc;
+    H_in = H;
+  }
+  if (H_in) {
+    constexpr int MB = DENSE_MB;
+    const int tn = 16 * MB / S;
+    const int ntiles = (n + tn - 1) / tn;
+    const int grid = ntiles < DENSE_MAX_BLOCKS ? ntiles : DENSE_MAX_BLOCKS;
+#define CALL(S_, D_, V_) \
+    hipLaunchKernelGGL((k_layer_dense<S_, D_, MB>), dim3(grid), dim3(512), 0, st, n, ntiles, H_in, X, W, b, wg, cg, Xn, Z, gate, \
+                       ks, th, rng_state, stream_id, colstats)
+    DISPATCH_SDV(S, d, false, CALL);
+#undef CALL
+    return launch_status();
+  }
   const int mb = pick_mb(n, S);
   const int tn = 16 * mb / S;
   const int blocks = (n + tn - 1) / tn;
   const bool deep = pick_deep(n, S, d);
-#define FWD(S_, D_, MB_, V_, C_, DP_)                                                                                 \
-  hipLaunchKernelGGL((k_layer_fwd<S_, D_, MB_, V_, C_, DP_>), dim3(blocks), blk, 0, st, n, rowptr, col, val, row_scale, \
-                     X, W, b, wg, cg, Xn, Z, H, gate, ks, th, rng_state, stream_id, H_in, colstats)
+#define FWD(S_, D_, MB_, V_, DP_)                                                                                     \
+  hipLaunchKernelGGL((k_layer_fwd<S_, D_, MB_, V_, DP_>), dim3(blocks), blk, 0, st, n, rowptr, col, val, row_scale,    \
+                     X, W, b, wg, cg, Xn, Z, H, gate, ks, th, rng_state, stream_id, colstats)
 #define CALL(S_, D_, V_)                                                                                              \
   do {                                                                                                                \
     const dim3 blk((D_ == 128 && CBW128 == 2) ? 256 : 512);                                                           \
-    if (H_in) FWD(S_, D_, 1, V_, true, false); /* no gather: depth irrelevant */                                      \
-    else if (deep) FWD(S_, D_, 1, V_, false, true);                                                                   \
-    else FWD(S_, D_, 1, V_, false, false);                                                                            \
+    if (deep) FWD(S_, D_, 1, V_, true);                                                                               \
+    else FWD(S_, D_, 1, V_, false);                                                                                   \
   } while (0)
   DISPATCH_SDV(S, d, val != nullptr, CALL);
 #undef CALL

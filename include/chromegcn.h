@@ -48,7 +48,7 @@ extern "C" {
 #define CGCN_ERR_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after a launch      */
 #define CGCN_ERR_WORKSPACE (-4)   /* workspace too small (see cgcn_*_workspace_bytes)    */
 
-#define CGCN_ABI_VERSION 13
+#define CGCN_ABI_VERSION 14
 
 typedef void *cgcn_stream_t; /* hipStream_t */
 
@@ -70,7 +70,8 @@ int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d,
               const float *X, float *Y);
 
 /*
- * One gated graph-convolution layer, forward, fused in one launch:
+ * One gated graph-convolution layer, forward (one fused launch; or two -- a feature-sliced aggregation into H and a
+ * row-local launch on it -- when H is wanted and the feature table S*n*d*4 is too large for the L2s; same results):
  *     H  = diag(row_scale) Ahat X          (aggregation)
  *     U  = H W + b                          (models/SubLayers.py:43-50; the reference
  *                                            computes A (X W) + b -- same value up to fp32
@@ -101,6 +102,10 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d,
 /* Number of node tiles cgcn_layer_fwd(n, S, d) writes column statistics for (0 = unsupported shape);
  * *rows_per_tile = nodes per tile (the last tile may be shorter). */
 int cgcn_layer_fwd_colstats_tiles(int n, int S, int d, int *rows_per_tile);
+
+/* Test / tuning hook: feature-table size in bytes from which cgcn_layer_fwd takes the two-launch route when H is
+ * given (0 = always, negative = restore the built-in default).  Process-wide. */
+void cgcn_debug_set_fwd_split_bytes(long long bytes);
 
 /*
  * State the fused head's backward leaves for the LAST gated layer's backward (cgcn_head_bwd with
@@ -160,11 +165,13 @@ size_t cgcn_layer_bwd_workspace_bytes(int n, int S, int d);
  *     gamma = g (1-g) (sum_k dXn (Z - X) + dgate)
  *     dU    = (g dXn + gamma wg^T) (1 - Z^2)
  *     db = sum_rows dU,  dwg = sum_rows gamma Z,  dcg = sum gamma,  dW = H^T dU
- *     dX    = (1-g) dXn + (Ahat^T (diag(row_scale) dU)) W^T
+ *     dHs   = diag(row_scale) dU W^T        (dL/dH, pre-scaled)
+ *     dX    = (1-g) dXn + Ahat^T dHs
  * dX: [S,n,d], must not alias dXn; NULL = parameter gradients only (the gather over Ahat^T is skipped:
  * use it for the first layer when nobody needs d loss / d features).  dW [d,d], db [d], dwg [d], dcg [1] are overwritten
- * when accumulate == 0 and added to when accumulate != 0.  dUs is a [S,n,d] scratch output
- * (holds diag(row_scale) dU on return).  Sums over rows are two-stage and deterministic
+ * when accumulate == 0 and added to when accumulate != 0.  dHs is a [S,n,d] output (the gather's operand; also
+ * the adjacency-saliency operand: dL/dA_ij = <dHs_i, X_j>, see cgcn_sddmm); it may be NULL when dX is NULL (then it
+ * is not computed) and must not alias dX.  Sums over rows are two-stage and deterministic
  * (no float atomics): results are bit-reproducible run to run.
  * in_dropout_p > 0: X was produced by a layer that applied dropout (in_stream_id = that layer's
  * stream_id); dX is then the gradient w.r.t. the pre-dropout tensor (mask / (1-p) applied).
@@ -178,7 +185,7 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d,
                    const float *X, const float *Z, const float *H, const float *gate,
                    const float *W, const float *wg,
                    const float *dXn, const float *dgate,
-                   float *dX, float *dUs, float *dW, float *db, float *dwg, float *dcg,
+                   float *dX, float *dHs, float *dW, float *db, float *dwg, float *dcg,
                    int accumulate, float in_dropout_p, const unsigned long long *rng_state,
                    unsigned int in_stream_id, const cgcn_head_grad *head,
                    void *workspace, size_t workspace_bytes, cgcn_stream_t aux_stream,

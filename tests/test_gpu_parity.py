@@ -78,8 +78,20 @@ def _layer_params(d, seed):
             (rng.randn(d) / np.sqrt(d) * 2).astype(np.float32), np.float32(rng.randn() * 0.3))
 
 
+@pytest.fixture
+def split_forward(request):
+    """route of cgcn_layer_fwd: 'fused' = built-in choice (one launch at these sizes), 'split' = forced two-launch route
+    (k_aggregate_sliced into H, then k_layer_dense), which full-size chromosomes take by default"""
+    from chromegcn_amd import _lib
+    lib = _lib.load()
+    lib.cgcn_debug_set_fwd_split_bytes(0 if request.param == "split" else -1)
+    yield request.param
+    lib.cgcn_debug_set_fwd_split_bytes(-1)
+
+
+@pytest.mark.parametrize("split_forward", ["fused", "split"], indirect=True)
 @pytest.mark.parametrize("S,d", [(1, 128), (2, 128), (1, 256), (2, 256)])
-def test_gated_layer_forward_backward_matches_oracle(S, d):
+def test_gated_layer_forward_backward_matches_oracle(S, d, split_forward):
     for name, h in graph_cases():
         g = G.upload(h, DEV)
         rng = np.random.RandomState(20)
@@ -172,8 +184,9 @@ def test_model_eval_forward_against_reference_golden(golden):
             assert gates[1] is None
 
 
+@pytest.mark.parametrize("split_forward", ["fused", "split"], indirect=True)
 @pytest.mark.parametrize("batched", [False, True])
-def test_model_train_steps_against_reference_golden(golden, batched):
+def test_model_train_steps_against_reference_golden(golden, batched, split_forward):
     """loss, every gradient (incl. d/dx_in, finetune.py:33-34), parameters and BatchNorm running
     statistics after one and two SGD steps (lr .25, momentum .9, wd 1e-6)."""
     z = golden("g3_model.npz")

@@ -104,6 +104,66 @@ __global__ __launch_bounds__(512) void k_rows8(int n, int tiles, const int* __re
   }
 }
 
+// PF 1: the column indices of the NEXT chunk are loaded before the current chunk's row loads are issued (the serial
+//       chain per row becomes index latency + chunks x line latency instead of chunks x (index + line) latency)
+// PF 2: additionally the lines of the next chunk are issued before the current chunk is summed (two chunks of 8 lines in
+//       flight per group)
+template <int PF>
+__global__ __launch_bounds__(512) void k_rows8_pf(int n, int tiles, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                  const float* __restrict__ rs, const float* __restrict__ X,
+                                                  float* __restrict__ H) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int slice = blockIdx.x & 7;
+  const int tile = blockIdx.x >> 3;
+  const int g = lane >> 3, j = lane & 7;
+  const size_t slice_off = ((size_t)(slice >> 2) * (size_t)n * 128u + (slice & 3) * 32u + j * 4u) * 4u;
+  const char* Xb = (const char*)X + slice_off;
+  const int i = tile * 64 + wave * 8 + g;
+  int k0 = 0, k1 = 0;
+  if (i < n) { k0 = rowptr[i]; k1 = rowptr[i + 1]; }
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (k0 < k1) {
+    int myc = col[min(k0 + j, k1 - 1)];
+    if (PF == 1) {
+      for (int k = k0; k < k1; k += 8) {
+        const int nextc = col[min(k + 8 + j, k1 - 1)];
+        f32x4 t[8];
+        Unroll<8>::run([&](auto U) {
+          constexpr int u = decltype(U)::value;
+          t[u] = *(const f32x4*)(Xb + (size_t)(unsigned)group8_bcast<u>(myc) * 512u);
+        });
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (k + u < k1) acc += t[u];
+        myc = nextc;
+      }
+    } else {
+      f32x4 t[8];
+      Unroll<8>::run([&](auto U) {
+        constexpr int u = decltype(U)::value;
+        t[u] = *(const f32x4*)(Xb + (size_t)(unsigned)group8_bcast<u>(myc) * 512u);
+      });
+      myc = col[min(k0 + 8 + j, k1 - 1)];
+      for (int k = k0; k < k1; k += 8) {
+        const int nextc = col[min(k + 16 + j, k1 - 1)];
+        f32x4 tn[8];
+        Unroll<8>::run([&](auto U) {
+          constexpr int u = decltype(U)::value;
+          tn[u] = *(const f32x4*)(Xb + (size_t)(unsigned)group8_bcast<u>(myc) * 512u);
+        });
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (k + u < k1) acc += t[u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = tn[u];
+        myc = nextc;
+      }
+    }
+  }
+  if (i < n) *(f32x4*)((char*)H + slice_off + (size_t)i * 512u) = acc * rs[i];
+}
+
 struct Graph {
   int n, nnz;
   std::vector<int> rowptr, col;
@@ -209,9 +269,18 @@ int main(int argc, char** argv) {
         printf("  %-34s %6.1f us  (max |diff| vs base %.2e)\n", label, t, max_err(ref, out));
       };
       sliced(std::true_type(), std::integral_constant<int, 1>(), "rows8 slice=b&7 (XCD-owned) RPW1");
-      sliced(std::true_type(), std::integral_constant<int, 2>(), "rows8 slice=b&7 (XCD-owned) RPW2");
-      sliced(std::true_type(), std::integral_constant<int, 4>(), "rows8 slice=b&7 (XCD-owned) RPW4");
-      sliced(std::false_type(), std::integral_constant<int, 1>(), "rows8 slice=b/tiles (control) RPW1");
+                  sliced(std::false_type(), std::integral_constant<int, 1>(), "rows8 slice=b/tiles (control) RPW1");
+      {
+        const int tiles = (n + 63) / 64;
+        CK(hipMemset(d_H, 0, X.size() * 4));
+        const float t1 = time_us([&] { hipLaunchKernelGGL((k_rows8_pf<1>), dim3(8 * tiles), dim3(512), 0, 0, n, tiles, d_rowptr, d_col, d_rs, d_X, d_H); }, reps);
+        CK(hipMemcpy(out.data(), d_H, X.size() * 4, hipMemcpyDeviceToHost));
+        printf("  %-34s %6.1f us  (max |diff| vs base %.2e)\n", "rows8 + next-chunk index prefetch", t1, max_err(ref, out));
+        CK(hipMemset(d_H, 0, X.size() * 4));
+        const float t2 = time_us([&] { hipLaunchKernelGGL((k_rows8_pf<2>), dim3(8 * tiles), dim3(512), 0, 0, n, tiles, d_rowptr, d_col, d_rs, d_X, d_H); }, reps);
+        CK(hipMemcpy(out.data(), d_H, X.size() * 4, hipMemcpyDeviceToHost));
+        printf("  %-34s %6.1f us  (max |diff| vs base %.2e)\n", "rows8 + index and line prefetch", t2, max_err(ref, out));
+      }
       CK(hipFree(d_rowptr)); CK(hipFree(d_col)); CK(hipFree(d_rs)); CK(hipFree(d_X)); CK(hipFree(d_H));
     }
   return 0;
