@@ -88,7 +88,8 @@ def layer_fwd_bytes(n, nnz, S, d):
 
 
 def time_layer_fwd(stage, name, reps, dropout_p):
-    """Average duration of k_layer_fwd (training variant, both strands) on one chromosome, measured with HIP events
+    """Average duration of one layer forward (cgcn_layer_fwd, training form, both strands: the fused k_layer_fwd or the
+    k_aggregate_sliced + k_layer_dense pair) on one chromosome, measured with HIP events
     on the stream the library launches on (torch's current stream), in the two forms a train step uses: layer 1
     (inter-layer dropout with the run's p and RNG state) and layer 2 (BatchNorm column statistics for the head)."""
     import ctypes
@@ -335,7 +336,7 @@ def main():
 
     out = None
     if rank == 0:
-        # ---- roofline of the dominant kernel (k_layer_fwd: largest share of the epoch), measured live
+        # ---- roofline of the dominant operation (the layer forward: largest share of the epoch), measured live
         reps = 30 if genome else 200
         tot_t = tot_b = tot_g = tot_f = 0.0
         per_chrom = {}
@@ -353,8 +354,9 @@ def main():
         traffic, ttag = stored_traffic(wl_key)
         nl = 2 * len(per_chrom)
         roof = {"bound": "hbm",
-                "kernel": "k_layer_fwd<S=2,D=%d> training variant (writes Z, H; layer 1 with dropout, last layer with "
-                          "BatchNorm column statistics), average over the %d launches of one %s" %
+                "kernel": "layer forward, training form (writes Z, H; layer 1 with dropout, last layer with BatchNorm column "
+                          "statistics) = one cgcn_layer_fwd call: k_aggregate_sliced + k_layer_dense<S=2,D=%d> on feature tables "
+                          ">= 8 MiB, the fused k_layer_fwd below; HIP events around the call, average over the %d calls of one %s" %
                           (args.d, nl, "train epoch" if genome else "train step"),
                 "achieved": tot_b / tot_t / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": tot_b / tot_t / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,

@@ -652,6 +652,9 @@ __global__ __launch_bounds__(512, DENSE_WAVES_PER_SIMD) void k_layer_dense(int n
     load_rows(hrow, Hin, blockIdx.x);
     load_rows(xnext, X, blockIdx.x);
   }
+#ifdef DENSE_STAGGER
+  if (blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_sleep(DENSE_STAGGER);
+#endif
   KT_STAMP(9);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int node0 = tile * R;
@@ -1432,6 +1435,19 @@ const char* cgcn_strerror(int code) {
   }
 }
 
+// the split forward (see cgcn_layer_fwd): tables from this size on; workgroups and tile height of k_layer_dense
+#ifndef FWD_SPLIT_TABLE_BYTES
+#define FWD_SPLIT_TABLE_BYTES (8u << 20)
+#endif
+#ifndef DENSE_MAX_BLOCKS
+#define DENSE_MAX_BLOCKS (256 * (DENSE_WAVES_PER_SIMD / 2))   // exactly the workgroups resident at once: one round
+#endif
+#ifndef DENSE_MB
+#define DENSE_MB 1
+#endif
+static std::atomic<long long> g_fwd_split_bytes{(long long)FWD_SPLIT_TABLE_BYTES};
+void cgcn_debug_set_fwd_split_bytes(long long bytes) { g_fwd_split_bytes.store(bytes < 0 ? (long long)FWD_SPLIT_TABLE_BYTES : bytes); }
+
 int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d, const int32_t* rowptr, const int32_t* col,
               const float* val, const float* row_scale, const float* X, float* Y) {
   const int nmax = n_rows > n_cols ? n_rows : n_cols;
@@ -1449,6 +1465,15 @@ int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d, const 
     hipLaunchKernelGGL(k_spmm_any, dim3(blocks), dim3(256), 0, st, n_rows, n_cols, S, d, rowptr, col, val, row_scale, X, Y);
     return launch_status();
   }
+  if (n_rows == n_cols && (double)n_rows * S * d * 4.0 >= (double)g_fwd_split_bytes.load()) {
+    // square operator on a table too large for the L2s: the feature-sliced aggregation (see k_aggregate_sliced)
+    const int gblocks = (S * d / 32) * ((n_rows + 63) / 64);
+#define CALL(S_, D_, V_) \
+    hipLaunchKernelGGL((k_aggregate_sliced<S_, D_, V_>), dim3(gblocks), dim3(512), 0, st, n_rows, rowptr, col, val, row_scale, X, Y)
+    DISPATCH_SDV(S, d, val != nullptr, CALL);
+#undef CALL
+    return launch_status();
+  }
   const int blocks = (n_rows + 3) / 4 < 4096 ? (n_rows + 3) / 4 : 4096;
   const bool deep = false;  // measured: the bare SpMM never gains from the deeper batches (chr10-like 48.7 vs 55.8 us)
 #define CALL(S_, D_, V_)                                                                                                  \
@@ -1460,19 +1485,6 @@ int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d, const 
 #undef CALL
   return launch_status();
 }
-
-// the split forward (see cgcn_layer_fwd): tables from this size on; workgroups and tile height of k_layer_dense
-#ifndef FWD_SPLIT_TABLE_BYTES
-#define FWD_SPLIT_TABLE_BYTES (8u << 20)
-#endif
-#ifndef DENSE_MAX_BLOCKS
-#define DENSE_MAX_BLOCKS (256 * (DENSE_WAVES_PER_SIMD / 2))   // exactly the workgroups resident at once: one round
-#endif
-#ifndef DENSE_MB
-#define DENSE_MB 1
-#endif
-static std::atomic<long long> g_fwd_split_bytes{(long long)FWD_SPLIT_TABLE_BYTES};
-void cgcn_debug_set_fwd_split_bytes(long long bytes) { g_fwd_split_bytes.store(bytes < 0 ? (long long)FWD_SPLIT_TABLE_BYTES : bytes); }
 
 int cgcn_layer_fwd_colstats_tiles(int n, int S, int d, int* rows_per_tile) {
   if (check_shape(n, S, d) != CGCN_OK || n == 0) return 0;

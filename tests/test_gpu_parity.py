@@ -55,8 +55,9 @@ def graph_cases():
     return out
 
 
+@pytest.mark.parametrize("split_forward", ["fused", "split"], indirect=True)
 @pytest.mark.parametrize("S,d", [(1, 128), (2, 128), (1, 256), (2, 256)])
-def test_spmm_matches_oracle(S, d):
+def test_spmm_matches_oracle(S, d, split_forward):
     for name, h in graph_cases():
         g = G.upload(h, DEV)
         rng = np.random.RandomState(10)
@@ -80,8 +81,9 @@ def _layer_params(d, seed):
 
 @pytest.fixture
 def split_forward(request):
-    """route of cgcn_layer_fwd: 'fused' = built-in choice (one launch at these sizes), 'split' = forced two-launch route
-    (k_aggregate_sliced into H, then k_layer_dense), which full-size chromosomes take by default"""
+    """route of cgcn_layer_fwd / cgcn_spmm: 'fused' = built-in choice (whole-row gathers at these sizes), 'split' =
+    forced feature-sliced route (k_aggregate_sliced; for the layer: into H, then k_layer_dense), which full-size
+    chromosomes take by default"""
     from chromegcn_amd import _lib
     lib = _lib.load()
     lib.cgcn_debug_set_fwd_split_bytes(0 if request.param == "split" else -1)

@@ -32,12 +32,12 @@ def counters(d):
     return vals, durs
 
 
-def is_gather_fwd(k):
-    """the gathering variants of k_layer_fwd<S; D; MB; HAS_VAL; FROM_CACHE; DEEP...> (FROM_CACHE = false)"""
-    if not k.startswith("void k_layer_fwd<"):
-        return False
-    args = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(";")]
-    return len(args) >= 5 and args[4] == "false"
+FWD_KERNELS = ("void k_layer_fwd<", "void k_aggregate_sliced<", "void k_layer_dense<")
+
+
+def is_fwd_kernel(k):
+    """kernels of one cgcn_layer_fwd call: the fused k_layer_fwd, or k_aggregate_sliced + k_layer_dense (split route)"""
+    return k.startswith(FWD_KERNELS)
 
 
 def main():
@@ -66,15 +66,18 @@ def main():
                 v = vals[k][cname]
                 o.write("%s,%s,%d,%.1f\n" % (k, cname, len(v), sum(v) / len(v)))
                 per.setdefault(k, {})[cname] = (sum(v), len(v))
-    fk = [k for k in per if is_gather_fwd(k) and "FETCH_SIZE" in per[k] and "WRITE_SIZE" in per[k]]
-    if fk:
-        fs = sum(per[k]["FETCH_SIZE"][0] for k in fk) / sum(per[k]["FETCH_SIZE"][1] for k in fk)
-        ws = sum(per[k]["WRITE_SIZE"][0] for k in fk) / sum(per[k]["WRITE_SIZE"][1] for k in fk)
+    fk = [k for k in per if is_fwd_kernel(k) and "FETCH_SIZE" in per[k] and "WRITE_SIZE" in per[k]]
+    # one layer forward = one k_layer_fwd launch (fused route) or one k_aggregate_sliced + one k_layer_dense (split route)
+    calls = sum(per[k]["FETCH_SIZE"][1] for k in fk if not k.startswith("void k_aggregate_sliced<"))
+    if fk and calls:
+        fs = sum(per[k]["FETCH_SIZE"][0] for k in fk) / calls
+        ws = sum(per[k]["WRITE_SIZE"][0] for k in fk) / calls
         ent = {"bytes_per_launch": (2 * fs + ws) * 1024, "tag": tag, "fetch_KB": fs, "write_KB": ws,
-               "launches": sum(per[k]["FETCH_SIZE"][1] for k in fk), "kernels": fk}
+               "launches": calls, "kernels": fk}
         json.dump({"%s_d%d" % (wl, d): ent,
-                   "_note": "gathering k_layer_fwd variants, mean over their launches in one bench run: (2*FETCH_SIZE + WRITE_SIZE)*1024 "
-                            "bytes per launch (rocprofv3 --pmc, separate passes). gfx950: FETCH_SIZE reports half the bytes of wide (16 B/lane) "
+                   "_note": "per layer forward (one cgcn_layer_fwd call = k_layer_fwd, or k_aggregate_sliced + k_layer_dense), mean over "
+                            "the calls of one bench run: (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes "
+                            "(rocprofv3 --pmc, separate passes). gfx950: FETCH_SIZE reports half the bytes of wide (16 B/lane) "
                             "reads, hence the factor 2 (MI355X_MICROARCH.md, HBM). FETCH_SIZE counts L2->fabric reads and includes "
                             "Infinity-Cache hits: traffic beyond L2, not HBM-only."},
                   open(os.path.join(out, "traffic_%s.json" % wl), "w"), indent=1)
