@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--no-hip-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (profiling runs)")
+    ap.add_argument("--no-roofline", action="store_true", help="tuning runs only: skip the isolated layer-forward timing (roofline = null)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the host baseline sample")
     ap.add_argument("--backend", default=os.environ.get("CGCN_DIST_BACKEND", "nccl"),
                     help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU functional tests)")
@@ -341,7 +342,7 @@ def main():
         tot_t = tot_b = tot_g = tot_f = 0.0
         per_chrom = {}
         for nm, n, nnz in shapes:
-            if nm not in stage.chroms:
+            if nm not in stage.chroms or args.no_roofline:
                 continue
             t1, t2 = time_layer_fwd(stage, nm, reps, args.dropout)
             b = layer_fwd_bytes(n, nnz, 2, args.d)
@@ -353,7 +354,7 @@ def main():
         wl_key = ("genome" if genome else args.workload) + ("_hic" if args.hic_like else "") + "_d%d" % args.d
         traffic, ttag = stored_traffic(wl_key)
         nl = 2 * len(per_chrom)
-        roof = {"bound": "hbm",
+        roof = None if not per_chrom else {"bound": "hbm",
                 "kernel": "layer forward, training form (writes Z, H; layer 1 with dropout, last layer with BatchNorm column "
                           "statistics) = one cgcn_layer_fwd call: k_aggregate_sliced + k_layer_dense<S=2,D=%d> on feature tables "
                           ">= 8 MiB, the fused k_layer_fwd below; HIP events around the call, average over the %d calls of one %s" %

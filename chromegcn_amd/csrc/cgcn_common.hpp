@@ -10,9 +10,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define WAVE 64
 #define TILE_NODES 16   // nodes per workgroup tile in the gather kernels
-#ifndef BWD_TILE_ROWS
-#define BWD_TILE_ROWS 32  // rows per tile of k_bwd_rowlocal on large graphs (32, 48 or 64)
-#endif
 #ifndef BWD_MAX_PARTIALS
 #define BWD_MAX_PARTIALS 256
 #endif
@@ -20,15 +17,30 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // ------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
-  return v;
-}
-
 __device__ __forceinline__ int rl_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ float rl_f(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// v of the lane that DPP control CTRL pairs this lane with; 0 in the rows ROW_MASK leaves out
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_get(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+
+// Sum over the 64 lanes, the same value in every lane.  Must be called with all lanes active.  Six DPP adds (data
+// parallel primitives: register-to-register lane permutes on the VALU, no LDS crossbar) and one v_readlane: pairs,
+// quads, half rows and rows of 16 by quad_perm / row_half_mirror / row_mirror, then row_bcast15 / row_bcast31 carry
+// the row totals up to lane 63.  (Six dependent ds_bpermute round trips -- the __shfl_xor butterfly -- were a
+// 600-cycle latency chain in every row-wise pass.)
+__device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_get<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+  v += dpp_get<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+  v += dpp_get<0x141, 0xF>(v);   // row_half_mirror
+  v += dpp_get<0x140, 0xF>(v);   // row_mirror: every lane holds its row's total
+  v += dpp_get<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3
+  v += dpp_get<0x143, 0xC>(v);   // row_bcast31 into rows 2 and 3: lane 63 holds the wave's total
+  return rl_f(v, 63);
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }

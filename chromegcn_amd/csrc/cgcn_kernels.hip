@@ -756,18 +756,26 @@ __global__ __launch_bounds__(512, DENSE_WAVES_PER_SIMD) void k_layer_dense(int n
 // over Ahat^T that follows in k_bwd_sliced).  Persistent: each workgroup walks row tiles and keeps its D x D slice of
 // dW in accumulators, then writes one partial.  Rows are the flattened [S*n] axis.
 //   partial layout per workgroup: [D*D dW][D db][D dwg][1 dcg][3 pad]
-// D = 128: one workgroup of 16 waves per CU.  All 16 do the row pass (TR/16 rows each); in the MFMA phase waves 0-7
-// own 16 rows of dW each (8 accumulator blocks) and waves 8-15 own 16 output columns of dHs each, their W^T fragments
-// resident in the SAME 32 registers the other half uses as accumulators (R below): 64 KB of accumulators + 64 KB of
-// weights per workgroup in 32 registers per thread, which is what lets 16 waves (<= 128 VGPRs) live on one CU.
+// The two products are 4 M D^2 flop on the fp32 matrix pipe (157 TFLOP/s) -- about as long as streaming the five row
+// tensors takes -- so the kernel is arranged to keep that pipe busy.
+// D = 128: one workgroup of 16 waves per CU.  All 16 do the row pass (TR/16 rows each).  Waves 0-7 own 16 rows of dW
+// each (8 accumulator blocks), waves 8-15 own 16 output columns of dHs each, their W^T fragments resident in the SAME
+// 32 registers the other half uses as accumulators (R below): 64 KB of accumulators + 64 KB of weights per workgroup
+// in 32 registers per thread, which is what lets 16 waves (<= 128 VGPRs) live on one CU.  The H / dU tiles are double
+// buffered in LDS and the two halves run each step in OPPOSITE order -- dW waves: matrix product on tile t, then the
+// row pass of tile t+1; dHs waves: row pass of tile t+1, then the product on tile t -- so on every SIMD two waves
+// occupy the matrix pipe while the other two do the row math, and swap.  One barrier per tile.
 // D = 256: 8 waves, every wave owns 32 rows of dW (128 accumulator registers) and 32 columns of dHs, whose W^T
-// operand is read from L2 in the loop.
+// operand is read from L2 in the loop; single-buffered, row pass and products in turn.
 // ------------------------------------------------------------------------------------------
-// LDS row stride of the two tiles = D + RL_LD_PAD floats.  Ht / Ut are read column-wise (dW = Ht^T Ut: lanes (q, r)
+// LDS row stride of the tiles = D + RL_LD_PAD floats.  Ht / Ut are read column-wise (dW = Ht^T Ut: lanes (q, r)
 // read row 4kk+q, column c0+r: conflict-free in a half-wave when the stride is 16 mod 32) and Ut also row-wise with
 // ds_read_b128 (dHs = Ut W^T); measured: 4 / 12 / 16 / 20 make no difference to the step.
 #ifndef RL_LD_PAD
 #define RL_LD_PAD 16
+#endif
+#ifndef RL_ANTIPHASE
+#define RL_ANTIPHASE 1
 #endif
 template <int D, int TR>
 __global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, int n, const float* __restrict__ dXn,
@@ -778,7 +786,7 @@ __global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, i
                                                       float* __restrict__ part, HeadApply hp,
                                                       float* __restrict__ dxn_store, int row_blocks, int head_slabs,
                                                       const float* __restrict__ W) {
-  constexpr bool SPLIT = (D == 128);  // role-split MFMA phase (see above)
+  constexpr bool SPLIT = (D == 128);  // role-split, double-buffered (see above)
   constexpr int NW = SPLIT ? 16 : 8;
   // extra workgroups past the row tiles: the head's deferred dW_out / db_out second stage (independent work,
   // fused "horizontally" so it costs no launch of its own)
@@ -795,11 +803,12 @@ __global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, i
   constexpr int JB = D / 16;
   constexpr int MB = TR / 16;
   constexpr int RPW = TR / NW;        // rows per wave per tile
+  constexpr int NBUF = SPLIT ? 2 : 1;
   constexpr int PSTRIDE = D * D + 2 * D + 4;
   static_assert(TR % NW == 0 && TR % 16 == 0, "tile rows");
-  __shared__ __attribute__((aligned(16))) float Ht[TR * LD];
-  __shared__ __attribute__((aligned(16))) float Ut[TR * LD];
-  __shared__ float Sc[TR];            // row_scale of the tile's rows (0 past the end)
+  __shared__ __attribute__((aligned(16))) float Ht[NBUF][TR * LD];
+  __shared__ __attribute__((aligned(16))) float Ut[NBUF][TR * LD];
+  __shared__ float Sc[NBUF][TR];      // row_scale of the tile's rows (0 past the end)
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -833,8 +842,7 @@ __global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, i
   KT_STAMP(1);
   const int ntiles = (M + TR - 1) / TR;
   // The wave's RPW rows of a tile are loaded into registers in one go (all loads issued before the first use); the
-  // loads of the workgroup's NEXT tile are issued right after the row pass, so they are in flight during the
-  // barrier + MFMA phase of the current one.
+  // loads of the tile after it are issued right after its row pass, a whole tile time before they are needed.
   float gup[RPW][EPL], z[RPW][EPL], x[RPW][EPL], h[RPW][EPL], gt[RPW], dgt[RPW];
   auto load_tile = [&](int tile) {
 #pragma unroll
@@ -842,11 +850,15 @@ __global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, i
       const int m = tile * TR + wave + t * NW;
       const bool ok = m < M;
       const size_t off = (size_t)m * D + lane * EPL;
+#ifdef RL_SKIP_LOADS
+      if (false) {
+#else
       if (ok) {
+#endif
         ld_row<EPL>(z[t], &Z[off]);
         ld_row<EPL>(x[t], &X[off]);
         ld_row<EPL>(h[t], &H[off]);
-        ld_row<EPL>(gup[t], hp.dym ? &hp.dym[(size_t)(m % n) * D + lane * EPL] : &dXn[off]);
+        ld_row<EPL>(gup[t], hp.dym ? &hp.dym[(size_t)(m >= n ? m - n : m) * D + lane * EPL] : &dXn[off]);  // S <= 2: m % n without the division
       } else {
         zero_row<EPL>(z[t]);
         zero_row<EPL>(x[t]);
@@ -857,9 +869,8 @@ __global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, i
       dgt[t] = (ok && dgate) ? dgate[m] : 0.f;
     }
   };
-  if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
-  for (int tile = blockIdx.x; tile < ntiles; tile += row_blocks) {
-    KT_STAMP(2);
+  // row math of the loaded tile -> H and dU tiles (and the row scales) in LDS buffer `buf`
+  auto row_pass = [&](int tile, int buf) {
 #pragma unroll
     for (int t = 0; t < RPW; ++t) {
       const int trow = wave + t * NW;
@@ -870,7 +881,7 @@ __global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, i
         const float g = gt[t];
         if (hp.dym) {
           // dL/dXn of the last layer from the head's backward state (see HeadApply)
-          const int s = m / n;
+          const int s = m >= n ? 1 : 0;   // S <= 2
           const float invS = 1.f / (float)hp.S;
           float is[EPL], mu[EPL], bw_[EPL], c0[EPL], c1[EPL];
           ld_row<EPL>(is, &hp.invstd[s * D + lane * EPL]);
@@ -903,87 +914,129 @@ __global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, i
           dwg_acc[e] += gamma * z[t][e];
         }
         dcg_acc += gamma;
-        if (lane == 0) Sc[trow] = rs ? rs[m % n] : 1.f;
+        if (lane == 0) Sc[buf][trow] = rs ? rs[m >= n ? m - n : m] : 1.f;
       } else {
 #pragma unroll
         for (int e = 0; e < EPL; ++e) du[e] = 0.f;
-        if (lane == 0) Sc[trow] = 0.f;
+        if (lane == 0) Sc[buf][trow] = 0.f;
       }
 #ifndef RL_SKIP_MFMA
 #pragma unroll
       for (int e = 0; e < EPL; ++e) {
-        Ht[trow * LD + lane * EPL + e] = h[t][e];
-        Ut[trow * LD + lane * EPL + e] = du[e];
+        Ht[buf][trow * LD + lane * EPL + e] = h[t][e];
+        Ut[buf][trow * LD + lane * EPL + e] = du[e];
       }
 #endif
     }
-    if (tile + row_blocks < ntiles) load_tile(tile + row_blocks);  // prefetch (see above)
-    KT_STAMP(3);
-    __syncthreads();
-    KT_STAMP(4);
+  };
+  // dW += Ht^T Ut  (K = TR rows)
+  auto mma_dw = [&](int buf) {
 #ifndef RL_SKIP_MFMA
-    // ---- dW += Ht^T Ut  (K = TR rows)
-    if (dw_wave) {
+    const float* __restrict__ Hb = Ht[buf];
+    const float* __restrict__ Ub = Ut[buf];
 #pragma unroll
-      for (int kk = 0; kk < TR / 4; ++kk) {
-        const int k = 4 * kk + q;
-        float a[IBW];
+    for (int kk = 0; kk < TR / 4; ++kk) {
+      const int k = 4 * kk + q;
+      float a[IBW];
 #pragma unroll
-        for (int ib = 0; ib < IBW; ++ib) a[ib] = Ht[k * LD + (IBW * own + ib) * 16 + r];
+      for (int ib = 0; ib < IBW; ++ib) a[ib] = Hb[k * LD + (IBW * own + ib) * 16 + r];
 #pragma unroll
-        for (int jb = 0; jb < JB; ++jb) {
-          const float b = Ut[k * LD + jb * 16 + r];
+      for (int jb = 0; jb < JB; ++jb) {
+        const float b = Ub[k * LD + jb * 16 + r];
 #pragma unroll
-          for (int ib = 0; ib < IBW; ++ib) R[ib][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ib], b, R[ib][jb], 0, 0, 0);
-        }
-      }
-    }
-    // ---- dHs = diag(row_scale) Ut W^T: this wave's 16*IBW output columns, straight from the accumulators
-    // (64-byte row segments; the other column blocks of the same rows are written by the neighbouring waves)
-    if (dh_wave) {
-      constexpr int MBG = SPLIT ? MB : 1;   // row blocks in flight (independent accumulation chains); registers at D = 256
-#pragma unroll 1
-      for (int mb0 = 0; mb0 < MB; mb0 += MBG) {
-        f32x4 hacc[MBG][IBW];
-#pragma unroll
-        for (int mb = 0; mb < MBG; ++mb)
-#pragma unroll
-          for (int ib = 0; ib < IBW; ++ib) hacc[mb][ib] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll(SPLIT ? JB : 2)
-        for (int t = 0; t < JB; ++t) {
-          f32x4 a[MBG], b[IBW];
-#pragma unroll
-          for (int mb = 0; mb < MBG; ++mb) a[mb] = *(const f32x4*)&Ut[((mb0 + mb) * 16 + r) * LD + 16 * t + 4 * q];
-#pragma unroll
-          for (int ib = 0; ib < IBW; ++ib)
-            b[ib] = SPLIT ? R[0][t] : *(const f32x4*)&W[(size_t)((IBW * own + ib) * 16 + r) * D + 16 * t + 4 * q];
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int mb = 0; mb < MBG; ++mb)
-#pragma unroll
-              for (int ib = 0; ib < IBW; ++ib)
-                hacc[mb][ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb][u], b[ib][u], hacc[mb][ib], 0, 0, 0);
-        }
-#pragma unroll
-        for (int mb = 0; mb < MBG; ++mb)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int trow = (mb0 + mb) * 16 + q * 4 + e;
-            const int m = tile * TR + trow;
-            const float sc = Sc[trow];
-            if (m < M) {
-#pragma unroll
-              for (int ib = 0; ib < IBW; ++ib) dHs[(size_t)m * D + (IBW * own + ib) * 16 + r] = hacc[mb][ib][e] * sc;
-            }
-          }
+        for (int ib = 0; ib < IBW; ++ib) R[ib][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ib], b, R[ib][jb], 0, 0, 0);
       }
     }
 #endif
+  };
+  // dHs = diag(row_scale) Ut W^T: this wave's 16*IBW output columns, straight from the accumulators
+  // (64-byte row segments; the other column blocks of the same rows are written by the neighbouring waves)
+  auto mma_dh = [&](int tile, int buf) {
+#ifndef RL_SKIP_MFMA
+    const float* __restrict__ Ub = Ut[buf];
+    constexpr int MBG = SPLIT ? MB : 1;   // row blocks in flight (independent accumulation chains); registers at D = 256
+#pragma unroll 1
+    for (int mb0 = 0; mb0 < MB; mb0 += MBG) {
+      f32x4 hacc[MBG][IBW];
+#pragma unroll
+      for (int mb = 0; mb < MBG; ++mb)
+#pragma unroll
+        for (int ib = 0; ib < IBW; ++ib) hacc[mb][ib] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll(SPLIT ? JB : 2)
+      for (int t = 0; t < JB; ++t) {
+        f32x4 a[MBG], b[IBW];
+#pragma unroll
+        for (int mb = 0; mb < MBG; ++mb) a[mb] = *(const f32x4*)&Ub[((mb0 + mb) * 16 + r) * LD + 16 * t + 4 * q];
+#pragma unroll
+        for (int ib = 0; ib < IBW; ++ib)
+          b[ib] = SPLIT ? R[0][t] : *(const f32x4*)&W[(size_t)((IBW * own + ib) * 16 + r) * D + 16 * t + 4 * q];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int mb = 0; mb < MBG; ++mb)
+#pragma unroll
+            for (int ib = 0; ib < IBW; ++ib)
+              hacc[mb][ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb][u], b[ib][u], hacc[mb][ib], 0, 0, 0);
+      }
+#pragma unroll
+      for (int mb = 0; mb < MBG; ++mb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int trow = (mb0 + mb) * 16 + q * 4 + e;
+          const int m = tile * TR + trow;
+          const float sc = Sc[buf][trow];
+          if (m < M) {
+#pragma unroll
+            for (int ib = 0; ib < IBW; ++ib) dHs[(size_t)m * D + (IBW * own + ib) * 16 + r] = hacc[mb][ib][e] * sc;
+          }
+        }
+    }
+#endif
+  };
+
+  const int tile0 = blockIdx.x;
+  if (SPLIT) {
+    if (tile0 < ntiles) {
+      load_tile(tile0);
+      row_pass(tile0, 0);
+      if (tile0 + row_blocks < ntiles) load_tile(tile0 + row_blocks);
+    }
     __syncthreads();
+    int buf = 0;
+    for (int tile = tile0; tile < ntiles; tile += row_blocks, buf ^= 1) {
+      const int next = tile + row_blocks;
+      if (tile == tile0 + 3 * row_blocks) KT_STAMP(2);
+      if (RL_ANTIPHASE && !dw_wave) {   // dHs waves: rows first, matrix pipe second
+        if (next < ntiles) {
+          row_pass(next, buf ^ 1);
+          if (next + row_blocks < ntiles) load_tile(next + row_blocks);
+        }
+        if (dh_wave) mma_dh(tile, buf);
+      } else {                          // dW waves: matrix pipe first, rows second
+        if (dw_wave) mma_dw(buf);
+        else if (dh_wave) mma_dh(tile, buf);
+        if (tile == tile0 + 3 * row_blocks) KT_STAMP(3);
+        if (next < ntiles) {
+          row_pass(next, buf ^ 1);
+          if (next + row_blocks < ntiles) load_tile(next + row_blocks);
+        }
+      }
+      if (tile == tile0 + 3 * row_blocks) KT_STAMP(4);
+      __syncthreads();
+      if (tile == tile0 + 3 * row_blocks) KT_STAMP(5);
+    }
+  } else {
+    if (tile0 < ntiles) load_tile(tile0);
+    for (int tile = tile0; tile < ntiles; tile += row_blocks) {
+      row_pass(tile, 0);
+      if (tile + row_blocks < ntiles) load_tile(tile + row_blocks);  // in flight during the barrier + MFMA phase
+      __syncthreads();
+      mma_dw(0);
+      if (dh_wave) mma_dh(tile, 0);
+      __syncthreads();
+    }
   }
 
-  KT_STAMP(5);
   // ---- write this workgroup's partial
   float* P = part + (size_t)blockIdx.x * PSTRIDE;
 #ifndef RL_SKIP_MFMA
@@ -1001,8 +1054,8 @@ __global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, i
   }
 #endif
   KT_STAMP(6);
-  // column sums: combine the NW waves through LDS in a fixed order
-  float* red = Ht;  // [NW][2*D + 1]
+  // column sums: combine the NW waves through LDS in a fixed order (the tile buffers are idle after the last barrier)
+  float* red = Ht[0];  // [NW][2*D + 1]
   constexpr int RS = 2 * D + 1;
   static_assert(NW * RS <= TR * LD, "column-sum staging fits the H tile");
 #pragma unroll
@@ -1551,19 +1604,9 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   return launch_status();
 }
 
-// Row-tile height and workgroup count of k_bwd_rowlocal: one persistent workgroup per CU at most (BWD_MAX_PARTIALS;
-// 16 waves at d = 128), the smallest tile that still gives every tile its own workgroup on small graphs (more CUs busy,
-// shorter load -> row math -> LDS -> MFMA chain), BWD_TILE_ROWS on large ones.  D = 256 is limited to 32 rows by registers.
-#ifndef BWD_MID_ROWS
-#define BWD_MID_ROWS 48
-#endif
-static int bwd_tile_rows(int n, int S, int d) {
-  if (d != 128) return 32;
-  const int M = n * S;
-  if (M <= 32 * BWD_MAX_PARTIALS) return 32;
-  if (M <= 48 * BWD_MAX_PARTIALS) return BWD_MID_ROWS;
-  return BWD_TILE_ROWS;
-}
+// Row-tile height and workgroup count of k_bwd_rowlocal: 32-row tiles (two H / dU tile pairs in LDS, <= 128 registers
+// for 16 waves at d = 128; registers at d = 256), one persistent workgroup per CU at most (BWD_MAX_PARTIALS).
+static int bwd_tile_rows(int, int, int) { return 32; }
 
 static int bwd_partials(int n, int S, int d) {
   const int M = n * S;
@@ -1630,14 +1673,8 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   const int P = bwd_partials(n, S, d);
   float* part = (float*)workspace;
   const int M = n * S;
-  if (d == 128) {
-#define RL(TR_) hipLaunchKernelGGL((k_bwd_rowlocal<128, TR_>), dim3(P + head_slabs), dim3(1024), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, P, head_slabs, W)
-    const int tr = bwd_tile_rows(n, S, d);
-    if (tr == 32) RL(32);
-    else if (tr == 48) RL(48);
-    else RL(64);
-#undef RL
-  }
+  if (d == 128)
+    hipLaunchKernelGGL((k_bwd_rowlocal<128, 32>), dim3(P + head_slabs), dim3(1024), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, P, head_slabs, W);
   else
     hipLaunchKernelGGL((k_bwd_rowlocal<256, 32>), dim3(P + head_slabs), dim3(512), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, P, head_slabs, W);
   if ((rc = launch_status())) return rc;

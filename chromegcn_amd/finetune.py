@@ -20,6 +20,8 @@ reference does per chromosome per epoch:
 Semantics at world_size 1 are exactly the reference's: one SGD step per chromosome, in dict order."""
 from __future__ import annotations
 
+import gc
+
 import os
 import pickle
 import time
@@ -391,9 +393,18 @@ class GCNStage:
             graph = torch.cuda.CUDAGraph()
             if self._pool is None:
                 self._pool = torch.cuda.graph_pool_handle()
-            # thread_local: an RCCL watchdog thread polling events while we capture must not invalidate the capture
-            with torch.cuda.graph(graph, pool=self._pool, capture_error_mode="thread_local"):
-                loss, probs, dx = body()
+            # thread_local: an RCCL watchdog thread polling events while we capture must not invalidate the capture.
+            # No cyclic garbage collection while the stream captures: a collection that happens to free an earlier
+            # stage's graphs / events / device buffers calls HIP APIs that are illegal during capture, and a failing
+            # destructor aborts the process (seen once in ~10 full test runs; torch.cuda.graph collects on entry only).
+            gc_was_enabled = gc.isenabled()
+            gc.disable()
+            try:
+                with torch.cuda.graph(graph, pool=self._pool, capture_error_mode="thread_local"):
+                    loss, probs, dx = body()
+            finally:
+                if gc_was_enabled:
+                    gc.enable()
         finally:
             # the warm-up steps mutated parameters / running statistics / optimizer state: whatever happened above,
             # hand the model back exactly as it came in (capture itself launches nothing)

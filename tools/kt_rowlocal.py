@@ -2,8 +2,8 @@
   CGCN_EXTRA_FLAGS="-DKT_TIMING" python -c "from chromegcn_amd import _build; _build.build_library(out='variants/libcgcn_kt.so')"
   CHROMEGCN_LIB=$PWD/variants/libcgcn_kt.so python tools/kt_rowlocal.py [chromosome]
 Stamps (100 MHz wall clock) of workgroups 0, 32, ... 224 of the LAST rowlocal launch of a train step (first layer's
-backward): 0 entry, 1 setup done, 2 top of the last tile, 3 its row pass done, 4 past the barrier, 5 loop done (MFMA +
-barrier), 6 partial written, 7 column sums written."""
+backward), wave 0 (a dW wave): 0 entry, 1 setup done, 2 top of the workgroup's 4th tile, 3 its dW product done, 4 row pass of
+the 5th tile done, 5 past the barrier, 6 loop done + partial written, 7 column sums written."""
 import ctypes
 import os
 import sys
@@ -36,7 +36,7 @@ def main():
     t0 = t[:, 0].min()
     print(name, "n =", stage.chroms[name].n)
     for b in range(8):
-        print("wg %3d start+%.2fus" % (b * 32, (t[b, 0] - t0) / 100.0), " setup %.2f | to last tile %.2f | row pass %.2f | barrier %.2f | mfma+barrier %.2f | partial %.2f | colsums %.2f | total %.2f"
+        print("wg %3d start+%.2fus" % (b * 32, (t[b, 0] - t0) / 100.0), " setup %.2f | to 4th tile %.2f | wave 0: dW product %.2f | row pass of the next tile %.2f | barrier %.2f | rest of the loop %.2f | partial %.2f | total %.2f"
               % (tuple((t[b, i + 1] - t[b, i]) / 100.0 for i in range(7)) + ((t[b, 7] - t[b, 0]) / 100.0,)))
 
 
