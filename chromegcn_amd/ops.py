@@ -89,6 +89,10 @@ def _sgd_fuse_arg(layer_id, dx, sink):
     return ctypes.byref(sg), sg
 
 
+# feature tables from this size on do not fit the L2s: cgcn_layer_fwd's split route (FWD_SPLIT_TABLE_BYTES in csrc)
+_SPLIT_TABLE_BYTES = 8 << 20
+
+
 def _resolve_h_cache(h_cache, x, need_bwd):
     """h_cache: None, or a dict holder {'h': tensor-or-None} for H = A X of a layer whose input never changes
     (the engine keeps one per chromosome for the first layer).  Returns (H_in to stream, H buffer to write)."""
@@ -97,7 +101,8 @@ def _resolve_h_cache(h_cache, x, need_bwd):
         if hc.shape != x.shape or hc.device != x.device:
             raise RuntimeError("chromegcn_amd: cached aggregation does not match the input")
         return hc, None
-    if need_bwd or h_cache is not None:
+    if need_bwd or h_cache is not None or x.numel() * 4 >= _SPLIT_TABLE_BYTES:
+        # inference on a large table too: with an H buffer cgcn_layer_fwd takes the feature-sliced two-launch route
         return None, torch.empty_like(x)
     return None, None
 
