@@ -5,11 +5,13 @@
 // no other target.
 //
 // Kernel inventory (DESIGN.md has the roofline for each):
-//   k_spmm<S,D>          unfused aggregation  Y = diag(rs) Ahat X                (HBM/L2 gather)
-//   k_layer_fwd<S,D>     gather -> LDS tile -> fp32 MFMA (x W) -> bias/tanh/gate/mix epilogue
-//   k_bwd_rowlocal<D>    per-row gate/tanh derivative, dUs, and H^T dU on fp32 MFMA (persistent)
-//   k_reduce_partials    deterministic second stage of the column / dW sums
-//   k_bwd_gather<S,D>    gather of dUs over Ahat^T -> LDS tile -> fp32 MFMA (x W^T) -> dX epilogue
+//   k_spmm<S,D>             unfused aggregation  Y = diag(rs) Ahat X, whole-row gather  (tables that fit the L2s)
+//   k_aggregate_sliced<S,D> the same aggregation, feature-sliced: one 128-byte column slice per XCD (large tables)
+//   k_layer_fwd<S,D>        fused layer forward: gather -> LDS tile -> fp32 MFMA (x W) -> bias/tanh/gate/mix epilogue
+//   k_layer_dense<S,D>      the row-local half of the layer forward on an H that is in memory (after k_aggregate_sliced)
+//   k_bwd_rowlocal<D>       per-row gate/tanh derivative, H^T dU and dHs = diag(rs) dU W^T on fp32 MFMA (persistent)
+//   k_reduce_partials       deterministic second stage of the column / dW sums
+//   k_bwd_sliced<S,D>       dX = mask ((1-g) dXn + Ahat^T dHs): feature-sliced gather + element-wise epilogue
 //
 // Reference semantics: models/SubLayers.py:42-52, models/ChromeModels.py:34-46 (forward);
 // SURVEY.md Appendix A (backward).
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(256) void k_spmm_any(int n_rows, int n_cols, int S,
 }
 
 // ------------------------------------------------------------------------------------------
-// Shared pieces of the two gather kernels (k_layer_fwd, k_bwd_gather).
+// Shared pieces of the fused kernels (k_layer_fwd; round 1: also the fused backward gather).
 //
 // Tile: TN = 16*MB/S nodes x S strands = 16*MB MFMA rows, staged in LDS as T[row][D+4].
 // MFMA: v_mfma_f32_16x16x4_f32.  A lane l: A[row l&15][k-slot l>>4]; B lane l: B[k-slot l>>4][col l&15];
@@ -774,6 +776,9 @@ __global__ __launch_bounds__(512, DENSE_WAVES_PER_SIMD) void k_layer_dense(int n
 #ifndef RL_LD_PAD
 #define RL_LD_PAD 16
 #endif
+#ifndef RL_MBG256
+#define RL_MBG256 0
+#endif
 #ifndef RL_ANTIPHASE
 #define RL_ANTIPHASE 1
 #endif
@@ -954,7 +959,7 @@ __global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, i
   auto mma_dh = [&](int tile, int buf) {
 #ifndef RL_SKIP_MFMA
     const float* __restrict__ Ub = Ut[buf];
-    constexpr int MBG = SPLIT ? MB : 1;   // row blocks in flight (independent accumulation chains); registers at D = 256
+    constexpr int MBG = (SPLIT || RL_MBG256) ? MB : 1;   // row blocks in flight (independent accumulation chains; one read of W^T serves them all)
 #pragma unroll 1
     for (int mb0 = 0; mb0 < MB; mb0 += MBG) {
       f32x4 hacc[MBG][IBW];
@@ -1096,7 +1101,7 @@ __device__ __forceinline__ void sgd_apply(const SgdFuse& sg, int idx, float g) {
 }
 
 // One 64-element slab of the second-stage sum, computed by a workgroup of NT threads (NT/64 partial slices).
-// Used by k_reduce_partials and, fused "horizontally", by the extra workgroups at the end of k_bwd_gather's grid.
+// Used by k_reduce_partials and, fused "horizontally", by the extra workgroups at the end of k_bwd_sliced's grid.
 template <int NT>
 __device__ __forceinline__ void reduce_slab(int slab, int P, int D, const float* __restrict__ part,
                                             float* __restrict__ dW, float* __restrict__ db, float* __restrict__ dwg,
@@ -1258,6 +1263,21 @@ __device__ __forceinline__ f32x4 sliced_row_sum(const int* __restrict__ col, con
   return mine;
 }
 
+// workgroup b -> (column slice, 64-row tile).  Up to 8 slices: slice = b mod NSL, so XCD x (workgroups b = x mod 8) owns
+// slice x.  16 slices (S*D = 512 floats): two passes over the tiles, XCD x works on slice x in the first half of the
+// grid and on slice x + 8 in the second, so that one slice (not two) is hot in its L2 at a time.
+template <int NSL>
+__device__ __forceinline__ void sliced_block(int b, int tiles, int& slice, int& tile) {
+  if (NSL <= 8) {
+    slice = b % NSL;
+    tile = b / NSL;
+  } else {
+    const int per = 8 * tiles, pass = b / per, rem = b - pass * per;
+    slice = (rem & 7) + 8 * pass;
+    tile = rem >> 3;
+  }
+}
+
 // H = diag(rs) Ahat X, [S, n, D] -> [S, n, D]  (grid: NSL * ceil(n / 64) workgroups of 512)
 template <int S, int D, bool HAS_VAL>
 __global__ __launch_bounds__(512) void k_aggregate_sliced(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
@@ -1265,7 +1285,8 @@ __global__ __launch_bounds__(512) void k_aggregate_sliced(int n, const int* __re
                                                           const float* __restrict__ X, float* __restrict__ H) {
   constexpr int NSL = S * D / 32, QPR = D / 32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int slice = blockIdx.x % NSL, tile = blockIdx.x / NSL;
+  int slice, tile;
+  sliced_block<NSL>(blockIdx.x, (n + 63) / 64, slice, tile);
   const int i = tile * 64 + wave * 8 + (lane >> 3);
   const size_t lane_el = (size_t)(slice / QPR) * n * D + (slice % QPR) * 32 + (lane & 7) * 4;
   int k0 = 0, k1 = 0;
@@ -1309,7 +1330,8 @@ __global__ __launch_bounds__(512) void k_bwd_sliced(int n, const int* __restrict
   }
   constexpr int NSL = S * D / 32, QPR = D / 32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int slice = blockIdx.x % NSL, tile = blockIdx.x / NSL;
+  int slice, tile;
+  sliced_block<NSL>(blockIdx.x, (n + 63) / 64, slice, tile);
   const int s = slice / QPR;
   const int i = tile * 64 + wave * 8 + (lane >> 3);
   const size_t lane_el = (size_t)s * n * D + (slice % QPR) * 32 + (lane & 7) * 4;
@@ -1563,7 +1585,10 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   hipStream_t st = (hipStream_t)stream;
   // Three routes.  H_in given: the row-local kernel alone.  Training (H is wanted anyway) on a table that does not
   // fit the L2s: feature-sliced aggregation into H, then the row-local kernel on it.  Otherwise the fused kernel.
-  const bool split = !H_in && H && (double)n * S * d * 4.0 >= (double)g_fwd_split_bytes.load();
+  // (payloads of 2 KiB per node -- d = 256, both strands -- keep the fused kernel at every size: measured 0.86 vs 0.92 ms
+  // per step at chr21 size, 1.26 vs 1.34 ms at chr1 size on a hic-like graph; the debug hook's 0 still forces the split)
+  const long long split_bytes = g_fwd_split_bytes.load();
+  const bool split = !H_in && H && (double)n * S * d * 4.0 >= (double)split_bytes && (S * d <= 256 || split_bytes == 0);
   if (split) {
     const int gblocks = (S * d / 32) * ((n + 63) / 64);
 #define CALL(S_, D_, V_) \

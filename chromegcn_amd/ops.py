@@ -101,7 +101,7 @@ def _resolve_h_cache(h_cache, x, need_bwd):
         if hc.shape != x.shape or hc.device != x.device:
             raise RuntimeError("chromegcn_amd: cached aggregation does not match the input")
         return hc, None
-    if need_bwd or h_cache is not None or x.numel() * 4 >= _SPLIT_TABLE_BYTES:
+    if need_bwd or h_cache is not None or (x.numel() * 4 >= _SPLIT_TABLE_BYTES and x.shape[0] * x.shape[2] <= 256):
         # inference on a large table too: with an H buffer cgcn_layer_fwd takes the feature-sliced two-launch route
         return None, torch.empty_like(x)
     return None, None
