@@ -776,6 +776,9 @@ __global__ __launch_bounds__(512, DENSE_WAVES_PER_SIMD) void k_layer_dense(int n
 #ifndef RL_LD_PAD
 #define RL_LD_PAD 16
 #endif
+#ifndef RL_T_UNROLL256
+#define RL_T_UNROLL256 2
+#endif
 #ifndef RL_MBG256
 #define RL_MBG256 0
 #endif
@@ -967,7 +970,7 @@ __global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, i
       for (int mb = 0; mb < MBG; ++mb)
 #pragma unroll
         for (int ib = 0; ib < IBW; ++ib) hacc[mb][ib] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll(SPLIT ? JB : 2)
+#pragma unroll(SPLIT ? JB : RL_T_UNROLL256)
       for (int t = 0; t < JB; ++t) {
         f32x4 a[MBG], b[IBW];
 #pragma unroll
