@@ -1,0 +1,60 @@
+"""Copy the summaries of a tools/final_profiles.sh run from gpurun_out/ into profiles/ (tracked) and rebuild
+profiles/traffic.json:  python tools/collect_profiles.py <tag> [<old tag to remove>]"""
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    tag = sys.argv[1]
+    old = sys.argv[2] if len(sys.argv) > 2 else None
+    prof = os.path.join(ROOT, "profiles")
+    if old:
+        for f in glob.glob(os.path.join(prof, old + "_*")):
+            if "_experiment" not in f and "parity_errors" not in f:
+                os.remove(f)
+    traffic = {}
+    for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", tag + "_*", "summary"))):
+        for f in glob.glob(os.path.join(d, "*")):
+            name = os.path.basename(f)
+            if name.startswith("traffic_"):
+                traffic.update(json.load(open(f)))
+            else:
+                shutil.copy(f, os.path.join(prof, name))
+    for f in glob.glob(os.path.join(ROOT, "gpurun_out", tag, "bench_*.json")):
+        lines = [l for l in open(f).read().splitlines() if l.startswith("{")]
+        if lines:
+            wl = os.path.basename(f)[len("bench_"):-len(".json")]
+            open(os.path.join(prof, "%s_bench_line_%s.json" % (tag, wl)), "w").write(lines[-1] + "\n")
+    if "chr21_d256L4_d256" in traffic:   # bench.py keys its lookup by workload + width
+        traffic["chr21_d256"] = traffic.pop("chr21_d256L4_d256")
+    note = traffic.pop("_note", None)
+    out = dict(sorted(traffic.items()))
+    if note:
+        out["_note"] = note
+    json.dump(out, open(os.path.join(prof, "traffic.json"), "w"), indent=1)
+    # the bench lines were printed before this traffic.json existed: their `roofline.traffic` is the stored value of the
+    # previous profile run; point the copies at the values collected from THIS run's PMC passes
+    for f in glob.glob(os.path.join(prof, "%s_bench_line_*.json" % tag)):
+        d = json.loads(open(f).read())
+        r = d.get("roofline")
+        if not r:
+            continue
+        wl = os.path.basename(f)[len(tag + "_bench_line_"):-len(".json")]
+        key = {"genome": "genome_d128", "genome_hic": "genome_hic_d128", "chr21": "chr21_d128", "chr21_hic": "chr21_hic_d128",
+               "chr1": "chr1_d128", "chr1_hic": "chr1_hic_d128", "chr21_d256L4": "chr21_d256"}.get(wl)
+        if key in out:
+            r["traffic"] = out[key]["bytes_per_launch"]
+            r["traffic_source"] = "stored profile value (profiles/traffic.json, tag %s: the PMC passes of the same run), not measured inside bench.py" % tag
+        else:
+            r["traffic"], r["traffic_source"] = None, None
+        open(f, "w").write(json.dumps(d) + "\n")
+    print("traffic keys:", [k for k in out if not k.startswith("_")])
+
+
+if __name__ == "__main__":
+    main()
