@@ -811,7 +811,8 @@ __global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, i
   constexpr int JB = D / 16;
   constexpr int MB = TR / 16;
   constexpr int RPW = TR / NW;        // rows per wave per tile
-  constexpr int NBUF = SPLIT ? 2 : 1;
+  constexpr bool DB = SPLIT && TR == 32;  // double-buffered tiles, halves in opposite order (48-row tiles: one tile per workgroup)
+  constexpr int NBUF = DB ? 2 : 1;
   constexpr int PSTRIDE = D * D + 2 * D + 4;
   static_assert(TR % NW == 0 && TR % 16 == 0, "tile rows");
   __shared__ __attribute__((aligned(16))) float Ht[NBUF][TR * LD];
@@ -1003,7 +1004,7 @@ __global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, i
   };
 
   const int tile0 = blockIdx.x;
-  if (SPLIT) {
+  if (DB) {
     if (tile0 < ntiles) {
       load_tile(tile0);
       row_pass(tile0, 0);
@@ -1039,7 +1040,7 @@ __global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, i
       row_pass(tile, 0);
       if (tile + row_blocks < ntiles) load_tile(tile + row_blocks);  // in flight during the barrier + MFMA phase
       __syncthreads();
-      mma_dw(0);
+      if (dw_wave) mma_dw(0);
       if (dh_wave) mma_dh(tile, 0);
       __syncthreads();
     }
@@ -1632,9 +1633,15 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   return launch_status();
 }
 
-// Row-tile height and workgroup count of k_bwd_rowlocal: 32-row tiles (two H / dU tile pairs in LDS, <= 128 registers
-// for 16 waves at d = 128; registers at d = 256), one persistent workgroup per CU at most (BWD_MAX_PARTIALS).
-static int bwd_tile_rows(int, int, int) { return 32; }
+// Row-tile height and workgroup count of k_bwd_rowlocal: one persistent workgroup per CU at most (BWD_MAX_PARTIALS).
+// d = 128: 48-row tiles while that gives every tile its own workgroup (chr21-size graphs: 241 workgroups of one tile
+// instead of 256 of which 105 walk two 32-row tiles; single-buffered), 32-row tiles (double-buffered, <= 128 registers
+// for 16 waves) above.  d = 256: 32 rows (registers).
+static int bwd_tile_rows(int n, int S, int d) {
+  if (d != 128) return 32;
+  const int M = n * S;
+  return (M > 32 * BWD_MAX_PARTIALS && M <= 48 * BWD_MAX_PARTIALS) ? 48 : 32;
+}
 
 static int bwd_partials(int n, int S, int d) {
   const int M = n * S;
@@ -1701,7 +1708,9 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   const int P = bwd_partials(n, S, d);
   float* part = (float*)workspace;
   const int M = n * S;
-  if (d == 128)
+  if (d == 128 && bwd_tile_rows(n, S, d) == 48)
+    hipLaunchKernelGGL((k_bwd_rowlocal<128, 48>), dim3(P + head_slabs), dim3(1024), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, P, head_slabs, W);
+  else if (d == 128)
     hipLaunchKernelGGL((k_bwd_rowlocal<128, 32>), dim3(P + head_slabs), dim3(1024), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, P, head_slabs, W);
   else
     hipLaunchKernelGGL((k_bwd_rowlocal<256, 32>), dim3(P + head_slabs), dim3(512), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, P, head_slabs, W);
