@@ -753,6 +753,54 @@ __global__ __launch_bounds__(512, DENSE_WAVES_PER_SIMD) void k_layer_dense(int n
 }
 
 // ------------------------------------------------------------------------------------------
+// k_dh_dense: B <- B W^T in place, B = diag(row_scale) dU [M, D]: the dHs product for d = 256, where k_bwd_rowlocal's
+// 128 accumulator registers leave no room for the W^T fragments (d = 128 does this product inside the row-local
+// kernel).  Persistent, one 8-wave workgroup per CU, W^T fragments resident in registers (128 at D = 256), 32-row
+// tiles: rows -> LDS -> MFMA -> back to the same rows straight from the accumulators (a tile is read completely
+// before any of it is written; tiles are disjoint across workgroups).
+// ------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(512) void k_dh_dense(int M, float* __restrict__ B, const float* __restrict__ W) {
+  constexpr int MB = 2, ROWS = 16 * MB, CBW = D / 128, NW = 8, LD = D + 4, EPL = D / 64, RPW = ROWS / NW;
+  __shared__ __attribute__((aligned(16))) float T[ROWS * LD];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float bw[CBW][D / 4];
+  load_wfrag<D, CBW, true>(W, wave, lane, bw);
+  const int ntiles = (M + ROWS - 1) / ROWS;
+  float rows[RPW][EPL];
+  auto load_tile = [&](int tile) {
+#pragma unroll
+    for (int t = 0; t < RPW; ++t) {
+      const int m = tile * ROWS + wave + t * NW;
+      if (m < M) ld_row<EPL>(rows[t], &B[(size_t)m * D + lane * EPL]);
+      else zero_row<EPL>(rows[t]);
+    }
+  };
+  if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+#pragma unroll
+    for (int t = 0; t < RPW; ++t) st_row<EPL>(&T[(wave + t * NW) * LD + lane * EPL], rows[t]);
+    if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
+    __syncthreads();
+    f32x4 acc[MB][CBW];
+    tile_mfma<MB, D, CBW, LD, true, true>(T, W, bw, wave, lane, acc);
+    const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = tile * ROWS + mb * 16 + q * 4 + e;
+        if (m < M) {
+#pragma unroll
+          for (int cb = 0; cb < CBW; ++cb) B[(size_t)m * D + wave * (16 * CBW) + cb * 16 + r] = acc[mb][cb][e];
+        }
+      }
+    __syncthreads();  // T is rewritten by the next tile
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_bwd_rowlocal: everything in the layer backward that is local to a (strand,node) row, plus the two dense
 // products on MFMA:  dW = H^T dU  and  dHs = diag(row_scale) dU W^T  (dL/dH, pre-scaled: the operand of the gather
 // over Ahat^T that follows in k_bwd_sliced).  Persistent: each workgroup walks row tiles and keeps its D x D slice of
@@ -767,20 +815,14 @@ __global__ __launch_bounds__(512, DENSE_WAVES_PER_SIMD) void k_layer_dense(int n
 // buffered in LDS and the two halves run each step in OPPOSITE order -- dW waves: matrix product on tile t, then the
 // row pass of tile t+1; dHs waves: row pass of tile t+1, then the product on tile t -- so on every SIMD two waves
 // occupy the matrix pipe while the other two do the row math, and swap.  One barrier per tile.
-// D = 256: 8 waves, every wave owns 32 rows of dW (128 accumulator registers) and 32 columns of dHs, whose W^T
-// operand is read from L2 in the loop; single-buffered, row pass and products in turn.
+// D = 256: 8 waves, every wave owns 32 rows of dW (128 accumulator registers: no room for W^T fragments), single-buffered,
+// row pass and dW product in turn; the rows of diag(row_scale) dU go to memory and k_dh_dense turns them into dHs.
 // ------------------------------------------------------------------------------------------
 // LDS row stride of the tiles = D + RL_LD_PAD floats.  Ht / Ut are read column-wise (dW = Ht^T Ut: lanes (q, r)
 // read row 4kk+q, column c0+r: conflict-free in a half-wave when the stride is 16 mod 32) and Ut also row-wise with
 // ds_read_b128 (dHs = Ut W^T); measured: 4 / 12 / 16 / 20 make no difference to the step.
 #ifndef RL_LD_PAD
 #define RL_LD_PAD 16
-#endif
-#ifndef RL_T_UNROLL256
-#define RL_T_UNROLL256 2
-#endif
-#ifndef RL_MBG256
-#define RL_MBG256 0
 #endif
 #ifndef RL_ANTIPHASE
 #define RL_ANTIPHASE 1
@@ -823,7 +865,7 @@ __global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, i
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, q = lane >> 4;
   const bool dw_wave = !SPLIT || wave < 8;
-  const bool dh_wave = dHs && (!SPLIT || wave >= 8);
+  const bool dh_wave = dHs && SPLIT && wave >= 8;   // d = 256: no registers left for W^T fragments -> k_dh_dense afterwards
   const int own = SPLIT ? (wave & 7) : wave;  // first 16-row block of dW / 16-column block of dHs of this wave: own * IBW
 
   float wgl[EPL], db_acc[EPL], dwg_acc[EPL];
@@ -923,7 +965,14 @@ __global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, i
           dwg_acc[e] += gamma * z[t][e];
         }
         dcg_acc += gamma;
-        if (lane == 0) Sc[buf][trow] = rs ? rs[m >= n ? m - n : m] : 1.f;
+        const float sc = rs ? rs[m >= n ? m - n : m] : 1.f;
+        if (lane == 0) Sc[buf][trow] = sc;
+        if (!SPLIT && dHs) {   // diag(row_scale) dU; k_dh_dense multiplies it by W^T in place
+          float dus[EPL];
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) dus[e] = du[e] * sc;
+          st_row<EPL>(&dHs[off], dus);
+        }
       } else {
 #pragma unroll
         for (int e = 0; e < EPL; ++e) du[e] = 0.f;
@@ -958,48 +1007,35 @@ __global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, i
     }
 #endif
   };
-  // dHs = diag(row_scale) Ut W^T: this wave's 16*IBW output columns, straight from the accumulators
-  // (64-byte row segments; the other column blocks of the same rows are written by the neighbouring waves)
+  // dHs = diag(row_scale) Ut W^T (d = 128 only): this wave's 16 output columns, all row blocks of the tile at once
+  // (independent accumulation chains), straight from the accumulators (64-byte row segments; the other column blocks
+  // of the same rows are written by the neighbouring waves)
   auto mma_dh = [&](int tile, int buf) {
 #ifndef RL_SKIP_MFMA
     const float* __restrict__ Ub = Ut[buf];
-    constexpr int MBG = (SPLIT || RL_MBG256) ? MB : 1;   // row blocks in flight (independent accumulation chains; one read of W^T serves them all)
-#pragma unroll 1
-    for (int mb0 = 0; mb0 < MB; mb0 += MBG) {
-      f32x4 hacc[MBG][IBW];
+    f32x4 hacc[MB];
 #pragma unroll
-      for (int mb = 0; mb < MBG; ++mb)
+    for (int mb = 0; mb < MB; ++mb) hacc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ib = 0; ib < IBW; ++ib) hacc[mb][ib] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll(SPLIT ? JB : RL_T_UNROLL256)
-      for (int t = 0; t < JB; ++t) {
-        f32x4 a[MBG], b[IBW];
+    for (int t = 0; t < JB; ++t) {
+      f32x4 a[MB];
 #pragma unroll
-        for (int mb = 0; mb < MBG; ++mb) a[mb] = *(const f32x4*)&Ub[((mb0 + mb) * 16 + r) * LD + 16 * t + 4 * q];
+      for (int mb = 0; mb < MB; ++mb) a[mb] = *(const f32x4*)&Ub[(mb * 16 + r) * LD + 16 * t + 4 * q];
+      const f32x4 b = R[0][t];
 #pragma unroll
-        for (int ib = 0; ib < IBW; ++ib)
-          b[ib] = SPLIT ? R[0][t] : *(const f32x4*)&W[(size_t)((IBW * own + ib) * 16 + r) * D + 16 * t + 4 * q];
+      for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int mb = 0; mb < MBG; ++mb)
-#pragma unroll
-            for (int ib = 0; ib < IBW; ++ib)
-              hacc[mb][ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb][u], b[ib][u], hacc[mb][ib], 0, 0, 0);
-      }
-#pragma unroll
-      for (int mb = 0; mb < MBG; ++mb)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int trow = (mb0 + mb) * 16 + q * 4 + e;
-          const int m = tile * TR + trow;
-          const float sc = Sc[buf][trow];
-          if (m < M) {
-#pragma unroll
-            for (int ib = 0; ib < IBW; ++ib) dHs[(size_t)m * D + (IBW * own + ib) * 16 + r] = hacc[mb][ib][e] * sc;
-          }
-        }
+        for (int mb = 0; mb < MB; ++mb) hacc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb][u], b[u], hacc[mb], 0, 0, 0);
     }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int trow = mb * 16 + q * 4 + e;
+        const int m = tile * TR + trow;
+        const float sc = Sc[buf][trow];
+        if (m < M) dHs[(size_t)m * D + own * 16 + r] = hacc[mb][e] * sc;
+      }
 #endif
   };
 
@@ -1715,6 +1751,11 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   else
     hipLaunchKernelGGL((k_bwd_rowlocal<256, 32>), dim3(P + head_slabs), dim3(512), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, P, head_slabs, W);
   if ((rc = launch_status())) return rc;
+  if (d == 256 && dHs && M > 0) {   // dHs = (diag(row_scale) dU) W^T: d = 128 did it inside the row-local kernel
+    const int dh_tiles = (M + 31) / 32;
+    hipLaunchKernelGGL((k_dh_dense<256>), dim3(dh_tiles < 256 ? dh_tiles : 256), dim3(512), 0, st, M, dHs, W);
+    if ((rc = launch_status())) return rc;
+  }
   // The reduction of the per-tile partials and the gather kernel are independent: with an auxiliary stream
   // they run side by side (fork after k_bwd_rowlocal, join before returning; both edges are events, so the
   // fork/join is captured as graph dependencies under HIP-graph capture).
