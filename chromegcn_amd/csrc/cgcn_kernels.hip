@@ -755,13 +755,16 @@ __global__ __launch_bounds__(512, DENSE_WAVES_PER_SIMD) void k_layer_dense(int n
 // ------------------------------------------------------------------------------------------
 // k_dh_dense: B <- B W^T in place, B = diag(row_scale) dU [M, D]: the dHs product for d = 256, where k_bwd_rowlocal's
 // 128 accumulator registers leave no room for the W^T fragments (d = 128 does this product inside the row-local
-// kernel).  Persistent, one 8-wave workgroup per CU, W^T fragments resident in registers (128 at D = 256), 32-row
+// kernel).  Persistent, one 8-wave workgroup per CU, W^T fragments resident in registers (128 at D = 256), 16-row
 // tiles: rows -> LDS -> MFMA -> back to the same rows straight from the accumulators (a tile is read completely
 // before any of it is written; tiles are disjoint across workgroups).
 // ------------------------------------------------------------------------------------------
+#ifndef DH_MB
+#define DH_MB 1
+#endif
 template <int D>
 __global__ __launch_bounds__(512) void k_dh_dense(int M, float* __restrict__ B, const float* __restrict__ W) {
-  constexpr int MB = 2, ROWS = 16 * MB, CBW = D / 128, NW = 8, LD = D + 4, EPL = D / 64, RPW = ROWS / NW;
+  constexpr int MB = DH_MB, ROWS = 16 * MB, CBW = D / 128, NW = 8, LD = D + 4, EPL = D / 64, RPW = ROWS / NW;
   __shared__ __attribute__((aligned(16))) float T[ROWS * LD];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1752,7 +1755,7 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
     hipLaunchKernelGGL((k_bwd_rowlocal<256, 32>), dim3(P + head_slabs), dim3(512), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, P, head_slabs, W);
   if ((rc = launch_status())) return rc;
   if (d == 256 && dHs && M > 0) {   // dHs = (diag(row_scale) dU) W^T: d = 128 did it inside the row-local kernel
-    const int dh_tiles = (M + 31) / 32;
+    const int dh_tiles = (M + 16 * DH_MB - 1) / (16 * DH_MB);
     hipLaunchKernelGGL((k_dh_dense<256>), dim3(dh_tiles < 256 ? dh_tiles : 256), dim3(512), 0, st, M, dHs, W);
     if ((rc = launch_status())) return rc;
   }
