@@ -45,6 +45,17 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Chan's exact merge of two (count, mean, sum of squared deviations) summaries: A <- A u B
+__device__ __forceinline__ void chan_combine(float& nA, float& meanA, float& m2A, float nB, float meanB, float m2B) {
+  const float nAB = nA + nB;
+  if (nAB > 0.f) {
+    const float delta = meanB - meanA;
+    meanA += delta * (nB / nAB);
+    m2A += m2B + delta * delta * (nA * nB / nAB);
+    nA = nAB;
+  }
+}
+
 
 // Counter-based dropout RNG: a mask bit is a pure function of (seed, step counter, stream id, element
 // index), so the backward regenerates the forward's mask instead of storing it.  rng_state lives in

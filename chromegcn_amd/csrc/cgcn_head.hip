@@ -37,15 +37,7 @@
 // ------------------------------------------------------------------------------------------
 // BatchNorm statistics
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void chan_combine(float& nA, float& meanA, float& m2A, float nB, float meanB, float m2B) {
-  const float nAB = nA + nB;
-  if (nAB > 0.f) {
-    const float delta = meanB - meanA;
-    meanA += delta * (nB / nAB);
-    m2A += m2B + delta * delta * (nA * nB / nAB);
-    nA = nAB;
-  }
-}
+// (chan_combine: cgcn_common.hpp)
 
 // Per-block (mean, M2) of relu(X) per column and strand over a contiguous chunk of nodes.  Sums are taken
 // relative to a pivot (the chunk's first row), so there is no division in the loop and no catastrophic

@@ -613,7 +613,7 @@ __global__ __launch_bounds__(512, DENSE_WAVES_PER_SIMD) void k_layer_dense(int n
                                                     float* __restrict__ Zout, float* __restrict__ gate,
                                                     float keep_scale, uint32_t thresh,
                                                     const unsigned long long* __restrict__ rng_state,
-                                                    uint32_t stream_id, float* __restrict__ colstats) {
+                                                    uint32_t stream_id, float* __restrict__ colstats, int stat_chunk) {
   constexpr int ROWS = 16 * MB;      // MFMA rows in the tile
   constexpr int R = ROWS / S;        // nodes in the tile
   constexpr int CBW = (D == 128) ? 1 : 2;  // 16-wide output column blocks per wave
@@ -650,15 +650,20 @@ __global__ __launch_bounds__(512, DENSE_WAVES_PER_SIMD) void k_layer_dense(int n
       else zero_row<EPL>(dst[t]);
     }
   };
-  if ((int)blockIdx.x < ntiles) {
-    load_rows(hrow, Hin, blockIdx.x);
-    load_rows(xnext, X, blockIdx.x);
+  // Tile walk.  Without column statistics: tiles b, b + G, b + 2G, ... (G = grid).  With them: the CONTIGUOUS tiles
+  // [b * stat_chunk, (b + 1) * stat_chunk), whose statistics are merged on chip (Chan) into ONE record per workgroup --
+  // a record then covers stat_chunk * R consecutive nodes, which is all the head's finalize kernel needs to know
+  // (cgcn_layer_fwd_colstats_tiles), and there are <= 512 of them instead of one per 16 / S nodes.
+  const int tfirst = colstats ? (int)blockIdx.x * stat_chunk : (int)blockIdx.x;
+  const int tstep = colstats ? 1 : (int)gridDim.x;
+  const int tend = colstats ? min(ntiles, tfirst + stat_chunk) : ntiles;
+  float st_cnt = 0.f, st_mean = 0.f, st_m2 = 0.f;   // running statistics of this thread's (strand, column)
+  if (tfirst < tend) {
+    load_rows(hrow, Hin, tfirst);
+    load_rows(xnext, X, tfirst);
   }
-#ifdef DENSE_STAGGER
-  if (blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_sleep(DENSE_STAGGER);
-#endif
   KT_STAMP(9);
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int tile = tfirst; tile < tend; tile += tstep) {
     const int node0 = tile * R;
     KT_STAMP(10);
 #pragma unroll
@@ -667,9 +672,9 @@ __global__ __launch_bounds__(512, DENSE_WAVES_PER_SIMD) void k_layer_dense(int n
 #pragma unroll
       for (int e = 0; e < EPL; ++e) xres[t][e] = xnext[t][e];
     }
-    if (tile + (int)gridDim.x < ntiles) {
-      load_rows(hrow, Hin, tile + gridDim.x);
-      load_rows(xnext, X, tile + gridDim.x);
+    if (tile + tstep < tend) {
+      load_rows(hrow, Hin, tile + tstep);
+      load_rows(xnext, X, tile + tstep);
     }
     __syncthreads();
     KT_STAMP(11);
@@ -723,32 +728,34 @@ __global__ __launch_bounds__(512, DENSE_WAVES_PER_SIMD) void k_layer_dense(int n
     KT_STAMP(14);
     // ---- optional: first stage of the classifier head's BatchNorm statistics while the tile is on chip: per
     // (strand, column) the exact two-pass (mean, M2) of relu(Xn) over this tile's nodes
-    if (colstats) {   // statistic tiles are 16 / S nodes (cgcn_layer_fwd_colstats_tiles), MB of them per tile here
+    if (colstats) {
       __syncthreads();
-      constexpr int CR = 16 / S;
-      for (int idx = threadIdx.x; idx < MB * S * D; idx += blockDim.x) {
-        const int sub = idx / (S * D), sc = idx % (S * D);
-        const int s = sc / D, c = sc % D;
-        const int cnt = min(CR, n - (node0 + sub * CR));
-        if (cnt <= 0) continue;
+      static_assert(MB * S * D <= 512, "one (strand, column) per thread");
+      const int idx = threadIdx.x;
+      if (idx < S * D) {
+        const int s = idx / D, c = idx % D;
+        const int cnt = min(R, n - node0);
         const float inv = 1.f / (float)cnt;
-        float v[CR];
+        float v[R];
         float sum = 0.f;
 #pragma unroll
-        for (int rr = 0; rr < CR; ++rr) {
-          v[rr] = T[(s * R + sub * CR + rr) * LD + c];
+        for (int rr = 0; rr < R; ++rr) {
+          v[rr] = T[(s * R + rr) * LD + c];
           sum += rr < cnt ? v[rr] : 0.f;
         }
         const float mean = sum * inv;
         float m2 = 0.f;
 #pragma unroll
-        for (int rr = 0; rr < CR; ++rr) m2 += rr < cnt ? (v[rr] - mean) * (v[rr] - mean) : 0.f;
-        float* out = colstats + ((size_t)(tile * MB + sub) * S * D + sc) * 2;
-        out[0] = mean;
-        out[1] = m2;
+        for (int rr = 0; rr < R; ++rr) m2 += rr < cnt ? (v[rr] - mean) * (v[rr] - mean) : 0.f;
+        chan_combine(st_cnt, st_mean, st_m2, (float)cnt, mean, m2);
       }
     }
     __syncthreads();  // T is rewritten by the next tile
+  }
+  if (colstats && threadIdx.x < S * D && tfirst < tend) {
+    float* out = colstats + ((size_t)blockIdx.x * S * D + threadIdx.x) * 2;
+    out[0] = st_mean;
+    out[1] = st_m2;
   }
 }
 
@@ -1604,9 +1611,25 @@ int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d, const 
   return launch_status();
 }
 
+// Nodes per column-statistics record of cgcn_layer_fwd(n, S, d).  The fused kernel emits one record per 16 / S-node
+// tile.  Tables that take the split route (and the same tables when an H_in is streamed) go through k_layer_dense,
+// which merges the tiles of one workgroup into one record: chunk tiles, so that at most DENSE_MAX_BLOCKS records exist.
+static bool fwd_split_shape(int n, int S, int d) {
+  const long long split_bytes = g_fwd_split_bytes.load();
+  // (payloads of 2 KiB per node -- d = 256, both strands -- keep the fused kernel at every size: measured 0.86 vs 0.92 ms
+  // per step at chr21 size, 1.26 vs 1.34 ms at chr1 size on a hic-like graph; the debug hook's 0 still forces the split)
+  return (double)n * S * d * 4.0 >= (double)split_bytes && (S * d <= 256 || split_bytes == 0);
+}
+static int dense_stat_chunk(int n, int S, int d) {
+  if (!fwd_split_shape(n, S, d)) return 1;
+  const int tn = 16 * DENSE_MB / S;
+  const int ntiles = (n + tn - 1) / tn;
+  return (ntiles + DENSE_MAX_BLOCKS - 1) / DENSE_MAX_BLOCKS;
+}
+
 int cgcn_layer_fwd_colstats_tiles(int n, int S, int d, int* rows_per_tile) {
   if (check_shape(n, S, d) != CGCN_OK || n == 0) return 0;
-  const int tn = 16 * pick_mb(n, S) / S;
+  const int tn = (16 * pick_mb(n, S) / S) * dense_stat_chunk(n, S, d);
   if (rows_per_tile) *rows_per_tile = tn;
   return (n + tn - 1) / tn;
 }
@@ -1628,10 +1651,7 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   hipStream_t st = (hipStream_t)stream;
   // Three routes.  H_in given: the row-local kernel alone.  Training (H is wanted anyway) on a table that does not
   // fit the L2s: feature-sliced aggregation into H, then the row-local kernel on it.  Otherwise the fused kernel.
-  // (payloads of 2 KiB per node -- d = 256, both strands -- keep the fused kernel at every size: measured 0.86 vs 0.92 ms
-  // per step at chr21 size, 1.26 vs 1.34 ms at chr1 size on a hic-like graph; the debug hook's 0 still forces the split)
-  const long long split_bytes = g_fwd_split_bytes.load();
-  const bool split = !H_in && H && (double)n * S * d * 4.0 >= (double)split_bytes && (S * d <= 256 || split_bytes == 0);
+  const bool split = !H_in && H && fwd_split_shape(n, S, d);
   if (split) {
     const int gblocks = (S * d / 32) * ((n + 63) / 64);
 #define CALL(S_, D_, V_) \
@@ -1645,10 +1665,11 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
     constexpr int MB = DENSE_MB;
     const int tn = 16 * MB / S;
     const int ntiles = (n + tn - 1) / tn;
-    const int grid = ntiles < DENSE_MAX_BLOCKS ? ntiles : DENSE_MAX_BLOCKS;
+    const int chunk = dense_stat_chunk(n, S, d);   // with column statistics: contiguous tiles per workgroup = per record
+    const int grid = colstats ? (ntiles + chunk - 1) / chunk : (ntiles < DENSE_MAX_BLOCKS ? ntiles : DENSE_MAX_BLOCKS);
 #define CALL(S_, D_, V_) \
     hipLaunchKernelGGL((k_layer_dense<S_, D_, MB>), dim3(grid), dim3(512), 0, st, n, ntiles, H_in, X, W, b, wg, cg, Xn, Z, gate, \
-                       ks, th, rng_state, stream_id, colstats)
+                       ks, th, rng_state, stream_id, colstats, chunk)
     DISPATCH_SDV(S, d, false, CALL);
 #undef CALL
     return launch_status();
