@@ -16,6 +16,7 @@
 // Reference semantics: models/SubLayers.py:42-52, models/ChromeModels.py:34-46 (forward);
 // SURVEY.md Appendix A (backward).
 #include <atomic>
+#include <cstdlib>
 
 #include "cgcn_common.hpp"
 
@@ -1570,8 +1571,12 @@ const char* cgcn_strerror(int code) {
 #ifndef DENSE_MB
 #define DENSE_MB 1
 #endif
-static std::atomic<long long> g_fwd_split_bytes{(long long)FWD_SPLIT_TABLE_BYTES};
-void cgcn_debug_set_fwd_split_bytes(long long bytes) { g_fwd_split_bytes.store(bytes < 0 ? (long long)FWD_SPLIT_TABLE_BYTES : bytes); }
+static long long fwd_split_default() {   // tuning: CGCN_FWD_SPLIT_BYTES in the environment overrides the built-in threshold
+  const char* e = getenv("CGCN_FWD_SPLIT_BYTES");
+  return (e && *e) ? atoll(e) : (long long)FWD_SPLIT_TABLE_BYTES;
+}
+static std::atomic<long long> g_fwd_split_bytes{fwd_split_default()};
+void cgcn_debug_set_fwd_split_bytes(long long bytes) { g_fwd_split_bytes.store(bytes < 0 ? fwd_split_default() : bytes); }
 
 int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d, const int32_t* rowptr, const int32_t* col,
               const float* val, const float* row_scale, const float* X, float* Y) {
