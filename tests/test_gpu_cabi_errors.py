@@ -58,12 +58,12 @@ def test_workspaces_are_checked(env):
     need = lib.cgcn_layer_bwd_workspace_bytes(n, S, d)
     assert need > 0 and lib.cgcn_layer_bwd_workspace_bytes(n, S, 100) == 0
     ws = torch.empty(need, dtype=torch.uint8, device=DEV)
-    dx, dus = torch.empty_like(env["x"]), torch.empty_like(env["x"])
+    dx, dhs = torch.empty_like(env["x"]), torch.empty_like(env["x"])
     dW, db, dwg, dcg = torch.empty(d, d, device=DEV), torch.empty(d, device=DEV), torch.empty(d, device=DEV), torch.empty(1, device=DEV)
 
     def bwd(ws_bytes, dxn=env["y"], wsp=P(ws)):
         return lib.cgcn_layer_bwd(_lib.stream_ptr(), n, S, d, P(g.rowptr_t), P(g.col_t), None, P(g.row_scale), P(env["x"]), P(env["z"]),
-                                  P(env["h"]), P(env["gate"]), P(env["W"]), P(env["wg"]), _lib.ptr(dxn), None, P(dx), P(dus), P(dW), P(db),
+                                  P(env["h"]), P(env["gate"]), P(env["W"]), P(env["wg"]), _lib.ptr(dxn), None, P(dx), P(dhs), P(dW), P(db),
                                   P(dwg), P(dcg), 0, 0.0, None, 0, None, wsp, ws_bytes, None, None)
     assert bwd(need) == OK
     assert bwd(need - 1) == WORKSPACE

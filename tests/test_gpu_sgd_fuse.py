@@ -38,13 +38,13 @@ def test_fused_step_equals_separate_step_bitwise(n, d, momentum, nesterov, want_
 
     def run(fused):
         param, grad, mom, rng = param0.clone(), grad0.clone(), mom0.clone(), rng0.clone()
-        dx, dus = torch.empty_like(x), torch.empty_like(x)
+        dx, dhs = torch.empty_like(x), torch.empty_like(x)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
         W, wg = param[off_W:off_W + d * d], param[off_wg:off_wg + d]
         sg = _lib.SgdFuse(param.data_ptr(), grad.data_ptr(), mom.data_ptr() if momentum else None, total, lr, momentum, wd, gs,
                           1 if nesterov else 0, rng.data_ptr())
         rc = lib.cgcn_layer_bwd(_lib.stream_ptr(), n, S, d, P(g.rowptr_t), P(g.col_t), None, P(g.row_scale), P(x), P(z), P(h),
-                                P(gate), W.data_ptr(), wg.data_ptr(), P(dxn), None, P(dx) if want_dx else None, P(dus),
+                                P(gate), W.data_ptr(), wg.data_ptr(), P(dxn), None, P(dx) if want_dx else None, P(dhs),
                                 grad[off_W:].data_ptr(), grad[off_b:].data_ptr(), grad[off_wg:].data_ptr(), grad[off_cg:].data_ptr(),
                                 0, 0.0, None, 0, None, P(ws), ws_bytes, None, ctypes.byref(sg) if fused else None)
         assert rc == 0
@@ -52,7 +52,7 @@ def test_fused_step_equals_separate_step_bitwise(n, d, momentum, nesterov, want_
             assert lib.cgcn_sgd_step(_lib.stream_ptr(), total, P(param), P(grad), P(mom) if momentum else None, lr, momentum, wd,
                                      1 if nesterov else 0, gs, P(rng)) == 0
         torch.cuda.synchronize()
-        return param, grad, mom, rng, (dx if want_dx else dus)
+        return param, grad, mom, rng, (dx if want_dx else dhs)
     a, b = run(True), run(False)
     for name, ta, tb in zip(("param", "grad", "momentum", "rng", "dX"), a, b):
         assert torch.equal(ta, tb), name
@@ -69,12 +69,12 @@ def test_fuse_request_is_validated():
     elsewhere = torch.zeros(d * d, device=DEV)
     ws_bytes = lib.cgcn_layer_bwd_workspace_bytes(n, S, d)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
-    dx, dus = torch.empty_like(x), torch.empty_like(x)
+    dx, dhs = torch.empty_like(x), torch.empty_like(x)
     sg = _lib.SgdFuse(arena_p.data_ptr(), arena_g.data_ptr(), None, 20000, 0.1, 0.0, 0.0, 1.0, 0, None)
 
     def call(dX, dW, accumulate=0, sgd=sg):
         return lib.cgcn_layer_bwd(_lib.stream_ptr(), n, S, d, P(g.rowptr_t), P(g.col_t), None, P(g.row_scale), P(x), P(x), P(x),
-                                  P(gate), arena_p[:d * d].data_ptr(), arena_p[17000:].data_ptr(), P(x), None, dX, P(dus), dW,
+                                  P(gate), arena_p[:d * d].data_ptr(), arena_p[17000:].data_ptr(), P(x), None, dX, P(dhs), dW,
                                   arena_g[16384:].data_ptr(), arena_g[16600:].data_ptr(), arena_g[16800:].data_ptr(), accumulate,
                                   0.0, None, 0, None, P(ws), ws_bytes, None, ctypes.byref(sgd) if sgd is not None else None)
     assert call(P(dx), arena_g.data_ptr()) == 0

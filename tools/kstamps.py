@@ -15,11 +15,11 @@ def main():
     h = G.normalize_graph("hic", synth.contact_graph(n, pairs, 7, False), n); g = G.upload(h, dev)
     W = torch.randn(d, d, device=dev) / d ** 0.5; wg = torch.randn(d, device=dev) / d ** 0.5
     x = torch.randn(S, n, d, device=dev); z = torch.tanh(torch.randn_like(x)); hh = torch.randn_like(x)
-    gate = torch.rand(S, n, device=dev); dxn = torch.randn_like(x); dx = torch.empty_like(x); dus = torch.empty_like(x)
+    gate = torch.rand(S, n, device=dev); dxn = torch.randn_like(x); dx = torch.empty_like(x); dhs = torch.empty_like(x)
     dW = torch.empty_like(W); db = torch.empty(d, device=dev); dwg = torch.empty(d, device=dev); dcg = torch.empty(1, device=dev)
     wsb = lib.cgcn_layer_bwd_workspace_bytes(n, S, d); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     st, P = _lib.stream_ptr, _lib.ptr
-    bwd = lambda: lib.cgcn_layer_bwd(st(), n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(z), P(hh), P(gate), P(W), P(wg), P(dxn), None, P(dx), P(dus), P(dW), P(db), P(dwg), P(dcg), 0, 0.0, None, 0, None, P(ws), wsb, None, None)
+    bwd = lambda: lib.cgcn_layer_bwd(st(), n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(z), P(hh), P(gate), P(W), P(wg), P(dxn), None, P(dx), P(dhs), P(dW), P(db), P(dwg), P(dcg), 0, 0.0, None, 0, None, P(ws), wsb, None, None)
     for _ in range(5): assert bwd() == 0
     torch.cuda.synchronize()
     buf = np.zeros(8 * 16, dtype=np.uint64)
