@@ -450,11 +450,17 @@ __device__ unsigned long long kt_stamps[8 * 16];
     __builtin_amdgcn_s_waitcnt(0);                                                       \
     if (threadIdx.x == 0 && (blockIdx.x % KT_STRIDE) == 0 && blockIdx.x < 8 * KT_STRIDE) kt_stamps[(blockIdx.x / KT_STRIDE) * 16 + (i)] = wall_clock64(); \
   } while (0)
+#define KT_STAMP_T(i, tid)                                                               \
+  do {                                                                                   \
+    __builtin_amdgcn_s_waitcnt(0);                                                       \
+    if (threadIdx.x == (tid) && (blockIdx.x % KT_STRIDE) == 0 && blockIdx.x < 8 * KT_STRIDE) kt_stamps[(blockIdx.x / KT_STRIDE) * 16 + (i)] = wall_clock64(); \
+  } while (0)
 extern "C" int cgcn_debug_kt_stamps(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(kt_stamps), sizeof(unsigned long long) * 8 * 16) == hipSuccess ? 0 : -1;
 }
 #else
 #define KT_STAMP(i)
+#define KT_STAMP_T(i, tid)
 #endif
 
 template <int S, int D, int MB, bool HAS_VAL, bool DEEP>
@@ -1063,11 +1069,14 @@ __global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, i
       const int next = tile + row_blocks;
       if (tile == tile0 + 3 * row_blocks) KT_STAMP(2);
       if (RL_ANTIPHASE && !dw_wave) {   // dHs waves: rows first, matrix pipe second
+        if (tile == tile0 + 3 * row_blocks) KT_STAMP_T(8, 512);
         if (next < ntiles) {
           row_pass(next, buf ^ 1);
           if (next + row_blocks < ntiles) load_tile(next + row_blocks);
         }
+        if (tile == tile0 + 3 * row_blocks) KT_STAMP_T(9, 512);
         if (dh_wave) mma_dh(tile, buf);
+        if (tile == tile0 + 3 * row_blocks) KT_STAMP_T(10, 512);
       } else {                          // dW waves: matrix pipe first, rows second
         if (dw_wave) mma_dw(buf);
         else if (dh_wave) mma_dh(tile, buf);

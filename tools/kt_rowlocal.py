@@ -40,6 +40,10 @@ def main():
               % (tuple((t[b, i + 1] - t[b, i]) / 100.0 for i in range(7)) + ((t[b, 7] - t[b, 0]) / 100.0,)))
 
 
+    print("wave 8 (a dHs wave), same tile: row pass of the next tile | dHs product (us)")
+    for b in range(8):
+        print("wg %3d  %.2f | %.2f" % (b * 32, (t[b, 9] - t[b, 8]) / 100.0, (t[b, 10] - t[b, 9]) / 100.0))
+    return
     print("k_layer_dense (last forward launch): setup | wait before last tile | lds+issue+barrier | mfma+barrier | tanh+barrier | epilogue | total to epilogue end")
     for b in range(8):
         print("wg %3d" % (b * 32), " ".join("%.2f" % ((t[b, i + 1] - t[b, i]) / 100.0) for i in range(8, 14)), " total %.2f" % ((t[b, 14] - t[b, 8]) / 100.0))
