@@ -37,6 +37,9 @@ CASES = [   # name, n, pairs, hic_like, adj_type, seed, d, layers
     ("chr1", synth.chrom_nodes("chr1"), 250000, True, "hic", 1, 128, 2),
     ("both13k", 13000, 60000, True, "both", 7, 128, 2),
     ("k562_d256_L4", synth.chrom_nodes("chr21"), 250000, False, "hic", 33, 256, 4),
+    # config 1 again with the forward's two-launch route forced (feature-sliced aggregation + row-local kernel, column
+    # statistics merged over 2 tiles per workgroup): the route chr1 / both13k take by size, at a table that fits the L2s
+    ("config1_forced_split", 5000, 125000, False, "hic", 0, 128, 2),
 ]
 
 
@@ -58,6 +61,15 @@ def _rel(a, b):
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_train_steps_match_oracle_at_full_size(case):
     name, n, pairs, hic_like, adj_type, seed, d, layers = case
+    from chromegcn_amd import _lib
+    _lib.load().cgcn_debug_set_fwd_split_bytes(0 if name.endswith("forced_split") else -1)
+    try:
+        _train_steps_case(name, n, pairs, hic_like, adj_type, seed, d, layers)
+    finally:
+        _lib.load().cgcn_debug_set_fwd_split_bytes(-1)
+
+
+def _train_steps_case(name, n, pairs, hic_like, adj_type, seed, d, layers):
     feats = synth.chrom_features(n, d, NC, 1000 + seed)
     hic = synth.contact_graph(n, pairs, seed, hic_like)
     orc = _scaled_oracle(seed, d, layers)
