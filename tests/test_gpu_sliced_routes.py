@@ -1,0 +1,65 @@
+"""The feature-sliced kernels against the whole-row kernels of the SAME library on seeded random graphs: shapes around
+the kernels' boundaries (n around multiples of 64, n < 8, rows around the 192-neighbour hub threshold of the sliced
+walk and the 512-neighbour one of the fused gather, empty-but-for-the-self-loop rows), both strand counts, both widths,
+binary and valued adjacency.  cgcn_spmm: the sliced route sums a row in list order like the whole-row kernel, so
+ordinary rows agree bitwise and hub rows to re-association; the gated layer (forward, every gradient): split route
+(k_aggregate_sliced + k_layer_dense, k_bwd_sliced) vs the fused forward, tolerance of fp32 re-association."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from chromegcn_amd import _lib
+from chromegcn_amd import graph as G
+from chromegcn_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def random_graph(rng, n, kind):
+    dens = rng.choice([0.002, 0.02, 0.2]) if n > 50 else 0.3
+    m = sp.random(n, n, dens, format="lil", random_state=rng.randint(1 << 30), dtype=np.float32)
+    m = ((m + m.T) > 0).astype(np.float32).tolil()
+    for deg in (191, 192, 193, 600):   # rows straddling the hub thresholds
+        if n > deg + 5 and rng.rand() < 0.6:
+            i = int(rng.randint(n))
+            sel = rng.choice(n, deg, replace=False)
+            m[i, sel] = 1
+            m[sel, i] = 1
+    m.setdiag(0)
+    return G.normalize_graph(kind, m.tocsr(), n)
+
+
+def run_layer(g, S, d, seed, split):
+    lib = _lib.load()
+    lib.cgcn_debug_set_fwd_split_bytes(0 if split else 1 << 40)
+    try:
+        rng = np.random.RandomState(seed)
+        t = {k: torch.from_numpy(v).to(DEV).requires_grad_(True) for k, v in dict(
+            x=rng.randn(S, g.n, d).astype(np.float32), W=(rng.randn(d, d) / np.sqrt(d)).astype(np.float32),
+            b=(rng.randn(d) * 0.2).astype(np.float32), wg=(rng.randn(1, d) / np.sqrt(d)).astype(np.float32),
+            cg=np.array([0.1], dtype=np.float32)).items()}
+        xn, gate = ops.gated_layer(t["x"], t["W"], t["b"], t["wg"], t["cg"], g)
+        gup = torch.from_numpy(rng.randn(S, g.n, d).astype(np.float32)).to(DEV)
+        (xn * gup).sum().add(gate.sum()).backward()
+        y = ops.spmm(t["x"].detach(), g)
+        return [xn.detach(), gate.detach(), y] + [t[k].grad for k in ("x", "W", "b", "wg", "cg")]
+    finally:
+        lib.cgcn_debug_set_fwd_split_bytes(-1)
+
+
+@pytest.mark.parametrize("S,d", [(2, 128), (1, 128), (2, 256), (1, 256)])
+def test_sliced_routes_agree_with_whole_row_routes(S, d):
+    rng = np.random.RandomState(100 * S + d)
+    sizes = [1, 2, 7, 8, 9, 63, 64, 65, 127, 128, 129, 200, 333, 640, 1000]
+    for n in sizes:
+        kind = ["hic", "both"][int(rng.randint(2))]
+        g = G.upload(random_graph(rng, n, kind), DEV)
+        a = run_layer(g, S, d, n, split=False)
+        b = run_layer(g, S, d, n, split=True)
+        names = ["Xn", "gate", "spmm", "dX", "dW", "db", "dwg", "dcg"]
+        for nm, u, v in zip(names, a, b):
+            scale = float(u.abs().max()) + 1e-30
+            err = float((u - v).abs().max()) / scale
+            assert err < 2e-5, "%s: n=%d %s S=%d d=%d: scale-relative difference %.2e" % (nm, n, kind, S, d, err)
