@@ -195,6 +195,43 @@ __global__ __launch_bounds__(512) void k_rows8_sorted(int n, int tiles, const in
   if (i < n) *(f32x4*)((char*)H + slice_off + (size_t)i * 512u) = acc * rs[i];
 }
 
+// RW rows per wave (8 / RW groups of 8 lanes share a row, 8 * 8 / RW neighbours per step, summed over the groups by a
+// butterfly at the end): fewer rows per wave = less time lost to the longest row of the wave, at a few shuffles per row
+template <int RW>
+__global__ __launch_bounds__(512) void k_rowsN(int n, int tiles, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                               const float* __restrict__ rs, const float* __restrict__ X,
+                                               float* __restrict__ H) {
+  constexpr int GPR = 8 / RW;          // groups per row
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int slice = blockIdx.x & 7;
+  const int tile = blockIdx.x >> 3;    // 8 * RW rows per workgroup
+  const int g = lane >> 3, j = lane & 7;
+  const int rw = g / GPR, gr = g % GPR;
+  const size_t slice_off = ((size_t)(slice >> 2) * (size_t)n * 128u + (slice & 3) * 32u + j * 4u) * 4u;
+  const char* Xb = (const char*)X + slice_off;
+  const int i = tile * (8 * RW) + wave * RW + rw;
+  int k0 = 0, k1 = 0;
+  if (i < n) { k0 = rowptr[i]; k1 = rowptr[i + 1]; }
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int k = k0 + gr * 8; k < k1; k += 8 * GPR) {
+    const int myc = col[min(k + j, k1 - 1)];
+    f32x4 t[8];
+    Unroll<8>::run([&](auto U) {
+      constexpr int u = decltype(U)::value;
+      t[u] = *(const f32x4*)(Xb + (size_t)(unsigned)group8_bcast<u>(myc) * 512u);
+    });
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (k + u < k1) acc += t[u];
+  }
+#pragma unroll
+  for (int o = 8; o < 8 * GPR; o <<= 1)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+  if (i < n && gr == 0) *(f32x4*)((char*)H + slice_off + (size_t)i * 512u) = acc * rs[i];
+}
+
 struct Graph {
   int n, nnz;
   std::vector<int> rowptr, col;
@@ -322,6 +359,19 @@ int main(int argc, char** argv) {
           CK(hipMemcpy(out.data(), d_H, X.size() * 4, hipMemcpyDeviceToHost));
           printf("  %-34s %6.1f us  (max |diff| vs base %.2e)\n", "rows8, rows degree-sorted in tile", ts, max_err(ref, out));
           CK(hipFree(d_perm));
+        }
+        {
+          auto rowsN = [&](auto RW, const char* label) {
+            constexpr int rw = decltype(RW)::value;
+            const int tl = (n + 8 * rw - 1) / (8 * rw);
+            CK(hipMemset(d_H, 0, X.size() * 4));
+            const float t = time_us([&] { hipLaunchKernelGGL((k_rowsN<rw>), dim3(8 * tl), dim3(512), 0, 0, n, tl, d_rowptr, d_col, d_rs, d_X, d_H); }, reps);
+            CK(hipMemcpy(out.data(), d_H, X.size() * 4, hipMemcpyDeviceToHost));
+            printf("  %-34s %6.1f us  (max |diff| vs base %.2e)\n", label, t, max_err(ref, out));
+          };
+          rowsN(std::integral_constant<int, 4>(), "4 rows per wave (2 groups per row)");
+          rowsN(std::integral_constant<int, 2>(), "2 rows per wave (4 groups per row)");
+          rowsN(std::integral_constant<int, 1>(), "1 row per wave (8 groups per row)");
         }
         CK(hipMemset(d_H, 0, X.size() * 4));
         const float t2 = time_us([&] { hipLaunchKernelGGL((k_rows8_pf<2>), dim3(8 * tiles), dim3(512), 0, 0, n, tiles, d_rowptr, d_col, d_rs, d_X, d_H); }, reps);
