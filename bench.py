@@ -61,7 +61,58 @@ def parse():
                     help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU functional tests)")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses cuda:0")
     ap.add_argument("--e2e-windows", type=int, default=4096, help="e2e: windows per chromosome pushed through the encoder")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous check only: every rank joins the process group, rank 0 prints one JSON line "
+                         "(n_gpus, ranks_seen_by_backend) and nothing touches a GPU")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment (README.md:34 runs the reference with ONE
+    command): start the N ranks ourselves -- `python -m torch.distributed.run`, one process per GPU, rendezvous on
+    127.0.0.1 -- BEFORE anything in this process touches the GPU (a process that has initialised HIP must neither fork
+    GPU work nor exec), relay rank 0's JSON line and the job's exit code.  Under a launcher (WORLD_SIZE set) this is a
+    no-op and the process is one rank."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return None
+    import socket
+    import subprocess
+    if not args.share_gpu and not args.dry_run:
+        have = torch.cuda.device_count()   # counts devices without initialising the runtime
+        if have < args.gpus:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (use --share-gpu --backend gloo for a "
+                             "single-GPU functional run)" % (args.gpus, have))
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:                 # rank 0's JSON line goes to our stdout; anything else to stderr
+        if ln.startswith("{"):
+            line = ln
+            sys.stdout.write(ln)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: the ranks exited 0 without printing a result line\n")
+        rc = 1
+    return rc
+
+
+def ranks_seen(world, dev):
+    """how many ranks the backend actually connected: an all-reduce of ones over the job's process group"""
+    if world <= 1:
+        return 1
+    t = torch.ones(1, device=dev, dtype=torch.float32)
+    dist.all_reduce(t)
+    return int(round(float(t.item())))
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -208,9 +259,28 @@ def cpu_baseline(args, chroms, budget_s):
 # ------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
+    rc = self_launch(args)
+    if rc is not None:
+        sys.exit(rc)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    if args.dry_run:
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        seen = ranks_seen(world, torch.device("cpu"))
+        out = {"dry_run": True, "n_gpus": world, "ranks_seen_by_backend": seen, "backend": "gloo",
+               "launcher": "self (torch.distributed.run child)" if os.environ.get("TORCHELASTIC_RUN_ID") else "none"}
+        if rank == 0:
+            print(json.dumps(out))
+            sys.stdout.flush()
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return out
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     if args.share_gpu:
@@ -223,7 +293,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
-    assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    seen = ranks_seen(world, dev)
     if args.workload == "e2e":
         from chromegcn_amd import e2e
         out = e2e.bench(args, dev, world, rank)
@@ -394,7 +464,8 @@ def main():
             "metric": "GCN windows/sec (2-layer, d_model=128) on GM12878 Hi-C graph" if genome else
                       "GCN windows/sec (2-layer, d_model=128) train step, one chromosome",
             "value": windows * steps / elapsed, "unit": "windows/s",
-            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+            "n_gpus": world, "ranks_seen_by_backend": seen, "backend": args.backend if world > 1 else None,
+            "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if genome else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": wl, "generator": "hic_like" if args.hic_like else "uniform",

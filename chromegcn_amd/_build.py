@@ -57,7 +57,13 @@ def is_stale() -> bool:
 
 def build_library(force=False, verbose=False, out=None):
     extra = _extra_flags()
-    if out is None and not force and not is_stale() and not extra:
+    if extra and out is None:
+        # a tuning build must never replace the product library (and be recorded as the canonical fresh build): a
+        # CGCN_EXTRA_FLAGS left over in the environment would otherwise silently swap kernels under every test
+        raise RuntimeError("chromegcn_amd: CGCN_EXTRA_FLAGS=%r is set; tuning builds need an explicit variant path "
+                           "(build_library(out='variants/libcgcn_<name>.so')), unset it to build the in-tree library"
+                           % " ".join(extra))
+    if out is None and not force and not is_stale():
         return LIB
     hipcc = hipcc_path()
     if hipcc is None:
@@ -75,7 +81,7 @@ def build_library(force=False, verbose=False, out=None):
             os.remove(tmp)
     if out is None:
         with open(HASH + ".tmp.%d" % os.getpid(), "w") as f:
-            f.write(source_hash([]) + "\n")  # extra (tuning) flags do not make the tree "stale"
+            f.write(source_hash([]) + "\n")
         os.replace(HASH + ".tmp.%d" % os.getpid(), HASH)
     return target
 

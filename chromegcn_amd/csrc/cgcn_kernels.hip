@@ -1666,6 +1666,10 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   // Three routes.  H_in given: the row-local kernel alone.  Training (H is wanted anyway) on a table that does not
   // fit the L2s: feature-sliced aggregation into H, then the row-local kernel on it.  Otherwise the fused kernel.
   const bool split = !H_in && H && fwd_split_shape(n, S, d);
+  // cgcn_layer_fwd_colstats_tiles() reports MERGED records on split-size tables (k_layer_dense's contiguous tile
+  // chunks); the fused kernel would write one record per 16 / S-node tile -- more than the caller allocated.  On such
+  // tables the column statistics therefore need the two-launch route, i.e. an H (or H_in) buffer.
+  if (colstats && !split && !H_in && dense_stat_chunk(n, S, d) != 1) return CGCN_ERR_BAD_ARG;
   if (split) {
     const int gblocks = (S * d / 32) * ((n + 63) / 64);
 #define CALL(S_, D_, V_) \
@@ -1755,6 +1759,9 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
                  sgd->grad_scale, sgd->nesterov, sgd->rng_state};
   }
   if ((dXn == nullptr) == (head == nullptr)) return CGCN_ERR_BAD_ARG;  // exactly one source of dL/dXn
+  // the launch that carries the optimizer step also advances the dropout step counter (rng_state[1]) in a trailing
+  // workgroup, unordered against the gather workgroups of the same launch that would read it for the input-dropout mask
+  if (sgd && dX && in_dropout_p > 0.f) return CGCN_ERR_BAD_ARG;
   if ((dX && dX == dXn) || (dHs && (misaligned16(dHs) || dHs == dX)) || (dX && misaligned16(dX)) || misaligned16(W)) return CGCN_ERR_BAD_ARG;
   if (misaligned16(X) || misaligned16(Z) || misaligned16(H) || (dXn && misaligned16(dXn))) return CGCN_ERR_BAD_ARG;  // vector row accesses
   HeadApply hp = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1.f, 0u, S, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr, nullptr, nullptr};

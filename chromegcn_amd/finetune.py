@@ -21,10 +21,10 @@ Semantics at world_size 1 are exactly the reference's: one SGD step per chromoso
 from __future__ import annotations
 
 import gc
-
 import os
 import pickle
 import time
+import weakref
 from typing import Dict, Iterable, List, Optional, Sequence
 
 import torch
@@ -43,21 +43,41 @@ class _Chrom:
         self.src_key = src_key  # identity + version of the caller's tensors / graph object this was built from
 
 
-def _source_key(feats, hic):
-    """What a cached chromosome was built from: storage address and in-place version of the three feature tensors
-    and the identity (+ nnz) of the Hi-C matrix.  A caller that hands in regenerated features, new targets or
-    another graph under the same chromosome name gets a rebuild instead of stale device copies."""
-    parts = []
-    for k in ("forward", "backward", "target"):
-        t = feats[k]
-        parts.append((t.data_ptr(), t._version, tuple(t.shape)) if torch.is_tensor(t) else id(t))
-    if hic is None:
-        parts.append(None)
-    else:   # identity alone can be recycled after garbage collection: add the size and the index buffers' addresses
-        ptrs = tuple(getattr(hic, a).__array_interface__["data"][0] for a in ("indptr", "indices")
-                     if hasattr(getattr(hic, a, None), "__array_interface__"))
-        parts.append((id(hic), getattr(hic, "nnz", None), getattr(hic, "shape", None), ptrs))
-    return tuple(parts)
+class _SourceKey:
+    """What a cached chromosome was built from: the caller's three feature tensors and Hi-C matrix THEMSELVES (weak
+    references) plus the tensors' in-place versions.  An address alone is not an identity: a caller that frees its
+    feature dict and regenerates it (handoff.FeatureCollector.finish() every epoch, `del feats; feats = ...`) routinely
+    gets the same storage address, version 0 and the same shape back from the caching allocator.  A hit needs the very
+    same live objects at the version they were uploaded at; anything else rebuilds (as graph_from_torch_sparse does)."""
+    __slots__ = ("refs", "versions", "hic_ref", "hic_sig")
+
+    def __init__(self, feats, hic):
+        self.refs, self.versions = [], []
+        for k in ("forward", "backward", "target"):
+            t = feats[k]
+            try:
+                self.refs.append(weakref.ref(t))
+            except TypeError:          # not weak-referenceable (a list, a numpy scalar ...): never a hit
+                self.refs.append(None)
+            self.versions.append(t._version if torch.is_tensor(t) else None)
+        self.hic_ref = None
+        if hic is not None:
+            try:
+                self.hic_ref = weakref.ref(hic)
+            except TypeError:
+                self.hic_ref = lambda: None
+        self.hic_sig = None if hic is None else (getattr(hic, "nnz", None), getattr(hic, "shape", None))
+
+    def matches(self, feats, hic) -> bool:
+        for r, v, k in zip(self.refs, self.versions, ("forward", "backward", "target")):
+            t = feats[k]
+            if r is None or r() is not t or (torch.is_tensor(t) and t._version != v):
+                return False
+        if hic is None:
+            return self.hic_ref is None
+        if self.hic_ref is None or self.hic_ref() is not hic:
+            return False
+        return self.hic_sig == (getattr(hic, "nnz", None), getattr(hic, "shape", None))
 
 
 class GCNStage:
@@ -126,7 +146,7 @@ class GCNStage:
         t = feats["target"].to(self.device, torch.float32).contiguous()
         d = x.shape[2]
         cost = float(h.nnz) * d + 3.0 * n * d * d / 16.0
-        self.chroms[name] = _Chrom(name, n, g, x, t, cost, _source_key(feats, hic))
+        self.chroms[name] = _Chrom(name, n, g, x, t, cost, _SourceKey(feats, hic))
         self._targets_cpu.clear()
         self._targets_dev.clear()
         self._gather_plans.clear()
@@ -137,15 +157,15 @@ class GCNStage:
 
     def load(self, chrom_feature_dict, split_adj_dict=None, only: Optional[Iterable[str]] = None):
         """Upload the chromosomes that are not cached yet.  The reference re-reads everything on every call
-        (finetune.py:20-36); here a chromosome is reused only while the caller's feature tensors (address, in-place
-        version) and graph object are the ones it was built from -- anything else rebuilds it, dropping its cached
+        (finetune.py:20-36); here a chromosome is reused only while the caller's feature tensors (the same live objects,
+        at the same in-place version) and graph object are the ones it was built from -- anything else rebuilds it, dropping its cached
         first-layer aggregation and captured HIP graphs (add_chromosome).  `invalidate()` forces a rebuild."""
         for name in chrom_feature_dict:
             if only is not None and name not in only:
                 continue
             hic = None if split_adj_dict is None else split_adj_dict.get(name)
             cur = self.chroms.get(name)
-            if cur is not None and cur.src_key == _source_key(chrom_feature_dict[name], hic):
+            if cur is not None and cur.src_key is not None and cur.src_key.matches(chrom_feature_dict[name], hic):
                 continue
             self.add_chromosome(name, chrom_feature_dict[name], hic)
 

@@ -55,7 +55,12 @@ class GraphConvolution(nn.Module):
         support = torch.mm(input, self.weight)                              # SubLayers.py:43
         if adj is not None:
             g = as_graph(adj, input.device)
-            output = ops.spmm(support.unsqueeze(0), g).squeeze(0)           # SubLayers.py:46 (any width % 4 == 0)
+            w = support.shape[1]
+            if w % 4:   # the kernels move 16-byte column groups: pad to the next multiple of 4 (e.g. out_features = C
+                support = F.pad(support, (0, 4 - w % 4))                    # = 103 labels), aggregate, cut back
+            output = ops.spmm(support.unsqueeze(0), g).squeeze(0)           # SubLayers.py:46
+            if w % 4:
+                output = output[:, :w]
         else:
             output = support                                                # SubLayers.py:48
         return output + self.bias if self.bias is not None else output

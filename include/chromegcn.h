@@ -91,6 +91,9 @@ int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d,
  * Per node tile and (strand, column): mean and sum of squared deviations of relu(Xn) -- the first stage of
  * the classifier head's BatchNorm batch statistics (models/ChromeModels.py:58-59, nn.BatchNorm1d in training
  * mode), taken while the tile is on chip; hand it to cgcn_head_train as col_stats.
+ * On tables for which cgcn_layer_fwd_colstats_tiles reports merged records (rows_per_tile > 16 / S: the feature table
+ * is too large for the L2s) colstats needs H or H_in as well -- the merged records are produced by the two-launch
+ * route only; colstats with H == NULL and H_in == NULL is CGCN_ERR_BAD_ARG there.
  */
 int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d,
                    const int32_t *rowptr, const int32_t *col, const float *val, const float *row_scale,
@@ -143,7 +146,9 @@ typedef struct cgcn_head_grad {
  * the flat arenas (their gradients were finished by earlier launches of the step): no cgcn_sgd_step launch.
  * param / grad / momentum_buf: flat fp32 arenas of `count` elements in which every parameter, its gradient and its
  * momentum buffer sit at the SAME offset; dW, db, dwg, dcg of this call must point into `grad`.  Semantics and the
- * rng_state counter advance are those of cgcn_sgd_step.  Needs n > 0, accumulate == 0, aux_stream == NULL.
+ * rng_state counter advance are those of cgcn_sgd_step.  Needs n > 0, accumulate == 0, aux_stream == NULL, and -- when
+ * dX is produced -- in_dropout_p == 0: the step advances the dropout counter inside the same launch that would read
+ * it for the input-dropout mask (the first layer's input is never a dropped tensor: models/ChromeModels.py:37-42).
  */
 typedef struct cgcn_sgd_fuse {
   float *param;

@@ -1,0 +1,58 @@
+"""bench.py starts its own ranks: `python bench.py --gpus N` with no launcher environment spawns N processes through
+torch.distributed.run (before anything touches a GPU), relays rank 0's JSON line and the job's exit code
+(the reference's multi-GPU run is one command too, README.md:34)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra=None, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return p.returncode, lines, p.stderr
+
+
+def test_self_launch_two_ranks_dry_run_prints_one_line():
+    rc, lines, err = _run(["--gpus", "2", "--dry-run"])
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen_by_backend"] == 2 and d["dry_run"] is True
+
+
+def test_single_rank_dry_run_needs_no_launcher():
+    rc, lines, err = _run(["--dry-run"])
+    assert rc == 0, err[-2000:]
+    assert json.loads(lines[0])["n_gpus"] == 1
+
+
+def test_launcher_mismatch_is_an_error_not_an_assert():
+    # under a launcher environment that disagrees with --gpus: refused with a message and a non-zero exit code
+    rc, lines, err = _run(["--gpus", "4", "--dry-run"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc != 0 and not lines and "WORLD_SIZE=1" in err
+
+
+def test_child_failure_is_relayed():
+    # two ranks that cannot find a GPU (this test runs on the CPU tier) or, on a GPU box, are told to use more devices
+    # than exist without --share-gpu: either way no JSON line and a non-zero exit code come back through the launcher
+    rc, lines, err = _run(["--gpus", "64", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras"])
+    assert rc != 0 and not lines
+
+
+@pytest.mark.gpu
+def test_self_launch_two_ranks_share_one_gpu_real_step():
+    """the real engine behind the launcher: 2 ranks on one device (gloo: RCCL refuses two ranks per GPU), one
+    chromosome per rank, gradient all-reduce + step"""
+    rc, lines, err = _run(["--gpus", "2", "--backend", "gloo", "--share-gpu", "--workload", "chr21", "--steps", "3", "--warmup", "1",
+                           "--no-cpu-baseline", "--no-extras", "--no-roofline"], timeout=900)
+    assert rc == 0, err[-3000:]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen_by_backend"] == 2 and d["value"] > 0 and d["scaling"] == "weak"

@@ -94,3 +94,50 @@ def test_sgd_and_spmm_argument_checks(env):
     assert lib.cgcn_spmm(_lib.stream_ptr(), env["n"], env["n"], env["S"], env["d"], P(g.rowptr), P(g.col), None, P(g.row_scale), P(env["x"]), P(y)) == OK
     assert lib.cgcn_spmm(_lib.stream_ptr(), env["n"], env["n"], env["S"], env["d"], None, P(g.col), None, P(g.row_scale), P(env["x"]), P(y)) == BAD_ARG
     assert lib.cgcn_spmm(_lib.stream_ptr(), env["n"], env["n"], env["S"], 98, P(g.rowptr), P(g.col), None, P(g.row_scale), P(env["x"]), P(y)) == UNSUPPORTED
+
+
+def test_colstats_on_a_split_size_table_needs_an_aggregation_buffer(env):
+    """cgcn_layer_fwd_colstats_tiles reports merged records on tables that take the two-launch route; the
+    fused kernel (no H, no H_in) would write one record per 16/S-node tile -- past the caller's buffer.  Rejected."""
+    lib = env["lib"]
+    P = _lib.ptr
+    n, S, d = 8192, 2, 128                      # 8 MiB table: split-size
+    rows = ctypes.c_int(0)
+    tiles = lib.cgcn_layer_fwd_colstats_tiles(n, S, d, ctypes.byref(rows))
+    assert rows.value > 16 // S and tiles == (n + rows.value - 1) // rows.value
+    g = G.upload(G.normalize_graph("hic", synth.contact_graph(n, 20000, 5), n), DEV)
+    x, y, z, h = (torch.randn(S, n, d, device=DEV) for _ in range(4))
+    gate = torch.empty(S, n, device=DEV)
+    cs = torch.full((tiles * S * d * 2 + 4096,), 7.0, device=DEV)   # guard zone behind the records
+    def call(hptr):
+        return lib.cgcn_layer_fwd(_lib.stream_ptr(), n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(env["W"]),
+                                  P(env["b"]), P(env["wg"]), P(env["cg"]), P(y), P(z), hptr, P(gate), 0.0, None, 0, None, P(cs))
+    assert call(None) == BAD_ARG
+    assert call(P(h)) == OK
+    torch.cuda.synchronize()
+    assert bool((cs[tiles * S * d * 2:] == 7.0).all())             # nothing written past the reported records
+
+
+def test_fused_sgd_rejects_input_dropout_with_an_input_gradient(env):
+    """the launch carrying cgcn_sgd_fuse advances rng_state[1] while its gather workgroups would read it."""
+    lib, n, S, d, g = env["lib"], env["n"], env["S"], env["d"], env["g"]
+    P = _lib.ptr
+    need = lib.cgcn_layer_bwd_workspace_bytes(n, S, d)
+    ws = torch.empty(need, dtype=torch.uint8, device=DEV)
+    dx, dhs = torch.empty_like(env["x"]), torch.empty_like(env["x"])
+    cnt = d * d + 2 * d + 4
+    param, grad, mom = torch.zeros(cnt, device=DEV), torch.zeros(cnt, device=DEV), torch.zeros(cnt, device=DEV)
+    rng = torch.tensor([5, 0], dtype=torch.int64, device=DEV)
+    sg = _lib.SgdFuse(param.data_ptr(), grad.data_ptr(), mom.data_ptr(), cnt, 0.1, 0.9, 0.0, 1.0, 0, rng.data_ptr())
+    dW, db, dwg, dcg = grad[:d * d], grad[d * d:d * d + d], grad[d * d + d:d * d + 2 * d], grad[d * d + 2 * d:d * d + 2 * d + 1]
+
+    def bwd(p_in, dxp):
+        return lib.cgcn_layer_bwd(_lib.stream_ptr(), n, S, d, P(g.rowptr_t), P(g.col_t), None, P(g.row_scale), P(env["x"]), P(env["z"]),
+                                  P(env["h"]), P(env["gate"]), P(env["W"]), P(env["wg"]), P(env["y"]), None, dxp, P(dhs), P(dW), P(db),
+                                  P(dwg), P(dcg), 0, p_in, P(rng), 1, None, P(ws), need, None, ctypes.byref(sg))
+    assert bwd(0.25, P(dx)) == BAD_ARG
+    torch.cuda.synchronize()
+    assert int(rng[1].item()) == 0
+    assert bwd(0.0, P(dx)) == OK
+    torch.cuda.synchronize()
+    assert int(rng[1].item()) == 1

@@ -20,7 +20,7 @@ def _dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
 
 
-@pytest.mark.parametrize("d_in,d_out", [(128, 128), (128, 256), (64, 192), (100, 36), (256, 128), (128, 4)])
+@pytest.mark.parametrize("d_in,d_out", [(128, 128), (128, 256), (64, 192), (100, 36), (256, 128), (128, 4), (128, 103), (77, 1), (128, 130)])
 @pytest.mark.parametrize("adj_kind", ["hic", "both", "coo", "none"])
 def test_graph_convolution_module_matches_oracle(d_in, d_out, adj_kind):
     """layers.GraphConvolution.forward(input, adj, deg) = adj @ (input @ W) + b  (models/SubLayers.py:42-52), forward and
@@ -57,10 +57,15 @@ def test_graph_convolution_module_matches_oracle(d_in, d_out, adj_kind):
 
 
 def test_graph_convolution_rejects_widths_the_kernels_cannot_serve_loudly():
-    gc = C.GraphConvolution(128, 130).to(DEV)
+    """any out_features works through the module (padded to the next multiple of 4, models/SubLayers.py:8-12 takes any);
+    the raw aggregation operator still says what it needs, and widths beyond 4096 columns are refused"""
     g = G.upload(G.normalize_graph("none", None, 10), DEV)
+    from chromegcn_amd import ops
     with pytest.raises(RuntimeError, match="multiple of 4"):
-        gc(torch.randn(10, 128, device=DEV), g, None)
+        ops.spmm(torch.randn(1, 10, 130, device=DEV), g)
+    gc = C.GraphConvolution(8, 4100).to(DEV)
+    with pytest.raises(RuntimeError, match="4096"):
+        gc(torch.randn(10, 8, device=DEV), g, None)
 
 
 @pytest.mark.parametrize("layers", [1, 2])
