@@ -26,6 +26,7 @@ _SIGNATURES = {
     "cgcn_debug_set_fwd_split_bytes": (None, [ctypes.c_longlong]),
     "cgcn_layer_bwd_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
     "cgcn_layer_bwd": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 18 + [_c_int, _c_float, _c_vp, _c_uint, _c_vp, _c_vp, _c_sz, _c_vp, _c_vp]),
+    "cgcn_debug_layer_bwd_phases": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 18 + [_c_int, _c_float, _c_vp, _c_uint, _c_vp, _c_vp, _c_sz, _c_int]),
     "cgcn_head_workspace_bytes": (_c_sz, [_c_int] * 4),
     "cgcn_head_workspace_layout": (_c_int, [_c_int] * 4 + [ctypes.POINTER(_c_sz)] * 3),
     "cgcn_head_bwd_partials": (_c_int, [_c_int]),
@@ -33,6 +34,8 @@ _SIGNATURES = {
                       + [_c_float] + [_c_vp] * 7 + [_c_sz]),
     "cgcn_head_train": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp] * 6 + [_c_float, _c_float] + [_c_vp] * 3 + [_c_float]
                         + [_c_vp] * 6 + [_c_int, _c_int, _c_vp, _c_sz]),
+    "cgcn_debug_head_train_phases": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp] * 6 + [_c_float, _c_float] + [_c_vp] * 3 + [_c_float]
+                                     + [_c_vp] * 6 + [_c_int, _c_int, _c_vp, _c_sz, _c_int]),
     "cgcn_head_bwd": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp] * 8 + [_c_float] + [_c_vp] * 6 + [_c_int, _c_vp, _c_sz]),
     "cgcn_sddmm": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 5),
     "cgcn_graph_count": (_c_int, [_c_vp, _c_int, _c_int] + [_c_vp] * 5),
@@ -41,7 +44,7 @@ _SIGNATURES = {
     "cgcn_multilabel_metrics": (_c_int, [_c_vp, ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_float, _c_vp, _c_vp, _c_sz]),
     "cgcn_sgd_step": (_c_int, [_c_vp, ctypes.c_longlong, _c_vp, _c_vp, _c_vp, _c_float, _c_float, _c_float, _c_int, _c_float, _c_vp]),
 }
-ABI_VERSION = 14
+ABI_VERSION = 15
 _lib = None
 
 

@@ -99,7 +99,7 @@ struct HeadApply {
   uint32_t thresh;
   int S;
   // deferred second stage of the head's dW_out / db_out sums (run by extra workgroups of k_bwd_rowlocal)
-  const float* hf_part;  // [P][CP*D + CP + 4*D] partials of k_head_bwd
+  const float* hf_part;  // [P][head_part_stride(CP, D)] partials of k_head_fused / k_head_bwd
   float* hf_dWout;       // [C][D]
   float* hf_dbout;       // [C]
   int hf_P, hf_C, hf_CP, hf_accumulate;
@@ -108,86 +108,118 @@ struct HeadApply {
   float* hf_dbn_b;       //     cgcn_head_train: nobody has summed the BatchNorm columns for the parameters yet)
 };
 
-// One 64-element slab of the head backward's second stage.  Elements: [CP*D dW_out][CP db_out][D BatchNorm columns].
-// BatchNorm columns reduce (sum dy, sum dy*xhat) of both strands -> d(bn bias), d(bn weight), bnc = means.
+// Partial record of one k_head_fused / k_head_bwd workgroup (floats):
+//   [CP*D dW_out][CP db_out][4*D doubles: sum dy (strand 0, 1), sum dy*xhat (strand 0, 1) per column]
+// The BatchNorm-backward column sums are kept in float64 from the per-row term to the final mean: bnc = (mean dy,
+// mean dy*xhat) is a per-COLUMN constant that enters every row's dL/dXn, so its rounding error is coherent over the
+// rows and is amplified by the cancellation of the gate-bias sum dcg = sum_i gamma_i (|sum| / sum|.| = 1.7e-3 at
+// chr21 size): measured, fp32 sums gave dW2.bias 2.2e-4 off the float64 truth where every other stage of the layer
+// backward is at 5e-7 (tools/bias_sum_probe.py, profiles/r03_bias_sum_probe.txt).
+__host__ __device__ __forceinline__ constexpr int head_part_stride(int CP, int D) { return CP * D + CP + 8 * D; }
+#define HEAD_STAT_COLS 16   // BatchNorm columns per workgroup of the statistics second stage
+
+// One 64-element slab of the head backward's second stage: elements [CP*D dW_out][CP db_out].
 template <int NT>
-__device__ __forceinline__ void head_finalize_slab(int slab, int P, int n, int S, int D, int C, int CP,
+__device__ __forceinline__ void head_finalize_slab(int slab, int P, int D, int C, int CP,
                                                    const float* __restrict__ part, float* __restrict__ dWout,
-                                                   float* __restrict__ dbout, float* __restrict__ dbn_w,
-                                                   float* __restrict__ dbn_b, float* __restrict__ bnc, int accumulate,
+                                                   float* __restrict__ dbout, int accumulate,
                                                    const float* __restrict__ dloss) {
   constexpr int NS = NT / 64;
   const float gl = dloss ? dloss[0] : 1.f;  // everything summed here is linear in the upstream d loss
-  const int PS = CP * D + CP + 4 * D;
-  const int total = CP * D + CP + D;
-  __shared__ __attribute__((aligned(16))) float hred[NS][4][64];
+  const int PS = head_part_stride(CP, D);
+  const int total = CP * D + CP;
+  __shared__ __attribute__((aligned(16))) float hred[NS][64];
   // lane = (el4, sub): 16 lanes x float4 cover the slab's 64 elements, the 4 sub-groups of a wave and the NS
   // waves each take a contiguous range of the P partials -> one or two batches of independent 16-byte loads
   // per thread instead of a long chain of 4-byte ones (the kernel is latency-, not bandwidth-limited).
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int el4 = lane & 15, sub = lane >> 4;
   const int e0 = slab * 64 + el4 * 4;  // region boundaries are multiples of 4: a float4 never straddles one
-  const int nq = e0 >= CP * D + CP ? 4 : 1;  // a stats element reduces (sdy_0, sdy_1, sdyx_0, sdyx_1) of one column
-  f32x4 s4[4];
-#pragma unroll
-  for (int qd = 0; qd < 4; ++qd) s4[qd] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
   if (e0 < total) {
     const int per = (P + NS * 4 - 1) / (NS * 4);
     const int p0 = (wave * 4 + sub) * per, p1 = min(P, p0 + per);
-    for (int qd = 0; qd < nq; ++qd) {
-      f32x4 a = {0.f, 0.f, 0.f, 0.f};
-      for (int p = p0; p < p1; p += 8) {
-        f32x4 t[8];
+    for (int p = p0; p < p1; p += 8) {
+      f32x4 t[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = *(const f32x4*)(part + (size_t)min(p + u, p1 - 1) * PS + e0 + qd * D);
+      for (int u = 0; u < 8; ++u) t[u] = *(const f32x4*)(part + (size_t)min(p + u, p1 - 1) * PS + e0);
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (p + u < p1) a += t[u];
-      }
-      s4[qd] = a;
+      for (int u = 0; u < 8; ++u)
+        if (p + u < p1) a += t[u];
     }
   }
 #pragma unroll
-  for (int qd = 0; qd < 4; ++qd) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float v = s4[qd][k];
-      v += __shfl_xor(v, 16);
-      v += __shfl_xor(v, 32);
-      s4[qd][k] = v;
-    }
-    if (sub == 0) *(f32x4*)&hred[wave][qd][el4 * 4] = s4[qd];
+  for (int k = 0; k < 4; ++k) {
+    float v = a[k];
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    a[k] = v;
   }
+  if (sub == 0) *(f32x4*)&hred[wave][el4 * 4] = a;
   __syncthreads();
   const int el = threadIdx.x & 63, slice = threadIdx.x >> 6;
   const int e = slab * 64 + el;
-  float s[4];
   if (slice != 0 || e >= total) return;
+  float s = 0.f;
 #pragma unroll
-  for (int qd = 0; qd < 4; ++qd) {
-    float a = 0.f;
-#pragma unroll
-    for (int w = 0; w < NS; ++w) a += hred[w][qd][el];
-    s[qd] = a * gl;
-  }
+  for (int w = 0; w < NS; ++w) s += hred[w][el];
+  s *= gl;
   if (e < CP * D) {
     const int i = e / D;
-    if (i < C) dWout[e] = accumulate ? dWout[e] + s[0] : s[0];
-  } else if (e < CP * D + CP) {
-    const int j = e - CP * D;
-    if (j < C) dbout[j] = accumulate ? dbout[j] + s[0] : s[0];
+    if (i < C) dWout[e] = accumulate ? dWout[e] + s : s;
   } else {
-    const int c = e - CP * D - CP;
-    // s[0], s[1] = sum dy (strand 0, 1); s[2], s[3] = sum dy*xhat (strand 0, 1); strand 1 is zero when S == 1
-    const float db_ = s[0] + s[1], dg_ = s[2] + s[3];
-    if (dbn_b) dbn_b[c] = accumulate ? dbn_b[c] + db_ : db_;
-    if (dbn_w) dbn_w[c] = accumulate ? dbn_w[c] + dg_ : dg_;
-    if (bnc) {
-      const float invn = 1.f / (float)n;
-      for (int st = 0; st < S; ++st) {
-        bnc[(st * 2 + 0) * D + c] = s[st] * invn;
-        bnc[(st * 2 + 1) * D + c] = s[2 + st] * invn;
-      }
+    const int j = e - CP * D;
+    if (j < C) dbout[j] = accumulate ? dbout[j] + s : s;
+  }
+}
+
+// Second stage of the BatchNorm-backward column sums, in float64: columns [blk * 16, blk * 16 + 16).  Thread =
+// (column, slice of the partial list); slices are merged through LDS in a fixed order => deterministic.
+// Writes d(bn bias) = sum dy, d(bn weight) = sum dy*xhat (both strands; scaled by the upstream d loss) and/or
+// bnc = the per-strand means for d loss = 1.
+template <int NT>
+__device__ __forceinline__ void head_stats_finalize(int blk, int P, int n, int S, int D, int CP,
+                                                    const float* __restrict__ part, float* __restrict__ dbn_w,
+                                                    float* __restrict__ dbn_b, float* __restrict__ bnc, int accumulate,
+                                                    const float* __restrict__ dloss) {
+  constexpr int NSL = NT / HEAD_STAT_COLS;
+  __shared__ double sred[4][NSL][HEAD_STAT_COLS + 1];
+  const int cl = threadIdx.x % HEAD_STAT_COLS, slice = threadIdx.x / HEAD_STAT_COLS;
+  const int c = blk * HEAD_STAT_COLS + cl;
+  const int PS = head_part_stride(CP, D);
+  const int per = (P + NSL - 1) / NSL;
+  const int p0 = slice * per, p1 = min(P, p0 + per);
+  double a[4] = {0.0, 0.0, 0.0, 0.0};
+  if (c < D) {
+#pragma unroll 2
+    for (int p = p0; p < p1; ++p) {
+      const double* st = (const double*)(part + (size_t)p * PS + CP * D + CP);
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) a[qd] += st[qd * D + c];
+    }
+  }
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) sred[qd][slice][cl] = a[qd];
+  __syncthreads();
+  if (slice != 0 || c >= D) return;
+  double s[4];
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) {
+    double t = 0.0;
+#pragma unroll 8
+    for (int o = 0; o < NSL; ++o) t += sred[qd][o][cl];
+    s[qd] = t;
+  }
+  // s[0], s[1] = sum dy (strand 0, 1); s[2], s[3] = sum dy*xhat (strand 0, 1); strand 1 is zero when S == 1
+  const double gl = dloss ? (double)dloss[0] : 1.0;
+  const float db_ = (float)((s[0] + s[1]) * gl), dg_ = (float)((s[2] + s[3]) * gl);
+  if (dbn_b) dbn_b[c] = accumulate ? dbn_b[c] + db_ : db_;
+  if (dbn_w) dbn_w[c] = accumulate ? dbn_w[c] + dg_ : dg_;
+  if (bnc) {
+    const double invn = 1.0 / (double)n;
+    for (int st = 0; st < S; ++st) {
+      bnc[(st * 2 + 0) * D + c] = (float)(s[st] * invn);
+      bnc[(st * 2 + 1) * D + c] = (float)(s[2 + st] * invn);
     }
   }
 }

@@ -92,6 +92,19 @@ __global__ __launch_bounds__(256) void k_head_colstats(int n, int S, int rows_pe
 // LDS in two fixed-order steps, and one thread per channel finishes both strands (the running-stat update is
 // sequential in the strand index).  The kernel is a pure latency chain, so it is laid out wide and shallow:
 // COLS = 16 for the <= 128 partials of k_head_colstats, COLS = 4 for the per-tile partials of cgcn_layer_fwd.
+// Chan's merge in float64 (the second stage below): the batch mean is a per-COLUMN constant of every row's BatchNorm
+// output, so its rounding error is coherent over the rows -- the same amplification channel as the BatchNorm-backward
+// column means (cgcn_common.hpp, head_part_stride): merged in fp32, dW2.bias stayed at 1.4e-4 of the float64 truth.
+__device__ __forceinline__ void chan_combine_d(double& nA, double& meanA, double& m2A, double nB, double meanB, double m2B) {
+  const double nAB = nA + nB;
+  if (nAB > 0.0) {
+    const double delta = meanB - meanA;
+    meanA += delta * (nB / nAB);
+    m2A += m2B + delta * delta * (nA * nB / nAB);
+    nA = nAB;
+  }
+}
+
 template <int COLS>
 __global__ __launch_bounds__(1024) void k_head_bn_finalize(int n, int S, int D, int nblk, int rows_per_blk,
                                                            const float* __restrict__ part, float momentum, float eps,
@@ -101,14 +114,14 @@ __global__ __launch_bounds__(1024) void k_head_bn_finalize(int n, int S, int D, 
   constexpr int NSL = 1024 / COLS;          // slices
   constexpr int G1 = (NSL == 64) ? 8 : 16;  // first merge step: NSL -> NSL / G1 (= G1 here), second: -> 1
   static_assert(NSL == G1 * G1, "two equal merge steps");
-  __shared__ float sm[3][NSL + 1][COLS + 1];
+  __shared__ double sm[3][NSL + 1][COLS + 1];
   const int cl = threadIdx.x % COLS, slice = threadIdx.x / COLS;
   const int CPB = COLS / S;  // channels per workgroup (S is 1 or 2)
   const int s = cl / CPB, c = blockIdx.x * CPB + cl % CPB;
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += S;
   const int per = (nblk + NSL - 1) / NSL;
   const int b0 = slice * per, b1 = min(nblk, b0 + per);
-  float cnt = 0.f, mean = 0.f, m2 = 0.f;
+  double cnt = 0.0, mean = 0.0, m2 = 0.0;
   if (c < D) {
     for (int b = b0; b < b1; b += 8) {
       float pm[8], p2[8];
@@ -122,8 +135,8 @@ __global__ __launch_bounds__(1024) void k_head_bn_finalize(int n, int S, int D, 
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         if (b + u < b1) {
-          const float nb = (float)max(0, min(n, (b + u + 1) * rows_per_blk) - (b + u) * rows_per_blk);
-          chan_combine(cnt, mean, m2, nb, pm[u], p2[u]);
+          const double nb = (double)max(0, min(n, (b + u + 1) * rows_per_blk) - (b + u) * rows_per_blk);
+          chan_combine_d(cnt, mean, m2, nb, (double)pm[u], (double)p2[u]);
         }
       }
     }
@@ -133,8 +146,8 @@ __global__ __launch_bounds__(1024) void k_head_bn_finalize(int n, int S, int D, 
   sm[2][slice][cl] = m2;
   __syncthreads();
   if (slice < G1) {  // slices G1*slice .. G1*slice + G1-1
-    cnt = mean = m2 = 0.f;
-    for (int o = 0; o < G1; ++o) chan_combine(cnt, mean, m2, sm[0][slice * G1 + o][cl], sm[1][slice * G1 + o][cl], sm[2][slice * G1 + o][cl]);
+    cnt = mean = m2 = 0.0;
+    for (int o = 0; o < G1; ++o) chan_combine_d(cnt, mean, m2, sm[0][slice * G1 + o][cl], sm[1][slice * G1 + o][cl], sm[2][slice * G1 + o][cl]);
   }
   __syncthreads();
   if (slice < G1) {
@@ -144,13 +157,13 @@ __global__ __launch_bounds__(1024) void k_head_bn_finalize(int n, int S, int D, 
   }
   __syncthreads();
   if (slice == 0) {
-    cnt = mean = m2 = 0.f;
-    for (int o = 0; o < G1; ++o) chan_combine(cnt, mean, m2, sm[0][o][cl], sm[1][o][cl], sm[2][o][cl]);
+    cnt = mean = m2 = 0.0;
+    for (int o = 0; o < G1; ++o) chan_combine_d(cnt, mean, m2, sm[0][o][cl], sm[1][o][cl], sm[2][o][cl]);
     sm[1][NSL][cl] = mean;
     sm[2][NSL][cl] = m2;
     if (c < D) {
-      save_mean[s * D + c] = mean;
-      save_invstd[s * D + c] = rsqrtf(m2 / (float)n + eps);
+      save_mean[s * D + c] = (float)mean;
+      save_invstd[s * D + c] = (float)(1.0 / sqrt(m2 / (double)n + (double)eps));
     }
   }
   __syncthreads();
@@ -158,8 +171,8 @@ __global__ __launch_bounds__(1024) void k_head_bn_finalize(int n, int S, int D, 
   float rm = run_mean[c], rv = run_var[c];
   for (int st = 0; st < S; ++st) {
     // sequential update: the reference calls the model on the forward strand, then the reverse one
-    rm = (1.f - momentum) * rm + momentum * sm[1][NSL][st * CPB + cl];
-    rv = (1.f - momentum) * rv + momentum * (sm[2][NSL][st * CPB + cl] / (float)(n - 1));
+    rm = (1.f - momentum) * rm + momentum * (float)sm[1][NSL][st * CPB + cl];
+    rv = (1.f - momentum) * rv + momentum * (float)(sm[2][NSL][st * CPB + cl] / (double)(n - 1));
   }
   run_mean[c] = rm;
   run_var[c] = rv;
@@ -382,9 +395,39 @@ __global__ __launch_bounds__(256) void k_sum_scale(int m, const float* __restric
   if (threadIdx.x == 0) out[0] = sm[0] * scale;
 }
 
+// Cross-wave merge of the per-thread BatchNorm-backward column sums into the workgroup's partial record, in float64
+// from here on (a thread's own sum covers 4 rows per tile -- a few dozen fp32 terms whose rounding is random across
+// threads; it is the LARGE partial sums of the later stages whose rounding is coherent over a column, cgcn_common.hpp):
+// two rounds (sum dy, then sum dy*xhat) through an LDS scratch of NW * 2 * D doubles, waves added in a fixed order.
+template <int D, int NW, int SCRATCH_FLOATS>
+__device__ __forceinline__ void head_stats_partial(float* __restrict__ scratch, double* __restrict__ out,
+                                                   const float (&sdy)[2][D / 64], const float (&sdyx)[2][D / 64],
+                                                   int wave, int lane) {
+  constexpr int EPL = D / 64, RS = 2 * D;
+  static_assert(NW * RS * 2 <= SCRATCH_FLOATS, "reduction scratch must fit in the tile buffer");
+  double* red = (double*)scratch;
+  for (int round = 0; round < 2; ++round) {
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) red[wave * RS + s * D + lane * EPL + e] = (double)(round ? sdyx[s][e] : sdy[s][e]);
+    __syncthreads();
+    for (int c = threadIdx.x; c < RS; c += NW * 64) {
+      double t = 0.0;
+      for (int w = 0; w < NW; ++w) t += red[w * RS + c];
+      out[round * RS + c] = t;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // k_head_bwd: persistent over 32-node tiles.
-//   partial layout per workgroup: [CP*D dW_out][CP db_out][S*D sum dy][S*D sum dy*xhat]
+//   partial layout per workgroup: head_part_stride (cgcn_common.hpp): [CPT*D dW_out][CPT db_out][4*D float64 column sums]
+// Labels are walked in PASSES of at most 128 (one launch per pass, labels [c0, c0 + Cp)): the accumulators of a
+// 256-label variant do not fit the register file (112 / 70 / 13 spilled registers in round 2's <*,16> instantiations).
+// A pass adds its share of dym = dpred W_out to what the earlier passes left in memory; the LAST pass, which sees the
+// complete dym, takes the BatchNorm-backward column sums.  CPT = padded label count of the partial layout (128 / 256).
 // ------------------------------------------------------------------------------------------
 template <int D, int CBMAX>
 __global__ __launch_bounds__(512) void k_head_bwd(int n, int S, int C, const float* __restrict__ X,
@@ -393,13 +436,14 @@ __global__ __launch_bounds__(512) void k_head_bwd(int n, int S, int C, const flo
                                                   const float* __restrict__ Wout, const float* __restrict__ dpred,
                                                   const float* __restrict__ dloss, float keep_scale, uint32_t thresh,
                                                   const unsigned long long* __restrict__ rng_state,
-                                                  float* __restrict__ dym, float* __restrict__ part) {
+                                                  float* __restrict__ dym, float* __restrict__ part,
+                                                  int c0, int Cp, int CPT, int first, int last) {
   constexpr int TR = HEADB_TILE, NW = 8, EPL = D / 64, RPW = TR / NW;
   constexpr int CP = CBMAX * 16;
   constexpr int LDP = CP + ((CP & 16) ? 2 : 18);  // = 18 (mod 32): row reads and transposed reads both (nearly) conflict-free
   constexpr int LDY = D + 16;                      // = 16 (mod 32): conflict-free transposed reads
   constexpr int JBW = D / 128;                     // 16-wide column blocks of D owned by one wave
-  constexpr int PS = CP * D + CP + 2 * 2 * D;      // partial stride (S <= 2)
+  const int PS = head_part_stride(CPT, D);
   constexpr int NLD = TR * CP / 512;               // dpred elements staged per thread per tile
   __shared__ __attribute__((aligned(16))) float Pt[TR * LDP];
   __shared__ __attribute__((aligned(16))) float Yt[TR * LDY];
@@ -409,7 +453,7 @@ __global__ __launch_bounds__(512) void k_head_bwd(int n, int S, int C, const flo
   const int r = lane & 15, q = lane >> 4;
   const uint32_t key = thresh ? dropout_key(rng_state, HEAD_STREAM_ID) : 0u;
   const float gl = dloss ? dloss[0] : 1.f;
-  const int CB = (C + 15) / 16;
+  const int CB = (Cp + 15) / 16;
   const float invS = 1.f / (float)S;
 
   f32x4 accW[CBMAX][JBW];
@@ -418,7 +462,7 @@ __global__ __launch_bounds__(512) void k_head_bwd(int n, int S, int C, const flo
 #pragma unroll
     for (int jb = 0; jb < JBW; ++jb) accW[ib][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float dbo = 0.f;                       // thread j < CP: column sum of dpred
-  float sdy[2][EPL], sdyx[2][EPL];
+  float sdy[2][EPL], sdyx[2][EPL];   // per thread: <= a few dozen rows in fp32; float64 from the cross-wave merge on
   float mu[2][EPL], is[2][EPL], gw[EPL], gb[EPL];
 #pragma unroll
   for (int e = 0; e < EPL; ++e) {
@@ -443,7 +487,7 @@ __global__ __launch_bounds__(512) void k_head_bwd(int n, int S, int C, const flo
 #pragma unroll
       for (int kk = 0; kk < CBMAX * 4; ++kk) {
         const int k = 4 * kk + q;
-        bwo[jb][kk] = (k < C) ? Wout[(size_t)k * D + (wave * JBW + jb) * 16 + r] : 0.f;
+        bwo[jb][kk] = (k < Cp) ? Wout[(size_t)(c0 + k) * D + (wave * JBW + jb) * 16 + r] : 0.f;
       }
   }
 
@@ -457,7 +501,7 @@ __global__ __launch_bounds__(512) void k_head_bwd(int n, int S, int C, const flo
       const int idx = threadIdx.x + u * 512;
       const int row = idx / CP, j = idx % CP;
       const int i = node0 + row;
-      pv[u] = (i < n && j < C) ? dpred[(size_t)i * C + j] : 0.f;
+      pv[u] = (i < n && j < Cp) ? dpred[(size_t)i * C + c0 + j] : 0.f;
     }
     float xv[RPW][2][EPL];
 #pragma unroll
@@ -549,7 +593,7 @@ __global__ __launch_bounds__(512) void k_head_bwd(int n, int S, int C, const flo
         const int k = 4 * kk + q;
         float b[JBW];
 #pragma unroll
-        for (int jb = 0; jb < JBW; ++jb) b[jb] = (k < C) ? Wout[(size_t)k * D + (wave * JBW + jb) * 16 + r] : 0.f;
+        for (int jb = 0; jb < JBW; ++jb) b[jb] = (k < Cp) ? Wout[(size_t)(c0 + k) * D + (wave * JBW + jb) * 16 + r] : 0.f;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
           const float a = Pt[(mb * 16 + r) * LDP + k];
@@ -575,7 +619,14 @@ __global__ __launch_bounds__(512) void k_head_bwd(int n, int S, int C, const flo
       float gv[EPL];
 #pragma unroll
       for (int e = 0; e < EPL; ++e) gv[e] = i < n ? Yt[rr * LDY + lane * EPL + e] : 0.f;
+      if (i < n && !first) {   // the earlier label passes' share of dym
+        float prev[EPL];
+        ld_row<EPL>(prev, &dym[(size_t)i * D + lane * EPL]);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) gv[e] += prev[e];
+      }
       if (i < n) st_row<EPL>(&dym[(size_t)i * D + lane * EPL], gv);
+      if (!last) continue;
 #pragma unroll
       for (int e = 0; e < EPL; ++e) {
         const int c = lane * EPL + e;
@@ -603,25 +654,11 @@ __global__ __launch_bounds__(512) void k_head_bwd(int n, int S, int C, const flo
 #pragma unroll
     for (int jb = 0; jb < JBW; ++jb)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) P[(ib * 16 + q * 4 + e) * D + (wave * JBW + jb) * 16 + r] = accW[ib][jb][e];
+      for (int e = 0; e < 4; ++e)
+        if (c0 + ib * 16 < CPT) P[(size_t)(c0 + ib * 16 + q * 4 + e) * D + (wave * JBW + jb) * 16 + r] = accW[ib][jb][e];
 #endif
-  if (threadIdx.x < CP) P[CP * D + threadIdx.x] = dbo;
-  float* red = Yt;  // [NW][4*D]
-  constexpr int RS = 4 * D;
-  static_assert(NW * RS <= TR * LDY, "reduction scratch must fit in Yt");
-#pragma unroll
-  for (int s = 0; s < 2; ++s)
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-      red[wave * RS + s * D + lane * EPL + e] = sdy[s][e];
-      red[wave * RS + 2 * D + s * D + lane * EPL + e] = sdyx[s][e];
-    }
-  __syncthreads();
-  for (int c = threadIdx.x; c < RS; c += 512) {
-    float s = 0.f;
-    for (int w = 0; w < NW; ++w) s += red[w * RS + c];
-    P[CP * D + CP + c] = s;
-  }
+  if (threadIdx.x < CP && c0 + (int)threadIdx.x < CPT) P[CPT * D + c0 + threadIdx.x] = dbo;
+  if (last) head_stats_partial<D, NW, TR * LDY>(Yt, (double*)(P + CPT * D + CPT), sdy, sdyx, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -632,7 +669,8 @@ __global__ __launch_bounds__(512) void k_head_bwd(int n, int S, int C, const flo
 // no dpred round trip through memory, no second read of X, no recomputation of ym / dropout masks, one launch
 // less.  Everything is computed for an upstream gradient of 1; cgcn_head_bwd / cgcn_layer_bwd scale by the
 // actual d loss (all of it is linear in that scalar).
-// Persistent over 32-node tiles like k_head_bwd; same partial layout.
+// Persistent over 32-node tiles like k_head_bwd; same partial layout, same label passes (labels [c0, c0 + Cp) per launch,
+// Cp <= 128; a pass adds its share of dym to the earlier passes', the last one takes the BatchNorm column sums).
 // ------------------------------------------------------------------------------------------
 #ifdef HF_TIMING  // tuning build only (tools/khead.py --stamps): phase timestamps of a few workgroups
 __device__ unsigned long long hf_stamps[8 * 16];
@@ -656,13 +694,13 @@ __global__ __launch_bounds__(512, HF_LOWREG ? 4 : 1) void k_head_fused(int n, in
                                                     const float* __restrict__ target, float keep_scale, uint32_t thresh,
                                                     const unsigned long long* __restrict__ rng_state, float inv_count,
                                                     float* __restrict__ probs, float* __restrict__ loss_part,
-                                                    float* __restrict__ dym, float* __restrict__ part) {
+                                                    float* __restrict__ dym, float* __restrict__ part,
+                                                    int c0, int Cp, int CPT, int first, int last) {
   constexpr int TR = HEADB_TILE, NW = 8, EPL = D / 64, RPW = TR / NW, KQ = D / 4;
   constexpr int CP = CBMAX * 16, NCBW = CBMAX / 8;
   constexpr int LDP = CP + ((CP & 16) ? 2 : 18);
   constexpr int LDY = D + 16;
   constexpr int JBW = D / 128;
-  constexpr int PS = CP * D + CP + 2 * 2 * D;
   constexpr bool PRE = (D == 128) && !HF_LOWREG;
   __shared__ __attribute__((aligned(16))) float Pt[TR * LDP];
   __shared__ __attribute__((aligned(16))) float Yt[TR * LDY];
@@ -672,8 +710,9 @@ __global__ __launch_bounds__(512, HF_LOWREG ? 4 : 1) void k_head_fused(int n, in
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, q = lane >> 4;
   const uint32_t key = thresh ? dropout_key(rng_state, HEAD_STREAM_ID) : 0u;
-  const int CB = (C + 15) / 16;
+  const int CB = (Cp + 15) / 16;
   const float invS = 1.f / (float)S;
+  const int PS = head_part_stride(CPT, D);
 
   HF_STAMP(0);
   HF_STAMP(1);
@@ -687,7 +726,7 @@ __global__ __launch_bounds__(512, HF_LOWREG ? 4 : 1) void k_head_fused(int n, in
 #pragma unroll
       for (int t = 0; t < KQ / 4; ++t) {
         f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (j < C) v = *(const f32x4*)&Wout[(size_t)j * D + 16 * t + 4 * q];
+        if (j < Cp) v = *(const f32x4*)&Wout[(size_t)(c0 + j) * D + 16 * t + 4 * q];
 #pragma unroll
         for (int u = 0; u < 4; ++u) bw[cbi][4 * t + u] = v[u];
       }
@@ -697,7 +736,7 @@ __global__ __launch_bounds__(512, HF_LOWREG ? 4 : 1) void k_head_fused(int n, in
 #pragma unroll
       for (int kk = 0; kk < CBMAX * 4; ++kk) {
         const int k = 4 * kk + q;
-        bwo[jb][kk] = (k < C) ? Wout[(size_t)k * D + (wave * JBW + jb) * 16 + r] : 0.f;
+        bwo[jb][kk] = (k < Cp) ? Wout[(size_t)(c0 + k) * D + (wave * JBW + jb) * 16 + r] : 0.f;
       }
   }
   HF_STAMP(2);
@@ -707,7 +746,7 @@ __global__ __launch_bounds__(512, HF_LOWREG ? 4 : 1) void k_head_fused(int n, in
 #pragma unroll
     for (int jb = 0; jb < JBW; ++jb) accW[ib][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float dbo = 0.f, lacc = 0.f;
-  float sdy[2][EPL], sdyx[2][EPL];
+  float sdy[2][EPL], sdyx[2][EPL];   // per thread: <= a few dozen rows in fp32; float64 from the cross-wave merge on
   float mu[2][EPL], is[2][EPL], gw[EPL], gb[EPL];
 #pragma unroll
   for (int e = 0; e < EPL; ++e) {
@@ -732,7 +771,7 @@ __global__ __launch_bounds__(512, HF_LOWREG ? 4 : 1) void k_head_fused(int n, in
 #pragma unroll
   for (int cbi = 0; cbi < NCBW; ++cbi) {
     const int j = (wave + NW * cbi) * 16 + r;
-    bjv[cbi] = j < C ? bout[j] : 0.f;
+    bjv[cbi] = j < Cp ? bout[c0 + j] : 0.f;
   }
   auto load_tile = [&](int tile, auto& xd, auto& td) {
     const int node0 = tile * TR;
@@ -753,7 +792,7 @@ __global__ __launch_bounds__(512, HF_LOWREG ? 4 : 1) void k_head_fused(int n, in
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int i = node0 + mb * 16 + q * 4 + e;
-          td[cbi][mb][e] = (i < n && j < C) ? target[(size_t)i * C + j] : 0.f;
+          td[cbi][mb][e] = (i < n && j < Cp) ? target[(size_t)i * C + c0 + j] : 0.f;
         }
     }
   };
@@ -822,7 +861,7 @@ __global__ __launch_bounds__(512, HF_LOWREG ? 4 : 1) void k_head_fused(int n, in
           } else {
             const int j = (wave + NW * cbi) * 16 + r;
             b = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (j < C) b = *(const f32x4*)&Wout[(size_t)j * D + 16 * t + 4 * q];
+            if (j < Cp) b = *(const f32x4*)&Wout[(size_t)(c0 + j) * D + 16 * t + 4 * q];
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u)
@@ -843,13 +882,13 @@ __global__ __launch_bounds__(512, HF_LOWREG ? 4 : 1) void k_head_fused(int n, in
           const int row = mb * 16 + q * 4 + e;
           const int i = node0 + row;
           float dp = 0.f;
-          if (i < n && j < C) {
+          if (i < n && j < Cp) {
             const float pred = acc[cbi][mb][e] + bjv[cbi];
             const float en = __expf(-fabsf(pred));
             const float inv = 1.f / (1.f + en);
             const float p = pred >= 0.f ? inv : en * inv;
             lacc += fmaxf(pred, 0.f) - pred * tgv[cbi][mb][e] + __logf(1.f + en);
-            probs[(size_t)i * C + j] = p;
+            probs[(size_t)i * C + c0 + j] = p;
             dp = (p - tgv[cbi][mb][e]) * inv_count;
           }
           Pt[row * LDP + j] = dp;
@@ -906,7 +945,7 @@ __global__ __launch_bounds__(512, HF_LOWREG ? 4 : 1) void k_head_fused(int n, in
         const int k = 4 * kk + q;
         float b[JBW];
 #pragma unroll
-        for (int jb = 0; jb < JBW; ++jb) b[jb] = (k < C) ? Wout[(size_t)k * D + (wave * JBW + jb) * 16 + r] : 0.f;
+        for (int jb = 0; jb < JBW; ++jb) b[jb] = (k < Cp) ? Wout[(size_t)(c0 + k) * D + (wave * JBW + jb) * 16 + r] : 0.f;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
           const float a = Pt[(mb * 16 + r) * LDP + k];
@@ -933,7 +972,14 @@ __global__ __launch_bounds__(512, HF_LOWREG ? 4 : 1) void k_head_fused(int n, in
       float gv[EPL];
 #pragma unroll
       for (int e = 0; e < EPL; ++e) gv[e] = i < n ? Yt[rr * LDY + lane * EPL + e] : 0.f;
+      if (i < n && !first) {   // the earlier label passes' share of dym
+        float prev[EPL];
+        ld_row<EPL>(prev, &dym[(size_t)i * D + lane * EPL]);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) gv[e] += prev[e];
+      }
       if (i < n) st_row<EPL>(&dym[(size_t)i * D + lane * EPL], gv);
+      if (!last) continue;
 #pragma unroll
       for (int e = 0; e < EPL; ++e) {
         const int c = lane * EPL + e;
@@ -961,49 +1007,41 @@ __global__ __launch_bounds__(512, HF_LOWREG ? 4 : 1) void k_head_fused(int n, in
 #pragma unroll
     for (int jb = 0; jb < JBW; ++jb)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) P[(ib * 16 + q * 4 + e) * D + (wave * JBW + jb) * 16 + r] = accW[ib][jb][e];
-  if (threadIdx.x < CP) P[CP * D + threadIdx.x] = dbo;
+      for (int e = 0; e < 4; ++e)
+        if (c0 + ib * 16 < CPT) P[(size_t)(c0 + ib * 16 + q * 4 + e) * D + (wave * JBW + jb) * 16 + r] = accW[ib][jb][e];
+  if (threadIdx.x < CP && c0 + (int)threadIdx.x < CPT) P[CPT * D + c0 + threadIdx.x] = dbo;
   HF_STAMP(11);
   lacc = wave_sum(lacc);
   if (lane == 0) lsum[wave] = lacc;
-  float* red = Yt;  // [NW][4*D]
-  constexpr int RS = 4 * D;
-#pragma unroll
-  for (int s = 0; s < 2; ++s)
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-      red[wave * RS + s * D + lane * EPL + e] = sdy[s][e];
-      red[wave * RS + 2 * D + s * D + lane * EPL + e] = sdyx[s][e];
-    }
+  if (last) head_stats_partial<D, NW, TR * LDY>(Yt, (double*)(P + CPT * D + CPT), sdy, sdyx, wave, lane);
   __syncthreads();
-  for (int c = threadIdx.x; c < RS; c += 512) {
-    float s = 0.f;
-    for (int w = 0; w < NW; ++w) s += red[w * RS + c];
-    P[CP * D + CP + c] = s;
-  }
   if (threadIdx.x == 0) {
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) t += lsum[w];
-    loss_part[blockIdx.x] = t;
+    loss_part[blockIdx.x] = first ? t : loss_part[blockIdx.x] + t;   // the label passes' shares add up
   }
   HF_STAMP(12);
 }
 
-// second stage (see head_finalize_slab): slabs [slab0, slab0 + gridDim.x)
-__global__ __launch_bounds__(512) void k_head_bwd_finalize(int slab0, int P, int n, int S, int D, int C, int CP,
+// second stage: workgroups [0, wslabs) sum the dW_out / db_out slabs wslab0 + b (head_finalize_slab), the rest the
+// BatchNorm columns in float64 (head_stats_finalize)
+__global__ __launch_bounds__(512) void k_head_bwd_finalize(int wslab0, int wslabs, int P, int n, int S, int D, int C, int CP,
                                                            const float* __restrict__ part, float* __restrict__ dWout,
                                                            float* __restrict__ dbout, float* __restrict__ dbn_w,
                                                            float* __restrict__ dbn_b, float* __restrict__ bnc,
                                                            int accumulate, const float* __restrict__ dloss) {
-  head_finalize_slab<512>(slab0 + blockIdx.x, P, n, S, D, C, CP, part, dWout, dbout, dbn_w, dbn_b, bnc, accumulate, dloss);
+  if ((int)blockIdx.x < wslabs)
+    head_finalize_slab<512>(wslab0 + blockIdx.x, P, D, C, CP, part, dWout, dbout, accumulate, dloss);
+  else
+    head_stats_finalize<512>((int)blockIdx.x - wslabs, P, n, S, D, CP, part, dbn_w, dbn_b, bnc, accumulate, dloss);
 }
 
 // Last launch of cgcn_head_train: workgroup 0 adds up the loss shares (fixed-order tree); the others sum the
-// BatchNorm-backward columns of the partials into bnc = (mean dy, mean dy*xhat) per strand, for an upstream d loss of
-// 1 (the consumer, k_bwd_rowlocal's head prologue, scales by the real one).  One launch instead of a loss-sum launch
-// in the forward plus a finalize launch in the backward.
-__global__ __launch_bounds__(512) void k_head_train_finish(int wslab0, int P, int n, int S, int D, int C, int CP,
+// BatchNorm-backward columns of the partials (float64) into bnc = (mean dy, mean dy*xhat) per strand, for an upstream
+// d loss of 1 (the consumer, k_bwd_rowlocal's head prologue, scales by the real one).  One launch instead of a
+// loss-sum launch in the forward plus a finalize launch in the backward.
+__global__ __launch_bounds__(512) void k_head_train_finish(int P, int n, int S, int D, int CP,
                                                            const float* __restrict__ part, float* __restrict__ bnc,
                                                            const float* __restrict__ loss_part, float inv_count,
                                                            float* __restrict__ loss) {
@@ -1020,7 +1058,7 @@ __global__ __launch_bounds__(512) void k_head_train_finish(int wslab0, int P, in
     if (threadIdx.x == 0) loss[0] = sm[0] * inv_count;
     return;
   }
-  head_finalize_slab<512>(wslab0 + blockIdx.x - 1, P, n, S, D, C, CP, part, nullptr, nullptr, nullptr, nullptr, bnc, 0, nullptr);
+  head_stats_finalize<512>((int)blockIdx.x - 1, P, n, S, D, CP, part, nullptr, nullptr, bnc, 0, nullptr);
 }
 
 template <int D>
@@ -1087,7 +1125,7 @@ static inline size_t ws_stats(int S, int d) { return (size_t)HEAD_STAT_BLOCKS * 
 static inline size_t ws_loss(int n) { return (size_t)((n + HEAD_TILE - 1) / HEAD_TILE + 4); }
 static inline size_t ws_dym(int n, int d) { return (size_t)n * d + 4; }
 static inline size_t ws_bnc(int d) { return (size_t)2 * 2 * d; }
-static inline size_t ws_part(int n, int d, int C) { return (size_t)head_bwd_partials(n) * ((size_t)head_cp(C) * d + head_cp(C) + 4 * d); }
+static inline size_t ws_part(int n, int d, int C) { return (size_t)head_bwd_partials(n) * (size_t)head_part_stride(head_cp(C), d); }
 static inline size_t align4(size_t x) { return (x + 3) & ~(size_t)3; }
 
 extern "C" {
@@ -1164,12 +1202,17 @@ int cgcn_head_fwd(cgcn_stream_t stream, int n, int S, int d, int C, const float*
   return launch_status();
 }
 
-int cgcn_head_train(cgcn_stream_t stream, int n, int S, int d, int C, const float* X, const float* bn_w,
+}  // extern "C"
+
+// phases: bit 0 = batch statistics (k_head_colstats when the producer did not supply them, k_head_bn_finalize),
+// bit 1 = k_head_fused (every label pass), bit 2 = k_head_train_finish.  cgcn_head_train runs all three;
+// cgcn_debug_head_train_phases lets a profiler time them one at a time (on the state an earlier full call left).
+static int head_train_impl(cgcn_stream_t stream, int n, int S, int d, int C, const float* X, const float* bn_w,
                     const float* bn_b, float* run_mean, float* run_var, long long* num_batches_tracked, float momentum,
                     float eps, const float* Wout, const float* bout, const float* target, float dropout_p,
                     const unsigned long long* rng_state, float* probs, float* loss, float* save_mean, float* save_invstd,
                     const float* col_stats, int col_stats_tiles, int col_stats_rows, void* workspace,
-                    size_t workspace_bytes) {
+                    size_t workspace_bytes, int phases) {
   int rc = head_check(n, S, d, C);
   if (rc) return rc;
   if (!X || !bn_w || !bn_b || !Wout || !bout || !target || !probs || !loss || !workspace || !run_mean || !run_var ||
@@ -1194,30 +1237,61 @@ int cgcn_head_train(cgcn_stream_t stream, int n, int S, int d, int C, const floa
     stats = col_stats;
     nblk = col_stats_tiles;
     rpb = col_stats_rows;
-  } else {
+  } else if (phases & 1) {
     if (d == 128) hipLaunchKernelGGL((k_head_colstats<128>), dim3(nblk), dim3(256), 0, st, n, S, rpb, X, w_stats);
     else hipLaunchKernelGGL((k_head_colstats<256>), dim3(nblk), dim3(256), 0, st, n, S, rpb, X, w_stats);
     if ((rc = launch_status())) return rc;
   }
-  launch_bn_finalize(st, n, S, d, nblk, rpb, stats, momentum, eps, run_mean, run_var, num_batches_tracked, save_mean, save_invstd);
-  if ((rc = launch_status())) return rc;
+  if (phases & 1) {
+    launch_bn_finalize(st, n, S, d, nblk, rpb, stats, momentum, eps, run_mean, run_var, num_batches_tracked, save_mean, save_invstd);
+    if ((rc = launch_status())) return rc;
+  }
   const int P = head_bwd_partials(n);
   const int CP = head_cp(C);
   const float keep_scale = drop ? 1.f / (1.f - dropout_p) : 1.f;
   const uint32_t thresh = drop ? dropout_threshold(dropout_p) : 0u;
   const float inv_count = 1.f / ((float)n * (float)C);
-#define HFU(D_, CB_)                                                                                                  \
-  hipLaunchKernelGGL((k_head_fused<D_, CB_>), dim3(P), dim3(512), 0, st, n, S, C, X, bn_w, bn_b, save_mean, save_invstd, \
-                     Wout, bout, target, keep_scale, thresh, rng_state, inv_count, probs, w_loss, w_dym, w_part)
-  if (d == 128) { if (CP == 128) HFU(128, 8); else HFU(128, 16); }
-  else { if (CP == 128) HFU(256, 8); else HFU(256, 16); }
+  // label passes of at most 128 (k_head_fused): one launch per pass
+  for (int c0 = 0; c0 < C && (phases & 2); c0 += 128) {
+    const int Cp = C - c0 < 128 ? C - c0 : 128;
+    const int first = c0 == 0, last = c0 + 128 >= C;
+#define HFU(D_)                                                                                                        \
+    hipLaunchKernelGGL((k_head_fused<D_, 8>), dim3(P), dim3(512), 0, st, n, S, C, X, bn_w, bn_b, save_mean, save_invstd, \
+                       Wout, bout, target, keep_scale, thresh, rng_state, inv_count, probs, w_loss, w_dym, w_part, c0, Cp, \
+                       CP, first, last)
+    if (d == 128) HFU(128); else HFU(256);
 #undef HFU
-  if ((rc = launch_status())) return rc;
-  const int total = CP * d + CP + d;
-  const int slabs = (total + 63) / 64, wslabs = (CP * d + CP) / 64;  // CP is 128 or 256: the split is slab aligned
-  hipLaunchKernelGGL(k_head_train_finish, dim3(1 + slabs - wslabs), dim3(512), 0, st, wslabs, P, n, S, d, C, CP, w_part, w_bnc,
+    if ((rc = launch_status())) return rc;
+  }
+  if (!(phases & 4)) return CGCN_OK;
+  hipLaunchKernelGGL(k_head_train_finish, dim3(1 + d / HEAD_STAT_COLS), dim3(512), 0, st, P, n, S, d, CP, w_part, w_bnc,
                      w_loss, inv_count, loss);
   return launch_status();
+}
+
+extern "C" {
+
+int cgcn_head_train(cgcn_stream_t stream, int n, int S, int d, int C, const float* X, const float* bn_w,
+                    const float* bn_b, float* run_mean, float* run_var, long long* num_batches_tracked, float momentum,
+                    float eps, const float* Wout, const float* bout, const float* target, float dropout_p,
+                    const unsigned long long* rng_state, float* probs, float* loss, float* save_mean, float* save_invstd,
+                    const float* col_stats, int col_stats_tiles, int col_stats_rows, void* workspace,
+                    size_t workspace_bytes) {
+  return head_train_impl(stream, n, S, d, C, X, bn_w, bn_b, run_mean, run_var, num_batches_tracked, momentum, eps, Wout, bout,
+                         target, dropout_p, rng_state, probs, loss, save_mean, save_invstd, col_stats, col_stats_tiles,
+                         col_stats_rows, workspace, workspace_bytes, 7);
+}
+
+int cgcn_debug_head_train_phases(cgcn_stream_t stream, int n, int S, int d, int C, const float* X, const float* bn_w,
+                                 const float* bn_b, float* run_mean, float* run_var, long long* num_batches_tracked,
+                                 float momentum, float eps, const float* Wout, const float* bout, const float* target,
+                                 float dropout_p, const unsigned long long* rng_state, float* probs, float* loss,
+                                 float* save_mean, float* save_invstd, const float* col_stats, int col_stats_tiles,
+                                 int col_stats_rows, void* workspace, size_t workspace_bytes, int phases) {
+  if (phases < 1 || phases > 7) return CGCN_ERR_BAD_ARG;
+  return head_train_impl(stream, n, S, d, C, X, bn_w, bn_b, run_mean, run_var, num_batches_tracked, momentum, eps, Wout, bout,
+                         target, dropout_p, rng_state, probs, loss, save_mean, save_invstd, col_stats, col_stats_tiles,
+                         col_stats_rows, workspace, workspace_bytes, phases);
 }
 
 int cgcn_head_bwd(cgcn_stream_t stream, int n, int S, int d, int C, const float* X, const float* bn_w,
@@ -1244,18 +1318,20 @@ int cgcn_head_bwd(cgcn_stream_t stream, int n, int S, int d, int C, const float*
   const int CP = head_cp(C);
   const float keep_scale = drop ? 1.f / (1.f - dropout_p) : 1.f;
   const uint32_t thresh = drop ? dropout_threshold(dropout_p) : 0u;
-#define HB(D_, CB_)                                                                                                   \
-  hipLaunchKernelGGL((k_head_bwd<D_, CB_>), dim3(P), dim3(512), 0, st, n, S, C, X, bn_w, bn_b, save_mean, save_invstd, Wout, \
-                     dpred, dloss, keep_scale, thresh, rng_state, w_dym, w_part)
   if (!fused) {
-    if (d == 128) { if (CP == 128) HB(128, 8); else HB(128, 16); }
-    else { if (CP == 128) HB(256, 8); else HB(256, 16); }
-  }
+    for (int c0 = 0; c0 < C; c0 += 128) {   // label passes of at most 128 (k_head_bwd)
+      const int Cp = C - c0 < 128 ? C - c0 : 128;
+      const int first = c0 == 0, last = c0 + 128 >= C;
+#define HB(D_)                                                                                                         \
+      hipLaunchKernelGGL((k_head_bwd<D_, 8>), dim3(P), dim3(512), 0, st, n, S, C, X, bn_w, bn_b, save_mean, save_invstd, \
+                         Wout, dpred, dloss, keep_scale, thresh, rng_state, w_dym, w_part, c0, Cp, CP, first, last)
+      if (d == 128) HB(128); else HB(256);
 #undef HB
-  if ((rc = launch_status())) return rc;
+      if ((rc = launch_status())) return rc;
+    }
+  }
   const float* fin_scale = fused ? dloss : nullptr;  // the unfused kernel already multiplied dpred by d loss
-  const int total = CP * d + CP + d;
-  const int slabs = (total + 63) / 64, wslabs = (CP * d + CP) / 64;  // CP is 128 or 256: the split is slab aligned
+  const int wslabs = (CP * d + CP) / 64, sblocks = d / HEAD_STAT_COLS;  // CP is 128 or 256: slab aligned
   if (fused) {
     // cgcn_head_train left dym, bnc (for d loss = 1) and the partials; every remaining sum -- dW_out, db_out, d(bn
     // weight), d(bn bias) -- rides in k_bwd_rowlocal's extra workgroups (cgcn_head_grad.part / dW_out / db_out /
@@ -1265,12 +1341,12 @@ int cgcn_head_bwd(cgcn_stream_t stream, int n, int S, int d, int C, const float*
   if (!dX) {
     // deferred mode: only the BatchNorm columns now (cgcn_layer_bwd needs bnc); the dW_out / db_out slabs ride at the
     // end of k_bwd_rowlocal's grid (cgcn_head_grad.part / dW_out / db_out)
-    hipLaunchKernelGGL(k_head_bwd_finalize, dim3(slabs - wslabs), dim3(512), 0, st, wslabs, P, n, S, d, C, CP, w_part, dWout,
+    hipLaunchKernelGGL(k_head_bwd_finalize, dim3(sblocks), dim3(512), 0, st, 0, 0, P, n, S, d, C, CP, w_part, dWout,
                        dbout, dbn_w, dbn_b, w_bnc, accumulate, fin_scale);
     return launch_status();
   }
-  hipLaunchKernelGGL(k_head_bwd_finalize, dim3(slabs), dim3(512), 0, st, 0, P, n, S, d, C, CP, w_part, dWout, dbout,
-                     dbn_w, dbn_b, w_bnc, accumulate, fin_scale);
+  hipLaunchKernelGGL(k_head_bwd_finalize, dim3(wslabs + sblocks), dim3(512), 0, st, 0, wslabs, P, n, S, d, C, CP, w_part,
+                     dWout, dbout, dbn_w, dbn_b, w_bnc, accumulate, fin_scale);
   if ((rc = launch_status())) return rc;
   const size_t total4 = (size_t)S * n * d / 4;
   int blocks = (int)((total4 + 255) / 256);

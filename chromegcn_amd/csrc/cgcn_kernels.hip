@@ -859,8 +859,13 @@ __global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, i
   // fused "horizontally" so it costs no launch of its own)
   if ((int)blockIdx.x >= row_blocks) {
     const int extra = (int)blockIdx.x - row_blocks;
-    head_finalize_slab<NW * 64>(extra, hp.hf_P, n, hp.S, D, hp.hf_C, hp.hf_CP, hp.hf_part, hp.hf_dWout,
-                                hp.hf_dbout, hp.hf_dbn_w, hp.hf_dbn_b, nullptr, hp.hf_accumulate, hp.dloss);
+    const int wslabs = (hp.hf_CP * D + hp.hf_CP) / 64;   // CP is 128 or 256: slab aligned
+    if (extra < wslabs)
+      head_finalize_slab<NW * 64>(extra, hp.hf_P, D, hp.hf_C, hp.hf_CP, hp.hf_part, hp.hf_dWout, hp.hf_dbout,
+                                  hp.hf_accumulate, hp.dloss);
+    else   // BatchNorm weight / bias gradients: float64 second stage of the column sums
+      head_stats_finalize<NW * 64>(extra - wslabs, hp.hf_P, n, hp.S, D, hp.hf_CP, hp.hf_part, hp.hf_dbn_w, hp.hf_dbn_b,
+                                   nullptr, hp.hf_accumulate, hp.dloss);
     return;
   }
   KT_STAMP(0);
@@ -1735,12 +1740,16 @@ size_t cgcn_layer_bwd_workspace_bytes(int n, int S, int d) {
   return (size_t)bwd_partials(n, S, d) * ((size_t)d * d + 2 * d + 4) * sizeof(float);
 }
 
-int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* rowptr_t, const int32_t* col_t,
-                   const float* val_t, const float* row_scale, const float* X, const float* Z, const float* H,
-                   const float* gate, const float* W, const float* wg, const float* dXn, const float* dgate, float* dX,
-                   float* dHs, float* dW, float* db, float* dwg, float* dcg, int accumulate, float in_dropout_p,
-                   const unsigned long long* rng_state, unsigned int in_stream_id, const cgcn_head_grad* head,
-                   void* workspace, size_t workspace_bytes, cgcn_stream_t aux_stream, const cgcn_sgd_fuse* sgd) {
+// phases: bit 0 = the row-local launch (k_bwd_rowlocal, + k_dh_dense at d = 256), bit 1 = the launch that follows it
+// (k_bwd_sliced with the second-stage sums / the optimizer step in its trailing workgroups, or k_reduce_partials).
+// cgcn_layer_bwd runs both; cgcn_debug_layer_bwd_phases lets a profiler time them one at a time.
+static int layer_bwd_impl(cgcn_stream_t stream, int n, int S, int d, const int32_t* rowptr_t, const int32_t* col_t,
+                          const float* val_t, const float* row_scale, const float* X, const float* Z, const float* H,
+                          const float* gate, const float* W, const float* wg, const float* dXn, const float* dgate, float* dX,
+                          float* dHs, float* dW, float* db, float* dwg, float* dcg, int accumulate, float in_dropout_p,
+                          const unsigned long long* rng_state, unsigned int in_stream_id, const cgcn_head_grad* head,
+                          void* workspace, size_t workspace_bytes, cgcn_stream_t aux_stream, const cgcn_sgd_fuse* sgd,
+                          int phases) {
   int rc = check_shape(n, S, d);
   if (rc) return rc;
   if (!rowptr_t || !col_t || !X || !Z || !H || !gate || !W || !wg || !dW || !db || !dwg || !dcg) return CGCN_ERR_BAD_ARG;
@@ -1778,7 +1787,7 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
                    head->dbn_w, head->dbn_b};
     if ((head->dbn_w == nullptr) != (head->dbn_b == nullptr)) return CGCN_ERR_BAD_ARG;
     // dW_out / db_out slabs, plus the BatchNorm-column slabs when their parameter gradients are still to be summed
-    head_slabs = head->dbn_w ? (CP * d + CP + d + 63) / 64 : (CP * d + CP) / 64;
+    head_slabs = (CP * d + CP) / 64 + (head->dbn_w ? d / HEAD_STAT_COLS : 0);
   }
   if (!workspace || workspace_bytes < cgcn_layer_bwd_workspace_bytes(n, S, d)) return CGCN_ERR_WORKSPACE;
   if (misaligned16(workspace)) return CGCN_ERR_BAD_ARG;
@@ -1789,18 +1798,21 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   const int P = bwd_partials(n, S, d);
   float* part = (float*)workspace;
   const int M = n * S;
-  if (d == 128 && bwd_tile_rows(n, S, d) == 48)
+  if (!(phases & 1)) {
+    // profiling only: the partials / dHs / dL/dXn of an earlier full call are still in place
+  } else if (d == 128 && bwd_tile_rows(n, S, d) == 48)
     hipLaunchKernelGGL((k_bwd_rowlocal<128, 48>), dim3(P + head_slabs), dim3(1024), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, P, head_slabs, W);
   else if (d == 128)
     hipLaunchKernelGGL((k_bwd_rowlocal<128, 32>), dim3(P + head_slabs), dim3(1024), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, P, head_slabs, W);
   else
     hipLaunchKernelGGL((k_bwd_rowlocal<256, 32>), dim3(P + head_slabs), dim3(512), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, P, head_slabs, W);
   if ((rc = launch_status())) return rc;
-  if (d == 256 && dHs && M > 0) {   // dHs = (diag(row_scale) dU) W^T: d = 128 did it inside the row-local kernel
+  if ((phases & 1) && d == 256 && dHs && M > 0) {   // dHs = (diag(row_scale) dU) W^T: d = 128 did it inside the row-local kernel
     const int dh_tiles = (M + 16 * DH_MB - 1) / (16 * DH_MB);
     hipLaunchKernelGGL((k_dh_dense<256>), dim3(dh_tiles < 256 ? dh_tiles : 256), dim3(512), 0, st, M, dHs, W);
     if ((rc = launch_status())) return rc;
   }
+  if (!(phases & 2)) return CGCN_OK;
   // The reduction of the per-tile partials and the gather kernel are independent: with an auxiliary stream
   // they run side by side (fork after k_bwd_rowlocal, join before returning; both edges are events, so the
   // fork/join is captured as graph dependencies under HIP-graph capture).
@@ -1840,6 +1852,29 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   if ((rc = launch_status())) return rc;
   if (rs_stream != st && hipStreamWaitEvent(st, ev_join, 0) != hipSuccess) return CGCN_ERR_LAUNCH;  // join
   return CGCN_OK;
+}
+
+int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* rowptr_t, const int32_t* col_t,
+                   const float* val_t, const float* row_scale, const float* X, const float* Z, const float* H,
+                   const float* gate, const float* W, const float* wg, const float* dXn, const float* dgate, float* dX,
+                   float* dHs, float* dW, float* db, float* dwg, float* dcg, int accumulate, float in_dropout_p,
+                   const unsigned long long* rng_state, unsigned int in_stream_id, const cgcn_head_grad* head,
+                   void* workspace, size_t workspace_bytes, cgcn_stream_t aux_stream, const cgcn_sgd_fuse* sgd) {
+  return layer_bwd_impl(stream, n, S, d, rowptr_t, col_t, val_t, row_scale, X, Z, H, gate, W, wg, dXn, dgate, dX, dHs, dW, db,
+                        dwg, dcg, accumulate, in_dropout_p, rng_state, in_stream_id, head, workspace, workspace_bytes,
+                        aux_stream, sgd, 3);
+}
+
+int cgcn_debug_layer_bwd_phases(cgcn_stream_t stream, int n, int S, int d, const int32_t* rowptr_t, const int32_t* col_t,
+                                const float* val_t, const float* row_scale, const float* X, const float* Z, const float* H,
+                                const float* gate, const float* W, const float* wg, const float* dXn, const float* dgate,
+                                float* dX, float* dHs, float* dW, float* db, float* dwg, float* dcg, int accumulate,
+                                float in_dropout_p, const unsigned long long* rng_state, unsigned int in_stream_id,
+                                const cgcn_head_grad* head, void* workspace, size_t workspace_bytes, int phases) {
+  if (phases < 1 || phases > 3) return CGCN_ERR_BAD_ARG;
+  return layer_bwd_impl(stream, n, S, d, rowptr_t, col_t, val_t, row_scale, X, Z, H, gate, W, wg, dXn, dgate, dX, dHs, dW, db,
+                        dwg, dcg, accumulate, in_dropout_p, rng_state, in_stream_id, head, workspace, workspace_bytes,
+                        nullptr, nullptr, phases);
 }
 
 int cgcn_sddmm(cgcn_stream_t stream, int n, int S, int d, const int32_t* rowptr, const int32_t* col, const float* A,

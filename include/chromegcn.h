@@ -48,7 +48,7 @@ extern "C" {
 #define CGCN_ERR_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after a launch      */
 #define CGCN_ERR_WORKSPACE (-4)   /* workspace too small (see cgcn_*_workspace_bytes)    */
 
-#define CGCN_ABI_VERSION 14
+#define CGCN_ABI_VERSION 15
 
 typedef void *cgcn_stream_t; /* hipStream_t */
 
@@ -196,6 +196,22 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d,
                    void *workspace, size_t workspace_bytes, cgcn_stream_t aux_stream,
                    const cgcn_sgd_fuse *sgd);
 
+/*
+ * Profiling hook: cgcn_layer_bwd one launch group at a time, so that each kernel can be bracketed with events on the
+ * caller's stream (bench.py's per-kernel roofline).  phases: bit 0 = the row-local launch (k_bwd_rowlocal; + k_dh_dense
+ * at d = 256), bit 1 = the launch after it (k_bwd_sliced with the second-stage sums, or k_reduce_partials when dX ==
+ * NULL).  phases == 3 is cgcn_layer_bwd without aux_stream / sgd.  A phase-2-only call works on the partials, dHs and
+ * (head mode) dL/dXn an earlier phase-1 call left in workspace / dHs / dX.  Stateless like everything else here.
+ */
+int cgcn_debug_layer_bwd_phases(cgcn_stream_t stream, int n, int S, int d,
+                                const int32_t *rowptr_t, const int32_t *col_t, const float *val_t, const float *row_scale,
+                                const float *X, const float *Z, const float *H, const float *gate,
+                                const float *W, const float *wg, const float *dXn, const float *dgate,
+                                float *dX, float *dHs, float *dW, float *db, float *dwg, float *dcg,
+                                int accumulate, float in_dropout_p, const unsigned long long *rng_state,
+                                unsigned int in_stream_id, const cgcn_head_grad *head,
+                                void *workspace, size_t workspace_bytes, int phases);
+
 /* Bytes of scratch cgcn_head_fwd / cgcn_head_bwd need for (n, S, d, C).  0 on unsupported shapes. */
 size_t cgcn_head_workspace_bytes(int n, int S, int d, int C);
 
@@ -212,7 +228,8 @@ int cgcn_head_bwd_partials(int n);
  *     pred  = mean_s (y_s W_out^T + b_out)        computed as (mean_s y_s) W_out^T + b_out
  *     loss  = mean over n*C of BCE-with-logits(pred, target);   probs = sigmoid(pred)
  * X: [S,n,d].  bn_w, bn_b, run_mean, run_var: [d]; num_batches_tracked: int64[1] or NULL.  W_out: [C,d],
- * b_out: [C], target: [n,C] (0/1 floats).  C <= 256.
+ * b_out: [C], target: [n,C] (0/1 floats).  C <= 256 (the reference takes C from the data, main.py:35; the training
+ * kernels walk the labels in passes of 128).
  * training != 0: batch statistics, running statistics updated once per strand in strand order (what two
  *   successive ChromeGCN.forward calls do), num_batches_tracked += S, dropout with probability dropout_p
  *   driven by rng_state (see Conventions; the head uses its own fixed stream id).  Outputs
@@ -244,6 +261,18 @@ int cgcn_head_train(cgcn_stream_t stream, int n, int S, int d, int C, const floa
                     float dropout_p, const unsigned long long *rng_state, float *probs, float *loss,
                     float *save_mean, float *save_invstd, const float *col_stats, int col_stats_tiles,
                     int col_stats_rows, void *workspace, size_t workspace_bytes);
+
+/*
+ * Profiling hook: cgcn_head_train one launch group at a time.  phases: bit 0 = batch statistics (k_head_colstats unless
+ * col_stats is given, k_head_bn_finalize -- this one updates the running statistics), bit 1 = k_head_fused (one launch
+ * per pass of <= 128 labels), bit 2 = k_head_train_finish.  phases == 7 is cgcn_head_train.
+ */
+int cgcn_debug_head_train_phases(cgcn_stream_t stream, int n, int S, int d, int C, const float *X, const float *bn_w,
+                                 const float *bn_b, float *run_mean, float *run_var, long long *num_batches_tracked,
+                                 float momentum, float eps, const float *W_out, const float *b_out, const float *target,
+                                 float dropout_p, const unsigned long long *rng_state, float *probs, float *loss,
+                                 float *save_mean, float *save_invstd, const float *col_stats, int col_stats_tiles,
+                                 int col_stats_rows, void *workspace, size_t workspace_bytes, int phases);
 
 /*
  * Backward of cgcn_head_fwd (training mode).  dloss: [1] upstream gradient of the loss or NULL (= 1).

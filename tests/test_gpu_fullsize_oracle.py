@@ -10,15 +10,20 @@ at BASELINE.json's shapes:
   k562      n =  5 776, d = 256, L = 4         (configs[3]; beyond the reference -- its constructor builds 1 or 2 layers --
                                                 so the oracle is the restatement rule "repeat models/ChromeModels.py:42-46")
 
+  chr21_C164 / chr21_C256 / d256_C256: the same chr21-size step with 164 and 256 labels (the reference takes C from the
+                data, main.py:35): the training head walks labels in passes of 128 (cgcn_head_train), so these are the
+                only cases in which a second pass accumulates dym and the 256-row partial layout is used.
+
 Checked per step: loss, sigmoid(pred), every parameter gradient, d loss / d features of both strands, the parameters
 after the SGD step, BatchNorm running statistics.  Tolerance: fp32 atol = rtol = 1e-4 (north star) on every tensor
 against the fp32 oracle, AND -- because gradients of a mean-reduced loss are ~1e-6 and pass any absolute 1e-4 -- the
 SCALE-RELATIVE error max|hip - truth| / max|truth| of every gradient, where truth is the same oracle step run in
-float64.  Bound: 1e-4 -- measured 1e-7 ... 5e-5 on every tensor but one kind: the gate-bias gradients `W*.bias` (a
-single scalar each: the sum of ~10^4-10^5 signed per-row terms that cancel to a few percent of their absolute sum)
-come out at 1e-5 ... 2.3e-4, where the fp32 ORACLE itself is 5e-6 ... 9e-5 off the float64 truth; for the bias-type
-sums (`GC*.bias`, `W*.bias`) the bound is therefore stated explicitly as 1e-3.  All measured figures (HIP and fp32
-oracle, side by side) are printed."""
+float64.  Bound: 1e-4 for EVERY tensor, the gate-bias gradients `W*.bias` included.  Those are single scalars -- the
+sum of ~10^4-10^5 signed per-row terms that cancel to 0.17 % of their absolute sum -- and they amplify any error that is
+COHERENT over the rows by 600x: round 2's fp32 BatchNorm-backward column means (per-column constants in every row's
+dL/dXn) put dW2.bias at 2.2e-4; the float64 second stage of those sums (cgcn_common.hpp, head_stats_finalize) is what
+keeps it below the fp32 oracle's own error now (tools/bias_sum_probe.py separates the stages).  All measured figures
+(HIP and fp32 oracle, side by side) are printed."""
 import numpy as np
 import pytest
 import torch
@@ -31,21 +36,26 @@ from oracle import chromegcn_oracle as O
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 D, NC = 128, 103
-CASES = [   # name, n, pairs, hic_like, adj_type, seed, d, layers
-    ("config1", 5000, 125000, False, "hic", 0, 128, 2),
-    ("chr21", synth.chrom_nodes("chr21"), 250000, False, "hic", 21, 128, 2),
-    ("chr1", synth.chrom_nodes("chr1"), 250000, True, "hic", 1, 128, 2),
-    ("both13k", 13000, 60000, True, "both", 7, 128, 2),
-    ("k562_d256_L4", synth.chrom_nodes("chr21"), 250000, False, "hic", 33, 256, 4),
+CASES = [   # name, n, pairs, hic_like, adj_type, seed, d, layers, labels
+    ("config1", 5000, 125000, False, "hic", 0, 128, 2, NC),
+    ("chr21", synth.chrom_nodes("chr21"), 250000, False, "hic", 21, 128, 2, NC),
+    ("chr1", synth.chrom_nodes("chr1"), 250000, True, "hic", 1, 128, 2, NC),
+    ("both13k", 13000, 60000, True, "both", 7, 128, 2, NC),
+    ("k562_d256_L4", synth.chrom_nodes("chr21"), 250000, False, "hic", 33, 256, 4, NC),
     # config 1 again with the forward's two-launch route forced (feature-sliced aggregation + row-local kernel, column
     # statistics merged over 2 tiles per workgroup): the route chr1 / both13k take by size, at a table that fits the L2s
-    ("config1_forced_split", 5000, 125000, False, "hic", 0, 128, 2),
+    ("config1_forced_split", 5000, 125000, False, "hic", 0, 128, 2, NC),
+    # more than 128 labels: two label passes of the fused head, 256-row partial records
+    ("chr21_C164", synth.chrom_nodes("chr21"), 250000, False, "hic", 22, 128, 2, 164),
+    ("chr21_C256", synth.chrom_nodes("chr21"), 250000, False, "hic", 23, 128, 2, 256),
+    ("d256_C256", synth.chrom_nodes("chr21"), 250000, False, "hic", 24, 256, 2, 256),
+    ("chr1_C129", synth.chrom_nodes("chr1"), 250000, False, "hic", 25, 128, 2, 129),
 ]
 
 
-def _scaled_oracle(seed, d=D, layers=2):
+def _scaled_oracle(seed, d=D, layers=2, labels=NC):
     torch.manual_seed(seed)
-    orc = O.GatedGCNOracle(d, NC, 0.0, layers)
+    orc = O.GatedGCNOracle(d, labels, 0.0, layers)
     with torch.no_grad():  # the reference init (gain 0.02) leaves tanh / gates in their linear range: scale up
         for k in range(1, layers + 1):
             getattr(orc, "GC%d" % k).weight.mul_(40 * (128.0 / d) ** 0.5)
@@ -60,20 +70,20 @@ def _rel(a, b):
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_train_steps_match_oracle_at_full_size(case):
-    name, n, pairs, hic_like, adj_type, seed, d, layers = case
+    name, n, pairs, hic_like, adj_type, seed, d, layers, labels = case
     from chromegcn_amd import _lib
     _lib.load().cgcn_debug_set_fwd_split_bytes(0 if name.endswith("forced_split") else -1)
     try:
-        _train_steps_case(name, n, pairs, hic_like, adj_type, seed, d, layers)
+        _train_steps_case(name, n, pairs, hic_like, adj_type, seed, d, layers, labels)
     finally:
         _lib.load().cgcn_debug_set_fwd_split_bytes(-1)
 
 
-def _train_steps_case(name, n, pairs, hic_like, adj_type, seed, d, layers):
-    feats = synth.chrom_features(n, d, NC, 1000 + seed)
+def _train_steps_case(name, n, pairs, hic_like, adj_type, seed, d, layers, labels):
+    feats = synth.chrom_features(n, d, labels, 1000 + seed)
     hic = synth.contact_graph(n, pairs, seed, hic_like)
-    orc = _scaled_oracle(seed, d, layers)
-    model = C.ChromeGCN(d, d, NC, 0.0, True, layers)
+    orc = _scaled_oracle(seed, d, layers, labels)
+    model = C.ChromeGCN(d, d, labels, 0.0, True, layers)
     model.load_state_dict(orc.state_dict())
     model.to(DEV)
     opt = torch.optim.SGD(model.parameters(), lr=0.25, momentum=0.9, weight_decay=1e-6)
@@ -118,15 +128,13 @@ def _train_steps_case(name, n, pairs, hic_like, adj_type, seed, d, layers):
     print("\n[%s] scale-relative max error vs the float64 oracle: HIP / fp32 oracle" % name)
     for k in sorted(worst):
         print("   %-22s %.2e / %.2e" % (k, worst[k], worst32[k]))
-    def bound(k):   # ill-conditioned scalar / column sums over all rows: explicit, looser bound (see the module docstring)
-        return 1e-3 if (k.endswith(".bias") and (k.startswith("dGC") or k.startswith("dW"))) else 1e-4
-    bad = {k: (v, worst32[k]) for k, v in worst.items() if v > bound(k)}
-    assert not bad, "scale-relative gradient error above its bound (1e-4; 1e-3 for the layer bias sums): %s" % bad
+    bad = {k: (v, worst32[k]) for k, v in worst.items() if v > 1e-4}
+    assert not bad, "scale-relative gradient error above 1e-4 (HIP, fp32 oracle): %s" % bad
 
 
 def test_eval_forward_matches_oracle_at_chr1_size():
     """inference path (eval-mode BatchNorm, no dropout) through the DEEP gather kernels"""
-    name, n, pairs, hic_like, adj_type, seed, _d, _layers = CASES[2]
+    name, n, pairs, hic_like, adj_type, seed, _d, _layers, _labels = CASES[2]
     feats = synth.chrom_features(n, D, NC, 1000 + seed)
     hic = synth.contact_graph(n, pairs, seed, hic_like)
     orc = _scaled_oracle(seed)
