@@ -1024,6 +1024,409 @@ __global__ __launch_bounds__(512, HF_LOWREG ? 4 : 1) void k_head_fused(int n, in
   HF_STAMP(12);
 }
 
+// ------------------------------------------------------------------------------------------
+// k_head_fused_rs (D = 128): k_head_fused as ONE 16-wave workgroup per CU with the waves split into two ROLES that
+// work on consecutive tiles at the same time, so that the vector work of one tile (BatchNorm rows, sigmoid / BCE
+// epilogue) runs under the matrix products of the other instead of between them.  k_head_fused (8 waves, 222 VGPRs,
+// one workgroup per CU) spent 13 us per 32-node tile of which 4.5 us are the three fp32 products' floor.
+//   P waves 0-7  ("pred"): X rows + targets of tile t -> ym rows -> Yt[t & 1];  pred = ym W_out^T (wave w: label block w);
+//                 sigmoid / BCE / probs;  d loss / d pred -> Pt[t & 1];  db_out.
+//   Q waves 8-15 ("grad"): one tile behind:  dW_out += Pt^T Yt (wave w: feature columns 16 (w-8) .., all label blocks:
+//                 28-32 accumulator registers);  dym = Pt W_out written straight from the accumulators;  the
+//                 BatchNorm-backward column sums from the accumulator layout (a lane owns ONE column: no cross-wave
+//                 merge), X re-read in that layout (L2 hits).
+// Period k, three sub-phases, in each of which one team is on the matrix pipe and the other on the vector pipe:
+//     S1:  P  ym(tile k) -> Yt            (vector)   |  Q  dym product of tile k-1              (matrix)
+//     S2:  P  pred product of tile k      (matrix)   |  Q  dym out, BatchNorm sums of tile k-1  (vector)
+//     S3:  P  sigmoid / BCE -> Pt, probs  (vector)   |  Q  dW_out product of tile k-1           (matrix)
+// (with both teams' products in one phase and both epilogues in the next, the first version of this kernel ran at the
+// 8-wave kernel's speed: the matrix phases contended, the vector phases did not overlap anything)
+// W_out (this pass's <= 128 label rows) sits in LDS for the whole launch and feeds the B operands of both products
+// that use it: 16 waves share ONE copy instead of holding 64 KB of fragments in registers, which is what lets both roles
+// stay under 128 registers (the roles' persistent state -- P: X rows, targets, BatchNorm constants; Q: dW_out
+// accumulators -- lives in the SAME 40 registers).  LDS: W_out 72 KB + two Yt + two Pt tiles 73 KB.
+// Same partial records, label passes and results as k_head_fused.
+// ------------------------------------------------------------------------------------------
+#ifndef HEAD_RS
+#define HEAD_RS 1   // 0: the 8-wave k_head_fused at d = 128 as well (A/B builds)
+#endif
+#ifdef RS_TIMING  // tuning build only (tools/khead_train.py --stamps): phase timestamps of period RS_STAMP_K of a few workgroups
+__device__ unsigned long long rs_stamps[8 * 2 * 8];
+#ifndef RS_STAMP_K
+#define RS_STAMP_K 1
+#endif
+#define RS_STAMP(i)                                                                                        \
+  do {                                                                                                     \
+    __builtin_amdgcn_s_waitcnt(0);                                                                         \
+    if (k == RS_STAMP_K && (threadIdx.x == 0 || threadIdx.x == 512) && (blockIdx.x & 31) == 0)             \
+      rs_stamps[((blockIdx.x >> 5) * 2 + (threadIdx.x >> 9)) * 8 + (i)] = wall_clock64();                  \
+  } while (0)
+extern "C" int cgcn_debug_rs_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(rs_stamps), sizeof(unsigned long long) * 8 * 2 * 8) == hipSuccess ? 0 : -1;
+}
+#else
+#define RS_STAMP(i)
+#endif
+// MULTI: more than one label pass (C > 128): a pass adds the earlier passes' dym; only the last takes the column sums.
+// NB: 16-label blocks the two backward products walk (7 when the pass has 97..112 labels -- C = 103 --, else 8; blocks
+// past the pass's labels hold zeros in Pt / W_out's LDS copy, so walking them is only wasted work).  A compile-time
+// count keeps the product loops free of branches: with `if (ib < CB)` inside them every MFMA sat behind its own
+// ds_read + lgkmcnt(0).
+template <bool MULTI, int NB, bool DROP>
+__global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, const float* __restrict__ X,
+                                                        const float* __restrict__ bn_w, const float* __restrict__ bn_b,
+                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                        const float* __restrict__ Wout, const float* __restrict__ bout,
+                                                        const float* __restrict__ target, float keep_scale, uint32_t thresh,
+                                                        const unsigned long long* __restrict__ rng_state, float inv_count,
+                                                        float* __restrict__ probs, float* __restrict__ loss_part,
+                                                        float* __restrict__ dym, float* __restrict__ part,
+                                                        int c0, int Cp, int CPT, int first_, int last_) {
+  constexpr int D = 128, TR = HEADB_TILE, EPL = 2, RPW = TR / 8, KQ = D / 4;
+  constexpr int CP = 128, CBMAX = 8;
+  constexpr int LDP = CP + 18, LDY = D + 16, LDW = D + 16;
+  __shared__ __attribute__((aligned(16))) float Wl[NB * 16 * LDW];   // W_out rows c0 .. c0 + 16 NB (zeros past Cp)
+  __shared__ __attribute__((aligned(16))) float Pt[2][TR * LDP];
+  __shared__ __attribute__((aligned(16))) float Yt[2][TR * LDY];
+  __shared__ float lsum[8];
+  const bool first = MULTI ? first_ != 0 : true, last = MULTI ? last_ != 0 : true;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int own = wave & 7;            // P: label block;  Q: 16-column block of D
+  const uint32_t key = DROP ? dropout_key(rng_state, HEAD_STREAM_ID) : 0u;
+  const float invS = 1.f / (float)S;
+  const bool S2 = S > 1;
+  const int PS = head_part_stride(CPT, D);
+  const int ntiles = (n + TR - 1) / TR;
+  const int G = (int)gridDim.x;
+  const int mt = (int)blockIdx.x < ntiles ? (ntiles - 1 - (int)blockIdx.x) / G + 1 : 0;   // tiles of this workgroup
+  float* P = part + (size_t)blockIdx.x * PS;
+
+  // ---- W_out -> LDS (all 16 waves, 16-byte pieces)
+  for (int idx = threadIdx.x; idx < NB * 16 * (D / 4); idx += 1024) {
+    const int j = idx / (D / 4), c4 = idx % (D / 4);
+    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (j < Cp) v = *(const f32x4*)&Wout[(size_t)(c0 + j) * D + c4 * 4];
+    *(f32x4*)&Wl[j * LDW + c4 * 4] = v;
+  }
+  // The two roles run SEPARATE loops (the register allocator then sees each role's state on its own path) that execute
+  // the same number of workgroup barriers: one before and one after the loop, three per period.
+  // In every role phase the lane-derived indices are re-derived from an opaque copy of the lane id: addresses kept live
+  // across the whole tile loop were what the allocator spilled, and every reload of one is a vmcnt(0) wait.
+#define OPAQUE_LANE(r_, q_, l_)          \
+  int l_ = lane;                         \
+  asm volatile("" : "+v"(l_));           \
+  const int r_ = l_ & 15, q_ = l_ >> 4
+
+  if (wave < 8) {
+    // =============================================================== P: pred team
+    float xv[RPW][2][EPL], tgv[2][4], mu[2][EPL], is[2][EPL], gw[EPL], gb[EPL];
+    float dbo = 0.f, lacc = 0.f;
+    const float bj = own * 16 + (lane & 15) < Cp ? bout[c0 + own * 16 + (lane & 15)] : 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      const int c = lane * EPL + e;
+      gw[e] = bn_w[c];
+      gb[e] = bn_b[c];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        mu[s][e] = mean[(s < S ? s : 0) * D + c];
+        is[s][e] = invstd[(s < S ? s : 0) * D + c];
+      }
+    }
+    // this wave's X rows of a tile are requested one tile ahead (at the top of phase B of the tile before: in flight
+    // during its pred product and epilogue); the targets of this lane's logits at the end of that phase B
+    auto load_rows = [&](int tile) {
+      const int node0 = tile * TR;
+#pragma unroll
+      for (int t = 0; t < RPW; ++t) {
+        const int i = node0 + own + t * 8;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          if (i < n && s < S) ld_row<EPL>(xv[t][s], &X[(unsigned)((s * n + i) * D + lane * EPL)]);
+          else zero_row<EPL>(xv[t][s]);
+        }
+      }
+    };
+    auto load_targets = [&](int tile) {
+      const int node0 = tile * TR;
+      const int j = own * 16 + (lane & 15), q = lane >> 4;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = node0 + mb * 16 + q * 4 + e;
+          tgv[mb][e] = (i < n && j < Cp) ? target[(unsigned)(i * C + c0 + j)] : 0.f;
+        }
+    };
+    if (mt > 0) {
+      load_rows(blockIdx.x);
+      load_targets(blockIdx.x);
+    }
+    __syncthreads();   // Wl complete
+    for (int k = 0; k <= mt; ++k) {
+      const int tile = (int)blockIdx.x + k * G;
+      const int node0 = tile * TR;
+      // ---- S1: ym rows of tile k -> Yt[k & 1]                                  (vector work; Q: dym product)
+      RS_STAMP(0);
+      if (k < mt) {
+        int lane_ = lane;
+        asm volatile("" : "+v"(lane_));
+        float* __restrict__ Yb = Yt[k & 1];
+        // (branch-free per element: with a branch per bound / strand / dropout test every element was its own serial
+        // chain -- 2.5 us for 16 elements a lane; rows past n were loaded as zeros and are zeroed again below)
+#pragma unroll
+        for (int t = 0; t < RPW; ++t) {
+          const int rr = own + t * 8;
+          const int i = node0 + rr;
+          f32x2 ym;
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) {
+            float y[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+              y[s] = (fmaxf(xv[t][s][e], 0.f) - mu[s][e]) * is[s][e] * gw[e] + gb[e];
+              if (DROP) y[s] = dropout_keep(key, (uint32_t)((s * n + i) * D + lane_ * EPL + e), thresh) ? y[s] * keep_scale : 0.f;
+            }
+            const float a = y[0] + (S2 ? y[1] : 0.f);
+            ym[e] = i < n ? a * invS : 0.f;
+          }
+          *(f32x2*)&Yb[rr * LDY + lane_ * EPL] = ym;
+        }
+      }
+      RS_STAMP(1);
+      __syncthreads();
+      // ---- S2: pred = ym W_out^T (M = 32 rows, K = D permuted, N = this wave's label block)   (matrix; Q: its epilogue)
+      RS_STAMP(2);
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      if (k < mt) {
+        if (k + 1 < mt) load_rows(tile + G);   // the rows were consumed in S1
+        if (own < NB) {
+          OPAQUE_LANE(r, q, lq);
+          const float* __restrict__ Ya = Yt[k & 1] + r * LDY + 4 * q;
+          const float* __restrict__ Wa = Wl + (own * 16 + r) * LDW + 4 * q;
+#pragma unroll
+          for (int t = 0; t < KQ / 4; ++t) {
+            const f32x4 a0 = *(const f32x4*)&Ya[16 * t], a1 = *(const f32x4*)&Ya[16 * LDY + 16 * t];
+            const f32x4 b = *(const f32x4*)&Wa[16 * t];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], b[u], acc[0], 0, 0, 0);
+              acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u], b[u], acc[1], 0, 0, 0);
+            }
+          }
+        }
+      }
+      RS_STAMP(3);
+      __syncthreads();
+      // ---- S3: sigmoid / BCE / probs; d loss / d pred -> Pt[k & 1] (zero outside the valid region)   (vector; Q: dW_out product)
+      RS_STAMP(4);
+      if (k < mt) {
+        float* __restrict__ Pb = Pt[k & 1];
+        OPAQUE_LANE(r, q, lq);
+        const int j = own * 16 + r;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {   // branch-free but for the predicated store (see S1)
+            const int row = mb * 16 + q * 4 + e;
+            const int i = node0 + row;
+            const bool ok = i < n && j < Cp;
+            const float pred = acc[mb][e] + bj;
+            const float en = __expf(-fabsf(pred));
+            const float inv = __builtin_amdgcn_rcpf(1.f + en);   // 1 ulp; the IEEE division is ten instructions
+            const float p = pred >= 0.f ? inv : en * inv;
+            const float l = fmaxf(pred, 0.f) - pred * tgv[mb][e] + __logf(1.f + en);
+            lacc += ok ? l : 0.f;
+            if (ok) probs[(unsigned)(i * C + c0 + j)] = p;
+            const float dp = ok ? (p - tgv[mb][e]) * inv_count : 0.f;
+            dbo += dp;
+            Pb[row * LDP + j] = dp;
+          }
+        if (k + 1 < mt) load_targets(tile + G);
+      }
+      RS_STAMP(5);
+      __syncthreads();
+    }
+    // ---- db_out share and the loss share of this workgroup
+    dbo += __shfl_xor(dbo, 16);
+    dbo += __shfl_xor(dbo, 32);
+    if ((lane >> 4) == 0 && c0 + own * 16 + (lane & 15) < CPT) P[CPT * D + c0 + own * 16 + (lane & 15)] = dbo;
+    lacc = wave_sum(lacc);
+    if (lane == 0) lsum[own] = lacc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) t += lsum[w];
+      loss_part[blockIdx.x] = first ? t : loss_part[blockIdx.x] + t;   // the label passes' shares add up
+    }
+  } else {
+    // =============================================================== Q: grad team, one tile behind
+    f32x4 accW[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) accW[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float sdy[2] = {0.f, 0.f}, sdyx[2] = {0.f, 0.f}, mu[2], is[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      mu[s] = mean[(s < S ? s : 0) * D + own * 16 + (lane & 15)];
+      is[s] = invstd[(s < S ? s : 0) * D + own * 16 + (lane & 15)];
+    }
+    __syncthreads();   // Wl complete
+    // X of this lane's (row, column) elements of a tile, for the BatchNorm sums of its epilogue: requested a whole matrix
+    // product before they are used -- the rows have left the L2 since P read them (a 30 MB table), and their latency was
+    // all of the epilogue's time when they were requested there
+    float xq[2][2][4];
+    auto load_xq = [&](int tile) {
+      OPAQUE_LANE(r, q, lq);
+      const int node0 = tile * TR, c = own * 16 + r;
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int i = node0 + mb * 16 + q * 4 + e;
+            xq[s][mb][e] = (last && i < n && s < S) ? X[(unsigned)((s * n + i) * D + c)] : 0.f;
+          }
+    };
+    for (int k = 0; k <= mt; ++k) {
+      const int node0 = ((int)blockIdx.x + (k - 1) * G) * TR;   // tile k-1
+      f32x4 accY[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      // ---- S1: dym tile = Pt W_out of tile k-1 (M = TR rows, K = labels, N = this wave's 16 columns)   (matrix; P: ym rows)
+      RS_STAMP(0);
+      if (k >= 1) {
+        const float* __restrict__ Pb = Pt[(k - 1) & 1];
+        OPAQUE_LANE(r, q, lq);
+        if (MULTI && !first) {   // the earlier label passes' share of dym seeds the accumulators
+          const int c = own * 16 + r;
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int i = node0 + mb * 16 + q * 4 + e;
+              accY[mb][e] = i < n ? dym[(unsigned)(i * D + c)] : 0.f;
+            }
+        }
+        // label groups of 16 (4 k-steps: 8 A reads from Pt, 4 B reads from W_out), the next group's reads under this group's MFMAs
+        const float* __restrict__ Pa = Pb + r * LDP + q;
+        const float* __restrict__ Wa = Wl + q * LDW + own * 16 + r;
+        float pa[2][8], wb[2][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          wb[0][u] = Wa[4 * u * LDW];
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb) pa[0][u * 2 + mb] = Pa[mb * 16 * LDP + 4 * u];
+        }
+#pragma unroll
+        for (int g = 0; g < NB; ++g) {
+          if (g + 1 < NB) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              wb[(g + 1) & 1][u] = Wa[4 * (4 * (g + 1) + u) * LDW];
+#pragma unroll
+              for (int mb = 0; mb < 2; ++mb) pa[(g + 1) & 1][u * 2 + mb] = Pa[mb * 16 * LDP + 4 * (4 * (g + 1) + u)];
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) accY[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[g & 1][u * 2 + mb], wb[g & 1][u], accY[mb], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      RS_STAMP(1);
+      __syncthreads();
+      // ---- S2: dym out, BatchNorm-backward column sums of tile k-1              (vector; P: pred product)
+      RS_STAMP(2);
+      if (k >= 1) {
+        OPAQUE_LANE(r, q, lq);
+        const int c = own * 16 + r;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {   // branch-free but for the predicated store: rows past n have d loss / d pred = 0,
+            const int i = node0 + mb * 16 + q * 4 + e;   // hence dym = 0 and contribute nothing to the sums
+            const float g = accY[mb][e];
+            if (i < n) dym[(unsigned)(i * D + c)] = g;    // 64-byte row segments; the other column blocks come from the neighbouring waves
+            if (last) {
+#pragma unroll
+              for (int s = 0; s < 2; ++s) {
+                float dy = g * invS;
+                if (DROP) dy = dropout_keep(key, (uint32_t)((s * n + i) * D + c), thresh) ? dy * keep_scale : 0.f;
+                if (s == 1) dy = S2 ? dy : 0.f;
+                const float xh = (fmaxf(xq[s][mb][e], 0.f) - mu[s]) * is[s];
+                sdy[s] += dy;
+                sdyx[s] += dy * xh;
+              }
+            }
+          }
+      }
+      RS_STAMP(3);
+      __syncthreads();
+      // ---- S3: dW_out += Pt^T Yt of tile k-1 (K = TR rows); operands of step kk + 1 are read under step kk   (matrix; P: epilogue)
+      RS_STAMP(4);
+      if (k < mt) load_xq((int)blockIdx.x + k * G);   // tile k's values, used in S2 of the next period
+      if (k >= 1) {
+        OPAQUE_LANE(r, q, lq);
+        const float* __restrict__ Pa = Pt[(k - 1) & 1] + q * LDP + r;
+        const float* __restrict__ Ya = Yt[(k - 1) & 1] + q * LDY + own * 16 + r;
+        float a0[NB], a1[NB], b0, b1;
+        b0 = Ya[0];
+#pragma unroll
+        for (int ib = 0; ib < NB; ++ib) a0[ib] = Pa[ib * 16];
+#pragma unroll
+        for (int kk = 0; kk < TR / 4; kk += 2) {
+          b1 = Ya[(kk + 1) * 4 * LDY];
+#pragma unroll
+          for (int ib = 0; ib < NB; ++ib) a1[ib] = Pa[(kk + 1) * 4 * LDP + ib * 16];
+          __builtin_amdgcn_sched_barrier(0);   // one step of operand reads ahead, no more (registers)
+#pragma unroll
+          for (int ib = 0; ib < NB; ++ib) accW[ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[ib], b0, accW[ib], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (kk + 2 < TR / 4) {
+            b0 = Ya[(kk + 2) * 4 * LDY];
+#pragma unroll
+            for (int ib = 0; ib < NB; ++ib) a0[ib] = Pa[(kk + 2) * 4 * LDP + ib * 16];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ib = 0; ib < NB; ++ib) accW[ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[ib], b1, accW[ib], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      RS_STAMP(5);
+      __syncthreads();
+    }
+    // ---- dW_out share; BatchNorm-backward column sums (float64 from the cross-lane merge on)
+    const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int ib = 0; ib < CBMAX; ++ib)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = ib < NB ? accW[ib < NB ? ib : 0][e] : 0.f;
+        if (c0 + ib * 16 < CPT) P[(size_t)(c0 + ib * 16 + q * 4 + e) * D + own * 16 + r] = v;
+      }
+    if (last) {   // column sums over this lane's rows -> over the four row groups of the wave
+      double* out = (double*)(P + CPT * D + CPT);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        double a = (double)sdy[s], b = (double)sdyx[s];
+        a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+        b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
+        if (q == 0) {
+          out[s * D + own * 16 + r] = a;
+          out[(2 + s) * D + own * 16 + r] = b;
+        }
+      }
+    }
+    __syncthreads();   // (the P team's loss merge)
+  }
+#undef OPAQUE_LANE
+}
+
 // second stage: workgroups [0, wslabs) sum the dW_out / db_out slabs wslab0 + b (head_finalize_slab), the rest the
 // BatchNorm columns in float64 (head_stats_finalize)
 __global__ __launch_bounds__(512) void k_head_bwd_finalize(int wslab0, int wslabs, int P, int n, int S, int D, int C, int CP,
@@ -1259,7 +1662,23 @@ static int head_train_impl(cgcn_stream_t stream, int n, int S, int d, int C, con
     hipLaunchKernelGGL((k_head_fused<D_, 8>), dim3(P), dim3(512), 0, st, n, S, C, X, bn_w, bn_b, save_mean, save_invstd, \
                        Wout, bout, target, keep_scale, thresh, rng_state, inv_count, probs, w_loss, w_dym, w_part, c0, Cp, \
                        CP, first, last)
-    if (d == 128) HFU(128); else HFU(256);
+    if (d == 128 && HEAD_RS) {
+      const bool nb7 = Cp > 96 && Cp <= 112;
+#define HRS(M_, NB_)                                                                                                   \
+      do {                                                                                                             \
+        if (thresh) hipLaunchKernelGGL((k_head_fused_rs<M_, NB_, true>), dim3(P), dim3(1024), 0, st, n, S, C, X, bn_w, bn_b, save_mean, save_invstd, \
+                         Wout, bout, target, keep_scale, thresh, rng_state, inv_count, probs, w_loss, w_dym, w_part, c0, Cp, \
+                         CP, first, last);                                                                             \
+        else hipLaunchKernelGGL((k_head_fused_rs<M_, NB_, false>), dim3(P), dim3(1024), 0, st, n, S, C, X, bn_w, bn_b, save_mean, save_invstd, \
+                         Wout, bout, target, keep_scale, thresh, rng_state, inv_count, probs, w_loss, w_dym, w_part, c0, Cp, \
+                         CP, first, last);                                                                             \
+      } while (0)
+      if (C <= 128) { if (nb7) HRS(false, 7); else HRS(false, 8); }
+      else { if (nb7) HRS(true, 7); else HRS(true, 8); }
+#undef HRS
+    }
+    else if (d == 128) HFU(128);
+    else HFU(256);
 #undef HFU
     if ((rc = launch_status())) return rc;
   }
