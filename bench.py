@@ -60,6 +60,10 @@ def parse():
     ap.add_argument("--backend", default=os.environ.get("CGCN_DIST_BACKEND", "nccl"),
                     help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU functional tests)")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses cuda:0")
+    ap.add_argument("--p2p-allreduce", action="store_true",
+                    help="N > 1: one-shot peer-to-peer gradient all-reduce over symmetric memory instead of RCCL's (SURVEY section 5)")
+    ap.add_argument("--no-group-graph", action="store_true",
+                    help="N > 1: do not capture the collective + optimizer step into the step's HIP graph")
     ap.add_argument("--e2e-windows", type=int, default=4096, help="e2e: windows per chromosome pushed through the encoder")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous check only: every rank joins the process group, rank 0 prints one JSON line "
@@ -320,15 +324,16 @@ def main():
     # reference.  (The engine's defaults cache A X of the first layer -- loop invariant, the features are fixed -- and
     # skip the unobservable input gradient; measured separately below, never as `value`.)
     stage = GCNStage(model, opt, "hic", dev, hip_graphs=not args.no_hip_graph, input_grad=True,
-                     group=dist.group.WORLD if world > 1 else None, cache_input_aggregation=False)
+                     group=dist.group.WORLD if world > 1 else None, cache_input_aggregation=False,
+                     group_graph=False if args.no_group_graph else None, p2p_allreduce=True if args.p2p_allreduce else None)
 
     if genome:
         names = genome_train_names()
         shapes = []
-        for nm in names:  # every rank holds every chromosome's inputs (a few GB of 288): the shard plan picks who runs what
+        for nm in names:  # N > 1: registered only -- a rank normalises and uploads the chromosomes the shard plan gives it
             feats, hic = synth.synthetic_chromosome(nm, d=args.d, hic_like=args.hic_like)
-            stage.add_chromosome(nm, feats, hic)
-            shapes.append((nm, stage.chroms[nm].n, stage.chroms[nm].graph.nnz))
+            stage.add_chromosome(nm, feats, hic, defer=world > 1)
+            shapes.append((nm, feats["forward"].shape[0], int(hic.nnz) + feats["forward"].shape[0]))
         windows = sum(s[1] for s in shapes)
 
         def step():
@@ -470,7 +475,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl, "generator": "hic_like" if args.hic_like else "uniform",
                        "hip_graph": not args.no_hip_graph,
-                       "parallelism": ("chromosomes sharded over %d rank(s)" % world) if genome else "chromosome-per-rank x%d" % world},
+                       "parallelism": ("chromosomes sharded over %d rank(s)" % world) if genome else "chromosome-per-rank x%d" % world,
+                       "allreduce": stage.allreduce_kind if world > 1 else None,
+                       "step_group_graph": bool(stage._group_graph_enabled()) if world > 1 else None},
             "step_ms": {"median": float(np.median(per_ms)), "p10": float(np.percentile(per_ms, 10)),
                         "p90": float(np.percentile(per_ms, 90)), "n": len(per),
                         "note": "per-step host time on rank 0" + (" (each epoch ends with its own loss sync)" if genome else " (launch only: steps are asynchronous)")},

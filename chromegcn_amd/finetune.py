@@ -96,8 +96,18 @@ class GCNStage:
 
     def __init__(self, model, optimizer=None, adj_type: str = "hic", device="cuda", hip_graphs: bool = True,
                  input_grad: bool = False, group=None, fused_head: bool = True, cache_input_aggregation: bool = True,
-                 force_collectives: bool = False):
+                 force_collectives: bool = False, group_graph: Optional[bool] = None, p2p_allreduce: Optional[bool] = None):
         self.model = model
+        # multi-rank step group as ONE HIP graph (fwd + bwd + gradient all-reduce + fused 1/k SGD step): needs a backend
+        # whose collectives are stream-ordered device work (nccl = RCCL); None = on when possible, CGCN_GROUP_GRAPH=0 disables
+        self._group_graph_opt = group_graph if group_graph is not None else os.environ.get("CGCN_GROUP_GRAPH", "1") != "0"
+        self._group_graph_ok = True
+        self._comm_warm = False
+        # one-shot peer-to-peer all-reduce over xGMI (every rank reads its peers' gradient arenas through symmetric
+        # memory and sums them in rank order) instead of RCCL's all-reduce: opt-in (CGCN_P2P_ALLREDUCE=1), SURVEY section 5
+        self._p2p_opt = p2p_allreduce if p2p_allreduce is not None else os.environ.get("CGCN_P2P_ALLREDUCE", "0") == "1"
+        self._p2p = None
+        self.allreduce_kind = "none"
         self.fused_head = fused_head
         # A X of the first layer is loop invariant across steps and epochs (like the normalised CSR): compute it once
         # per chromosome and stream it afterwards.  False = redo that gather every step, as the reference does.
@@ -117,6 +127,8 @@ class GCNStage:
             raise RuntimeError("force_collectives needs an initialised torch.distributed process group")
         self.multi = self.world > 1 or bool(force_collectives)
         self.chroms: Dict[str, _Chrom] = {}
+        self._pending: Dict[str, tuple] = {}   # chromosomes registered with defer=True: (feats, hic) on the host
+        self._meta: Dict[str, tuple] = {}      # name -> (n, C, cost) of every registered chromosome, resident or not
         self._graphs: Dict[tuple, dict] = {}
         self._pool = None
         self._flat_grad: Optional[torch.Tensor] = None
@@ -136,17 +148,37 @@ class GCNStage:
         self._pool = None
 
     # ------------------------------------------------------------------ data
-    def add_chromosome(self, name: str, feats: Dict[str, torch.Tensor], hic=None):
+    def add_chromosome(self, name: str, feats: Dict[str, torch.Tensor], hic=None, defer: bool = False):
         """feats: {'forward': [n,d], 'backward': [n,d], 'target': [n,C]} (utils/util_methods.py:183-199);
-        hic: scipy matrix for 'hic'/'both' graphs (data/7create_graph_new.py:118)."""
+        hic: scipy matrix for 'hic'/'both' graphs (data/7create_graph_new.py:118).
+        defer=True (multi-rank runs): only register the chromosome -- size, label count and a cost estimate that is the
+        same on every rank -- and keep the host tensors; the graph is normalised and everything uploaded when THIS rank
+        first runs the chromosome (run_split's shard plan), so a rank holds the chromosomes it owns, not the genome."""
         n = feats["forward"].shape[0]
+        if defer:
+            d = feats["forward"].shape[1]
+            nnz_est = (int(hic.nnz) if hic is not None and hasattr(hic, "nnz") else 0) + n   # nnz(A + I) up to duplicates
+            self._pending[name] = (feats, hic)
+            self._meta[name] = (n, feats["target"].shape[1], float(nnz_est) * d + 3.0 * n * d * d / 16.0)
+            self.chroms.pop(name, None)
+            self._invalidate_layout(name)
+            return
+        self._pending.pop(name, None)
         h = G.normalize_graph(self.adj_type, hic, n)
         g = G.upload(h, self.device)
         x = torch.stack([feats["forward"], feats["backward"]]).to(self.device, torch.float32).contiguous()
         t = feats["target"].to(self.device, torch.float32).contiguous()
         d = x.shape[2]
         cost = float(h.nnz) * d + 3.0 * n * d * d / 16.0
-        self.chroms[name] = _Chrom(name, n, g, x, t, cost, _SourceKey(feats, hic))
+        known = self._meta.get(name)
+        self.chroms[name] = _Chrom(name, n, g, x, t, known[2] if known else cost, _SourceKey(feats, hic))
+        if known is None or known[:2] != (n, t.shape[1]):
+            self._meta[name] = (n, t.shape[1], cost)
+            self._invalidate_layout(name)
+        else:   # a deferred chromosome materialising: the arena / gather layout already accounts for it
+            self._graphs = {k: v for k, v in self._graphs.items() if k[0] != name}
+
+    def _invalidate_layout(self, name):
         self._targets_cpu.clear()
         self._targets_dev.clear()
         self._gather_plans.clear()
@@ -155,7 +187,16 @@ class GCNStage:
         if not self._graphs:
             self._pool = None
 
-    def load(self, chrom_feature_dict, split_adj_dict=None, only: Optional[Iterable[str]] = None):
+    def _resident(self, name: str) -> _Chrom:
+        """the device-resident chromosome, uploading a deferred one on first use"""
+        c = self.chroms.get(name)
+        if c is None:
+            feats, hic = self._pending[name]
+            self.add_chromosome(name, feats, hic)
+            c = self.chroms[name]
+        return c
+
+    def load(self, chrom_feature_dict, split_adj_dict=None, only: Optional[Iterable[str]] = None, defer: bool = False):
         """Upload the chromosomes that are not cached yet.  The reference re-reads everything on every call
         (finetune.py:20-36); here a chromosome is reused only while the caller's feature tensors (the same live objects,
         at the same in-place version) and graph object are the ones it was built from -- anything else rebuilds it, dropping its cached
@@ -167,12 +208,17 @@ class GCNStage:
             cur = self.chroms.get(name)
             if cur is not None and cur.src_key is not None and cur.src_key.matches(chrom_feature_dict[name], hic):
                 continue
-            self.add_chromosome(name, chrom_feature_dict[name], hic)
+            pend = self._pending.get(name)
+            if defer and pend is not None and pend[0] is chrom_feature_dict[name] and pend[1] is hic:
+                continue
+            self.add_chromosome(name, chrom_feature_dict[name], hic, defer=defer)
 
     def invalidate(self, name: Optional[str] = None):
         """forget the device copy of one chromosome (or of all of them) and every HIP graph captured on it"""
-        for nm in ([name] if name is not None else list(self.chroms)):
+        for nm in ([name] if name is not None else list(self._meta)):
             self.chroms.pop(nm, None)
+            self._pending.pop(nm, None)
+            self._meta.pop(nm, None)
             self._graphs = {k: v for k, v in self._graphs.items() if k[0] != nm}
         if not self._graphs:
             self._pool = None
@@ -187,19 +233,19 @@ class GCNStage:
         chromosome, in insertion order (= the reference's chromosome iteration order, finetune.py:29).  The fused head
         writes each chromosome's sigmoid(pred) and mean BCE straight into its slice, so the concatenation of
         finetune.py:52 and the loss sum of :51 need no per-chromosome copy / add kernels."""
-        if self._arena is not None or not self.chroms:
+        if self._arena is not None or not self._meta:
             return
-        C = next(iter(self.chroms.values())).target.shape[1]
-        total = sum(c.n for c in self.chroms.values())
+        C = next(iter(self._meta.values()))[1]
+        total = sum(m[0] for m in self._meta.values())
         probs = torch.empty((total, C), device=self.device, dtype=torch.float32)
-        loss = torch.zeros(len(self.chroms), device=self.device, dtype=torch.float32)
+        loss = torch.zeros(len(self._meta), device=self.device, dtype=torch.float32)
         slots, rows, order = {}, {}, {}
         off = 0
-        for i, (nm, c) in enumerate(self.chroms.items()):
-            slots[nm] = {"probs": probs[off:off + c.n], "loss": loss[i:i + 1]}
-            rows[nm] = (off, off + c.n)
+        for i, (nm, (n_, _c, _cost)) in enumerate(self._meta.items()):   # registration order, resident or deferred
+            slots[nm] = {"probs": probs[off:off + n_], "loss": loss[i:i + 1]}
+            rows[nm] = (off, off + n_)
             order[nm] = i
-            off += c.n
+            off += n_
         self._arena = {"probs": probs, "loss": loss, "slots": slots, "rows": rows, "order": order}
         self._drop_graphs()  # captured graphs wrote into the previous arena
 
@@ -261,7 +307,7 @@ class GCNStage:
                 flat_p[off:off + p.numel()].copy_(p.data.reshape(-1))
                 p.data = flat_p[off:off + p.numel()].view(p.shape)
             self._flat_param = flat_p
-            self._flat_grad = torch.zeros(total, device=dev, dtype=torch.float32)
+            self._flat_grad = self._alloc_flat_grad(total, dev)
             for p, off in zip(ps, offs):
                 p.grad = self._flat_grad[off:off + p.numel()].view(p.shape)
             self._fused_sgd = self._fused_sgd_eligible(ps)
@@ -383,18 +429,29 @@ class GCNStage:
             return None
         return tuple((g.get("lr"), g.get("momentum"), g.get("weight_decay"), g.get("nesterov")) for g in self.optimizer.param_groups)
 
-    def _capture(self, c: _Chrom, kind: str):
-        """kind: 'train' (zero_grad+fwd+bwd+step), 'fwdbwd' (no optimizer step: multi-rank), 'eval'."""
+    def _capture(self, c: Optional[_Chrom], kind: str, group_size: int = 1):
+        """kind: 'train' (zero_grad+fwd+bwd+step), 'fwdbwd' (no optimizer step: multi-rank), 'eval', 'group' (multi-rank:
+        fwd+bwd of `c` -- or a zeroed gradient when this rank sits the round out --, all-reduce, fused 1/k step)."""
         was_training = self.model.training
         self.model.train(kind != "eval")
         snap = self._snapshot()
 
-        def body():
+        def body(collective=True):
             if kind == "eval":
                 loss, probs = self._eval(c)
                 return loss, probs, None
             if kind == "train":
                 return self._fwd_bwd_step(c)
+            if kind == "group":
+                if c is not None:
+                    out = self._fwd_bwd(c)
+                else:
+                    self._flat_grad.zero_()
+                    out = (None, None, None)
+                if collective:   # NOT in the warm-up passes: ranks capture at different times (a rank replays a graph it
+                    self._allreduce_grads()   # already holds while a peer captures), the collective count must match
+                self._optimizer_step(1.0 / group_size if group_size > 1 else 1.0)
+                return out
             return self._fwd_bwd(c)
 
         if kind == "train" and not self._fused_sgd:
@@ -406,7 +463,7 @@ class GCNStage:
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):
                 for _ in range(2):  # warm-up: allocator pools, rocBLAS/MIOpen handles, lazy optimizer state
-                    body()
+                    body(collective=False)
             torch.cuda.current_stream(self.device).wait_stream(side)
             torch.cuda.synchronize(self.device)
             self._restore(snap)
@@ -432,14 +489,14 @@ class GCNStage:
             self.model.train(was_training)
         return {"graph": graph, "loss": loss, "probs": probs, "dx": dx}
 
-    def _replay(self, c: _Chrom, kind: str):
+    def _replay(self, c: Optional[_Chrom], kind: str, group_size: int = 1):
         if self._captured_lr != self._lr_signature():
             self._drop_graphs()  # the learning rate is baked into the captured optimizer kernels
             self._captured_lr = self._lr_signature()
-        key = (c.name, kind)
+        key = (c.name if c is not None else None, kind) if kind != "group" else (c.name if c is not None else None, kind, group_size)
         ent = self._graphs.get(key)
         if ent is None:
-            ent = self._graphs[key] = self._capture(c, kind)
+            ent = self._graphs[key] = self._capture(c, kind, group_size)
         ent["graph"].replay()
         return ent["loss"], ent["probs"], ent["dx"]
 
@@ -447,7 +504,7 @@ class GCNStage:
     def train_step(self, name: str):
         """One reference train step on one chromosome (finetune.py:38-49).  Returns device tensors
         (loss [], probs [n,C], dx [2,n,d] or None); valid until the next step."""
-        c = self.chroms[name]
+        c = self._resident(name)
         self.model.train()
         self._ensure_flat_grad()
         self._ensure_arena()
@@ -462,7 +519,7 @@ class GCNStage:
         return loss, probs, dx
 
     def eval_step(self, name: str):
-        c = self.chroms[name]
+        c = self._resident(name)
         self.model.eval()
         self._ensure_arena()
         if self.hip_graphs:
@@ -473,20 +530,82 @@ class GCNStage:
     def train_group(self, name: Optional[str], group_size: int):
         """Multi-rank step group: every rank runs fwd+bwd on its own chromosome (or none), gradients are
         summed across ranks in ONE all-reduce of the flat buffer and divided by the number of chromosomes
-        in the group, then every rank takes the same optimizer step."""
+        in the group, then every rank takes the same optimizer step.
+        With a stream-ordered collective backend (nccl = RCCL) and the fused SGD the WHOLE group step -- forward,
+        backward, all-reduce, 1/k scaling + optimizer step -- is one HIP graph per (chromosome, group size): nothing
+        is launched from the host between the last backward kernel and the collective, or between the collective and
+        the step.  Otherwise: captured fwd+bwd, then the collective and ONE fused scale+step launch, stream-ordered."""
         self.model.train()
         self._ensure_flat_grad()
         self._ensure_arena()
+        c = self._resident(name) if name is not None else None
+        scale = 1.0 / group_size if group_size > 1 else 1.0
+        if self.multi and not self._comm_warm:
+            # the communicator's lazy initialisation must not happen under stream capture: one tiny eager collective
+            # (every rank reaches its first train_group call in the same round)
+            torch.distributed.all_reduce(torch.zeros(1, device=self.device), group=self.group)
+            self._comm_warm = True
+        if self._group_graph_enabled():
+            try:
+                return self._replay(c, "group", group_size)
+            except Exception as e:   # capture refused by the backend: every rank fails alike, before any collective ran
+                import warnings
+                warnings.warn("chromegcn_amd: capturing the step group (collective included) failed (%r); "
+                              "using the captured fwd+bwd + stream-ordered collective + fused step instead" % (e,))
+                self._group_graph_ok = False
+                self._drop_graphs()
         out = (None, None, None)
-        if name is not None:
-            c = self.chroms[name]
+        if c is not None:
             out = self._replay(c, "fwdbwd") if self.hip_graphs else self._fwd_bwd(c)
         else:
             self._flat_grad.zero_()
         if self.multi:
-            torch.distributed.all_reduce(self._flat_grad, op=torch.distributed.ReduceOp.SUM, group=self.group)
-        self._optimizer_step(1.0 / group_size if group_size > 1 else 1.0)
+            self._allreduce_grads()
+        self._optimizer_step(scale)
         return out
+
+    def _group_graph_enabled(self) -> bool:
+        if not (self.multi and self.hip_graphs and self._fused_sgd and self._group_graph_opt and self._group_graph_ok):
+            return False
+        return torch.distributed.get_backend(self.group) == "nccl"
+
+    def _allreduce_grads(self):
+        """SUM of the flat gradient arena over the ranks (the 1/k is folded into the optimizer step)."""
+        h = self._p2p
+        if h is None:
+            torch.distributed.all_reduce(self._flat_grad, op=torch.distributed.ReduceOp.SUM, group=self.group)
+            return
+        # one-shot peer-to-peer all-reduce: the arena is symmetric memory; after a device-side barrier every rank reads
+        # its peers' arenas over its direct xGMI links and adds them IN RANK ORDER (the same order everywhere: all ranks
+        # end up with bit-identical sums), a second barrier keeps any rank from overwriting an arena a peer still reads
+        h.barrier(channel=0)
+        acc = self._p2p_acc
+        torch.add(self._p2p_views[0], self._p2p_views[1], out=acc) if len(self._p2p_views) > 1 else acc.copy_(self._p2p_views[0])
+        for v in self._p2p_views[2:]:
+            acc.add_(v)
+        h.barrier(channel=1)
+        self._flat_grad.copy_(acc)
+
+    def _alloc_flat_grad(self, total, dev):
+        """the flat gradient arena: plain device memory, or (opt-in P2P all-reduce) symmetric memory every peer can read"""
+        self._p2p = None
+        self.allreduce_kind = "rccl" if self.multi else "none"
+        if self.multi and self._p2p_opt and dev.type == "cuda" and torch.distributed.get_backend(self.group) == "nccl":
+            try:   # collective: every rank takes this branch in the same call
+                import torch.distributed._symmetric_memory as symm
+                gname = (self.group or torch.distributed.group.WORLD).group_name
+                buf = symm.empty(total, dtype=torch.float32, device=dev)
+                buf.zero_()
+                h = symm.rendezvous(buf, gname)
+                self._p2p_views = [h.get_buffer(r, (total,), torch.float32) for r in range(h.world_size)]
+                self._p2p_acc = torch.zeros(total, device=dev, dtype=torch.float32)
+                self._p2p = h
+                self.allreduce_kind = "p2p_one_shot"
+                return buf
+            except Exception as e:
+                import warnings
+                warnings.warn("chromegcn_amd: symmetric-memory P2P all-reduce unavailable (%r); using RCCL" % (e,))
+        return torch.zeros(total, device=dev, dtype=torch.float32)
 
     def sync_running_stats(self, extra: Optional[torch.Tensor] = None, calls_total: int = 0, calls_mine: int = 0):
         """BatchNorm running statistics see different chromosomes on different ranks; average them so every rank
@@ -525,9 +644,9 @@ class GCNStage:
         predictions to the host); to_cpu=False leaves them on the device for chromegcn_amd.metrics -- the
         predictions are then a view of the stage's output arena, valid until the next step on this stage.
         Multi-rank: every rank returns the full concatenation."""
-        names = list(self.chroms) if names is None else list(names)
+        names = list(self._meta) if names is None else list(names)
         train = split == "train"
-        C = next(iter(self.chroms.values())).target.shape[1] if self.chroms else 0
+        C = next(iter(self._meta.values()))[1] if self._meta else 0
         if not self.multi:
             self._ensure_arena()
             for nm in names:
@@ -547,7 +666,7 @@ class GCNStage:
                 return preds_dev, self._split_targets_dev(names, C), total
             preds = preds_dev.cpu()
         else:
-            plan = plan_shards({nm: self.chroms[nm].cost for nm in names}, self.world)
+            plan = plan_shards({nm: self._meta[nm][2] for nm in names}, self.world)
             gp = self._gather_plan(names, plan, C)
             nccl = torch.distributed.get_backend(self.group) == "nccl"
             loss_sum = torch.zeros((), device=self.device)
@@ -573,7 +692,7 @@ class GCNStage:
                     pending.append(torch.distributed.all_gather(list(recv.view(self.world, -1, C).unbind(0)), send,
                                                                 group=self.group, async_op=True))
             mine = sum(1 for nm in names if plan.owner[nm] == self.rank)
-            S = next(iter(self.chroms.values())).x.shape[0] if self.chroms else 0
+            S = 2   # strands per chromosome: forward + reverse complement (add_chromosome stacks both)
             if train:   # running statistics + the loss in one all-reduce; counters without communication
                 loss_sum = self.sync_running_stats(loss_sum, calls_total=S * len(names), calls_mine=S * mine)
             else:
@@ -588,15 +707,20 @@ class GCNStage:
             preds = preds_dev.cpu()
         key = tuple(names)
         if key not in self._targets_cpu:  # targets never change: one D2H per split, not one per epoch
-            self._targets_cpu[key] = torch.cat([self.chroms[nm].target for nm in names], 0).cpu() if names else torch.empty(0, C)
+            self._targets_cpu[key] = torch.cat([self._target_of(nm).cpu() for nm in names], 0) if names else torch.empty(0, C)
         return preds, self._targets_cpu[key], total
 
     def _split_targets_dev(self, names, C):
         key = tuple(names)
         if key not in self._targets_dev:  # targets never change: concatenated once per split, not once per epoch
-            self._targets_dev[key] = (torch.cat([self.chroms[nm].target for nm in names], 0) if names
+            self._targets_dev[key] = (torch.cat([self._target_of(nm).to(self.device) for nm in names], 0) if names
                                       else torch.empty(0, C, device=self.device))
         return self._targets_dev[key]
+
+    def _target_of(self, nm):
+        """targets [n, C] of a registered chromosome: the device copy when resident, the caller's host tensor otherwise"""
+        c = self.chroms.get(nm)
+        return c.target if c is not None else self._pending[nm][0]["target"].to(torch.float32)
 
     def _gather_plan(self, names, plan: ShardPlan, C: int):
         """Buffers and the row permutation of the prediction gathers, built once per (split, plan).  Round r of the
@@ -607,7 +731,7 @@ class GCNStage:
         gp = self._gather_plans.get(key)
         if gp is not None:
             return gp
-        sizes = {nm: self.chroms[nm].n for nm in names}
+        sizes = {nm: self._meta[nm][0] for nm in names}
         max_r = [max([sizes[g] for g in group if g is not None] + [0]) for group in plan.rounds]
         base_r, tot = [], 0
         for m in max_r:

@@ -89,7 +89,7 @@ def worker(rank, world, port, epochs, q):
     m = make_model()
     opt = O.make_sgd(m, 0.1)
     stage = GCNStage(m, opt, "hic", "cpu", hip_graphs=False, group=dist.group.WORLD)
-    stage.load(feats, graphs)
+    stage.load(feats, graphs, defer=True)   # a rank materialises only the chromosomes the shard plan hands it
     tot = []
     for _ in range(epochs):
         preds, targets, t = stage.run_split("train")

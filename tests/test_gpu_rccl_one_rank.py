@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 EPOCHS = 2
 
 
-def worker(port, q):
+def worker(port, q, group_graph=True):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -35,13 +35,20 @@ def worker(port, q):
     m = T.make_model(dev)
     opt = torch.optim.SGD(m.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-6)
     stage = GCNStage(m, opt, "hic", dev, hip_graphs=True, input_grad=True, group=dist.group.WORLD,
-                     cache_input_aggregation=False, force_collectives=True)
+                     cache_input_aggregation=False, force_collectives=True, group_graph=group_graph)
     assert stage.multi and stage.world == 1
-    stage.load(feats, graphs)
+    stage.load(feats, graphs, defer=True)      # registered only: uploaded when the shard plan hands them to this rank
+    assert not stage.chroms and len(stage._meta) == len(feats)
     tot = []
     for _ in range(EPOCHS):
         preds, targets, t = stage.run_split("train")
         tot.append(t)
+    assert len(stage.chroms) == len(feats)
+    kinds = {k[1] for k in stage._graphs}
+    if group_graph:   # the whole step group -- RCCL all-reduce and fused step included -- was captured and replayed
+        assert stage._group_graph_ok and "group" in kinds and "fwdbwd" not in kinds, kinds
+    else:
+        assert "fwdbwd" in kinds and "group" not in kinds, kinds
     pd, td, tv = stage.run_split("valid", to_cpu=False)
     with pytest.raises(RuntimeError):
         stage.train_step(next(iter(feats)))
@@ -52,12 +59,13 @@ def worker(port, q):
 
 
 @pytest.mark.timeout(900)
-def test_engine_collectives_run_over_rccl_with_one_rank():
+@pytest.mark.parametrize("group_graph", [True, False], ids=["step_group_as_one_hip_graph", "captured_fwdbwd_then_collective"])
+def test_engine_collectives_run_over_rccl_with_one_rank(group_graph):
     import torch.multiprocessing as mp
     import test_gpu_two_rank as T
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=worker, args=(T.free_port(), q))
+    p = ctx.Process(target=worker, args=(T.free_port(), q, group_graph))
     p.start()
     sd, tot, preds, vpreds, tv = q.get(timeout=600)
     p.join(120)

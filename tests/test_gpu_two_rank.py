@@ -61,12 +61,15 @@ def worker(rank, world, port, q, genome=False, epochs=EPOCHS):
     opt = torch.optim.SGD(m.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-6)
     stage = GCNStage(m, opt, "hic", "cuda:0", hip_graphs=True, input_grad=True, group=dist.group.WORLD,
                      cache_input_aggregation=False)
-    stage.load(feats, graphs)
+    stage.load(feats, graphs, defer=True)   # a rank uploads only what the shard plan gives it
     tot = []
     for _ in range(epochs):
         preds, targets, t = stage.run_split("train")
         tot.append(t)
         assert preds.shape == (rows, NC) and targets.shape == preds.shape
+    owned = sum(1 for g in __import__("chromegcn_amd.dist", fromlist=["plan_shards"]).plan_shards(
+        {c: stage._meta[c][2] for c in feats}, world).owner.values() if g == rank)
+    assert len(stage.chroms) == owned < len(feats)
     pd, td, tv = stage.run_split("valid", to_cpu=False)          # device-resident gather path
     assert pd.is_cuda and pd.shape == (rows, NC)
     if genome:   # 243 k x 23 predictions: send checksums and a strided sample instead of everything
