@@ -75,3 +75,103 @@ def test_e2e_pipeline_runs_and_reports_both_rates():
     assert t["windows"] == 512 and t["feat_device"].startswith("cuda")
     assert t["encoder_s"] > 0 and t["gcn_epoch_s"] > 0 and np.isfinite(t["final_loss"])
     assert names == ["chr20", "chr22"] and all(stage.chroms[c].n == 256 for c in names)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# config 5 across ranks: every rank encodes the windows of the chromosomes it owns and trains them (e2e.run_pipeline
+# with a process group).  Two spawned ranks share cuda:0 (gloo: RCCL refuses two ranks on one device).
+# ------------------------------------------------------------------------------------------------------------------
+E2E_KW = dict(windows=256, seq_length=320, dropout=0.0, epochs=2, warmup=1, chroms=("chr19", "chr20", "chr22"), batch_size=64)
+
+
+def _e2e_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t, stage, names = e2e.run_pipeline(torch.device("cuda:0"), group=dist.group.WORLD, return_feats=True, **E2E_KW)
+    preds, _, loss = stage.run_split("valid", names)
+    q.put((rank, t["owned"], {c: {k: v.cpu().numpy() for k, v in f.items()} for c, f in t["feats"].items()},
+           {k: v.cpu().numpy() for k, v in stage.model.state_dict().items()}, preds.numpy(), t["encoded_windows_this_rank"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_e2e_sharded_over_two_ranks_features_bitwise_parameters_match_emulation():
+    import sys
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_two_rank import free_port
+    from chromegcn_amd.dist import plan_shards
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_e2e_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    chroms = E2E_KW["chroms"]
+    # every chromosome was encoded by exactly one rank, and no rank encoded windows it does not own
+    owned = [set(r[1]) for r in res]
+    assert owned[0] | owned[1] == set(chroms) and not (owned[0] & owned[1]) and all(owned)
+    assert [r[5] for r in res] == [len(o) * E2E_KW["windows"] for o in owned]
+    # ---- single process: the same encoder pass over ALL windows; the ranks' features must be these, bit for bit
+    dev = torch.device(DEV)
+    n_labels = synth.N_LABELS
+    tokens, targets, locs = e2e.synthetic_windows(chroms, E2E_KW["windows"], E2E_KW["seq_length"], n_labels)
+    torch.manual_seed(0)
+    enc = StrandPair(WindowEncoder(n_labels, E2E_KW["seq_length"])).to(dev)
+    model = C.ChromeGCN(128, 128, n_labels, 0.0, True, 2).to(dev)
+    with torch.no_grad():
+        model.out.load_state_dict(enc.model.classifier.state_dict())
+        model.batch_norm.load_state_dict(enc.model.batch_norm.state_dict())
+    feats = extract_features(enc, tokens.to(dev), targets.to(dev), locs, FeatureCollector(), E2E_KW["batch_size"]).finish()
+    for r in res:
+        for c, f in r[2].items():
+            for k in ("forward", "backward", "target"):
+                assert np.array_equal(f[k], feats[c][k].cpu().numpy()), (r[0], c, k)
+    # ---- and the trained parameters: single-process emulation of the sharded epochs (gradients of a step group's
+    # chromosomes averaged, one fused step), same kernels, eager
+    graphs = {c: synth.contact_graph(E2E_KW["windows"], max(1, int(round(synth.PAIRS_PER_CHROM * E2E_KW["windows"] / synth.chrom_nodes(c)))),
+                                     synth.chrom_seed(c)) for c in chroms}
+    opt = torch.optim.SGD(model.parameters(), lr=0.25, momentum=0.9, weight_decay=1e-6)
+    st = GCNStage(model, opt, "hic", dev, hip_graphs=False, input_grad=True, cache_input_aggregation=False)
+    st.load(feats, graphs)
+    plan = plan_shards({c: st._meta[c][2] for c in chroms}, world)
+    assert {c for c in chroms if plan.owner[c] == 0} == owned[0]
+    model.train()
+    for _ in range(E2E_KW["warmup"] + E2E_KW["epochs"]):
+        for group in plan.rounds:
+            members = [g for g in group if g is not None]
+            acc = None
+            for nm in members:
+                st._ensure_flat_grad()
+                st._fwd_bwd(st.chroms[nm])
+                acc = st._flat_grad.clone() if acc is None else acc + st._flat_grad
+            st._flat_grad.copy_(acc)
+            st._optimizer_step(1.0 / len(members))
+    ref = {k: v.cpu().numpy() for k, v in model.state_dict().items()}
+    for r in res:
+        for k, v in ref.items():
+            if "running" in k or "num_batches" in k:
+                continue   # BatchNorm running statistics are rank-averaged (documented deviation)
+            np.testing.assert_allclose(r[3][k], v, rtol=1e-4, atol=1e-4, err_msg="rank %d %s" % (r[0], k))
+    for k in res[0][3]:   # both ranks end with the same model and the same full predictions
+        assert np.array_equal(res[0][3][k], res[1][3][k]), k
+    assert np.array_equal(res[0][4], res[1][4])
+
+
+def test_e2e_pipeline_at_full_sequence_length():
+    """configs[4]'s window shape: 2 000-token windows (config_args.py:39), 4 096 of them on one chromosome slot"""
+    t, stage, names = e2e.run_pipeline(torch.device(DEV), windows=4096, seq_length=2000, epochs=2, warmup=1,
+                                       chroms=("chr22",), batch_size=64)
+    assert t["windows"] == 4096 and names == ["chr22"] and stage.chroms["chr22"].n == 4096
+    assert stage.chroms["chr22"].x.shape == (2, 4096, 128) and np.isfinite(t["final_loss"])
+    assert t["encoder_s"] > 0 and t["gcn_epoch_s"] > 0
