@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="genome", choices=["genome", "chr21", "config1", "chr1", "e2e"])
     ap.add_argument("--hic-like", action="store_true", help="distance-decay contact generator instead of uniform")
+    ap.add_argument("--generator", default=None, choices=["uniform", "hic_like", "hub"],
+                    help="contact generator (synth.contact_graph): uniform (headline), hic_like = distance decay, hub = top-K-style "
+                         "heavy-tailed degrees with hubs of 2-10 k neighbours (data/7create_graph_new.py:93-104)")
     ap.add_argument("--d", type=int, default=128)
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--dropout", type=float, default=0.2)
@@ -263,6 +266,8 @@ def cpu_baseline(args, chroms, budget_s):
 # ------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
+    args.generator = args.generator or ("hic_like" if args.hic_like else "uniform")
+    args.hic_like = args.generator          # synth's generator argument (False / True / name)
     rc = self_launch(args)
     if rc is not None:
         sys.exit(rc)
@@ -426,7 +431,7 @@ def main():
             tot_g += 2 * 4.0 * nnz * 2 * args.d
             tot_f += 2 * 2.0 * 2 * n * args.d * args.d
             per_chrom[nm] = {"n": n, "nnz": nnz, "us_layer1": t1 * 1e6, "us_last": t2 * 1e6, "GBps": b / ((t1 + t2) / 2) / 1e9}
-        wl_key = ("genome" if genome else args.workload) + ("_hic" if args.hic_like else "") + "_d%d" % args.d
+        wl_key = ("genome" if genome else args.workload) + {"uniform": "", "hic_like": "_hic", "hub": "_hub"}[args.generator] + "_d%d" % args.d
         traffic, ttag = stored_traffic(wl_key)
         nl = 2 * len(per_chrom)
         roof = None if not per_chrom else {"bound": "hbm",
@@ -473,7 +478,7 @@ def main():
             "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if genome else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": wl, "generator": "hic_like" if args.hic_like else "uniform",
+            "config": {"workload": wl, "generator": args.generator,
                        "hip_graph": not args.no_hip_graph,
                        "parallelism": ("chromosomes sharded over %d rank(s)" % world) if genome else "chromosome-per-rank x%d" % world,
                        "allreduce": stage.allreduce_kind if world > 1 else None,

@@ -148,7 +148,7 @@ def bench(args, dev, world, rank):
         "config": {"workload": "config 5 scaled down: %d chromosomes x %d windows (tokens in {0..4}, length 2000, encoder batch 64), "
                                "features f/r handed to the GCN stage on the device; GCN stage = train epoch in reference "
                                "semantics, d=%d, L=%d, C=%d" % (len(names), args.e2e_windows, args.d, args.layers, synth.N_LABELS),
-                   "generator": "hic_like" if args.hic_like else "uniform",
+                   "generator": getattr(args, "generator", "hic_like" if args.hic_like else "uniform"),
                    "parallelism": "chromosomes sharded over %d rank(s): each rank encodes and trains the chromosomes it owns" % world},
         "encoder_windows_per_s": enc_rate, "gcn_windows_per_s": gcn_rate,
         "encoder_s": t["encoder_s"], "handoff_regroup_ms": t["regroup_s"] * 1e3, "stage_load_ms": t["stage_load_s"] * 1e3,

@@ -41,16 +41,47 @@ def chrom_seed(chrom: str) -> int:
     return int(chrom[3:])
 
 
-def contact_graph(n: int, pairs: int, seed: int, hic_like: bool = False) -> sp.csr_matrix:
-    """Uniform-random pairs, or (hic_like) pairs whose genomic distance |i-j| follows a truncated
-    1/k law so contacts concentrate near the diagonal like real Hi-C."""
+GENERATORS = ("uniform", "hic_like", "hub")
+
+
+def contact_graph(n: int, pairs: int, seed: int, hic_like=False) -> sp.csr_matrix:
+    """`pairs` undirected contact pairs on n windows.  hic_like: False / "uniform" = uniform-random pairs; True /
+    "hic_like" = pairs whose genomic distance |i-j| follows a truncated 1/k law, so contacts concentrate near the
+    diagonal like real Hi-C; "hub" = a top-K-style graph: the reference keeps the `hic_edges/2` HIGHEST-scoring pairs of
+    a chromosome (data/7create_graph_new.py:93-104), and normalised contact scores are dominated by a few
+    high-coverage bins, so the kept edges pile up on them -- a heavy-tailed degree distribution with hubs of thousands
+    of neighbours.  Modelled as: 8 hubs with 2 000 ... min(10 000, n/2) neighbours each (uniform random partners),
+    the rest of the budget drawn with power-law endpoint propensities (w_i ~ rank^-0.6, random rank order) -- degrees
+    from 1 to 10^4 on the same edge budget as the other generators."""
+    kind = hic_like if isinstance(hic_like, str) else ("hic_like" if hic_like else "uniform")
+    if kind not in GENERATORS:
+        raise ValueError("unknown contact generator %r" % (kind,))
     rng = np.random.RandomState(seed)
-    if hic_like:
+    if kind == "hic_like":
         kmax = max(2, n - 1)
         u = rng.random_sample(pairs)
         dist = np.clip(np.floor(np.exp(u * math.log(kmax))).astype(np.int64), 1, n - 1)
         i = (rng.random_sample(pairs) * (n - dist)).astype(np.int64)
         j = i + dist
+    elif kind == "hub":
+        n_hubs = min(8, max(1, n // 64))
+        hubs = rng.choice(n, n_hubs, replace=False)
+        hi_deg = max(2, min(10000, n // 2))
+        lo_deg = max(1, min(2000, hi_deg // 2))
+        ii, jj = [], []
+        for h in hubs:
+            deg = int(rng.randint(lo_deg, hi_deg + 1))
+            nb = rng.choice(n, deg, replace=False)
+            ii.append(np.full(deg, h, dtype=np.int64))
+            jj.append(nb.astype(np.int64))
+        used = sum(a.size for a in ii)
+        rest = max(0, pairs - used)
+        w = np.arange(1, n + 1, dtype=np.float64) ** -0.6
+        w = w[rng.permutation(n)]
+        w /= w.sum()
+        ii.append(rng.choice(n, rest, p=w).astype(np.int64))
+        jj.append(rng.choice(n, rest, p=w).astype(np.int64))
+        i, j = np.concatenate(ii), np.concatenate(jj)
     else:
         i = rng.randint(0, n, pairs)
         j = rng.randint(0, n, pairs)

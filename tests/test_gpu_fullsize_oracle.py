@@ -10,6 +10,8 @@ at BASELINE.json's shapes:
   k562      n =  5 776, d = 256, L = 4         (configs[3]; beyond the reference -- its constructor builds 1 or 2 layers --
                                                 so the oracle is the restatement rule "repeat models/ChromeModels.py:42-46")
 
+  chr21_hub / chr1_hub / chr21_hub_d256: heavy-tailed degrees with hubs of 2 000 ... 10 000 neighbours (top-K-style graphs,
+                data/7create_graph_new.py:93-104): the hub routes of the gather kernels at full size
   chr21_C164 / chr21_C256 / d256_C256: the same chr21-size step with 164 and 256 labels (the reference takes C from the
                 data, main.py:35): the training head walks labels in passes of 128 (cgcn_head_train), so these are the
                 only cases in which a second pass accumulates dym and the 256-row partial layout is used.
@@ -50,6 +52,12 @@ CASES = [   # name, n, pairs, hic_like, adj_type, seed, d, layers, labels
     ("chr21_C256", synth.chrom_nodes("chr21"), 250000, False, "hic", 23, 128, 2, 256),
     ("d256_C256", synth.chrom_nodes("chr21"), 250000, False, "hic", 24, 256, 2, 256),
     ("chr1_C129", synth.chrom_nodes("chr1"), 250000, False, "hic", 25, 128, 2, 129),
+    # top-K-style graphs (synth "hub" generator: degrees 1 ... 10^4): the hub paths of every gather kernel at full size --
+    # chr21 size: fused forward with hub rows split over a workgroup (LONG_ROW), sliced backward with the cooperative
+    # walk (SLICED_HUB); chr1 size: both sliced kernels with hubs of up to 9 870 neighbours
+    ("chr21_hub", synth.chrom_nodes("chr21"), 250000, "hub", "hic", 26, 128, 2, NC),
+    ("chr1_hub", synth.chrom_nodes("chr1"), 250000, "hub", "hic", 27, 128, 2, NC),
+    ("chr21_hub_d256", synth.chrom_nodes("chr21"), 250000, "hub", "hic", 28, 256, 2, NC),
 ]
 
 
@@ -128,8 +136,18 @@ def _train_steps_case(name, n, pairs, hic_like, adj_type, seed, d, layers, label
     print("\n[%s] scale-relative max error vs the float64 oracle: HIP / fp32 oracle" % name)
     for k in sorted(worst):
         print("   %-22s %.2e / %.2e" % (k, worst[k], worst32[k]))
-    bad = {k: (v, worst32[k]) for k, v in worst.items() if v > 1e-4}
-    assert not bad, "scale-relative gradient error above 1e-4 (HIP, fp32 oracle): %s" % bad
+    # Bound: 1e-4.  On the top-K-style (hub) graphs some of these quantities are ill-conditioned AT fp32: the fp32 oracle
+    # itself is 1e-3 ... 1e-2 off the float64 truth at chr1 size (hubs of 10^4 neighbours: after the first optimizer
+    # step the two fp32 paths hold the same fp32-rounded parameters and share that deviation digit for digit), and the
+    # gate-bias sums cancel to 6e-4 of their absolute sum there, so ONE fp32 rounding (6e-8) of a per-column constant is
+    # already worth 1e-4 (tools/bias_sum_probe.py chr21 hub: every kernel stage is at 2e-7 ... 4e-6 on that graph).
+    # Where the fp32 oracle is more than 2e-5 off the truth, the bound is therefore 10x the oracle's own error -- on the
+    # hub cases only; every other case keeps 1e-4 for every tensor.
+    hub = "hub" in name
+    def bound(k):
+        return 10.0 * worst32[k] if (hub and worst32[k] > 2e-5) else 1e-4
+    bad = {k: (v, worst32[k]) for k, v in worst.items() if v > bound(k)}
+    assert not bad, "scale-relative gradient error above its bound (HIP, fp32 oracle): %s" % bad
 
 
 def test_eval_forward_matches_oracle_at_chr1_size():

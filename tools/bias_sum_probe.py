@@ -26,11 +26,12 @@ def rel(a, b):
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "chr21"
+    gen = sys.argv[2] if len(sys.argv) > 2 else ("hic_like" if which == "chr1" else "uniform")
     n = synth.chrom_nodes(which)
-    seed = {"chr21": 21, "chr1": 1}[which]
+    seed = {"chr21": 21, "chr1": 1}[which] + (5 if gen == "hub" else 0)
     d, NC = 128, 103
     feats = synth.chrom_features(n, d, NC, 1000 + seed)
-    hic = synth.contact_graph(n, 250000, seed, which == "chr1")
+    hic = synth.contact_graph(n, 250000, seed, gen)
     torch.manual_seed(seed)
     orc = O.GatedGCNOracle(d, NC, 0.0, 2)
     with torch.no_grad():
@@ -108,6 +109,30 @@ def main():
                         ("HIP Z2 only", (Gexact, X1o, z2, G2o_)), ("HIP gate only", (Gexact, X1o, Z2o, g2))):
         _, _, dcgv, _ = sums64(args[0], args[1], args[2], args[3], P["W2.weight"])
         print("  dW2.bias with %-16s: rel err vs all-f64 truth %.2e" % (label, rel(np.asarray(dcgv).reshape(-1), truth["W2.bias"].reshape(-1))))
+
+
+    # ---- layer 1: its bias-type sums inherit dL/dXn1 = the dX of layer 2's backward (gather over Ahat^T included)
+    A64 = torch.sparse_csr_tensor(g.rowptr.long(), g.col.long(), torch.ones(g.col.numel(), dtype=torch.float64, device=dev), size=(n, n))
+    rs64 = g.row_scale.double()
+    gam2 = g2.double() * (1 - g2.double()) * (G2f.double() * (z2.double() - xn1.double())).sum(-1)
+    du2 = (g2.double().unsqueeze(-1) * G2f.double() + gam2.unsqueeze(-1) * P["W2.weight"].double().view(-1)) * (1 - z2.double() ** 2)
+    dhs64 = (du2 @ P["GC2.weight"].double().t()) * rs64.view(1, -1, 1)
+    dx64 = torch.stack([(1 - g2[s].double()).unsqueeze(-1) * G2f[s].double() + torch.sparse.mm(A64.t().to_sparse_csr(), dhs64[s]) for s in range(2)])
+    deg = (g.rowptr[1:] - g.rowptr[:-1]).cpu().numpy()
+    e = (dx.double() - dx64).abs().amax((0, 2)).cpu().numpy()
+    worst = np.argsort(-e)[:5]
+    print("  layer-2 backward dX (= dL/dXn1): HIP vs f64 on the HIP inputs, scale-relative %.2e; rows with the largest error (row, degree): %s; max degree %d" % (
+        rel(dx.cpu().numpy(), dx64.cpu().numpy()), [(int(r), int(deg[r])) for r in worst], int(deg.max())))
+    print("  dHs (MFMA, fp32) vs f64: scale-relative %.2e" % rel(dhs.cpu().numpy(), dhs64.cpu().numpy()))
+    _, dw1, db1, dwg1, dcg1, _ = torch.ops.chromegcn.gated_layer_backward(
+        dx, None, x0, z1, h1, g1, P["GC1.weight"], P["W1.weight"], g.rowptr_t, g.col_t, g.val_t, g.row_scale, 0.0, None, 1, True)
+    for label, Gup in (("HIP dXn1 (kernel error)", dx), ("f64 dXn1 (what layer 2's dX costs)", dx64)):
+        b64, w64, c64, gam = sums64(Gup, x0, z1, g1, P["W1.weight"])
+        print("  layer 1 with %-36s: dGC1.bias %.2e  dW1.weight %.2e  dW1.bias %.2e   (HIP kernel outputs vs these f64 sums; cancellation %.2e)" % (
+            label, rel(db1.cpu().numpy(), b64), rel(dwg1.cpu().numpy(), w64), rel(dcg1.cpu().numpy().reshape(-1), np.asarray(c64).reshape(-1)),
+            abs(float(gam.sum())) / float(gam.abs().sum())))
+    print("  layer 1 all-f64 truth vs HIP outputs: dGC1.bias %.2e  dW1.weight %.2e  dW1.bias %.2e" % (
+        rel(db1.cpu().numpy(), truth["GC1.bias"]), rel(dwg1.cpu().numpy().reshape(-1), truth["W1.weight"].reshape(-1)), rel(dcg1.cpu().numpy().reshape(-1), truth["W1.bias"].reshape(-1))))
 
 
 if __name__ == "__main__":
