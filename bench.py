@@ -139,6 +139,9 @@ def single_shape(name):
     return "cfg1", 5000, 125000
 
 
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA = the fp32 vector rate (dense)
+
+
 def layer_fwd_bytes(n, nnz, S, d):
     """Algorithmic HBM bytes of ONE fused-layer forward launch in training, SURVEY.md 8(d): CSR (rowptr + col) +
     1/deg + X read + parameters + X' write + gate write + the saved Z.  (The kernel also writes H = A X for the
@@ -146,60 +149,148 @@ def layer_fwd_bytes(n, nnz, S, d):
     return 4 * (n + 1) + 4 * nnz + 4 * n + S * 4 * n * d + (4 * d * d + 8 * d + 4) + S * 4 * n * d + S * 4 * n + S * 4 * n * d
 
 
-def time_layer_fwd(stage, name, reps, dropout_p):
-    """Average duration of one layer forward (cgcn_layer_fwd, training form, both strands: the fused k_layer_fwd or the
-    k_aggregate_sliced + k_layer_dense pair) on one chromosome, measured with HIP events
-    on the stream the library launches on (torch's current stream), in the two forms a train step uses: layer 1
-    (inter-layer dropout with the run's p and RNG state) and layer 2 (BatchNorm column statistics for the head)."""
+# Algorithmic bytes / flops of ONE launch of each kernel of the train step (column "algorithmic
+# bytes per launch"); n nodes, nnz = nnz(A + I), S strands, d features, C labels, P partial records.
+def kernel_costs(n, nnz, S, d, C, P_rl, P_head):
+    csr = 4 * (n + 1) + 4 * nnz + 4 * n
+    t = S * 4 * n * d                      # one [S, n, d] tensor
+    par = 4 * d * d + 8 * d + 4
+    CP = 128 if C <= 128 else 256
+    return {
+        "k_aggregate_sliced": (csr + 2 * t, 2.0 * nnz * S * d),                               # X in, H out
+        "k_layer_dense": (4 * t + S * 4 * n + par, 2.0 * S * n * d * d),                      # H, X in; X', Z out; gate
+        "k_layer_fwd": (csr + 4 * t + S * 4 * n + par, 2.0 * nnz * S * d + 2.0 * S * n * d * d),   # X in; X', Z, H out
+        "k_bwd_rowlocal": (5 * t + S * 4 * n + P_rl * (4 * d * d + 8 * d + 16), 4.0 * S * n * d * d),   # Z, X, H, dXn in; dHs out
+        "k_bwd_rowlocal(head)": (4 * t + 4 * n * d + t + S * 4 * n + P_rl * (4 * d * d + 8 * d + 16), 4.0 * S * n * d * d),   # dym [n,d] in, dL/dXn out
+        "k_bwd_sliced": (4 * (n + 1) + 4 * nnz + 3 * t + S * 4 * n, 2.0 * nnz * S * d),      # dHs, dXn in; dX out
+        "k_head_fused": (t + 2 * 4 * n * C + 4 * n * d + P_head * 4 * (CP * d + CP + 8 * d), 6.0 * n * d * C),   # X, targets in; probs, dym out
+    }
+
+
+def time_kernels(stage, name, reps, dropout_p):
+    """Average duration (seconds) of every kernel of one chromosome's train step, each launched in isolation `reps`
+    times back to back and bracketed by HIP events on the stream the library launches on (torch's current stream):
+    the C ABI runs the forward's two launches as cgcn_spmm (k_aggregate_sliced on tables >= 8 MiB) and cgcn_layer_fwd
+    with H_in (k_layer_dense), the backward's and the head's through the cgcn_debug_*_phases hooks.
+    Returns {kernel: (seconds per launch, launches per train step)}."""
     import ctypes
     from chromegcn_amd import _lib
     c = stage.chroms[name]
     m = stage.model
     g = c.graph
     S, n, d = c.x.shape
-    xn, z, h = torch.empty_like(c.x), torch.empty_like(c.x), torch.empty_like(c.x)
-    gate = torch.empty(S, n, device=c.x.device)
+    C = c.target.shape[1]
+    dev = c.x.device
     lib = _lib.load()
+    P, st = _lib.ptr, _lib.stream_ptr
+    xn, z, h, dx, dhs = (torch.empty_like(c.x) for _ in range(5))
+    gate = torch.empty(S, n, device=dev)
     rng = m._rng_state
     rows = ctypes.c_int(0)
     tiles = lib.cgcn_layer_fwd_colstats_tiles(n, S, d, ctypes.byref(rows))
-    colstats = torch.empty((tiles, S, d, 2), device=c.x.device)
+    colstats = torch.empty((tiles, S, d, 2), device=dev)
+    L = m.n_layers
+    gc1, w1, gcL, wL, bn, out = m.GC1, m.W1, getattr(m, "GC%d" % L), getattr(m, "W%d" % L), m.batch_norm, m.out
+    split = n * S * d * 4 >= (8 << 20) and S * d <= 256
+    drop = dropout_p > 0
 
-    def launch(layer):
-        gc, wk = getattr(m, "GC%d" % layer), getattr(m, "W%d" % layer)
-        last = layer == m.n_layers
-        _lib.check(lib.cgcn_layer_fwd(_lib.stream_ptr(), n, S, d, _lib.ptr(g.rowptr), _lib.ptr(g.col), _lib.ptr(g.val),
-                                      _lib.ptr(g.row_scale), c.x.data_ptr(), gc.weight.data_ptr(), gc.bias.data_ptr(),
-                                      wk.weight.data_ptr(), wk.bias.data_ptr(), xn.data_ptr(), z.data_ptr(),
-                                      h.data_ptr(), gate.data_ptr(), 0.0 if last else float(dropout_p),
-                                      None if (last or dropout_p <= 0) else _lib.ptr(rng), layer, None,
-                                      colstats.data_ptr() if last else None), "fwd")
-    out = []
-    for layer in (1, m.n_layers):
+    def ev_time(fn):
         for _ in range(3):
-            launch(layer)
+            _lib.check(fn(), "roofline launch")
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            launch(layer)
+            fn()
         e1.record()
         e1.synchronize()
-        out.append(e0.elapsed_time(e1) / reps * 1e-3)
-    return out  # seconds: [layer 1 form, last-layer form]
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    def fwd(layer, h_in, hbuf, cs):   # layer 1: inter-layer dropout; last layer: BatchNorm column statistics
+        gc, wk = (gc1, w1) if layer == 1 else (gcL, wL)
+        last = layer == L
+        return lib.cgcn_layer_fwd(st(), n, S, d, P(g.rowptr), P(g.col), P(g.val), P(g.row_scale), c.x.data_ptr(),
+                                  gc.weight.data_ptr(), gc.bias.data_ptr(), wk.weight.data_ptr(), wk.bias.data_ptr(),
+                                  xn.data_ptr(), z.data_ptr(), P(hbuf), gate.data_ptr(), 0.0 if (last or not drop) else float(dropout_p),
+                                  None if (last or not drop) else P(rng), layer, P(h_in), cs.data_ptr() if (last and cs is not None) else None)
+
+    out_t = {}
+    if split:
+        t_agg = ev_time(lambda: lib.cgcn_spmm(st(), n, n, S, d, P(g.rowptr), P(g.col), P(g.val), P(g.row_scale), c.x.data_ptr(), h.data_ptr()))
+        t_d1 = ev_time(lambda: fwd(1, h, None, None))
+        t_d2 = ev_time(lambda: fwd(L, h, None, colstats))
+        out_t["k_aggregate_sliced"] = (t_agg, 2)
+        out_t["k_layer_dense"] = ((t_d1 + t_d2) / 2, 2)
+    else:
+        t_f1 = ev_time(lambda: fwd(1, None, h, None))
+        t_f2 = ev_time(lambda: fwd(L, None, h, colstats))
+        out_t["k_layer_fwd"] = ((t_f1 + t_f2) / 2, 2)
+    # ---- head: cgcn_head_train once in full (valid state for the phases and for the backward's head mode), then k_head_fused alone
+    hws_b = lib.cgcn_head_workspace_bytes(n, S, d, C)
+    hws = torch.empty(hws_b, dtype=torch.uint8, device=dev)
+    probs, loss = torch.empty(n, C, device=dev), torch.empty(1, device=dev)
+    sm, si = torch.empty(S, d, device=dev), torch.empty(S, d, device=dev)
+    rm, rv = bn.running_mean.clone(), bn.running_var.clone()
+
+    def head(ph):
+        return lib.cgcn_debug_head_train_phases(st(), n, S, d, C, xn.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), rm.data_ptr(),
+                                                rv.data_ptr(), None, 0.1, 1e-5, out.weight.data_ptr(), out.bias.data_ptr(),
+                                                c.target.data_ptr(), float(dropout_p) if drop else 0.0, P(rng) if drop else None,
+                                                probs.data_ptr(), loss.data_ptr(), sm.data_ptr(), si.data_ptr(), colstats.data_ptr(), tiles,
+                                                rows.value, hws.data_ptr(), hws_b, ph)
+    _lib.check(fwd(L, h if split else None, None if split else h, colstats), "fwd")
+    _lib.check(head(7), "head")
+    out_t["k_head_fused"] = (ev_time(lambda: head(2)), 1)
+    out_t["k_head_bn_finalize"] = (ev_time(lambda: head(1)), 1)
+    out_t["k_head_train_finish"] = (ev_time(lambda: head(4)), 1)
+    # ---- backward: row-local launch (head mode = last layer, plain = first layer), then the sliced gather launch
+    o_dym, o_bnc, o_part = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+    _lib.check(lib.cgcn_head_workspace_layout(n, S, d, C, ctypes.byref(o_dym), ctypes.byref(o_bnc), ctypes.byref(o_part)), "layout")
+    one = torch.ones(1, device=dev)
+    dW_out, db_out = torch.empty_like(out.weight), torch.empty(C, device=dev)
+    dbn_w, dbn_b = torch.empty(d, device=dev), torch.empty(d, device=dev)
+    hg = _lib.HeadGrad(hws.data_ptr() + o_dym.value, hws.data_ptr() + o_bnc.value, sm.data_ptr(), si.data_ptr(), bn.weight.data_ptr(),
+                       float(dropout_p) if drop else 0.0, P(rng) if drop else None, hws.data_ptr() + o_part.value,
+                       lib.cgcn_head_bwd_partials(n), C, dW_out.data_ptr(), db_out.data_ptr(), 0, one.data_ptr(), dbn_w.data_ptr(), dbn_b.data_ptr())
+    ws_b = lib.cgcn_layer_bwd_workspace_bytes(n, S, d)
+    ws = torch.empty(ws_b, dtype=torch.uint8, device=dev)
+    dW, db, dwg, dcg = torch.empty(d, d, device=dev), torch.empty(d, device=dev), torch.empty(d, device=dev), torch.empty(1, device=dev)
+    dxn = torch.randn_like(c.x) * 1e-6
+
+    def bwd(ph, head_mode):
+        gc, wk = (gcL, wL) if head_mode else (gc1, w1)
+        return lib.cgcn_debug_layer_bwd_phases(st(), n, S, d, P(g.rowptr_t), P(g.col_t), P(g.val_t), P(g.row_scale), c.x.data_ptr(), z.data_ptr(),
+                                               h.data_ptr(), gate.data_ptr(), gc.weight.data_ptr(), wk.weight.data_ptr(),
+                                               None if head_mode else dxn.data_ptr(), None, dx.data_ptr(), dhs.data_ptr(), dW.data_ptr(),
+                                               db.data_ptr(), dwg.data_ptr(), dcg.data_ptr(), 0, float(dropout_p) if (head_mode and drop and L > 1) else 0.0,
+                                               P(rng) if drop else None, max(L - 1, 0) if head_mode else 0,
+                                               ctypes.byref(hg) if head_mode else None, ws.data_ptr(), ws_b, ph)
+    _lib.check(bwd(3, True), "bwd")
+    out_t["k_bwd_rowlocal(head)"] = (ev_time(lambda: bwd(1, True)), 1)
+    out_t["k_bwd_rowlocal"] = (ev_time(lambda: bwd(1, False)), max(L - 1, 0))
+    _lib.check(bwd(3, False), "bwd")
+    out_t["k_bwd_sliced"] = (ev_time(lambda: bwd(2, False)), L)
+    torch.cuda.synchronize()
+    return out_t, (lib.cgcn_layer_bwd_workspace_bytes(n, S, d) // ((d * d + 2 * d + 4) * 4), lib.cgcn_head_bwd_partials(n))
 
 
-def stored_traffic(key):
-    """HBM bytes per launch from the PMC passes of an earlier profiling run (profiles/traffic.json; FETCH_SIZE doubled
-    per MI355X_MICROARCH.md + WRITE_SIZE).  A stored, offline value: the bench line says so and names the tag."""
+def stored_traffic(key, kernel=None):
+    """Bytes beyond L2 per launch from the PMC passes of an earlier profiling run (profiles/traffic.json;
+    FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE), for one kernel of one workload.  A stored, offline value:
+    the bench line says so and names the tag."""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         t = json.load(open(tpath))
     except Exception:
         return None, None
     ent = t.get(key)
-    if isinstance(ent, dict):
-        return ent.get("bytes_per_launch"), ent.get("tag")
-    return ent, t.get("_tag")
+    if not isinstance(ent, dict):
+        return None, None
+    if kernel is not None:
+        for k, v in (ent.get("per_kernel") or {}).items():
+            if k.startswith("void " + kernel.split("(")[0] + "<") or k.startswith(kernel.split("(")[0]):
+                return v.get("bytes_per_launch"), ent.get("tag")
+        return None, ent.get("tag")
+    return ent.get("bytes_per_launch"), ent.get("tag")
 
 
 def host_info():
@@ -417,35 +508,58 @@ def main():
 
     out = None
     if rank == 0:
-        # ---- roofline of the dominant operation (the layer forward: largest share of the epoch), measured live
-        reps = 30 if genome else 200
-        tot_t = tot_b = tot_g = tot_f = 0.0
-        per_chrom = {}
+        # ---- roofline: every kernel of the train step timed live (HIP events, each kernel launched alone through the C
+        # ABI / its profiling hooks on the chromosomes this rank holds); the DOMINANT kernel = the largest share of the
+        # epoch's summed kernel time; roofline_top3 = the three largest, each against both roofs
+        reps = 20 if genome else 100
+        agg = {}
         for nm, n, nnz in shapes:
             if nm not in stage.chroms or args.no_roofline:
                 continue
-            t1, t2 = time_layer_fwd(stage, nm, reps, args.dropout)
-            b = layer_fwd_bytes(n, nnz, 2, args.d)
-            tot_t += t1 + t2
-            tot_b += 2 * b
-            tot_g += 2 * 4.0 * nnz * 2 * args.d
-            tot_f += 2 * 2.0 * 2 * n * args.d * args.d
-            per_chrom[nm] = {"n": n, "nnz": nnz, "us_layer1": t1 * 1e6, "us_last": t2 * 1e6, "GBps": b / ((t1 + t2) / 2) / 1e9}
+            kt, (p_rl, p_head) = time_kernels(stage, nm, reps, args.dropout)
+            costs = kernel_costs(n, stage.chroms[nm].graph.nnz, 2, args.d, synth.N_LABELS, p_rl, p_head)
+            for k, (sec, per_step) in kt.items():
+                # (one kernel, two forms: k_bwd_rowlocal with the head prologue -- last layer -- and without)
+                e = agg.setdefault(k.split("(")[0], {"s": 0.0, "launches": 0, "bytes": 0.0, "flops": 0.0})
+                e["s"] += sec * per_step
+                e["launches"] += per_step
+                if k in costs:
+                    e["bytes"] += costs[k][0] * per_step
+                    e["flops"] += costs[k][1] * per_step
         wl_key = ("genome" if genome else args.workload) + {"uniform": "", "hic_like": "_hic", "hub": "_hub"}[args.generator] + "_d%d" % args.d
-        traffic, ttag = stored_traffic(wl_key)
-        nl = 2 * len(per_chrom)
-        roof = None if not per_chrom else {"bound": "hbm",
-                "kernel": "layer forward, training form (writes Z, H; layer 1 with dropout, last layer with BatchNorm column "
-                          "statistics) = one cgcn_layer_fwd call: k_aggregate_sliced + k_layer_dense<S=2,D=%d> on feature tables "
-                          ">= 8 MiB, the fused k_layer_fwd below; HIP events around the call, average over the %d calls of one %s" %
-                          (args.d, nl, "train epoch" if genome else "train step"),
-                "achieved": tot_b / tot_t / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": tot_b / tot_t / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
-                "traffic_source": None if traffic is None else "stored profile value (profiles/traffic.json, tag %s), not measured in this run" % ttag,
-                "algorithmic_bytes_per_launch": tot_b / nl, "avg_kernel_us": tot_t / nl * 1e6,
-                "bytes_formula": "SURVEY 8(d): 4(n+1)+4nnz+4n + S*4nd (X) + 4d^2+8d+4 + S*4nd (X') + S*4n (gate) + S*4nd (Z); H not counted",
-                "gather_GBps": tot_g / tot_t / 1e9, "mfma_TFLOPs": tot_f / tot_t / 1e12,
-                "per_chromosome": per_chrom if genome else None}
+
+        def roof_entry(k, e):
+            if not e["launches"] or not e["bytes"]:
+                return None
+            us = e["s"] / e["launches"] * 1e6
+            gbps, tfl = e["bytes"] / e["s"] / 1e9, e["flops"] / e["s"] / 1e12
+            traffic, ttag = stored_traffic(wl_key, k)
+            fh, fm = gbps / HBM_PEAK_GBPS, tfl / MFMA_F32_PEAK_TFLOPS
+            return {"kernel": k, "bound": "hbm" if fh >= fm else "mfma",
+                    "achieved": gbps if fh >= fm else tfl, "peak": HBM_PEAK_GBPS if fh >= fm else MFMA_F32_PEAK_TFLOPS,
+                    "unit": "GB/s" if fh >= fm else "TFLOP/s", "frac": max(fh, fm), "traffic": traffic,
+                    "traffic_source": None if traffic is None else "stored profile value (profiles/traffic.json, tag %s; 2*FETCH_SIZE + WRITE_SIZE per launch, "
+                                      "beyond-L2 bytes incl. Infinity-Cache hits), not measured in this run" % ttag,
+                    "algorithmic_bytes_per_launch": e["bytes"] / e["launches"], "flops_per_launch": e["flops"] / e["launches"],
+                    "avg_kernel_us": us, "launches_per_step": e["launches"], "share_of_kernel_time": None,
+                    "hbm_GBps": gbps, "frac_hbm": fh, "mfma_f32_TFLOPs": tfl, "frac_mfma_f32": fm}
+        tot_s = sum(e["s"] for e in agg.values())
+        ranked = sorted(((k, e) for k, e in agg.items() if e["bytes"]), key=lambda kv: -kv[1]["s"])
+        top3 = []
+        for k, e in ranked[:3]:
+            r = roof_entry(k, e)
+            r["share_of_kernel_time"] = e["s"] / tot_s
+            top3.append(r)
+        roof = None
+        if top3:
+            roof = dict(top3[0])
+            roof["kernel"] = ("%s: the largest share (%.0f %%) of the summed kernel time of one %s; HIP events around %d isolated launches "
+                              "per chromosome on the library's stream, average over its %d launches per step; bytes / flops: DESIGN.md "
+                              "section 4 (algorithmic, per launch)" %
+                              (top3[0]["kernel"], 100 * top3[0]["share_of_kernel_time"], "train epoch" if genome else "train step", reps,
+                               top3[0]["launches_per_step"]))
+            roof["sum_kernel_ms_per_step"] = tot_s * 1e3
+            roof["all_kernels_us"] = {k: round(e["s"] / max(e["launches"], 1) * 1e6, 2) for k, e in agg.items()}
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # the host baseline is reported at N=1 only
             if genome:  # bounded sample of the same genome: its smallest, a middle and its largest train chromosome
@@ -487,7 +601,7 @@ def main():
                         "p90": float(np.percentile(per_ms, 90)), "n": len(per),
                         "note": "per-step host time on rank 0" + (" (each epoch ends with its own loss sync)" if genome else " (launch only: steps are asynchronous)")},
             "value_at_median": windows / (float(np.median(per_ms)) * 1e-3) if genome else None,
-            "roofline": roof, "cpu_baseline": cpu, "final_loss": final_loss,
+            "roofline": roof, "roofline_top3": top3 if roof else None, "cpu_baseline": cpu, "final_loss": final_loss,
         }
         out.update(extras)
         print(json.dumps(out))

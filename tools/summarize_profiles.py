@@ -51,8 +51,8 @@ def main():
     if f:
         rows = list(csv.DictReader(open(f)))
         with open(os.path.join(out, f"{tag}_{wl}_kernel_stats.csv"), "w") as o:
-            o.write("# rocprofv3 --kernel-trace --stats -- %s --steps 10 --warmup 3\n" % cmd)
-            o.write("# (timed steps + bench.py's isolated k_layer_fwd launches for the roofline)\n")
+            o.write("# rocprofv3 --kernel-trace --stats -- %s --no-roofline --steps 10 --warmup 3\n" % cmd)
+            o.write("# (epoch / step replays only: --no-roofline, no isolated launches)\n")
             o.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
             for r in rows:
                 o.write("%s,%s,%s,%s,%s,%s,%s\n" % (short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]))
@@ -66,17 +66,16 @@ def main():
                 v = vals[k][cname]
                 o.write("%s,%s,%d,%.1f\n" % (k, cname, len(v), sum(v) / len(v)))
                 per.setdefault(k, {})[cname] = (sum(v), len(v))
-    fk = [k for k in per if is_fwd_kernel(k) and "FETCH_SIZE" in per[k] and "WRITE_SIZE" in per[k]]
-    # one layer forward = one k_layer_fwd launch (fused route) or one k_aggregate_sliced + one k_layer_dense (split route)
-    calls = sum(per[k]["FETCH_SIZE"][1] for k in fk if not k.startswith("void k_aggregate_sliced<"))
-    if fk and calls:
-        fs = sum(per[k]["FETCH_SIZE"][0] for k in fk) / calls
-        ws = sum(per[k]["WRITE_SIZE"][0] for k in fk) / calls
-        ent = {"bytes_per_launch": (2 * fs + ws) * 1024, "tag": tag, "fetch_KB": fs, "write_KB": ws,
-               "launches": calls, "kernels": fk}
-        json.dump({"%s_d%d" % (wl, d): ent,
-                   "_note": "per layer forward (one cgcn_layer_fwd call = k_layer_fwd, or k_aggregate_sliced + k_layer_dense), mean over "
-                            "the calls of one bench run: (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes "
+    # traffic beyond L2 per launch of every hand-written kernel of the step (bench.py looks its dominant kernel up here)
+    per_kernel = {}
+    for k, v in per.items():
+        if not k.startswith(("void k_", "k_")) or "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
+            continue
+        fs, ws = v["FETCH_SIZE"][0] / v["FETCH_SIZE"][1], v["WRITE_SIZE"][0] / v["WRITE_SIZE"][1]
+        per_kernel[k] = {"bytes_per_launch": (2 * fs + ws) * 1024, "fetch_KB": fs, "write_KB": ws, "launches": v["FETCH_SIZE"][1]}
+    if per_kernel:
+        json.dump({"%s_d%d" % (wl, d): {"tag": tag, "per_kernel": per_kernel},
+                   "_note": "per launch, mean over the launches of one bench run: (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes "
                             "(rocprofv3 --pmc, separate passes). gfx950: FETCH_SIZE reports half the bytes of wide (16 B/lane) "
                             "reads, hence the factor 2 (MI355X_MICROARCH.md, HBM). FETCH_SIZE counts L2->fabric reads and includes "
                             "Infinity-Cache hits: traffic beyond L2, not HBM-only."},
