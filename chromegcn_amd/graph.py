@@ -323,12 +323,15 @@ def graph_from_torch_sparse(adj: torch.Tensor, device=None) -> ChromGraph:
             return g
         del _coo_cache[key]
     dev = adj.device if device is None else torch.device(device)
-    i = idx.detach().cpu().numpy()
-    v = vals.detach().cpu().numpy().astype(np.float32)
     if adj.shape[0] != adj.shape[1]:
         raise ValueError("adjacency must be square")
-    m = sp.coo_matrix((v, (i[0], i[1])), shape=tuple(adj.shape)).tocsr()
-    g = upload(host_csr_from_matrix(m), dev)
+    if adj.is_cuda and dev.type == "cuda":
+        g = _graph_from_coo_device(adj, dev)       # no host round trip (finetune.py:36 hands a fresh COO per chromosome per epoch)
+    else:
+        i = idx.detach().cpu().numpy()
+        v = vals.detach().cpu().numpy().astype(np.float32)
+        m = sp.coo_matrix((v, (i[0], i[1])), shape=tuple(adj.shape)).tocsr()
+        g = upload(host_csr_from_matrix(m), dev)
     for k in [k for k, e in _coo_cache.items() if e[1]() is None]:
         del _coo_cache[k]            # entries whose source tensor died: do not pin their device CSRs
     if len(_coo_cache) >= _COO_CACHE_MAX:
@@ -336,6 +339,57 @@ def graph_from_torch_sparse(adj: torch.Tensor, device=None) -> ChromGraph:
     import weakref
     _coo_cache[key] = (g, weakref.ref(adj), (idx._version, vals._version))
     return g
+
+
+def _graph_from_coo_device(adj: torch.Tensor, dev) -> ChromGraph:
+    """COO -> device CSR without leaving the GPU.  torch device ops for the plumbing (coalesce = sort + duplicate sum,
+    searchsorted for the row pointers), then the device normaliser (cgcn_graph_count / cgcn_graph_fill) RECOGNISES the
+    reference's own normalisation: if the tensor is D^-1 A-hat with a binary, symmetric A-hat that contains its diagonal
+    -- what process_graph produces for 'hic', 'constant' and 'none' (utils/util_methods.py:148-178) -- every stored
+    value of row i equals fp32(1 / deg_i) bit for bit, and the graph is handed to the kernels in their implicit form
+    (no value array, row_scale = 1/deg, the same CSR for A-hat^T: no transpose build).  Anything else ('both' graphs,
+    arbitrary adjacencies) keeps explicit values, and the CSR of the transpose comes from one more device sort."""
+    from . import _lib
+    a = adj.detach()
+    a = a.to(dev) if a.device != dev else a
+    a = a if a.is_coalesced() else a.coalesce()
+    n = int(a.shape[0])
+    row, colx = a.indices()
+    v = a.values().to(torch.float32).contiguous()
+    nnz = int(v.numel())
+    if nnz >= 2 ** 31:
+        raise ValueError("graph too large for int32 CSR")
+    ar = torch.arange(n + 1, device=dev, dtype=row.dtype)
+    rowptr = torch.searchsorted(row.contiguous(), ar).to(torch.int32)
+    col = colx.to(torch.int32).contiguous()
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        if n > 0 and nnz > 0:
+            counts = torch.empty(n, dtype=torch.int32, device=dev)
+            rowptr2 = torch.empty(n + 1, dtype=torch.int32, device=dev)
+            _lib.check(lib.cgcn_graph_count(_lib.stream_ptr(), n, ADJ_CODES["hic"], rowptr.data_ptr(), col.data_ptr(), None,
+                                            counts.data_ptr(), rowptr2.data_ptr()), "cgcn_graph_count")
+            if bool(torch.equal(rowptr2, rowptr)):   # binarise(pattern + I) == pattern: the diagonal is already there
+                col2 = torch.empty(nnz, dtype=torch.int32, device=dev)
+                rs = torch.empty(n, dtype=torch.float32, device=dev)
+                flag = torch.ones(1, dtype=torch.int32, device=dev)
+                _lib.check(lib.cgcn_graph_fill(_lib.stream_ptr(), n, ADJ_CODES["hic"], rowptr.data_ptr(), col.data_ptr(), None,
+                                               rowptr2.data_ptr(), col2.data_ptr(), None, rs.data_ptr(), flag.data_ptr()),
+                           "cgcn_graph_fill")
+                if bool(flag.item()) and bool(torch.equal(v, rs[row])):
+                    return ChromGraph(n=n, nnz=nnz, rowptr=rowptr, col=col, val=None, row_scale=rs, rowptr_t=rowptr, col_t=col,
+                                      val_t=None, symmetric=True, host=None)
+        # explicit values; CSR of the transpose by sorting the (column, row) keys on the device
+        perm = torch.argsort(colx * n + row, stable=True)
+        rowptr_t = torch.searchsorted(colx[perm].contiguous(), ar).to(torch.int32)
+        col_t = row[perm].to(torch.int32).contiguous()
+        val_t = v[perm].contiguous()
+        symmetric = bool(torch.equal(rowptr, rowptr_t) and torch.equal(col, col_t) and torch.equal(v, val_t))
+    if symmetric:
+        return ChromGraph(n=n, nnz=nnz, rowptr=rowptr, col=col, val=v, row_scale=None, rowptr_t=rowptr, col_t=col, val_t=v,
+                          symmetric=True, host=None)
+    return ChromGraph(n=n, nnz=nnz, rowptr=rowptr, col=col, val=v, row_scale=None, rowptr_t=rowptr_t, col_t=col_t, val_t=val_t,
+                      symmetric=False, host=None)
 
 
 _identity_cache: Dict[tuple, ChromGraph] = {}

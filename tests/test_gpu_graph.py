@@ -71,3 +71,43 @@ def test_process_graph_uses_device_path_and_bad_types_raise():
         G.normalize_graph_device("random", a, 40, DEV)
     with pytest.raises(ValueError):
         G.normalize_graph_device("hic", a, 41, DEV)
+
+
+def test_reference_style_coo_adjacency_is_converted_on_the_device():
+    """finetune.py:36 hands `process_graph(...).cuda()` -- a torch sparse COO of the row-normalised adjacency -- to the
+    model for every chromosome of every epoch.  graph_from_torch_sparse converts it without a host round trip and
+    recognises the reference's own normalisation: 'hic' / 'constant' / 'none' come back in the kernels' implicit form
+    (no values, row_scale = fp32(1/deg), one CSR for both directions), identical to normalize_graph's result; 'both'
+    (values {1,2,3}/rowsum) keeps explicit values and gets the CSR of its transpose from a device sort."""
+    from chromegcn_amd import ops
+    n = 700
+    a = O.random_symmetric_graph(n, 5000, 4)
+    x = torch.randn(2, n, 128, device=DEV)
+    for adj_type in ("hic", "constant", "none", "both"):
+        coo = O.process_graph(adj_type, {"c": a}, n, "c").to(DEV)
+        assert coo.is_cuda and coo.layout == torch.sparse_coo
+        g = G.graph_from_torch_sparse(coo, DEV)
+        h = G.normalize_graph(adj_type, a, n)
+        np.testing.assert_array_equal(g.rowptr.cpu().numpy(), h.rowptr)
+        np.testing.assert_array_equal(g.col.cpu().numpy(), h.col)
+        if adj_type != "both":
+            assert g.val is None and g.symmetric and g.rowptr_t is g.rowptr
+            np.testing.assert_array_equal(g.row_scale.cpu().numpy(), h.row_scale)
+        else:
+            assert g.val is not None and g.row_scale is None and not g.symmetric    # row-normalised values: A != A^T
+            ref = sp.csr_matrix(O.normalized_adjacency("both", a, n)); ref.sort_indices()
+            np.testing.assert_array_equal(g.val.cpu().numpy(), ref.data.astype(np.float32))
+            rt = sp.csr_matrix(ref.T); rt.sort_indices()
+            np.testing.assert_array_equal(g.rowptr_t.cpu().numpy(), rt.indptr)
+            np.testing.assert_array_equal(g.col_t.cpu().numpy(), rt.indices)
+            np.testing.assert_array_equal(g.val_t.cpu().numpy(), rt.data.astype(np.float32))
+        # and the aggregation over it equals the oracle's A X
+        want = np.stack([O.normalized_adjacency(adj_type, a, n).astype(np.float64) @ x[s].cpu().numpy().astype(np.float64) for s in range(2)])
+        np.testing.assert_allclose(ops.spmm(x, g).cpu().numpy(), want, atol=1e-5, rtol=1e-5)
+    # an adjacency without its diagonal / with unequal row values is NOT mistaken for the reference form
+    m = sp.csr_matrix(a, dtype=np.float32)
+    coo = torch.sparse_coo_tensor(torch.from_numpy(np.vstack(m.tocoo().coords)).long(), torch.from_numpy(m.tocoo().data), (n, n)).to(DEV)
+    g = G.graph_from_torch_sparse(coo, DEV)
+    assert g.val is not None and g.row_scale is None and g.symmetric
+    # the cache returns the same object for the same live tensor
+    assert G.graph_from_torch_sparse(coo, DEV) is g
