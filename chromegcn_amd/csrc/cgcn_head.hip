@@ -1050,6 +1050,9 @@ __global__ __launch_bounds__(512, HF_LOWREG ? 4 : 1) void k_head_fused(int n, in
 #ifndef HEAD_RS
 #define HEAD_RS 1   // 0: the 8-wave k_head_fused at d = 128 as well (A/B builds)
 #endif
+#ifndef HEAD_RS_PRIO
+#define HEAD_RS_PRIO 0   // wave priority inside the matrix sub-phases (measured: 2 is neutral for the head, -2 % for the row-local kernel)
+#endif
 #ifdef RS_TIMING  // tuning build only (tools/khead_train.py --stamps): phase timestamps of period RS_STAMP_K of a few workgroups
 __device__ unsigned long long rs_stamps[8 * 2 * 8];
 #ifndef RS_STAMP_K
@@ -1204,6 +1207,7 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
         if (k + 1 < mt) load_rows(tile + G);   // the rows were consumed in S1
         if (own < NB) {
           OPAQUE_LANE(r, q, lq);
+          __builtin_amdgcn_s_setprio(HEAD_RS_PRIO);   // matrix sub-phase: issue ahead of the other team's vector work
           const float* __restrict__ Ya = Yt[k & 1] + r * LDY + 4 * q;
           const float* __restrict__ Wa = Wl + (own * 16 + r) * LDW + 4 * q;
 #pragma unroll
@@ -1216,6 +1220,7 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
               acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u], b[u], acc[1], 0, 0, 0);
             }
           }
+          __builtin_amdgcn_s_setprio(0);
         }
       }
       RS_STAMP(3);
@@ -1310,6 +1315,7 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
             }
         }
         // label groups of 16 (4 k-steps: 8 A reads from Pt, 4 B reads from W_out), the next group's reads under this group's MFMAs
+        __builtin_amdgcn_s_setprio(HEAD_RS_PRIO);
         const float* __restrict__ Pa = Pb + r * LDP + q;
         const float* __restrict__ Wa = Wl + q * LDW + own * 16 + r;
         float pa[2][8], wb[2][4];
@@ -1336,6 +1342,7 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
             for (int mb = 0; mb < 2; ++mb) accY[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[g & 1][u * 2 + mb], wb[g & 1][u], accY[mb], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
+        __builtin_amdgcn_s_setprio(0);
       }
       RS_STAMP(1);
       __syncthreads();
@@ -1371,6 +1378,7 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
       if (k < mt) load_xq((int)blockIdx.x + k * G);   // tile k's values, used in S2 of the next period
       if (k >= 1) {
         OPAQUE_LANE(r, q, lq);
+        __builtin_amdgcn_s_setprio(HEAD_RS_PRIO);
         const float* __restrict__ Pa = Pt[(k - 1) & 1] + q * LDP + r;
         const float* __restrict__ Ya = Yt[(k - 1) & 1] + q * LDY + own * 16 + r;
         float a0[NB], a1[NB], b0, b1;
@@ -1396,6 +1404,7 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
           for (int ib = 0; ib < NB; ++ib) accW[ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[ib], b1, accW[ib], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
+        __builtin_amdgcn_s_setprio(0);
       }
       RS_STAMP(5);
       __syncthreads();

@@ -458,9 +458,22 @@ __device__ unsigned long long kt_stamps[8 * 16];
 extern "C" int cgcn_debug_kt_stamps(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(kt_stamps), sizeof(unsigned long long) * 8 * 16) == hipSuccess ? 0 : -1;
 }
+// stamp WITHOUT a vector-memory wait (loads in flight across the stamp stay in flight): k_bwd_rowlocal_rs, period KT_PERIOD
+#ifndef KT_PERIOD
+#define KT_PERIOD 2
+#endif
+#define KT_STAMP_NW(i, tid, cond)                                                        \
+  do {                                                                                   \
+    if ((cond) && threadIdx.x == (tid) && (blockIdx.x % KT_STRIDE) == 0 && blockIdx.x < 8 * KT_STRIDE) { \
+      __builtin_amdgcn_sched_barrier(0);                                                 \
+      kt_stamps[(blockIdx.x / KT_STRIDE) * 16 + (i)] = wall_clock64();                   \
+      __builtin_amdgcn_sched_barrier(0);                                                 \
+    }                                                                                    \
+  } while (0)
 #else
 #define KT_STAMP(i)
 #define KT_STAMP_T(i, tid)
+#define KT_STAMP_NW(i, tid, cond)
 #endif
 
 template <int S, int D, int MB, bool HAS_VAL, bool DEEP>
@@ -1143,6 +1156,348 @@ __global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, i
   KT_STAMP(7);
 }
 
+// ------------------------------------------------------------------------------------------
+// k_bwd_rowlocal_rs (D = 128): the same work as k_bwd_rowlocal<128, 32> with the 16 waves split by PIPE instead of by
+// product: waves 0-7 ("row team") stream the four row tensors and do all the row math on the vector pipe; waves 8-15
+// ("matrix team") do both MFMA products -- dW += Ht^T Ut (16 rows of dW each) and dHs = diag(rs) Ut W^T (16 columns
+// each) -- one tile behind, from the LDS tiles the row team left.  One barrier per 32-row tile.
+// Why: in k_bwd_rowlocal every wave alternates a row pass and a product, holds accumulators / W^T fragments AND one
+// tile of rows in 124 of 128 registers, and its loads have ONE phase of flight time: the stream (33 us alone at
+// n = 29 k) and the products (24 us floor) added up to 70 us.  The two teams run SEPARATE loops (each role's state on
+// its own path for the register allocator, like k_head_fused_rs): the row team has no accumulators, so it keeps TWO
+// tiles of rows in flight (64 registers); the matrix team has no rows, so both products' operands fit with a one-step
+// software pipeline of LDS reads.  Same results as k_bwd_rowlocal up to the order of the column sums.
+//   partial layout per workgroup: [D*D dW][D db][D dwg][1 dcg][3 pad]   (as k_bwd_rowlocal)
+// ------------------------------------------------------------------------------------------
+#ifndef RL_RS
+#define RL_RS 0   // 1: the role-split kernel on the large tables (measured: no gain, profiles/r03_rowlocal_rs_experiment.txt)
+#endif
+// HEAD: the last layer (dL/dXn recomputed from the head's backward state, HeadApply); DROP: ... with the head's dropout
+template <bool HEAD, bool DROP>
+__global__ __launch_bounds__(1024) void k_bwd_rowlocal_rs(int M, int n, const float* __restrict__ dXn,
+                                                          const float* __restrict__ Z, const float* __restrict__ X,
+                                                          const float* __restrict__ gate, const float* __restrict__ dgate,
+                                                          const float* __restrict__ H, const float* __restrict__ wg,
+                                                          const float* __restrict__ rs, float* __restrict__ dHs,
+                                                          float* __restrict__ part, HeadApply hp,
+                                                          float* __restrict__ dxn_store, int row_blocks, int head_slabs,
+                                                          const float* __restrict__ W) {
+  constexpr int D = 128, TR = 32, NW = 16, EPL = 2, JB = D / 16;
+  if ((int)blockIdx.x >= row_blocks) {   // extra workgroups: the head's deferred second stage (see k_bwd_rowlocal)
+    const int extra = (int)blockIdx.x - row_blocks;
+    const int wslabs = (hp.hf_CP * D + hp.hf_CP) / 64;
+    if (extra < wslabs)
+      head_finalize_slab<NW * 64>(extra, hp.hf_P, D, hp.hf_C, hp.hf_CP, hp.hf_part, hp.hf_dWout, hp.hf_dbout,
+                                  hp.hf_accumulate, hp.dloss);
+    else
+      head_stats_finalize<NW * 64>(extra - wslabs, hp.hf_P, n, hp.S, D, hp.hf_CP, hp.hf_part, hp.hf_dbn_w, hp.hf_dbn_b,
+                                   nullptr, hp.hf_accumulate, hp.dloss);
+    return;
+  }
+  constexpr int LD = D + RL_LD_PAD;
+  constexpr int PSTRIDE = D * D + 2 * D + 4;
+  constexpr int RPW = TR / 8;          // rows per row-team wave per tile
+  __shared__ __attribute__((aligned(16))) float Ht[2][TR * LD];
+  __shared__ __attribute__((aligned(16))) float Ut[2][TR * LD];
+  __shared__ float Sc[2][TR];          // row_scale of the tile's rows (0 past the end)
+  __shared__ __attribute__((aligned(16))) float Hc[HEAD ? 9 * D : 4];   // head mode: BatchNorm constants (row team)
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int own = wave & 7;
+  const int ntiles = (M + TR - 1) / TR;
+  const int tile0 = blockIdx.x;
+  const int nt = tile0 < ntiles ? (ntiles - 1 - tile0) / row_blocks + 1 : 0;   // tiles of this workgroup
+  float* P = part + (size_t)blockIdx.x * PSTRIDE;
+  KT_STAMP_NW(4, 0, true);
+#define OPAQUE_LANE(r_, q_, l_)          \
+  int l_ = lane;                         \
+  asm volatile("" : "+v"(l_));           \
+  const int r_ = l_ & 15, q_ = l_ >> 4
+
+  if (wave < 8) {
+    // =============================================================== row team
+    float wgl[EPL], db_acc[EPL], dwg_acc[EPL];
+    float dcg_acc = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      wgl[e] = wg[lane * EPL + e];
+      db_acc[e] = dwg_acc[e] = 0.f;
+    }
+    const uint32_t hkey = (HEAD && DROP) ? dropout_key(hp.rng_state, HEAD_STREAM_ID) : 0u;
+    const float hgl = (HEAD && hp.dloss) ? hp.dloss[0] : 1.f;
+    // head mode: the per-column BatchNorm constants of both strands in LDS (a row's strand is m >= n): [s][invstd, mean,
+    // c0, c1][D] and bn weight; staged by this team before its first row pass (the first workgroup barrier orders it)
+    if (HEAD) {
+      for (int i = threadIdx.x; i < 2 * D; i += 512) {
+        const int s = i / D, c = i % D, ss = s < hp.S ? s : 0;
+        Hc[(s * 4 + 0) * D + c] = hp.invstd[ss * D + c];
+        Hc[(s * 4 + 1) * D + c] = hp.mean[ss * D + c];
+        Hc[(s * 4 + 2) * D + c] = hp.bnc[(ss * 2 + 0) * D + c];
+        Hc[(s * 4 + 3) * D + c] = hp.bnc[(ss * 2 + 1) * D + c];
+        if (s == 0) Hc[8 * D + c] = hp.bn_w[c];
+      }
+      __syncthreads();   // (matched by the matrix team)
+    }
+    // two register sets of rows: tile it is consumed from set it & 1 while the loads of tile it + 1 are in flight in the
+    // other set and those of tile it + 2 are issued into this one right after its row pass
+    float gupA[RPW][EPL], zA[RPW][EPL], xA[RPW][EPL], hA[RPW][EPL], gtA[RPW];
+    float gupB[RPW][EPL], zB[RPW][EPL], xB[RPW][EPL], hB[RPW][EPL], gtB[RPW];
+    auto load_tile = [&](int tile, float (&gup)[RPW][EPL], float (&z)[RPW][EPL], float (&x)[RPW][EPL], float (&h)[RPW][EPL],
+                         float (&gt)[RPW]) {
+#pragma unroll
+      for (int t = 0; t < RPW; ++t) {
+        const int m = tile * TR + own + t * 8;
+        const bool ok = m < M;
+        const unsigned off = (unsigned)(m * D + lane * EPL);
+#ifdef RLRS_SKIP_LOADS
+        if (false) {
+#else
+        if (ok) {
+#endif
+          ld_row<EPL>(z[t], &Z[off]);
+          ld_row<EPL>(x[t], &X[off]);
+          ld_row<EPL>(h[t], &H[off]);
+          ld_row<EPL>(gup[t], HEAD ? &hp.dym[(unsigned)((m >= n ? m - n : m) * D + lane * EPL)] : &dXn[off]);  // S <= 2
+        } else {
+          zero_row<EPL>(z[t]);
+          zero_row<EPL>(x[t]);
+          zero_row<EPL>(h[t]);
+          zero_row<EPL>(gup[t]);
+        }
+        gt[t] = ok ? gate[m] : 0.f;
+      }
+    };
+    // row math of the loaded tile -> H and dU tiles (and the row scales) in LDS buffer `buf` (k_bwd_rowlocal::row_pass,
+    // written without a branch per row: with one, the RPW rows of a wave ran as RPW serial chains; rows past M were
+    // loaded as zeros -- gate 0, so gamma = dU = 0 -- and only their stores are predicated)
+    auto row_pass = [&](int tile, int buf, float (&gup)[RPW][EPL], float (&z)[RPW][EPL], float (&x)[RPW][EPL],
+                        float (&h)[RPW][EPL], float (&gt)[RPW]) {
+      int lane_ = lane;
+      asm volatile("" : "+v"(lane_));
+      float dg[RPW];
+#pragma unroll
+      for (int t = 0; t < RPW; ++t) {
+        const int m = tile * TR + own + t * 8;
+        const unsigned off = (unsigned)(m * D + lane_ * EPL);
+        const float g = gt[t];
+        if (HEAD) {   // dL/dXn of the last layer from the head's backward state (see HeadApply)
+          const int s = m >= n ? 1 : 0;   // S <= 2
+          const float invS = 1.f / (float)hp.S;
+          const float* __restrict__ hc = Hc + s * 4 * D + lane_ * EPL;
+          const f32x2 is2 = *(const f32x2*)&hc[0], mu2 = *(const f32x2*)&hc[D], c02 = *(const f32x2*)&hc[2 * D], c12 = *(const f32x2*)&hc[3 * D];
+          const f32x2 bw2 = *(const f32x2*)&Hc[8 * D + lane_ * EPL];
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) {
+            const float is = is2[e], mu = mu2[e], c0 = c02[e], c1 = c12[e];
+            const float xn = (1.f - g) * x[t][e] + g * z[t][e];
+            float dy = gup[t][e] * invS * hgl;
+            if (DROP) dy = dropout_keep(hkey, (uint32_t)(off + e), hp.thresh) ? dy * hp.keep_scale : 0.f;
+            const float xh = (fmaxf(xn, 0.f) - mu) * is;
+            const float dr = bw2[e] * is * (dy - hgl * c0 - xh * (hgl * c1));
+            gup[t][e] = xn > 0.f ? dr : 0.f;
+          }
+          if (dxn_store && m < M) st_row<EPL>(&dxn_store[off], gup[t]);  // k_bwd_sliced reads it back as dL/dXn for the (1-g) dXn term
+        }
+        float a = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) a += gup[t][e] * (z[t][e] - x[t][e]);
+        dg[t] = a;
+      }
+#pragma unroll
+      for (int t = 0; t < RPW; ++t) dg[t] = wave_sum(dg[t]);   // RPW independent DPP chains
+      if (dgate) {   // an upstream gradient on the gate output itself (return_gate consumers): rare, read in place
+#pragma unroll
+        for (int t = 0; t < RPW; ++t) {
+          const int m = tile * TR + own + t * 8;
+          dg[t] += m < M ? dgate[m] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < RPW; ++t) {
+        const int trow = own + t * 8;
+        const int m = tile * TR + trow;
+        const float g = gt[t];
+        const float gamma = g * (1.f - g) * dg[t];
+        float du[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+          const float dz = g * gup[t][e] + gamma * wgl[e];
+          du[e] = dz * (1.f - z[t][e] * z[t][e]);
+          db_acc[e] += du[e];
+          dwg_acc[e] += gamma * z[t][e];
+        }
+        dcg_acc += gamma;
+        const int mi = m < M ? (m >= n ? m - n : m) : 0;
+        const float sc = m < M ? (rs ? rs[mi] : 1.f) : 0.f;
+        if (lane_ == 0) Sc[buf][trow] = sc;
+        *(f32x2*)&Ht[buf][trow * LD + lane_ * EPL] = (f32x2){h[t][0], h[t][1]};
+        *(f32x2*)&Ut[buf][trow * LD + lane_ * EPL] = (f32x2){du[0], du[1]};
+      }
+    };
+    if (nt > 0) load_tile(tile0, gupA, zA, xA, hA, gtA);
+    if (nt > 1) load_tile(tile0 + row_blocks, gupB, zB, xB, hB, gtB);
+    for (int it = 0; it <= nt; it += 2) {   // two periods per trip: register set A, then B (static register indexing)
+      KT_STAMP_NW(0, 0, it == KT_PERIOD);
+#ifdef RLRS_SKIP_ROWTEAM
+      if (false) {
+#else
+      if (it < nt) {
+#endif
+        row_pass(tile0 + it * row_blocks, 0, gupA, zA, xA, hA, gtA);
+        KT_STAMP_NW(1, 0, it == KT_PERIOD);
+        if (it + 2 < nt) load_tile(tile0 + (it + 2) * row_blocks, gupA, zA, xA, hA, gtA);
+      }
+      KT_STAMP_NW(2, 0, it == KT_PERIOD);
+      __syncthreads();
+      KT_STAMP_NW(3, 0, it == KT_PERIOD);
+      if (it + 1 > nt) break;
+#ifdef RLRS_SKIP_ROWTEAM
+      if (false) {
+#else
+      if (it + 1 < nt) {
+#endif
+        row_pass(tile0 + (it + 1) * row_blocks, 1, gupB, zB, xB, hB, gtB);
+        if (it + 3 < nt) load_tile(tile0 + (it + 3) * row_blocks, gupB, zB, xB, hB, gtB);
+      }
+      __syncthreads();
+    }
+    // column sums: combine the 8 row waves through LDS in a fixed order (the tile buffers are idle now)
+    __syncthreads();   // (the matrix team's last products are done)
+    float* red = Ht[0];  // [8][2*D + 1]
+    constexpr int RS = 2 * D + 1;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      red[own * RS + lane * EPL + e] = db_acc[e];
+      red[own * RS + D + lane * EPL + e] = dwg_acc[e];
+    }
+    if (lane == 0) red[own * RS + 2 * D] = dcg_acc;
+    __syncthreads();
+    for (int c = threadIdx.x; c < RS; c += 512) {
+      float sacc = 0.f;
+      for (int w = 0; w < 8; ++w) sacc += red[w * RS + c];
+      P[D * D + c] = sacc;
+    }
+    KT_STAMP_NW(5, 0, true);
+  } else {
+    // =============================================================== matrix team, one tile behind
+    f32x4 accW[JB], WT[JB];
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb) accW[jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+      const int r = lane & 15, q = lane >> 4;
+      // W^T fragments of this wave's 16 output columns of dHs: B operand of k-step (t, u) = W[16 own + r][16 t + 4 q + u]
+#pragma unroll
+      for (int t = 0; t < JB; ++t) WT[t] = dHs ? *(const f32x4*)&W[(size_t)(16 * own + r) * D + 16 * t + 4 * q] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    if (HEAD) __syncthreads();   // the row team's staging of the head constants
+#ifndef RLRS_PRIO
+#define RLRS_PRIO 0
+#endif
+    // the matrix waves issue ahead of the (older) row waves that share their SIMDs: an MFMA takes the issue port for a
+    // quarter of its 32 cycles and the row math fills the rest, but not the other way round
+    if (RLRS_PRIO) __builtin_amdgcn_s_setprio(RLRS_PRIO);
+    for (int it = 0; it <= nt; ++it) {
+      KT_STAMP_NW(8, 512, it == KT_PERIOD);
+#ifdef RLRS_SKIP_MFMA
+      if (false) {
+#else
+      if (it >= 1) {
+#endif
+        const int buf = (it - 1) & 1;
+        const int tile = tile0 + (it - 1) * row_blocks;
+        OPAQUE_LANE(r, q, lq);
+        {   // dW += Ht^T Ut  (K = TR rows): this wave's 16 rows of dW (H columns 16 own ..), all 8 column blocks; the
+            // operands of k-step kk + 1 are read under the MFMAs of step kk
+          const float* __restrict__ Ha = Ht[buf] + q * LD + own * 16 + r;
+          const float* __restrict__ Ua = Ut[buf] + q * LD + r;
+          float a0, a1, b0[JB], b1[JB];
+          a0 = Ha[0];
+#pragma unroll
+          for (int jb = 0; jb < JB; ++jb) b0[jb] = Ua[jb * 16];
+#pragma unroll
+          for (int kk = 0; kk < TR / 4; kk += 2) {
+            a1 = Ha[(kk + 1) * 4 * LD];
+#pragma unroll
+            for (int jb = 0; jb < JB; ++jb) b1[jb] = Ua[(kk + 1) * 4 * LD + jb * 16];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int jb = 0; jb < JB; ++jb) accW[jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[jb], accW[jb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + 2 < TR / 4) {
+              a0 = Ha[(kk + 2) * 4 * LD];
+#pragma unroll
+              for (int jb = 0; jb < JB; ++jb) b0[jb] = Ua[(kk + 2) * 4 * LD + jb * 16];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int jb = 0; jb < JB; ++jb) accW[jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[jb], accW[jb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        KT_STAMP_NW(9, 512, it == KT_PERIOD);
+        if (dHs) {   // dHs = diag(row_scale) Ut W^T: this wave's 16 output columns, both row blocks of the tile
+          const float* __restrict__ Ua = Ut[buf] + r * LD + 4 * q;
+#ifndef RLRS_DH_CHAINS
+#define RLRS_DH_CHAINS 2   // accumulation chains per row block (K split into halves by parity of the step), summed at the end
+#endif
+          f32x4 hacc[2 * RLRS_DH_CHAINS];
+#pragma unroll
+          for (int i = 0; i < 2 * RLRS_DH_CHAINS; ++i) hacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          f32x4 ua[2][2];
+          ua[0][0] = *(const f32x4*)&Ua[0];
+          ua[0][1] = *(const f32x4*)&Ua[16 * LD];
+#pragma unroll
+          for (int t = 0; t < JB; ++t) {
+            if (t + 1 < JB) {
+              ua[(t + 1) & 1][0] = *(const f32x4*)&Ua[16 * (t + 1)];
+              ua[(t + 1) & 1][1] = *(const f32x4*)&Ua[16 * LD + 16 * (t + 1)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int mb = 0; mb < 2; ++mb) {
+                f32x4& h4 = hacc[mb + 2 * (u % RLRS_DH_CHAINS)];
+                h4 = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[t & 1][mb][u], WT[t][u], h4, 0, 0, 0);
+              }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (RLRS_DH_CHAINS == 2) { hacc[0] += hacc[2]; hacc[1] += hacc[3]; }
+          if (RLRS_DH_CHAINS == 4) { hacc[0] += hacc[2]; hacc[1] += hacc[3]; hacc[4] += hacc[6]; hacc[5] += hacc[7]; hacc[0] += hacc[4]; hacc[1] += hacc[5]; }
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int trow = mb * 16 + q * 4 + e;
+              const int m = tile * TR + trow;
+              const float sc = Sc[buf][trow];
+#ifdef RLRS_SKIP_DHS_STORE
+              if (m < M && sc == 12345.f) dHs[(unsigned)(m * D + own * 16 + r)] = hacc[mb][e] * sc;
+#else
+              if (m < M) dHs[(unsigned)(m * D + own * 16 + r)] = hacc[mb][e] * sc;   // 64-byte row segments
+#endif
+            }
+        }
+      }
+      KT_STAMP_NW(10, 512, it == KT_PERIOD);
+      __syncthreads();
+      KT_STAMP_NW(11, 512, it == KT_PERIOD);
+    }
+    // ---- this workgroup's dW partial
+    {
+      const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+      for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) P[(own * 16 + q * 4 + e) * D + jb * 16 + r] = accW[jb][e];
+    }
+    __syncthreads();   // the row team's column-sum staging
+    __syncthreads();
+  }
+#undef OPAQUE_LANE
+}
+
 // Fused optimizer step (cgcn_sgd_fuse): torch.optim.SGD on the flat arenas, element `idx`, given its final gradient g.
 struct SgdFuse {
   float* param;          // nullptr = no fusion
@@ -1802,6 +2157,13 @@ static int layer_bwd_impl(cgcn_stream_t stream, int n, int S, int d, const int32
     // profiling only: the partials / dHs / dL/dXn of an earlier full call are still in place
   } else if (d == 128 && bwd_tile_rows(n, S, d) == 48)
     hipLaunchKernelGGL((k_bwd_rowlocal<128, 48>), dim3(P + head_slabs), dim3(1024), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, P, head_slabs, W);
+  else if (d == 128 && RL_RS) {
+#define RLRS(H_, D_) hipLaunchKernelGGL((k_bwd_rowlocal_rs<H_, D_>), dim3(P + head_slabs), dim3(1024), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, P, head_slabs, W)
+    if (!head) RLRS(false, false);
+    else if (hp.thresh) RLRS(true, true);
+    else RLRS(true, false);
+#undef RLRS
+  }
   else if (d == 128)
     hipLaunchKernelGGL((k_bwd_rowlocal<128, 32>), dim3(P + head_slabs), dim3(1024), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, P, head_slabs, W);
   else

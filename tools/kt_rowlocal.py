@@ -33,20 +33,12 @@ def main():
     buf = np.zeros(8 * 16, dtype=np.uint64)
     assert raw.cgcn_debug_kt_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
     t = buf.reshape(8, 16).astype(np.int64)
-    t0 = t[:, 0].min()
-    print(name, "n =", stage.chroms[name].n)
+    print(name, "n =", stage.chroms[name].n, "(k_bwd_rowlocal_rs, last row-local launch of the step = first layer; period KT_PERIOD)")
     for b in range(8):
-        print("wg %3d start+%.2fus" % (b * 32, (t[b, 0] - t0) / 100.0), " setup %.2f | to 4th tile %.2f | wave 0: dW product %.2f | row pass of the next tile %.2f | barrier %.2f | rest of the loop %.2f | partial %.2f | total %.2f"
-              % (tuple((t[b, i + 1] - t[b, i]) / 100.0 for i in range(7)) + ((t[b, 7] - t[b, 0]) / 100.0,)))
-
-
-    print("wave 8 (a dHs wave), same tile: row pass of the next tile | dHs product (us)")
-    for b in range(8):
-        print("wg %3d  %.2f | %.2f" % (b * 32, (t[b, 9] - t[b, 8]) / 100.0, (t[b, 10] - t[b, 9]) / 100.0))
-    return
-    print("k_layer_dense (last forward launch): setup | wait before last tile | lds+issue+barrier | mfma+barrier | tanh+barrier | epilogue | total to epilogue end")
-    for b in range(8):
-        print("wg %3d" % (b * 32), " ".join("%.2f" % ((t[b, i + 1] - t[b, i]) / 100.0) for i in range(8, 14)), " total %.2f" % ((t[b, 14] - t[b, 8]) / 100.0))
+        v = t[b]
+        print("wg %3d  kernel %.2f us | row team wave 0: row pass %.2f  load issue %.2f  barrier wait %.2f   (period %.2f) | matrix team wave 8: dW %.2f  dHs %.2f  barrier wait %.2f  (period %.2f)" % (
+            b * 32, (v[5] - v[4]) / 100., (v[1] - v[0]) / 100., (v[2] - v[1]) / 100., (v[3] - v[2]) / 100., (v[3] - v[0]) / 100.,
+            (v[9] - v[8]) / 100., (v[10] - v[9]) / 100., (v[11] - v[10]) / 100., (v[11] - v[8]) / 100.))
 
 
 if __name__ == "__main__":
