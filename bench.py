@@ -193,6 +193,8 @@ def time_kernels(stage, name, reps, dropout_p):
     gc1, w1, gcL, wL, bn, out = m.GC1, m.W1, getattr(m, "GC%d" % L), getattr(m, "W%d" % L), m.batch_norm, m.out
     split = n * S * d * 4 >= (8 << 20) and S * d <= 256
     drop = dropout_p > 0
+    from chromegcn_amd.graph import col16_ptr
+    c16, c16t = col16_ptr(g.col), col16_ptr(g.col_t)   # the engine's own choice of index width
 
     def ev_time(fn):
         for _ in range(3):
@@ -211,11 +213,12 @@ def time_kernels(stage, name, reps, dropout_p):
         return lib.cgcn_layer_fwd(st(), n, S, d, P(g.rowptr), P(g.col), P(g.val), P(g.row_scale), c.x.data_ptr(),
                                   gc.weight.data_ptr(), gc.bias.data_ptr(), wk.weight.data_ptr(), wk.bias.data_ptr(),
                                   xn.data_ptr(), z.data_ptr(), P(hbuf), gate.data_ptr(), 0.0 if (last or not drop) else float(dropout_p),
-                                  None if (last or not drop) else P(rng), layer, P(h_in), cs.data_ptr() if (last and cs is not None) else None)
+                                  None if (last or not drop) else P(rng), layer, P(h_in), cs.data_ptr() if (last and cs is not None) else None,
+                                  c16)
 
     out_t = {}
     if split:
-        t_agg = ev_time(lambda: lib.cgcn_spmm(st(), n, n, S, d, P(g.rowptr), P(g.col), P(g.val), P(g.row_scale), c.x.data_ptr(), h.data_ptr()))
+        t_agg = ev_time(lambda: lib.cgcn_spmm(st(), n, n, S, d, P(g.rowptr), P(g.col), P(g.val), P(g.row_scale), c.x.data_ptr(), h.data_ptr(), c16))
         t_d1 = ev_time(lambda: fwd(1, h, None, None))
         t_d2 = ev_time(lambda: fwd(L, h, None, colstats))
         out_t["k_aggregate_sliced"] = (t_agg, 2)
@@ -263,7 +266,7 @@ def time_kernels(stage, name, reps, dropout_p):
                                                None if head_mode else dxn.data_ptr(), None, dx.data_ptr(), dhs.data_ptr(), dW.data_ptr(),
                                                db.data_ptr(), dwg.data_ptr(), dcg.data_ptr(), 0, float(dropout_p) if (head_mode and drop and L > 1) else 0.0,
                                                P(rng) if drop else None, max(L - 1, 0) if head_mode else 0,
-                                               ctypes.byref(hg) if head_mode else None, ws.data_ptr(), ws_b, ph)
+                                               ctypes.byref(hg) if head_mode else None, ws.data_ptr(), ws_b, ph, c16t)
     _lib.check(bwd(3, True), "bwd")
     out_t["k_bwd_rowlocal(head)"] = (ev_time(lambda: bwd(1, True)), 1)
     out_t["k_bwd_rowlocal"] = (ev_time(lambda: bwd(1, False)), max(L - 1, 0))

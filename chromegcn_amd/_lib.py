@@ -20,13 +20,13 @@ _SIGNATURES = {
     # name: (restype, argtypes)
     "cgcn_abi_version": (_c_int, []),
     "cgcn_strerror": (ctypes.c_char_p, [_c_int]),
-    "cgcn_spmm": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp]),
-    "cgcn_layer_fwd": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 13 + [_c_float, _c_vp, _c_uint, _c_vp, _c_vp]),
+    "cgcn_spmm": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp]),
+    "cgcn_layer_fwd": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 13 + [_c_float, _c_vp, _c_uint, _c_vp, _c_vp, _c_vp]),
     "cgcn_layer_fwd_colstats_tiles": (_c_int, [_c_int, _c_int, _c_int, _c_vp]),
     "cgcn_debug_set_fwd_split_bytes": (None, [ctypes.c_longlong]),
     "cgcn_layer_bwd_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
-    "cgcn_layer_bwd": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 18 + [_c_int, _c_float, _c_vp, _c_uint, _c_vp, _c_vp, _c_sz, _c_vp, _c_vp]),
-    "cgcn_debug_layer_bwd_phases": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 18 + [_c_int, _c_float, _c_vp, _c_uint, _c_vp, _c_vp, _c_sz, _c_int]),
+    "cgcn_layer_bwd": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 18 + [_c_int, _c_float, _c_vp, _c_uint, _c_vp, _c_vp, _c_sz, _c_vp, _c_vp, _c_vp]),
+    "cgcn_debug_layer_bwd_phases": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 18 + [_c_int, _c_float, _c_vp, _c_uint, _c_vp, _c_vp, _c_sz, _c_int, _c_vp]),
     "cgcn_head_workspace_bytes": (_c_sz, [_c_int] * 4),
     "cgcn_head_workspace_layout": (_c_int, [_c_int] * 4 + [ctypes.POINTER(_c_sz)] * 3),
     "cgcn_head_bwd_partials": (_c_int, [_c_int]),
@@ -44,7 +44,7 @@ _SIGNATURES = {
     "cgcn_multilabel_metrics": (_c_int, [_c_vp, ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_float, _c_vp, _c_vp, _c_sz]),
     "cgcn_sgd_step": (_c_int, [_c_vp, ctypes.c_longlong, _c_vp, _c_vp, _c_vp, _c_float, _c_float, _c_float, _c_int, _c_float, _c_vp]),
 }
-ABI_VERSION = 15
+ABI_VERSION = 16
 _lib = None
 
 

@@ -1640,13 +1640,16 @@ struct SlicedIssue<0, HAS_VAL> {
 
 // neighbours k, k + step, ... of [k0, k1) in chunks of 8 (k0 already offset by the caller for the cooperative walk);
 // Xb = this lane's 16 bytes of row 0 of its slice, rowb = bytes per (strand, node) row
-template <bool HAS_VAL>
-__device__ __forceinline__ f32x4 sliced_walk(const int* __restrict__ col, const float* __restrict__ val, int k0, int k1,
+// IT: column index type -- int32, or uint16 when the graph has at most 65 536 columns (every chromosome of the genome):
+// the index list is re-read once per column slice (8 x 2 MB per launch at int32), and the 16-bit list halves that:
+// 0 ... -7 % per launch (profiles/r03_u16_index_experiment.txt), sums bit-identical.
+template <bool HAS_VAL, typename IT>
+__device__ __forceinline__ f32x4 sliced_walk(const IT* __restrict__ col, const float* __restrict__ val, int k0, int k1,
                                              int step, const char* __restrict__ Xb, unsigned rowb, int j) {
   f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
   for (int k = k0; k < k1; k += step) {
     const int kk = min(k + j, k1 - 1);   // ragged tail: re-read the last neighbour (an L1 hit), add a selected zero
-    const int myc = col[kk];
+    const int myc = (int)col[kk];
     const float myv = HAS_VAL ? val[kk] : 0.f;
     f32x4 t[8];
     float w[8];
@@ -1662,16 +1665,16 @@ __device__ __forceinline__ f32x4 sliced_walk(const int* __restrict__ col, const 
 }
 
 // sum over the neighbours of this lane's group's row (k0, k1: that row's range; equal inside a group)
-template <bool HAS_VAL>
-__device__ __forceinline__ f32x4 sliced_row_sum(const int* __restrict__ col, const float* __restrict__ val, int k0, int k1,
+template <bool HAS_VAL, typename IT>
+__device__ __forceinline__ f32x4 sliced_row_sum(const IT* __restrict__ col, const float* __restrict__ val, int k0, int k1,
                                                 const char* __restrict__ Xb, unsigned rowb, int lane) {
   const int g = lane >> 3, j = lane & 7;
-  if (!__any(k1 - k0 > SLICED_HUB)) return sliced_walk<HAS_VAL>(col, val, k0, k1, 8, Xb, rowb, j);
+  if (!__any(k1 - k0 > SLICED_HUB)) return sliced_walk<HAS_VAL, IT>(col, val, k0, k1, 8, Xb, rowb, j);
   f32x4 mine = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
   for (int rr = 0; rr < 8; ++rr) {   // wave-uniform: every group helps with row rr of the wave
     const int a0 = __shfl(k0, rr * 8, WAVE), a1 = __shfl(k1, rr * 8, WAVE);
-    f32x4 acc = sliced_walk<HAS_VAL>(col, val, a0 + g * 8, a1, 64, Xb, rowb, j);
+    f32x4 acc = sliced_walk<HAS_VAL, IT>(col, val, a0 + g * 8, a1, 64, Xb, rowb, j);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       acc[e] += __shfl_xor(acc[e], 8, WAVE);
@@ -1699,8 +1702,8 @@ __device__ __forceinline__ void sliced_block(int b, int tiles, int& slice, int& 
 }
 
 // H = diag(rs) Ahat X, [S, n, D] -> [S, n, D]  (grid: NSL * ceil(n / 64) workgroups of 512)
-template <int S, int D, bool HAS_VAL>
-__global__ __launch_bounds__(512) void k_aggregate_sliced(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
+template <int S, int D, bool HAS_VAL, typename IT = int>
+__global__ __launch_bounds__(512) void k_aggregate_sliced(int n, const int* __restrict__ rowptr, const IT* __restrict__ col,
                                                           const float* __restrict__ val, const float* __restrict__ rs,
                                                           const float* __restrict__ X, float* __restrict__ H) {
   constexpr int NSL = S * D / 32, QPR = D / 32;
@@ -1716,7 +1719,7 @@ __global__ __launch_bounds__(512) void k_aggregate_sliced(int n, const int* __re
     k1 = rowptr[i + 1];
     sc = rs ? rs[i] : 1.f;
   }
-  const f32x4 acc = sliced_row_sum<HAS_VAL>(col, val, k0, k1, (const char*)(X + lane_el), D * 4u, lane);
+  const f32x4 acc = sliced_row_sum<HAS_VAL, IT>(col, val, k0, k1, (const char*)(X + lane_el), D * 4u, lane);
   if (i < n) *(f32x4*)&H[lane_el + (size_t)i * D] = acc * sc;
 }
 
@@ -1725,8 +1728,8 @@ __global__ __launch_bounds__(512) void k_aggregate_sliced(int n, const int* __re
 // the transposed adjacency with an element-wise epilogue, feature-sliced (above).
 // mask: the dropout the PREVIOUS layer applied to this layer's input (stream_id of that layer).
 // ------------------------------------------------------------------------------------------
-template <int S, int D, bool HAS_VAL>
-__global__ __launch_bounds__(512) void k_bwd_sliced(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
+template <int S, int D, bool HAS_VAL, typename IT = int>
+__global__ __launch_bounds__(512) void k_bwd_sliced(int n, const int* __restrict__ rowptr, const IT* __restrict__ col,
                                                     const float* __restrict__ val, const float* __restrict__ dHs,
                                                     const float* dXn, const float* __restrict__ gate, float* dX,
                                                     float keep_scale, uint32_t thresh,
@@ -1762,7 +1765,7 @@ __global__ __launch_bounds__(512) void k_bwd_sliced(int n, const int* __restrict
     k1 = rowptr[i + 1];
     res = *(const f32x4*)&dXn[lane_el + (size_t)i * D] * (1.f - gate[(size_t)s * n + i]);
   }
-  const f32x4 acc = sliced_row_sum<HAS_VAL>(col, val, k0, k1, (const char*)(dHs + lane_el), D * 4u, lane);
+  const f32x4 acc = sliced_row_sum<HAS_VAL, IT>(col, val, k0, k1, (const char*)(dHs + lane_el), D * 4u, lane);
   if (i >= n) return;
   const size_t g_off = lane_el + (size_t)i * D;
   f32x4 o = res + acc;
@@ -1915,6 +1918,23 @@ static int dropout_args(float p, const unsigned long long* rng_state, float* kee
   return CGCN_OK;
 }
 
+// H = diag(rs) Ahat X, feature-sliced: int32 column indices, or the 16-bit copy when given (implicit values only)
+static void launch_aggregate_sliced(hipStream_t st, int gblocks, int n, int S, int d, const int32_t* rowptr, const int32_t* col,
+                                    const uint16_t* col16, const float* val, const float* rs, const float* X, float* H) {
+  if (col16) {
+#define CALL16(S_, D_) hipLaunchKernelGGL((k_aggregate_sliced<S_, D_, false, uint16_t>), dim3(gblocks), dim3(512), 0, st, n, rowptr, col16, val, rs, X, H)
+    if (S == 1 && d == 128) CALL16(1, 128);
+    else if (S == 2 && d == 128) CALL16(2, 128);
+    else if (S == 1 && d == 256) CALL16(1, 256);
+    else CALL16(2, 256);
+#undef CALL16
+    return;
+  }
+#define CALL(S_, D_, V_) hipLaunchKernelGGL((k_aggregate_sliced<S_, D_, V_, int>), dim3(gblocks), dim3(512), 0, st, n, rowptr, col, val, rs, X, H)
+  DISPATCH_SDV(S, d, val != nullptr, CALL);
+#undef CALL
+}
+
 extern "C" {
 
 int cgcn_abi_version(void) { return CGCN_ABI_VERSION; }
@@ -1947,8 +1967,11 @@ static long long fwd_split_default() {   // tuning: CGCN_FWD_SPLIT_BYTES in the 
 static std::atomic<long long> g_fwd_split_bytes{fwd_split_default()};
 void cgcn_debug_set_fwd_split_bytes(long long bytes) { g_fwd_split_bytes.store(bytes < 0 ? fwd_split_default() : bytes); }
 
+// 16-bit column indices serve the feature-sliced kernels of implicit-value graphs (HAS_VAL = false) with <= 65 536 columns
+static inline bool use_col16(const uint16_t* col16, const float* val, int n_cols) { return col16 && !val && n_cols <= 65536; }
+
 int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d, const int32_t* rowptr, const int32_t* col,
-              const float* val, const float* row_scale, const float* X, float* Y) {
+              const float* val, const float* row_scale, const float* X, float* Y, const uint16_t* col16) {
   const int nmax = n_rows > n_cols ? n_rows : n_cols;
   if (nmax < 0) return CGCN_ERR_BAD_ARG;
   // the bare aggregation takes any width that is a multiple of 4 (k_spmm_any); S*D in {128, 256, 512} has tuned kernels
@@ -1967,10 +1990,7 @@ int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d, const 
   if (n_rows == n_cols && (double)n_rows * S * d * 4.0 >= (double)g_fwd_split_bytes.load()) {
     // square operator on a table too large for the L2s: the feature-sliced aggregation (see k_aggregate_sliced)
     const int gblocks = (S * d / 32) * ((n_rows + 63) / 64);
-#define CALL(S_, D_, V_) \
-    hipLaunchKernelGGL((k_aggregate_sliced<S_, D_, V_>), dim3(gblocks), dim3(512), 0, st, n_rows, rowptr, col, val, row_scale, X, Y)
-    DISPATCH_SDV(S, d, val != nullptr, CALL);
-#undef CALL
+    launch_aggregate_sliced(st, gblocks, n_rows, S, d, rowptr, col, use_col16(col16, val, n_cols) ? col16 : nullptr, val, row_scale, X, Y);
     return launch_status();
   }
   const int blocks = (n_rows + 3) / 4 < 4096 ? (n_rows + 3) / 4 : 4096;
@@ -2011,7 +2031,8 @@ int cgcn_layer_fwd_colstats_tiles(int n, int S, int d, int* rows_per_tile) {
 int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* rowptr, const int32_t* col, const float* val,
                    const float* row_scale, const float* X, const float* W, const float* b, const float* wg,
                    const float* cg, float* Xn, float* Z, float* H, float* gate, float dropout_p,
-                   const unsigned long long* rng_state, unsigned int stream_id, const float* H_in, float* colstats) {
+                   const unsigned long long* rng_state, unsigned int stream_id, const float* H_in, float* colstats,
+                   const uint16_t* col16) {
   int rc = check_shape(n, S, d);
   if (rc) return rc;
   if (n == 0) return CGCN_OK;
@@ -2032,10 +2053,7 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   if (colstats && !split && !H_in && dense_stat_chunk(n, S, d) != 1) return CGCN_ERR_BAD_ARG;
   if (split) {
     const int gblocks = (S * d / 32) * ((n + 63) / 64);
-#define CALL(S_, D_, V_) \
-    hipLaunchKernelGGL((k_aggregate_sliced<S_, D_, V_>), dim3(gblocks), dim3(512), 0, st, n, rowptr, col, val, row_scale, X, H)
-    DISPATCH_SDV(S, d, val != nullptr, CALL);
-#undef CALL
+    launch_aggregate_sliced(st, gblocks, n, S, d, rowptr, col, use_col16(col16, val, n) ? col16 : nullptr, val, row_scale, X, H);
     if ((rc = launch_status())) return rc;
     H_in = H;
   }
@@ -2104,7 +2122,7 @@ static int layer_bwd_impl(cgcn_stream_t stream, int n, int S, int d, const int32
                           float* dHs, float* dW, float* db, float* dwg, float* dcg, int accumulate, float in_dropout_p,
                           const unsigned long long* rng_state, unsigned int in_stream_id, const cgcn_head_grad* head,
                           void* workspace, size_t workspace_bytes, cgcn_stream_t aux_stream, const cgcn_sgd_fuse* sgd,
-                          int phases) {
+                          int phases, const uint16_t* col16_t) {
   int rc = check_shape(n, S, d);
   if (rc) return rc;
   if (!rowptr_t || !col_t || !X || !Z || !H || !gate || !W || !wg || !dW || !db || !dwg || !dcg) return CGCN_ERR_BAD_ARG;
@@ -2205,12 +2223,24 @@ static int layer_bwd_impl(cgcn_stream_t stream, int n, int S, int d, const int32
   const int blocks = (S * d / 32) * ((n + 63) / 64);   // slices x 64-row tiles (k_bwd_sliced)
   if (head) dXn = dX;  // k_bwd_rowlocal left dL/dXn there; each thread reads its elements before overwriting them
   const int sgd_blocks = sg.param ? (sg.count + 511) / 512 : 0;
+  if (use_col16(col16_t, val_t, n)) {
+#define CALL16(S_, D_)                                                                                               \
+  hipLaunchKernelGGL((k_bwd_sliced<S_, D_, false, uint16_t>), dim3(blocks + (fuse_reduce ? slabs : 0) + sgd_blocks), dim3(512), 0, \
+                     st, n, rowptr_t, col16_t, val_t, dHs, dXn, gate, dX, ks, th, rng_state, in_stream_id, blocks, P, \
+                     part, dW, db, dwg, dcg, accumulate, sg, fuse_reduce ? slabs : 0)
+    if (S == 1 && d == 128) CALL16(1, 128);
+    else if (S == 2 && d == 128) CALL16(2, 128);
+    else if (S == 1 && d == 256) CALL16(1, 256);
+    else CALL16(2, 256);
+#undef CALL16
+  } else {
 #define CALL(S_, D_, V_)                                                                                             \
-  hipLaunchKernelGGL((k_bwd_sliced<S_, D_, V_>), dim3(blocks + (fuse_reduce ? slabs : 0) + sgd_blocks), dim3(512), 0, \
+  hipLaunchKernelGGL((k_bwd_sliced<S_, D_, V_, int>), dim3(blocks + (fuse_reduce ? slabs : 0) + sgd_blocks), dim3(512), 0, \
                      st, n, rowptr_t, col_t, val_t, dHs, dXn, gate, dX, ks, th, rng_state, in_stream_id, blocks, P,  \
                      part, dW, db, dwg, dcg, accumulate, sg, fuse_reduce ? slabs : 0)
-  DISPATCH_SDV(S, d, val_t != nullptr, CALL);
+    DISPATCH_SDV(S, d, val_t != nullptr, CALL);
 #undef CALL
+  }
   if ((rc = launch_status())) return rc;
   if (rs_stream != st && hipStreamWaitEvent(st, ev_join, 0) != hipSuccess) return CGCN_ERR_LAUNCH;  // join
   return CGCN_OK;
@@ -2221,10 +2251,11 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
                    const float* gate, const float* W, const float* wg, const float* dXn, const float* dgate, float* dX,
                    float* dHs, float* dW, float* db, float* dwg, float* dcg, int accumulate, float in_dropout_p,
                    const unsigned long long* rng_state, unsigned int in_stream_id, const cgcn_head_grad* head,
-                   void* workspace, size_t workspace_bytes, cgcn_stream_t aux_stream, const cgcn_sgd_fuse* sgd) {
+                   void* workspace, size_t workspace_bytes, cgcn_stream_t aux_stream, const cgcn_sgd_fuse* sgd,
+                   const uint16_t* col16_t) {
   return layer_bwd_impl(stream, n, S, d, rowptr_t, col_t, val_t, row_scale, X, Z, H, gate, W, wg, dXn, dgate, dX, dHs, dW, db,
                         dwg, dcg, accumulate, in_dropout_p, rng_state, in_stream_id, head, workspace, workspace_bytes,
-                        aux_stream, sgd, 3);
+                        aux_stream, sgd, 3, col16_t);
 }
 
 int cgcn_debug_layer_bwd_phases(cgcn_stream_t stream, int n, int S, int d, const int32_t* rowptr_t, const int32_t* col_t,
@@ -2232,11 +2263,12 @@ int cgcn_debug_layer_bwd_phases(cgcn_stream_t stream, int n, int S, int d, const
                                 const float* gate, const float* W, const float* wg, const float* dXn, const float* dgate,
                                 float* dX, float* dHs, float* dW, float* db, float* dwg, float* dcg, int accumulate,
                                 float in_dropout_p, const unsigned long long* rng_state, unsigned int in_stream_id,
-                                const cgcn_head_grad* head, void* workspace, size_t workspace_bytes, int phases) {
+                                const cgcn_head_grad* head, void* workspace, size_t workspace_bytes, int phases,
+                                const uint16_t* col16_t) {
   if (phases < 1 || phases > 3) return CGCN_ERR_BAD_ARG;
   return layer_bwd_impl(stream, n, S, d, rowptr_t, col_t, val_t, row_scale, X, Z, H, gate, W, wg, dXn, dgate, dX, dHs, dW, db,
                         dwg, dcg, accumulate, in_dropout_p, rng_state, in_stream_id, head, workspace, workspace_bytes,
-                        nullptr, nullptr, phases);
+                        nullptr, nullptr, phases, col16_t);
 }
 
 int cgcn_sddmm(cgcn_stream_t stream, int n, int S, int d, const int32_t* rowptr, const int32_t* col, const float* A,

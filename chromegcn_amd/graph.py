@@ -115,6 +115,31 @@ def host_csr_from_matrix(a: sp.spmatrix) -> HostCSR:
 # ----------------------------------------------------------------------------------------------
 # device handle
 # ----------------------------------------------------------------------------------------------
+# 16-bit copies of the column-index arrays of graphs with at most 65 536 columns (every chromosome at 1 kb windows): the
+# feature-sliced kernels re-read the index list once per column slice, and the uint16 list halves those bytes
+# (include/chromegcn.h, col16).  Built when a ChromGraph is created (never lazily: a first use may sit inside HIP-graph
+# capture), found again by the address of the int32 array -- the registered operators carry tensors, not graph objects.
+_COL16: Dict[int, tuple] = {}
+
+
+def _register_col16(col: torch.Tensor, n_cols: int):
+    if not (torch.is_tensor(col) and col.is_cuda and col.numel() > 0 and n_cols <= 65536):
+        return
+    import weakref
+    for k in [k for k, e in _COL16.items() if e[0]() is None]:
+        del _COL16[k]
+    _COL16[col.data_ptr()] = (weakref.ref(col), col.to(torch.int16))   # two's-complement truncation = the uint16 bits
+
+
+def col16_ptr(col: Optional[torch.Tensor]):
+    """device pointer of the registered uint16 copy of `col` (None if there is none, or its int32 array has died)"""
+    if col is None:
+        return None
+    ent = _COL16.get(col.data_ptr())
+    if ent is None or ent[0]() is None or ent[1].numel() != col.numel():
+        return None
+    return ent[1].data_ptr()
+
 @dataclass
 class ChromGraph:
     """Device-resident CSR of one chromosome's adjacency, plus the CSR of Ahat^T for the backward
@@ -131,6 +156,11 @@ class ChromGraph:
     val_t: Optional[torch.Tensor]
     symmetric: bool
     host: Optional[HostCSR] = field(default=None, repr=False)
+
+    def __post_init__(self):
+        _register_col16(self.col, self.n)
+        if self.col_t is not self.col:
+            _register_col16(self.col_t, self.n)
 
     @property
     def device(self):

@@ -22,8 +22,8 @@ int main(void) {
     if (cgcn_head_workspace_bytes(5000, 2, 128, 103) == 0) return 5;
     if (cgcn_metrics_workspace_bytes(1000, 103) == 0) return 6;
     /* argument checking happens before any launch: NULL pointers are rejected without touching a device */
-    if (cgcn_spmm((cgcn_stream_t)0, 10, 10, 1, 128, NULL, NULL, NULL, NULL, NULL, NULL) != CGCN_ERR_BAD_ARG) return 7;
-    if (cgcn_spmm((cgcn_stream_t)0, 10, 10, 1, 130, NULL, NULL, NULL, NULL, NULL, NULL) != CGCN_ERR_UNSUPPORTED) return 8;
+    if (cgcn_spmm((cgcn_stream_t)0, 10, 10, 1, 128, NULL, NULL, NULL, NULL, NULL, NULL, NULL) != CGCN_ERR_BAD_ARG) return 7;
+    if (cgcn_spmm((cgcn_stream_t)0, 10, 10, 1, 130, NULL, NULL, NULL, NULL, NULL, NULL, NULL) != CGCN_ERR_UNSUPPORTED) return 8;
     printf("c-abi ok v%d\n", cgcn_abi_version());
     return 0;
 }

@@ -30,7 +30,7 @@ def test_library_builds_loads_and_exports_everything():
     assert lib.cgcn_layer_bwd_workspace_bytes(5000, 2, 128) > 0
     assert lib.cgcn_layer_bwd_workspace_bytes(5000, 3, 128) == 0
     assert lib.cgcn_layer_bwd_workspace_bytes(5000, 2, 100) == 0
-    assert lib.cgcn_spmm(None, 10, 10, 1, 102, None, None, None, None, None, None) == -2   # width not a multiple of 4
-    assert lib.cgcn_spmm(None, 10, 10, 3, 128, None, None, None, None, None, None) == -2   # strands
-    assert lib.cgcn_spmm(None, 10, 10, 1, 100, None, None, None, None, None, None) == -1   # any width % 4: null pointers
-    assert lib.cgcn_spmm(None, 10, 10, 1, 128, None, None, None, None, None, None) == -1
+    assert lib.cgcn_spmm(None, 10, 10, 1, 102, None, None, None, None, None, None, None) == -2   # width not a multiple of 4
+    assert lib.cgcn_spmm(None, 10, 10, 3, 128, None, None, None, None, None, None, None) == -2   # strands
+    assert lib.cgcn_spmm(None, 10, 10, 1, 100, None, None, None, None, None, None, None) == -1   # any width % 4: null pointers
+    assert lib.cgcn_spmm(None, 10, 10, 1, 128, None, None, None, None, None, None, None) == -1

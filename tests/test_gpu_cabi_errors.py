@@ -27,7 +27,7 @@ def fwd(e, **over):
     P, g = _lib.ptr, a["g"]
     return a["lib"].cgcn_layer_fwd(_lib.stream_ptr(), a["n"], a["S"], a["d"], P(g.rowptr), P(g.col), None, P(g.row_scale),
                                    a.get("xptr", P(a["x"])), P(a["W"]), P(a["b"]), P(a["wg"]), P(a["cg"]), a.get("yptr", P(a["y"])),
-                                   P(a["z"]), P(a["h"]), P(a["gate"]), a.get("p", 0.0), None, 0, None, None)
+                                   P(a["z"]), P(a["h"]), P(a["gate"]), a.get("p", 0.0), None, 0, None, None, None)
 
 
 def test_strerror_names_every_code(env):
@@ -64,7 +64,7 @@ def test_workspaces_are_checked(env):
     def bwd(ws_bytes, dxn=env["y"], wsp=P(ws)):
         return lib.cgcn_layer_bwd(_lib.stream_ptr(), n, S, d, P(g.rowptr_t), P(g.col_t), None, P(g.row_scale), P(env["x"]), P(env["z"]),
                                   P(env["h"]), P(env["gate"]), P(env["W"]), P(env["wg"]), _lib.ptr(dxn), None, P(dx), P(dhs), P(dW), P(db),
-                                  P(dwg), P(dcg), 0, 0.0, None, 0, None, wsp, ws_bytes, None, None)
+                                  P(dwg), P(dcg), 0, 0.0, None, 0, None, wsp, ws_bytes, None, None, None)
     assert bwd(need) == OK
     assert bwd(need - 1) == WORKSPACE
     assert bwd(need, wsp=None) == WORKSPACE
@@ -91,9 +91,9 @@ def test_sgd_and_spmm_argument_checks(env):
     assert torch.allclose(p, torch.full((8,), -0.1, device=DEV))
     g = env["g"]
     y = torch.empty_like(env["x"])
-    assert lib.cgcn_spmm(_lib.stream_ptr(), env["n"], env["n"], env["S"], env["d"], P(g.rowptr), P(g.col), None, P(g.row_scale), P(env["x"]), P(y)) == OK
-    assert lib.cgcn_spmm(_lib.stream_ptr(), env["n"], env["n"], env["S"], env["d"], None, P(g.col), None, P(g.row_scale), P(env["x"]), P(y)) == BAD_ARG
-    assert lib.cgcn_spmm(_lib.stream_ptr(), env["n"], env["n"], env["S"], 98, P(g.rowptr), P(g.col), None, P(g.row_scale), P(env["x"]), P(y)) == UNSUPPORTED
+    assert lib.cgcn_spmm(_lib.stream_ptr(), env["n"], env["n"], env["S"], env["d"], P(g.rowptr), P(g.col), None, P(g.row_scale), P(env["x"]), P(y), None) == OK
+    assert lib.cgcn_spmm(_lib.stream_ptr(), env["n"], env["n"], env["S"], env["d"], None, P(g.col), None, P(g.row_scale), P(env["x"]), P(y), None) == BAD_ARG
+    assert lib.cgcn_spmm(_lib.stream_ptr(), env["n"], env["n"], env["S"], 98, P(g.rowptr), P(g.col), None, P(g.row_scale), P(env["x"]), P(y), None) == UNSUPPORTED
 
 
 def test_colstats_on_a_split_size_table_needs_an_aggregation_buffer(env):
@@ -111,7 +111,7 @@ def test_colstats_on_a_split_size_table_needs_an_aggregation_buffer(env):
     cs = torch.full((tiles * S * d * 2 + 4096,), 7.0, device=DEV)   # guard zone behind the records
     def call(hptr):
         return lib.cgcn_layer_fwd(_lib.stream_ptr(), n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(env["W"]),
-                                  P(env["b"]), P(env["wg"]), P(env["cg"]), P(y), P(z), hptr, P(gate), 0.0, None, 0, None, P(cs))
+                                  P(env["b"]), P(env["wg"]), P(env["cg"]), P(y), P(z), hptr, P(gate), 0.0, None, 0, None, P(cs), None)
     assert call(None) == BAD_ARG
     assert call(P(h)) == OK
     torch.cuda.synchronize()
@@ -134,7 +134,7 @@ def test_fused_sgd_rejects_input_dropout_with_an_input_gradient(env):
     def bwd(p_in, dxp):
         return lib.cgcn_layer_bwd(_lib.stream_ptr(), n, S, d, P(g.rowptr_t), P(g.col_t), None, P(g.row_scale), P(env["x"]), P(env["z"]),
                                   P(env["h"]), P(env["gate"]), P(env["W"]), P(env["wg"]), P(env["y"]), None, dxp, P(dhs), P(dW), P(db),
-                                  P(dwg), P(dcg), 0, p_in, P(rng), 1, None, P(ws), need, None, ctypes.byref(sg))
+                                  P(dwg), P(dcg), 0, p_in, P(rng), 1, None, P(ws), need, None, ctypes.byref(sg), None)
     assert bwd(0.25, P(dx)) == BAD_ARG
     torch.cuda.synchronize()
     assert int(rng[1].item()) == 0

@@ -160,7 +160,7 @@ def test_layer_fwd_colstats_are_the_tile_statistics_of_relu_output(S, n, d):
     cs = torch.full((tiles, S, d, 2), float("nan"), device=DEV)
     P = _lib.ptr
     _lib.check(lib.cgcn_layer_fwd(_lib.stream_ptr(), n, S, d, P(g.rowptr), P(g.col), P(g.val), P(g.row_scale), P(x), P(W), P(b),
-                                  P(wg), P(cg), P(xn), None, None, P(gate), 0.0, None, 0, None, P(cs)), "cgcn_layer_fwd")
+                                  P(wg), P(cg), P(xn), None, None, P(gate), 0.0, None, 0, None, P(cs), None), "cgcn_layer_fwd")
     y = torch.relu(xn).double().cpu().numpy()
     cs = cs.cpu().numpy()
     for t in range(tiles):

@@ -46,7 +46,7 @@ def test_fused_step_equals_separate_step_bitwise(n, d, momentum, nesterov, want_
         rc = lib.cgcn_layer_bwd(_lib.stream_ptr(), n, S, d, P(g.rowptr_t), P(g.col_t), None, P(g.row_scale), P(x), P(z), P(h),
                                 P(gate), W.data_ptr(), wg.data_ptr(), P(dxn), None, P(dx) if want_dx else None, P(dhs),
                                 grad[off_W:].data_ptr(), grad[off_b:].data_ptr(), grad[off_wg:].data_ptr(), grad[off_cg:].data_ptr(),
-                                0, 0.0, None, 0, None, P(ws), ws_bytes, None, ctypes.byref(sg) if fused else None)
+                                0, 0.0, None, 0, None, P(ws), ws_bytes, None, ctypes.byref(sg) if fused else None, None)
         assert rc == 0
         if not fused:
             assert lib.cgcn_sgd_step(_lib.stream_ptr(), total, P(param), P(grad), P(mom) if momentum else None, lr, momentum, wd,
@@ -76,7 +76,7 @@ def test_fuse_request_is_validated():
         return lib.cgcn_layer_bwd(_lib.stream_ptr(), n, S, d, P(g.rowptr_t), P(g.col_t), None, P(g.row_scale), P(x), P(x), P(x),
                                   P(gate), arena_p[:d * d].data_ptr(), arena_p[17000:].data_ptr(), P(x), None, dX, P(dhs), dW,
                                   arena_g[16384:].data_ptr(), arena_g[16600:].data_ptr(), arena_g[16800:].data_ptr(), accumulate,
-                                  0.0, None, 0, None, P(ws), ws_bytes, None, ctypes.byref(sgd) if sgd is not None else None)
+                                  0.0, None, 0, None, P(ws), ws_bytes, None, ctypes.byref(sgd) if sgd is not None else None, None)
     assert call(P(dx), arena_g.data_ptr()) == 0
     assert call(None, arena_g.data_ptr()) == 0                       # no gather launch: the partial-sum launch carries the step
     assert call(P(dx), elsewhere.data_ptr()) == -1                   # dW outside the gradient arena

@@ -63,3 +63,52 @@ def test_sliced_routes_agree_with_whole_row_routes(S, d):
             scale = float(u.abs().max()) + 1e-30
             err = float((u - v).abs().max()) / scale
             assert err < 2e-5, "%s: n=%d %s S=%d d=%d: scale-relative difference %.2e" % (nm, n, kind, S, d, err)
+
+
+@pytest.mark.parametrize("S,d", [(2, 128), (1, 256)])
+def test_sixteen_bit_column_indices_give_bit_identical_results(S, d):
+    """graphs with at most 65 536 columns carry a uint16 copy of their column indices (graph.col16_ptr), which the
+    feature-sliced kernels walk instead of the int32 list: same neighbours in the same order -> identical bits, for the
+    aggregation (cgcn_spmm's sliced route) and for the backward gather (cgcn_layer_bwd); hub rows included."""
+    lib = _lib.load()
+    P = _lib.ptr
+    rng = np.random.RandomState(7 + d)
+    for n in (65, 1000, 40000):
+        i = rng.randint(0, n, 15 * n); j = rng.randint(0, n, 15 * n)       # COO pairs (scipy's lil path takes minutes at 40 k)
+        for deg in (193, 600):
+            if n > deg + 5:
+                i = np.concatenate([i, np.full(deg, int(rng.randint(n)))]); j = np.concatenate([j, rng.choice(n, deg, replace=False)])
+        keep = i != j
+        m = sp.coo_matrix((np.ones(int(keep.sum()), dtype=np.float32), (i[keep], j[keep])), shape=(n, n)).tocsr()
+        m = m + m.T
+        m.data[:] = 1.0
+        g = G.upload(G.normalize_graph("hic", m, n), DEV)
+        c16 = G.col16_ptr(g.col)
+        assert c16 is not None and g.val is None
+        x = torch.randn(S, n, d, device=DEV)
+        lib.cgcn_debug_set_fwd_split_bytes(0)       # the sliced route at every size
+        try:
+            y32, y16 = torch.empty_like(x), torch.empty_like(x)
+            for y, c in ((y32, None), (y16, c16)):
+                _lib.check(lib.cgcn_spmm(_lib.stream_ptr(), n, n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(y), c), "spmm")
+            assert torch.equal(y32, y16)
+            z, h, dxn = torch.tanh(torch.randn_like(x)), torch.randn_like(x), torch.randn_like(x)
+            gate = torch.rand(S, n, device=DEV)
+            W, wg = torch.randn(d, d, device=DEV) / d ** 0.5, torch.randn(d, device=DEV)
+            ws_b = lib.cgcn_layer_bwd_workspace_bytes(n, S, d)
+            ws = torch.empty(ws_b, dtype=torch.uint8, device=DEV)
+            outs = []
+            for c in (None, c16):
+                dx, dhs = torch.empty_like(x), torch.empty_like(x)
+                dW, db, dwg, dcg = torch.empty(d, d, device=DEV), torch.empty(d, device=DEV), torch.empty(d, device=DEV), torch.empty(1, device=DEV)
+                _lib.check(lib.cgcn_layer_bwd(_lib.stream_ptr(), n, S, d, P(g.rowptr_t), P(g.col_t), None, P(g.row_scale), P(x), P(z), P(h),
+                                              P(gate), P(W), P(wg), P(dxn), None, P(dx), P(dhs), P(dW), P(db), P(dwg), P(dcg), 0, 0.0, None, 0,
+                                              None, P(ws), ws_b, None, None, c), "bwd")
+                outs.append((dx, dW, db, dwg, dcg))
+            for a, b in zip(*outs):
+                assert torch.equal(a, b)
+        finally:
+            lib.cgcn_debug_set_fwd_split_bytes(-1)
+    # more than 65 536 columns: no 16-bit copy is registered
+    big = G.upload(G.normalize_graph("none", None, 70000), DEV)
+    assert G.col16_ptr(big.col) is None

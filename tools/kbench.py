@@ -47,10 +47,10 @@ def main():
                     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
                     st = _lib.stream_ptr
                     P = _lib.ptr
-                    t_spmm = timeit(lambda: lib.cgcn_spmm(st(), n, n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(y)))
-                    t_fwd = timeit(lambda: lib.cgcn_layer_fwd(st(), n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(W), P(b), P(wg), P(cg), P(xn), P(z), P(hh), P(gate), 0.0, None, 0, None, None))
-                    t_inf = timeit(lambda: lib.cgcn_layer_fwd(st(), n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(W), P(b), P(wg), P(cg), P(xn), None, None, P(gate), 0.0, None, 0, None, None))
-                    t_bwd = timeit(lambda: lib.cgcn_layer_bwd(st(), n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(z), P(hh), P(gate), P(W), P(wg), P(dxn), None, P(dx), P(dhs), P(dW), P(db), P(dwg), P(dcg), 0, 0.0, None, 0, None, P(ws), wsb, None, None))
+                    t_spmm = timeit(lambda: lib.cgcn_spmm(st(), n, n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(y), None))
+                    t_fwd = timeit(lambda: lib.cgcn_layer_fwd(st(), n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(W), P(b), P(wg), P(cg), P(xn), P(z), P(hh), P(gate), 0.0, None, 0, None, None, None))
+                    t_inf = timeit(lambda: lib.cgcn_layer_fwd(st(), n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(W), P(b), P(wg), P(cg), P(xn), None, None, P(gate), 0.0, None, 0, None, None, None))
+                    t_bwd = timeit(lambda: lib.cgcn_layer_bwd(st(), n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(z), P(hh), P(gate), P(W), P(wg), P(dxn), None, P(dx), P(dhs), P(dW), P(db), P(dwg), P(dcg), 0, 0.0, None, 0, None, P(ws), wsb, None, None, None))
                     gb = 4.0 * h.nnz * S * d
                     print(json.dumps({"shape": name, "hic_like": hic_like, "n": n, "nnz": h.nnz, "S": S, "d": d,
                                       "spmm_us": round(t_spmm, 1), "fwd_us": round(t_fwd, 1), "fwd_infer_us": round(t_inf, 1),

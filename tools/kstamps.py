@@ -19,7 +19,7 @@ def main():
     dW = torch.empty_like(W); db = torch.empty(d, device=dev); dwg = torch.empty(d, device=dev); dcg = torch.empty(1, device=dev)
     wsb = lib.cgcn_layer_bwd_workspace_bytes(n, S, d); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     st, P = _lib.stream_ptr, _lib.ptr
-    bwd = lambda: lib.cgcn_layer_bwd(st(), n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(z), P(hh), P(gate), P(W), P(wg), P(dxn), None, P(dx), P(dhs), P(dW), P(db), P(dwg), P(dcg), 0, 0.0, None, 0, None, P(ws), wsb, None, None)
+    bwd = lambda: lib.cgcn_layer_bwd(st(), n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(z), P(hh), P(gate), P(W), P(wg), P(dxn), None, P(dx), P(dhs), P(dW), P(db), P(dwg), P(dcg), 0, 0.0, None, 0, None, P(ws), wsb, None, None, None)
     for _ in range(5): assert bwd() == 0
     torch.cuda.synchronize()
     buf = np.zeros(8 * 16, dtype=np.uint64)
@@ -34,7 +34,7 @@ def main():
         print("wg", b_ * 32, "start+%.2fus" % ((t[b_, 0] - t0) / 100.0), " ".join("%.2f" % ((t[b_, i + 1] - t[b_, i]) / 100.0) for i in range(7)), " total %.2f" % ((t[b_, 7] - t[b_, 0]) / 100.0))
     print("layer_bwd_us", round(timeit(bwd), 1))
     b = torch.zeros(d, device=dev); cg = torch.zeros(1, device=dev); xn = torch.empty_like(x)
-    fwd = lambda: lib.cgcn_layer_fwd(st(), n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(W), P(b), P(wg), P(cg), P(xn), P(z), P(hh), P(gate), 0.0, None, 0, None, None)
+    fwd = lambda: lib.cgcn_layer_fwd(st(), n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(W), P(b), P(wg), P(cg), P(xn), P(z), P(hh), P(gate), 0.0, None, 0, None, None, None)
     for _ in range(5): assert fwd() == 0
     torch.cuda.synchronize()
     assert raw.cgcn_debug_kt_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0

@@ -34,7 +34,7 @@ def main():
 
             def fwd(S, xs, xns, zs, hs, gs):
                 rc = lib.cgcn_layer_fwd(st(), n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), xs.data_ptr(), P(W), P(b), P(wg),
-                                        P(cg), xns.data_ptr(), zs.data_ptr(), hs.data_ptr(), gs.data_ptr(), 0.0, None, 1, None, None)
+                                        P(cg), xns.data_ptr(), zs.data_ptr(), hs.data_ptr(), gs.data_ptr(), 0.0, None, 1, None, None, None)
                 assert rc == 0
             both = lambda: fwd(2, x, xn, z, h, gate)
             split = lambda: (fwd(1, x[0], xn[0], z[0], h[0], gate[0]), fwd(1, x[1], xn[1], z[1], h[1], gate[1]))
