@@ -1624,36 +1624,44 @@ __global__ __launch_bounds__(256) void k_reduce_partials(int P, int D, const flo
 template <int U>
 __device__ __forceinline__ int group8_bcast(int v) { return __builtin_amdgcn_ds_swizzle(v, 0x18 | (U << 5)); }
 
+// index (and value) broadcasts of one chunk of 8 neighbours: all eight ds_swizzle issued back to back into eight
+// registers (interleaved with the loads the compiler reused one register and waited lgkmcnt(0) after every swizzle:
+// eight serial LDS round trips per chunk), 32-bit byte offsets from the uniform table base (global_load ... saddr form:
+// one v_lshl_add_u32 per address instead of two 64-bit operations).  tools/micro/sliced_gather.hip "v2": -1 ... -2.5 %.
 template <int U, bool HAS_VAL>
-struct SlicedIssue {
-  static __device__ __forceinline__ void run(f32x4 (&t)[8], float (&w)[8], int myc, float myv, const char* __restrict__ Xb,
-                                             unsigned rowb) {
-    SlicedIssue<U - 1, HAS_VAL>::run(t, w, myc, myv, Xb, rowb);
-    t[U - 1] = *(const f32x4*)(Xb + (size_t)(unsigned)group8_bcast<U - 1>(myc) * rowb);
+struct SlicedBcast {
+  static __device__ __forceinline__ void run(unsigned (&off)[8], float (&w)[8], int myc, float myv, unsigned rowsh,
+                                             unsigned lane_off) {
+    SlicedBcast<U - 1, HAS_VAL>::run(off, w, myc, myv, rowsh, lane_off);
+    off[U - 1] = ((unsigned)group8_bcast<U - 1>(myc) << rowsh) + lane_off;
     if (HAS_VAL) w[U - 1] = __int_as_float(group8_bcast<U - 1>(__float_as_int(myv)));
   }
 };
 template <bool HAS_VAL>
-struct SlicedIssue<0, HAS_VAL> {
-  static __device__ __forceinline__ void run(f32x4 (&)[8], float (&)[8], int, float, const char* __restrict__, unsigned) {}
+struct SlicedBcast<0, HAS_VAL> {
+  static __device__ __forceinline__ void run(unsigned (&)[8], float (&)[8], int, float, unsigned, unsigned) {}
 };
 
 // neighbours k, k + step, ... of [k0, k1) in chunks of 8 (k0 already offset by the caller for the cooperative walk);
-// Xb = this lane's 16 bytes of row 0 of its slice, rowb = bytes per (strand, node) row
+// base = the table (uniform), lane_off = byte offset of this lane's 16 bytes of row 0 of its slice, rowsh = log2(bytes per
+// (strand, node) row).
 // IT: column index type -- int32, or uint16 when the graph has at most 65 536 columns (every chromosome of the genome):
 // the index list is re-read once per column slice (8 x 2 MB per launch at int32), and the 16-bit list halves that:
 // 0 ... -7 % per launch (profiles/r03_u16_index_experiment.txt), sums bit-identical.
 template <bool HAS_VAL, typename IT>
 __device__ __forceinline__ f32x4 sliced_walk(const IT* __restrict__ col, const float* __restrict__ val, int k0, int k1,
-                                             int step, const char* __restrict__ Xb, unsigned rowb, int j) {
+                                             int step, const char* __restrict__ base, unsigned lane_off, unsigned rowsh, int j) {
   f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
   for (int k = k0; k < k1; k += step) {
     const int kk = min(k + j, k1 - 1);   // ragged tail: re-read the last neighbour (an L1 hit), add a selected zero
     const int myc = (int)col[kk];
     const float myv = HAS_VAL ? val[kk] : 0.f;
-    f32x4 t[8];
+    unsigned off[8];
     float w[8];
-    SlicedIssue<8, HAS_VAL>::run(t, w, myc, myv, Xb, rowb);
+    SlicedBcast<8, HAS_VAL>::run(off, w, myc, myv, rowsh, lane_off);
+    f32x4 t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = *(const f32x4*)(base + (size_t)off[u]);
     const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -1667,14 +1675,14 @@ __device__ __forceinline__ f32x4 sliced_walk(const IT* __restrict__ col, const f
 // sum over the neighbours of this lane's group's row (k0, k1: that row's range; equal inside a group)
 template <bool HAS_VAL, typename IT>
 __device__ __forceinline__ f32x4 sliced_row_sum(const IT* __restrict__ col, const float* __restrict__ val, int k0, int k1,
-                                                const char* __restrict__ Xb, unsigned rowb, int lane) {
+                                                const char* __restrict__ base, unsigned lane_off, unsigned rowsh, int lane) {
   const int g = lane >> 3, j = lane & 7;
-  if (!__any(k1 - k0 > SLICED_HUB)) return sliced_walk<HAS_VAL, IT>(col, val, k0, k1, 8, Xb, rowb, j);
+  if (!__any(k1 - k0 > SLICED_HUB)) return sliced_walk<HAS_VAL, IT>(col, val, k0, k1, 8, base, lane_off, rowsh, j);
   f32x4 mine = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
   for (int rr = 0; rr < 8; ++rr) {   // wave-uniform: every group helps with row rr of the wave
     const int a0 = __shfl(k0, rr * 8, WAVE), a1 = __shfl(k1, rr * 8, WAVE);
-    f32x4 acc = sliced_walk<HAS_VAL, IT>(col, val, a0 + g * 8, a1, 64, Xb, rowb, j);
+    f32x4 acc = sliced_walk<HAS_VAL, IT>(col, val, a0 + g * 8, a1, 64, base, lane_off, rowsh, j);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       acc[e] += __shfl_xor(acc[e], 8, WAVE);
@@ -1719,7 +1727,7 @@ __global__ __launch_bounds__(512) void k_aggregate_sliced(int n, const int* __re
     k1 = rowptr[i + 1];
     sc = rs ? rs[i] : 1.f;
   }
-  const f32x4 acc = sliced_row_sum<HAS_VAL, IT>(col, val, k0, k1, (const char*)(X + lane_el), D * 4u, lane);
+  const f32x4 acc = sliced_row_sum<HAS_VAL, IT>(col, val, k0, k1, (const char*)X, (unsigned)(lane_el * 4), D == 128 ? 9u : 10u, lane);
   if (i < n) *(f32x4*)&H[lane_el + (size_t)i * D] = acc * sc;
 }
 
@@ -1765,7 +1773,7 @@ __global__ __launch_bounds__(512) void k_bwd_sliced(int n, const int* __restrict
     k1 = rowptr[i + 1];
     res = *(const f32x4*)&dXn[lane_el + (size_t)i * D] * (1.f - gate[(size_t)s * n + i]);
   }
-  const f32x4 acc = sliced_row_sum<HAS_VAL, IT>(col, val, k0, k1, (const char*)(dHs + lane_el), D * 4u, lane);
+  const f32x4 acc = sliced_row_sum<HAS_VAL, IT>(col, val, k0, k1, (const char*)dHs, (unsigned)(lane_el * 4), D == 128 ? 9u : 10u, lane);
   if (i >= n) return;
   const size_t g_off = lane_el + (size_t)i * D;
   f32x4 o = res + acc;

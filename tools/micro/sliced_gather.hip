@@ -105,6 +105,40 @@ __global__ __launch_bounds__(512) void k_rows8(int n, int tiles, const int* __re
   }
 }
 
+// v2: (a) all 8 index broadcasts of a chunk issued back to back into 8 registers (the product kernel's ISA reuses one
+// register and waits lgkmcnt(0) after every ds_swizzle: 8 serial LDS round trips per chunk), (b) 32-bit offsets from the
+// uniform table base (global_load ... saddr form: one VALU per address instead of two 64-bit ones)
+template <typename IT>
+__global__ __launch_bounds__(512) void k_rows8_v2(int n, int tiles, const int* __restrict__ rowptr, const IT* __restrict__ col,
+                                                  const float* __restrict__ rs, const float* __restrict__ X,
+                                                  float* __restrict__ H) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int slice = blockIdx.x & 7, tile = blockIdx.x >> 3;
+  const int g = lane >> 3, j = lane & 7;
+  const unsigned slice_off = ((unsigned)(slice >> 2) * (unsigned)n * 128u + (slice & 3) * 32u + j * 4u) * 4u;
+  const char* Xb = (const char*)X;
+  const int i = tile * 64 + wave * 8 + g;
+  int k0 = 0, k1 = 0;
+  if (i < n) { k0 = rowptr[i]; k1 = rowptr[i + 1]; }
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int k = k0; k < k1; k += 8) {
+    const int myc = (int)col[min(k + j, k1 - 1)];
+    unsigned off[8];
+    Unroll<8>::run([&](auto U) {
+      constexpr int u = decltype(U)::value;
+      off[u] = ((unsigned)group8_bcast<u>(myc) << 9) + slice_off;
+    });
+    f32x4 t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = *(const f32x4*)(Xb + (size_t)off[u]);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (k + u < k1) acc += t[u];
+  }
+  if (i < n) *(f32x4*)((char*)H + (size_t)slice_off + (size_t)i * 512u) = acc * rs[i];
+}
+
 // PF 1: the column indices of the NEXT chunk are loaded before the current chunk's row loads are issued (the serial
 //       chain per row becomes index latency + chunks x line latency instead of chunks x (index + line) latency)
 // PF 2: additionally the lines of the next chunk are issued before the current chunk is summed (two chunks of 8 lines in
@@ -351,6 +385,12 @@ int main(int argc, char** argv) {
         const float b2 = time_us([&] { hipLaunchKernelGGL((k_rows8<true, 1, unsigned short>), dim3(8 * tiles), dim3(512), 0, 0, n, tiles, d_rowptr, d_c16, d_rs, d_X, d_H); }, reps);
         CK(hipMemcpy(out.data(), d_H, X.size() * 4, hipMemcpyDeviceToHost));
         printf("  %-34s int32 %6.1f / %6.1f us   uint16 %6.1f / %6.1f us  (interleaved; max |diff| vs base %.2e)\n", "rows8 XCD-owned, index width", a, a2, b, b2, max_err(ref, out));
+        CK(hipMemset(d_H, 0, X.size() * 4));
+        const float c1 = time_us([&] { hipLaunchKernelGGL((k_rows8_v2<unsigned short>), dim3(8 * tiles), dim3(512), 0, 0, n, tiles, d_rowptr, d_c16, d_rs, d_X, d_H); }, reps);
+        const float b3 = time_us([&] { hipLaunchKernelGGL((k_rows8<true, 1, unsigned short>), dim3(8 * tiles), dim3(512), 0, 0, n, tiles, d_rowptr, d_c16, d_rs, d_X, d_H); }, reps);
+        const float c2 = time_us([&] { hipLaunchKernelGGL((k_rows8_v2<unsigned short>), dim3(8 * tiles), dim3(512), 0, 0, n, tiles, d_rowptr, d_c16, d_rs, d_X, d_H); }, reps);
+        CK(hipMemcpy(out.data(), d_H, X.size() * 4, hipMemcpyDeviceToHost));
+        printf("  %-34s uint16 %6.1f us   v2 %6.1f / %6.1f us  (max |diff| vs base %.2e)\n", "rows8 v2 (batched swizzles, saddr)", b3, c1, c2, max_err(ref, out));
         CK(hipFree(d_c16));
       }
                   sliced(std::false_type(), std::integral_constant<int, 1>(), "rows8 slice=b/tiles (control) RPW1");
