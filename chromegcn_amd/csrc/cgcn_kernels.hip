@@ -2016,11 +2016,28 @@ int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d, const 
 // Nodes per column-statistics record of cgcn_layer_fwd(n, S, d).  The fused kernel emits one record per 16 / S-node
 // tile.  Tables that take the split route (and the same tables when an H_in is streamed) go through k_layer_dense,
 // which merges the tiles of one workgroup into one record: chunk tiles, so that at most DENSE_MAX_BLOCKS records exist.
+// payloads of 2 KiB per node (d = 256, both strands): the split route only between these table sizes (default: never)
+#ifndef FWD_SPLIT_WIDE_LO
+#define FWD_SPLIT_WIDE_LO (1ull << 40)
+#endif
+#ifndef FWD_SPLIT_WIDE_HI
+#define FWD_SPLIT_WIDE_HI 0ull
+#endif
 static bool fwd_split_shape(int n, int S, int d) {
   const long long split_bytes = g_fwd_split_bytes.load();
-  // (payloads of 2 KiB per node -- d = 256, both strands -- keep the fused kernel at every size: measured 0.86 vs 0.92 ms
-  // per step at chr21 size, 1.26 vs 1.34 ms at chr1 size on a hic-like graph; the debug hook's 0 still forces the split)
-  return (double)n * S * d * 4.0 >= (double)split_bytes && (S * d <= 256 || split_bytes == 0);
+  const double table = (double)n * S * d * 4.0;
+  if (split_bytes == 0) return true;   // the debug hook's 0 forces the split at every shape
+  if (table < (double)split_bytes) return false;
+  if (S * d <= 256) return true;
+  // d = 256, both strands (16 column slices, strand = pass): k_aggregate_sliced + k_layer_dense against the fused
+  // k_layer_fwd<2,256>, us per launch (tools/strand_split_probe.py, profiles/r03_d256_strand_split_experiment.txt):
+  //   uniform  n 5 776: 79 vs 73   7 000: 90 vs 99   10 000: 101 vs 120   16 264: 132 vs 164   29 910: 218 vs 226
+  //   hic-like n 5 776: 73 vs 72   8 500: 93 vs 100  12 000: 107 vs 108   16 264: 129 vs 127   29 910: 207 vs 183
+  // One launch per strand loses everywhere (2 x S = 1 fused: 116 / 173 / 246 us).  A 13.5 ... 40 MiB band for the split
+  // makes the d = 256, 4-layer genome epoch 4.2 % faster on uniform graphs (23.52 -> 22.53 ms) and 2.5 % slower on
+  // distance-decay graphs (20.81 -> 21.34 ms): whole 2 KiB rows of near-diagonal neighbours hit L2 in the fused kernel at
+  // any table size.  Hi-C contacts decay with distance, so the fused kernel stays the route at this payload.
+  return table >= (double)FWD_SPLIT_WIDE_LO && table <= (double)FWD_SPLIT_WIDE_HI;
 }
 static int dense_stat_chunk(int n, int S, int d) {
   if (!fwd_split_shape(n, S, d)) return 1;
