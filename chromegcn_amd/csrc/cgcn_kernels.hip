@@ -1620,6 +1620,12 @@ __global__ __launch_bounds__(256) void k_reduce_partials(int P, int D, const flo
 #ifndef SLICED_HUB
 #define SLICED_HUB 192
 #endif
+#ifndef SLICED_COST_MODEL
+#define SLICED_COST_MODEL 1
+#endif
+#ifndef SLICED_COOP_OVERHEAD
+#define SLICED_COOP_OVERHEAD 3
+#endif
 // lane (8*group + U) of every 8-lane group: ds_swizzle bit-mask mode, lane' = (lane & 0x18) | U inside each 32
 template <int U>
 __device__ __forceinline__ int group8_bcast(int v) { return __builtin_amdgcn_ds_swizzle(v, 0x18 | (U << 5)); }
@@ -1677,7 +1683,20 @@ template <bool HAS_VAL, typename IT>
 __device__ __forceinline__ f32x4 sliced_row_sum(const IT* __restrict__ col, const float* __restrict__ val, int k0, int k1,
                                                 const char* __restrict__ base, unsigned lane_off, unsigned rowsh, int lane) {
   const int g = lane >> 3, j = lane & 7;
+#if SLICED_COST_MODEL
+  // per-row walk: every group steps until the wave's longest row is done (8 neighbours per row and step); cooperative
+  // walk: the rows one after the other, 64 neighbours per step, plus eight butterflies.  Take the cheaper one: a wave
+  // whose rows are 5, 5, ..., 5, 200 neighbours long walks 11 steps together instead of 25 apart.
+  int mx = k1 - k0, sm = (k1 - k0 + 63) >> 6;
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) {
+    mx = max(mx, __shfl_xor(mx, o, WAVE));
+    sm += __shfl_xor(sm, o, WAVE);
+  }
+  if (sm + SLICED_COOP_OVERHEAD >= ((mx + 7) >> 3)) return sliced_walk<HAS_VAL, IT>(col, val, k0, k1, 8, base, lane_off, rowsh, j);
+#else
   if (!__any(k1 - k0 > SLICED_HUB)) return sliced_walk<HAS_VAL, IT>(col, val, k0, k1, 8, base, lane_off, rowsh, j);
+#endif
   f32x4 mine = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
   for (int rr = 0; rr < 8; ++rr) {   // wave-uniform: every group helps with row rr of the wave
@@ -1691,6 +1710,74 @@ __device__ __forceinline__ f32x4 sliced_row_sum(const IT* __restrict__ col, cons
     }
     if (g == rr) mine = acc;
   }
+  return mine;
+}
+
+// The 64 rows of a workgroup's tile, rows of more than SLICED_SUPER neighbours (top-K Hi-C hubs: thousands) included.
+// One CU pulls at most 64 B/clk through its L1, and one wave walking a 10 000-neighbour row exposes an L2 round trip
+// per 64 neighbours: such rows are walked by all 8 waves of the workgroup, wave w taking the w-th eighth of the list
+// (64-aligned), combined through LDS in wave order (bit-reproducible).
+// Every wave reads the tile's 65 row pointers itself (lane l: row 64*tile + l; one coalesced load of lines its
+// neighbours read too) and ballots the super rows, so all 8 waves know the same mask without a barrier: tiles without a
+// super row -- every tile of a regular graph -- pay nothing.
+#ifndef SLICED_SUPER
+#define SLICED_SUPER 768
+#endif
+struct SlicedTile {
+  int t0, t1;                 // lane l: neighbour range of row 64*tile + l (empty past n)
+  unsigned long long super;   // wave-uniform (and workgroup-uniform): rows of the tile with more than SLICED_SUPER neighbours
+  int k0, k1;                 // this lane's own row (row 8*wave + lane/8 of the tile)
+};
+__device__ __forceinline__ SlicedTile sliced_tile(const int* __restrict__ rowptr, int n, int tile, int wave, int lane) {
+  SlicedTile t;
+  const int r = tile * 64 + lane;
+  t.t0 = t.t1 = 0;
+  if (r < n) {
+    t.t0 = rowptr[r];
+    t.t1 = rowptr[r + 1];
+  }
+  t.super = __ballot(t.t1 - t.t0 > SLICED_SUPER);
+  t.k0 = __shfl(t.t0, wave * 8 + (lane >> 3), WAVE);
+  t.k1 = __shfl(t.t1, wave * 8 + (lane >> 3), WAVE);
+  return t;
+}
+// the tile's sums when it holds super rows (t.super != 0: every wave of the workgroup takes this branch)
+template <bool HAS_VAL, typename IT>
+__device__ __forceinline__ f32x4 sliced_super_sum(const IT* __restrict__ col, const float* __restrict__ val, const SlicedTile& t,
+                                                  const char* __restrict__ base, unsigned lane_off, unsigned rowsh, int lane,
+                                                  int wave) {
+  __shared__ float s_part[8][32];
+  __shared__ float s_res[64][32];
+  const int g = lane >> 3, j = lane & 7;
+  // the super rows first, results parked in LDS (nothing but the row ranges stays live across these walks)
+  unsigned long long m = t.super;
+  while (m) {
+    const int r = __builtin_ctzll(m);
+    m &= m - 1;
+    const int a0 = __builtin_amdgcn_readlane(t.t0, r), a1 = __builtin_amdgcn_readlane(t.t1, r);
+    const int seg = (((a1 - a0 + 7) >> 3) + 63) & ~63;
+    const int w0 = a0 + wave * seg, w1 = min(a1, w0 + seg);
+    f32x4 acc = sliced_walk<HAS_VAL, IT>(col, val, w0 + g * 8, w1, 64, base, lane_off, rowsh, j);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc[e] += __shfl_xor(acc[e], 8, WAVE);
+      acc[e] += __shfl_xor(acc[e], 16, WAVE);
+      acc[e] += __shfl_xor(acc[e], 32, WAVE);
+    }
+    if (lane < 8) *(f32x4*)&s_part[wave][lane * 4] = acc;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      float x = s_part[0][threadIdx.x];
+#pragma unroll
+      for (int ww = 1; ww < 8; ++ww) x += s_part[ww][threadIdx.x];
+      s_res[r][threadIdx.x] = x;
+    }
+    __syncthreads();
+  }
+  // the ordinary rows (super rows walk an empty range here and pick their sum up from LDS)
+  const bool super = (t.k1 - t.k0) > SLICED_SUPER;
+  f32x4 mine = sliced_row_sum<HAS_VAL, IT>(col, val, t.k0, super ? t.k0 : t.k1, base, lane_off, rowsh, lane);
+  if (super) mine = *(const f32x4*)&s_res[wave * 8 + g][j * 4];
   return mine;
 }
 
@@ -1711,7 +1798,7 @@ __device__ __forceinline__ void sliced_block(int b, int tiles, int& slice, int& 
 
 // H = diag(rs) Ahat X, [S, n, D] -> [S, n, D]  (grid: NSL * ceil(n / 64) workgroups of 512)
 template <int S, int D, bool HAS_VAL, typename IT = int>
-__global__ __launch_bounds__(512) void k_aggregate_sliced(int n, const int* __restrict__ rowptr, const IT* __restrict__ col,
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HAS_VAL ? 6 : 8))) void k_aggregate_sliced(int n, const int* __restrict__ rowptr, const IT* __restrict__ col,
                                                           const float* __restrict__ val, const float* __restrict__ rs,
                                                           const float* __restrict__ X, float* __restrict__ H) {
   constexpr int NSL = S * D / 32, QPR = D / 32;
@@ -1720,14 +1807,11 @@ __global__ __launch_bounds__(512) void k_aggregate_sliced(int n, const int* __re
   sliced_block<NSL>(blockIdx.x, (n + 63) / 64, slice, tile);
   const int i = tile * 64 + wave * 8 + (lane >> 3);
   const size_t lane_el = (size_t)(slice / QPR) * n * D + (slice % QPR) * 32 + (lane & 7) * 4;
-  int k0 = 0, k1 = 0;
-  float sc = 0.f;
-  if (i < n) {
-    k0 = rowptr[i];
-    k1 = rowptr[i + 1];
-    sc = rs ? rs[i] : 1.f;
-  }
-  const f32x4 acc = sliced_row_sum<HAS_VAL, IT>(col, val, k0, k1, (const char*)X, (unsigned)(lane_el * 4), D == 128 ? 9u : 10u, lane);
+  const SlicedTile t = sliced_tile(rowptr, n, tile, wave, lane);
+  const float sc = (i < n && rs) ? rs[i] : 1.f;
+  const unsigned lane_off = (unsigned)(lane_el * 4), rowsh = D == 128 ? 9u : 10u;
+  const f32x4 acc = !t.super ? sliced_row_sum<HAS_VAL, IT>(col, val, t.k0, t.k1, (const char*)X, lane_off, rowsh, lane)
+                             : sliced_super_sum<HAS_VAL, IT>(col, val, t, (const char*)X, lane_off, rowsh, lane, wave);
   if (i < n) *(f32x4*)&H[lane_el + (size_t)i * D] = acc * sc;
 }
 
@@ -1737,7 +1821,7 @@ __global__ __launch_bounds__(512) void k_aggregate_sliced(int n, const int* __re
 // mask: the dropout the PREVIOUS layer applied to this layer's input (stream_id of that layer).
 // ------------------------------------------------------------------------------------------
 template <int S, int D, bool HAS_VAL, typename IT = int>
-__global__ __launch_bounds__(512) void k_bwd_sliced(int n, const int* __restrict__ rowptr, const IT* __restrict__ col,
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HAS_VAL ? 6 : 8))) void k_bwd_sliced(int n, const int* __restrict__ rowptr, const IT* __restrict__ col,
                                                     const float* __restrict__ val, const float* __restrict__ dHs,
                                                     const float* dXn, const float* __restrict__ gate, float* dX,
                                                     float keep_scale, uint32_t thresh,
@@ -1766,14 +1850,17 @@ __global__ __launch_bounds__(512) void k_bwd_sliced(int n, const int* __restrict
   const int s = slice / QPR;
   const int i = tile * 64 + wave * 8 + (lane >> 3);
   const size_t lane_el = (size_t)s * n * D + (slice % QPR) * 32 + (lane & 7) * 4;
-  int k0 = 0, k1 = 0;
-  f32x4 res = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (i < n) {   // the (1-g) dXn term first: its loads are in flight during the walk
-    k0 = rowptr[i];
-    k1 = rowptr[i + 1];
-    res = *(const f32x4*)&dXn[lane_el + (size_t)i * D] * (1.f - gate[(size_t)s * n + i]);
+  const SlicedTile t = sliced_tile(rowptr, n, tile, wave, lane);
+  const unsigned lane_off = (unsigned)(lane_el * 4), rowsh = D == 128 ? 9u : 10u;
+  f32x4 res = (f32x4){0.f, 0.f, 0.f, 0.f}, acc;
+  if (!t.super) {
+    // the (1-g) dXn term first: its loads are in flight during the walk
+    if (i < n) res = *(const f32x4*)&dXn[lane_el + (size_t)i * D] * (1.f - gate[(size_t)s * n + i]);
+    acc = sliced_row_sum<HAS_VAL, IT>(col, val, t.k0, t.k1, (const char*)dHs, lane_off, rowsh, lane);
+  } else {
+    acc = sliced_super_sum<HAS_VAL, IT>(col, val, t, (const char*)dHs, lane_off, rowsh, lane, wave);
+    if (i < n) res = *(const f32x4*)&dXn[lane_el + (size_t)i * D] * (1.f - gate[(size_t)s * n + i]);
   }
-  const f32x4 acc = sliced_row_sum<HAS_VAL, IT>(col, val, k0, k1, (const char*)dHs, (unsigned)(lane_el * 4), D == 128 ? 9u : 10u, lane);
   if (i >= n) return;
   const size_t g_off = lane_el + (size_t)i * D;
   f32x4 o = res + acc;

@@ -112,3 +112,48 @@ def test_sixteen_bit_column_indices_give_bit_identical_results(S, d):
     # more than 65 536 columns: no 16-bit copy is registered
     big = G.upload(G.normalize_graph("none", None, 70000), DEV)
     assert G.col16_ptr(big.col) is None
+
+
+@pytest.mark.parametrize("S,d,kind", [(2, 128, "hic"), (1, 256, "both")])
+def test_super_hub_rows_and_skewed_waves(S, d, kind):
+    """rows of thousands of neighbours (walked by all 8 waves of the workgroup, SLICED_SUPER), two of them in one 64-row
+    tile, next to rows of 1 ... 200 neighbours (the cost-model choice between the per-row and the cooperative walk of a
+    wave): the sliced aggregation against float64 scipy, and the whole layer forward + backward against the fused /
+    whole-row route of the same library."""
+    rng = np.random.RandomState(3 + d)
+    n = 6000
+    i = rng.randint(0, n, 4 * n); j = rng.randint(0, n, 4 * n)
+    hubs = [(70, 800), (71, 2500), (3000, 5000), (n - 1, 1200)]          # (row, degree); rows 70 and 71 share a tile
+    hubs += [(int(r), int(dg)) for r, dg in zip(rng.choice(np.arange(200, 2900), 40, replace=False), rng.randint(100, 260, 40))]
+    for r, deg in hubs:
+        i = np.concatenate([i, np.full(deg, r)]); j = np.concatenate([j, rng.choice(n, deg, replace=False)])
+    keep = i != j
+    m = sp.coo_matrix((np.ones(int(keep.sum()), dtype=np.float32), (i[keep], j[keep])), shape=(n, n)).tocsr()
+    m = m + m.T
+    m.data[:] = 1.0
+    host = G.normalize_graph(kind, m, n)
+    g = G.upload(host, DEV)
+    deg = np.diff(g.rowptr.cpu().numpy())
+    assert deg.max() > 4000 and (deg > 768).sum() >= 4
+    lib = _lib.load()
+    P = _lib.ptr
+    x = torch.randn(S, n, d, device=DEV)
+    y = torch.empty_like(x)
+    lib.cgcn_debug_set_fwd_split_bytes(0)
+    try:
+        _lib.check(lib.cgcn_spmm(_lib.stream_ptr(), n, n, S, d, P(g.rowptr), P(g.col), None if g.val is None else P(g.val),
+                                 P(g.row_scale), P(x), P(y), G.col16_ptr(g.col)), "spmm")
+    finally:
+        lib.cgcn_debug_set_fwd_split_bytes(-1)
+    A = sp.csr_matrix((np.ones(g.col.numel()) if g.val is None else g.val.cpu().numpy().astype(np.float64),
+                       g.col.cpu().numpy(), g.rowptr.cpu().numpy()), shape=(n, n))
+    rs = g.row_scale.cpu().numpy().astype(np.float64)
+    for s in range(S):
+        want = (A @ x[s].cpu().numpy().astype(np.float64)) * rs[:, None]
+        err = np.abs(y[s].cpu().numpy() - want).max() / np.abs(want).max()
+        assert err < 2e-6, "strand %d: scale-relative error %.2e" % (s, err)
+    a = run_layer(g, S, d, 5, split=False)
+    b = run_layer(g, S, d, 5, split=True)
+    for nm, u, v in zip(["Xn", "gate", "spmm", "dX", "dW", "db", "dwg", "dcg"], a, b):
+        err = float((u - v).abs().max()) / (float(u.abs().max()) + 1e-30)
+        assert err < 2e-5, "%s: scale-relative difference %.2e" % (nm, err)
