@@ -193,8 +193,8 @@ def time_kernels(stage, name, reps, dropout_p):
     gc1, w1, gcL, wL, bn, out = m.GC1, m.W1, getattr(m, "GC%d" % L), getattr(m, "W%d" % L), m.batch_norm, m.out
     split = n * S * d * 4 >= (8 << 20) and S * d <= 256
     drop = dropout_p > 0
-    from chromegcn_amd.graph import col16_ptr
-    c16, c16t = col16_ptr(g.col), col16_ptr(g.col_t)   # the engine's own choice of index width
+    from chromegcn_amd.graph import aux_ptr
+    c16, c16t = aux_ptr(g.col), aux_ptr(g.col_t)   # the engine's own cgcn_graph_aux (16-bit indices, longest row)
 
     def ev_time(fn):
         for _ in range(3):

@@ -2063,10 +2063,17 @@ static std::atomic<long long> g_fwd_split_bytes{fwd_split_default()};
 void cgcn_debug_set_fwd_split_bytes(long long bytes) { g_fwd_split_bytes.store(bytes < 0 ? fwd_split_default() : bytes); }
 
 // 16-bit column indices serve the feature-sliced kernels of implicit-value graphs (HAS_VAL = false) with <= 65 536 columns
-static inline bool use_col16(const uint16_t* col16, const float* val, int n_cols) { return col16 && !val && n_cols <= 65536; }
+static inline const uint16_t* use_col16(const cgcn_graph_aux* aux, const float* val, int n_cols) {
+  return (aux && aux->col16 && !val && n_cols <= 65536) ? aux->col16 : nullptr;
+}
+// graphs with a row this long take the feature-sliced route at every table size (cgcn_graph_aux::max_row_len)
+#ifndef FWD_HUB_ROW
+#define FWD_HUB_ROW 2048
+#endif
+static inline bool hub_graph(const cgcn_graph_aux* aux) { return aux && aux->max_row_len > FWD_HUB_ROW; }
 
 int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d, const int32_t* rowptr, const int32_t* col,
-              const float* val, const float* row_scale, const float* X, float* Y, const uint16_t* col16) {
+              const float* val, const float* row_scale, const float* X, float* Y, const cgcn_graph_aux* aux) {
   const int nmax = n_rows > n_cols ? n_rows : n_cols;
   if (nmax < 0) return CGCN_ERR_BAD_ARG;
   // the bare aggregation takes any width that is a multiple of 4 (k_spmm_any); S*D in {128, 256, 512} has tuned kernels
@@ -2082,10 +2089,10 @@ int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d, const 
     hipLaunchKernelGGL(k_spmm_any, dim3(blocks), dim3(256), 0, st, n_rows, n_cols, S, d, rowptr, col, val, row_scale, X, Y);
     return launch_status();
   }
-  if (n_rows == n_cols && (double)n_rows * S * d * 4.0 >= (double)g_fwd_split_bytes.load()) {
+  if (n_rows == n_cols && ((double)n_rows * S * d * 4.0 >= (double)g_fwd_split_bytes.load() || hub_graph(aux))) {
     // square operator on a table too large for the L2s: the feature-sliced aggregation (see k_aggregate_sliced)
     const int gblocks = (S * d / 32) * ((n_rows + 63) / 64);
-    launch_aggregate_sliced(st, gblocks, n_rows, S, d, rowptr, col, use_col16(col16, val, n_cols) ? col16 : nullptr, val, row_scale, X, Y);
+    launch_aggregate_sliced(st, gblocks, n_rows, S, d, rowptr, col, use_col16(aux, val, n_cols), val, row_scale, X, Y);
     return launch_status();
   }
   const int blocks = (n_rows + 3) / 4 < 4096 ? (n_rows + 3) / 4 : 4096;
@@ -2144,7 +2151,7 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
                    const float* row_scale, const float* X, const float* W, const float* b, const float* wg,
                    const float* cg, float* Xn, float* Z, float* H, float* gate, float dropout_p,
                    const unsigned long long* rng_state, unsigned int stream_id, const float* H_in, float* colstats,
-                   const uint16_t* col16) {
+                   const cgcn_graph_aux* aux) {
   int rc = check_shape(n, S, d);
   if (rc) return rc;
   if (n == 0) return CGCN_OK;
@@ -2158,14 +2165,14 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   hipStream_t st = (hipStream_t)stream;
   // Three routes.  H_in given: the row-local kernel alone.  Training (H is wanted anyway) on a table that does not
   // fit the L2s: feature-sliced aggregation into H, then the row-local kernel on it.  Otherwise the fused kernel.
-  const bool split = !H_in && H && fwd_split_shape(n, S, d);
+  const bool split = !H_in && H && (fwd_split_shape(n, S, d) || hub_graph(aux));
   // cgcn_layer_fwd_colstats_tiles() reports MERGED records on split-size tables (k_layer_dense's contiguous tile
   // chunks); the fused kernel would write one record per 16 / S-node tile -- more than the caller allocated.  On such
   // tables the column statistics therefore need the two-launch route, i.e. an H (or H_in) buffer.
   if (colstats && !split && !H_in && dense_stat_chunk(n, S, d) != 1) return CGCN_ERR_BAD_ARG;
   if (split) {
     const int gblocks = (S * d / 32) * ((n + 63) / 64);
-    launch_aggregate_sliced(st, gblocks, n, S, d, rowptr, col, use_col16(col16, val, n) ? col16 : nullptr, val, row_scale, X, H);
+    launch_aggregate_sliced(st, gblocks, n, S, d, rowptr, col, use_col16(aux, val, n), val, row_scale, X, H);
     if ((rc = launch_status())) return rc;
     H_in = H;
   }
@@ -2234,7 +2241,7 @@ static int layer_bwd_impl(cgcn_stream_t stream, int n, int S, int d, const int32
                           float* dHs, float* dW, float* db, float* dwg, float* dcg, int accumulate, float in_dropout_p,
                           const unsigned long long* rng_state, unsigned int in_stream_id, const cgcn_head_grad* head,
                           void* workspace, size_t workspace_bytes, cgcn_stream_t aux_stream, const cgcn_sgd_fuse* sgd,
-                          int phases, const uint16_t* col16_t) {
+                          int phases, const cgcn_graph_aux* aux_t) {
   int rc = check_shape(n, S, d);
   if (rc) return rc;
   if (!rowptr_t || !col_t || !X || !Z || !H || !gate || !W || !wg || !dW || !db || !dwg || !dcg) return CGCN_ERR_BAD_ARG;
@@ -2335,7 +2342,7 @@ static int layer_bwd_impl(cgcn_stream_t stream, int n, int S, int d, const int32
   const int blocks = (S * d / 32) * ((n + 63) / 64);   // slices x 64-row tiles (k_bwd_sliced)
   if (head) dXn = dX;  // k_bwd_rowlocal left dL/dXn there; each thread reads its elements before overwriting them
   const int sgd_blocks = sg.param ? (sg.count + 511) / 512 : 0;
-  if (use_col16(col16_t, val_t, n)) {
+  if (const uint16_t* col16_t = use_col16(aux_t, val_t, n)) {
 #define CALL16(S_, D_)                                                                                               \
   hipLaunchKernelGGL((k_bwd_sliced<S_, D_, false, uint16_t>), dim3(blocks + (fuse_reduce ? slabs : 0) + sgd_blocks), dim3(512), 0, \
                      st, n, rowptr_t, col16_t, val_t, dHs, dXn, gate, dX, ks, th, rng_state, in_stream_id, blocks, P, \
@@ -2364,10 +2371,10 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
                    float* dHs, float* dW, float* db, float* dwg, float* dcg, int accumulate, float in_dropout_p,
                    const unsigned long long* rng_state, unsigned int in_stream_id, const cgcn_head_grad* head,
                    void* workspace, size_t workspace_bytes, cgcn_stream_t aux_stream, const cgcn_sgd_fuse* sgd,
-                   const uint16_t* col16_t) {
+                   const cgcn_graph_aux* aux_t) {
   return layer_bwd_impl(stream, n, S, d, rowptr_t, col_t, val_t, row_scale, X, Z, H, gate, W, wg, dXn, dgate, dX, dHs, dW, db,
                         dwg, dcg, accumulate, in_dropout_p, rng_state, in_stream_id, head, workspace, workspace_bytes,
-                        aux_stream, sgd, 3, col16_t);
+                        aux_stream, sgd, 3, aux_t);
 }
 
 int cgcn_debug_layer_bwd_phases(cgcn_stream_t stream, int n, int S, int d, const int32_t* rowptr_t, const int32_t* col_t,
@@ -2376,11 +2383,11 @@ int cgcn_debug_layer_bwd_phases(cgcn_stream_t stream, int n, int S, int d, const
                                 float* dX, float* dHs, float* dW, float* db, float* dwg, float* dcg, int accumulate,
                                 float in_dropout_p, const unsigned long long* rng_state, unsigned int in_stream_id,
                                 const cgcn_head_grad* head, void* workspace, size_t workspace_bytes, int phases,
-                                const uint16_t* col16_t) {
+                                const cgcn_graph_aux* aux_t) {
   if (phases < 1 || phases > 3) return CGCN_ERR_BAD_ARG;
   return layer_bwd_impl(stream, n, S, d, rowptr_t, col_t, val_t, row_scale, X, Z, H, gate, W, wg, dXn, dgate, dX, dHs, dW, db,
                         dwg, dcg, accumulate, in_dropout_p, rng_state, in_stream_id, head, workspace, workspace_bytes,
-                        nullptr, nullptr, phases, col16_t);
+                        nullptr, nullptr, phases, aux_t);
 }
 
 int cgcn_sddmm(cgcn_stream_t stream, int n, int S, int d, const int32_t* rowptr, const int32_t* col, const float* A,

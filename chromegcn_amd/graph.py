@@ -7,6 +7,7 @@ per-edge values, fp32 1/deg row scale -- instead of a torch COO tensor, and cach
 chromosome (the reference rebuilds it every chromosome every epoch, finetune.py:36)."""
 from __future__ import annotations
 
+import ctypes
 from dataclasses import dataclass, field
 from typing import Dict, Optional
 
@@ -115,30 +116,56 @@ def host_csr_from_matrix(a: sp.spmatrix) -> HostCSR:
 # ----------------------------------------------------------------------------------------------
 # device handle
 # ----------------------------------------------------------------------------------------------
-# 16-bit copies of the column-index arrays of graphs with at most 65 536 columns (every chromosome at 1 kb windows): the
-# feature-sliced kernels re-read the index list once per column slice, and the uint16 list halves those bytes
-# (include/chromegcn.h, col16).  Built when a ChromGraph is created (never lazily: a first use may sit inside HIP-graph
-# capture), found again by the address of the int32 array -- the registered operators carry tensors, not graph objects.
-_COL16: Dict[int, tuple] = {}
+# Optional per-graph facts the C ABI takes as a cgcn_graph_aux (include/chromegcn.h): a 16-bit copy of the column-index
+# array for graphs with at most 65 536 columns (every chromosome at 1 kb windows: the feature-sliced kernels re-read the
+# index list once per column slice, and the uint16 list halves those bytes) and the length of the longest row (hub-heavy
+# top-K graphs take the feature-sliced forward at every size).  Built when a ChromGraph is created (never lazily: a first
+# use may sit inside HIP-graph capture), found again by the address of the int32 array -- the registered operators
+# carry tensors, not graph objects.
+class GraphAux(ctypes.Structure):
+    _fields_ = [("col16", ctypes.c_void_p), ("max_row_len", ctypes.c_int32)]
 
 
-def _register_col16(col: torch.Tensor, n_cols: int):
-    if not (torch.is_tensor(col) and col.is_cuda and col.numel() > 0 and n_cols <= 65536):
+_AUX: Dict[int, tuple] = {}
+
+
+def _register_aux(rowptr: torch.Tensor, col: torch.Tensor, n_cols: int):
+    if not (torch.is_tensor(col) and col.is_cuda and col.numel() > 0):
         return
     import weakref
-    for k in [k for k, e in _COL16.items() if e[0]() is None]:
-        del _COL16[k]
-    _COL16[col.data_ptr()] = (weakref.ref(col), col.to(torch.int16))   # two's-complement truncation = the uint16 bits
+    for k in [k for k, e in _AUX.items() if e[0]() is None]:
+        del _AUX[k]
+    c16 = col.to(torch.int16) if n_cols <= 65536 else None   # two's-complement truncation = the uint16 bits
+    longest = int((rowptr[1:] - rowptr[:-1]).max().item()) if rowptr.numel() > 1 else 0
+    _AUX[col.data_ptr()] = (weakref.ref(col), c16, GraphAux(None if c16 is None else c16.data_ptr(), longest))
+
+
+def _aux_entry(col: Optional[torch.Tensor]):
+    if col is None:
+        return None
+    ent = _AUX.get(col.data_ptr())
+    if ent is None or ent[0]() is None or (ent[1] is not None and ent[1].numel() != col.numel()):
+        return None
+    return ent
+
+
+def aux_ptr(col: Optional[torch.Tensor]):
+    """address of the cgcn_graph_aux registered for the graph whose int32 column array is `col` (None if there is
+    none, or the array has died)"""
+    ent = _aux_entry(col)
+    return None if ent is None else ctypes.addressof(ent[2])
 
 
 def col16_ptr(col: Optional[torch.Tensor]):
-    """device pointer of the registered uint16 copy of `col` (None if there is none, or its int32 array has died)"""
-    if col is None:
-        return None
-    ent = _COL16.get(col.data_ptr())
-    if ent is None or ent[0]() is None or ent[1].numel() != col.numel():
-        return None
-    return ent[1].data_ptr()
+    """device pointer of the registered uint16 copy of `col` (None if there is none)"""
+    ent = _aux_entry(col)
+    return None if ent is None or ent[1] is None else ent[1].data_ptr()
+
+
+def max_row_len(col: Optional[torch.Tensor]) -> int:
+    ent = _aux_entry(col)
+    return 0 if ent is None else int(ent[2].max_row_len)
+
 
 @dataclass
 class ChromGraph:
@@ -158,9 +185,9 @@ class ChromGraph:
     host: Optional[HostCSR] = field(default=None, repr=False)
 
     def __post_init__(self):
-        _register_col16(self.col, self.n)
+        _register_aux(self.rowptr, self.col, self.n)
         if self.col_t is not self.col:
-            _register_col16(self.col_t, self.n)
+            _register_aux(self.rowptr_t, self.col_t, self.n)
 
     @property
     def device(self):

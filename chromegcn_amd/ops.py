@@ -170,7 +170,7 @@ class GatedLayerFn(torch.autograd.Function):
                                       bias.data_ptr(), wg.data_ptr(), cg.data_ptr(), xn.data_ptr(), _lib.ptr(z),
                                       _lib.ptr(h), gate.data_ptr(), float(dropout_out),
                                       _lib.ptr(rng_state) if dropout_out > 0 else None, int(layer_id), _lib.ptr(h_in), None,
-                                      G.col16_ptr(graph.col)),
+                                      G.aux_ptr(graph.col)),
                    "cgcn_layer_fwd")
         h = _store_h_cache(h_cache, h_in, h)
         if need_bwd:
@@ -213,7 +213,7 @@ class GatedLayerFn(torch.autograd.Function):
                                       dxn.data_ptr(), _lib.ptr(dgate), _lib.ptr(dx), _lib.ptr(dhs), dw.data_ptr(),
                                       db.data_ptr(), dwg.data_ptr(), dcg.data_ptr(), 0, ctx.dropout_in,
                                       _lib.ptr(rng_state), max(ctx.layer_id - 1, 0), None, ws.data_ptr(), ws_bytes,
-                                      _lib.aux_stream_ptr(), sg_ref, G.col16_ptr(g.col_t)),
+                                      _lib.aux_stream_ptr(), sg_ref, G.aux_ptr(g.col_t)),
                    "cgcn_layer_bwd")
         if sg_ref is not None:
             _sgd_fuse["done"] = True
@@ -360,7 +360,7 @@ class LastLayerHeadLossFn(torch.autograd.Function):
                                       _lib.ptr(graph.val), _lib.ptr(graph.row_scale), x.data_ptr(), weight.data_ptr(),
                                       bias.data_ptr(), wg.data_ptr(), cg.data_ptr(), xn.data_ptr(), _lib.ptr(z),
                                       _lib.ptr(h), gate.data_ptr(), 0.0, None, int(layer_id), _lib.ptr(h_in), _lib.ptr(colstats),
-                                      G.col16_ptr(graph.col)), "cgcn_layer_fwd")
+                                      G.aux_ptr(graph.col)), "cgcn_layer_fwd")
         h = _store_h_cache(h_cache, h_in, h)
         ws_bytes = lib.cgcn_head_workspace_bytes(n, S, d, C)
         if ws_bytes == 0:
@@ -447,7 +447,7 @@ class LastLayerHeadLossFn(torch.autograd.Function):
                                       None, None, _lib.ptr(dx), _lib.ptr(dhs), dw.data_ptr(), db.data_ptr(),
                                       dwg.data_ptr(), dcg.data_ptr(), 0, ctx.dropout_in, _lib.ptr(rng_state),
                                       max(ctx.layer_id - 1, 0), ctypes.byref(hg), ws.data_ptr(), ws_bytes,
-                                      _lib.aux_stream_ptr(), sg_ref, G.col16_ptr(g.col_t)), "cgcn_layer_bwd")
+                                      _lib.aux_stream_ptr(), sg_ref, G.aux_ptr(g.col_t)), "cgcn_layer_bwd")
         if sg_ref is not None:
             _sgd_fuse["done"] = True
         gl = (None,) * 4 if ctx.layer_sink is not None else (dw, db, dwg.view(ctx.shapes[0]), dcg.view(ctx.shapes[1]))

@@ -24,7 +24,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from .graph import col16_ptr
+from .graph import aux_ptr
 
 _P = _lib.ptr
 
@@ -58,7 +58,7 @@ def spmm(x: Tensor, rowptr: Tensor, col: Tensor, val: Optional[Tensor], row_scal
     y = torch.empty((S, n_rows, d), device=x.device, dtype=torch.float32)
     lib = _lib.load()
     _lib.check(lib.cgcn_spmm(_lib.stream_ptr(), n_rows, n_cols, S, d, _P(rowptr), _P(col), _P(val), _P(row_scale),
-                             x.data_ptr(), y.data_ptr(), col16_ptr(col)), "cgcn_spmm")
+                             x.data_ptr(), y.data_ptr(), aux_ptr(col)), "cgcn_spmm")
     return y
 
 
@@ -111,7 +111,7 @@ def gated_layer(x: Tensor, weight: Tensor, bias: Tensor, gate_w: Tensor, gate_b:
     _lib.check(lib.cgcn_layer_fwd(_lib.stream_ptr(), n, S, d, _P(rowptr), _P(col), _P(val), _P(row_scale), x.data_ptr(),
                                   weight.data_ptr(), bias.data_ptr(), wg.data_ptr(), cg.data_ptr(), xn.data_ptr(),
                                   z.data_ptr(), h.data_ptr(), gate.data_ptr(), float(dropout_out),
-                                  _P(rng_state) if dropout_out > 0 else None, int(layer_id), None, None, col16_ptr(col)), "cgcn_layer_fwd")
+                                  _P(rng_state) if dropout_out > 0 else None, int(layer_id), None, None, aux_ptr(col)), "cgcn_layer_fwd")
     return xn, gate, z, h
 
 
@@ -145,7 +145,7 @@ def gated_layer_backward(dxn: Tensor, dgate: Optional[Tensor], x: Tensor, z: Ten
                                   wg.data_ptr(), dxn.data_ptr(), _P(None if dgate is None else dgate.contiguous()),
                                   dx.data_ptr() if need_dx else None, dhs.data_ptr(), dw.data_ptr(), db.data_ptr(),
                                   dwg.data_ptr(), dcg.data_ptr(), 0, float(dropout_in), _P(rng_state) if dropout_in > 0 else None,
-                                  max(int(layer_id) - 1, 0), None, ws.data_ptr(), ws_bytes, None, None, col16_ptr(col_t)), "cgcn_layer_bwd")
+                                  max(int(layer_id) - 1, 0), None, ws.data_ptr(), ws_bytes, None, None, aux_ptr(col_t)), "cgcn_layer_bwd")
     return dx, dw, db, dwg, dcg, dhs
 
 

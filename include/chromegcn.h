@@ -27,10 +27,8 @@
  *     'both' graphs carry val in {1,2,3}.
  *   - The backward needs Ahat^T; (rowptr_t, col_t, val_t) is its CSR.  Hi-C graphs are
  *     symmetric (data/7create_graph_new.py:115-116) so callers pass the same arrays.
- *   - col16 / col16_t (may be NULL): the same column indices as uint16, for graphs with at most 65 536
- *     columns (every chromosome at 1 kb windows with peaks).  The feature-sliced aggregation kernels re-read
- *     the index list once per 128-byte column slice; the 16-bit copy halves those bytes.  Used only with
- *     implicit values (val == NULL); results are bit-identical.
+ *   - aux / aux_t (may be NULL): optional facts about the graph (cgcn_graph_aux below) that change speed, never
+ *     results beyond fp32 re-association: a uint16 copy of the column indices and the length of the longest row.
  *   - Dropout (F.dropout of models/ChromeModels.py:42,50) is counter based: a mask bit is a pure
  *     function of rng_state = {seed, step counter} (uint64[2] in DEVICE memory), a stream id and
  *     the element index, so the backward regenerates the forward's mask.  Every kernel of one
@@ -52,9 +50,27 @@ extern "C" {
 #define CGCN_ERR_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after a launch      */
 #define CGCN_ERR_WORKSPACE (-4)   /* workspace too small (see cgcn_*_workspace_bytes)    */
 
-#define CGCN_ABI_VERSION 16
+#define CGCN_ABI_VERSION 17
 
 typedef void *cgcn_stream_t; /* hipStream_t */
+
+/*
+ * Optional per-graph facts (HOST struct; the arrays it points to are device memory).  Pass NULL for none.
+ *   col16       : the same column indices as uint16, for graphs with at most 65 536 columns (every chromosome at 1 kb
+ *                 windows with peaks), or NULL.  The feature-sliced aggregation kernels re-read the index list once per
+ *                 128-byte column slice; the 16-bit copy halves those bytes.  Used only with implicit values
+ *                 (val == NULL); results are bit-identical.
+ *   max_row_len : number of stored entries of the longest row (0 = unknown).  The reference keeps the top-K contacts of a
+ *                 chromosome (data/7create_graph_new.py:93-104), so a few windows can have thousands of neighbours.  A
+ *                 row is aggregated inside one workgroup by the fused forward (one CU's L1: ~65 us for 10 000
+ *                 neighbours of 1 KiB); graphs whose longest row exceeds 2 048 entries therefore take the feature-sliced
+ *                 route (8 ... 16 workgroups per row) at every table size.
+ * For the backward (aux_t) both describe the CSR of Ahat^T.
+ */
+typedef struct cgcn_graph_aux {
+  const uint16_t *col16;
+  int32_t max_row_len;
+} cgcn_graph_aux;
 
 /* ABI version of the loaded library (compare with CGCN_ABI_VERSION). */
 int cgcn_abi_version(void);
@@ -71,7 +87,7 @@ const char *cgcn_strerror(int code);
  */
 int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d,
               const int32_t *rowptr, const int32_t *col, const float *val, const float *row_scale,
-              const float *X, float *Y, const uint16_t *col16);
+              const float *X, float *Y, const cgcn_graph_aux *aux);
 
 /*
  * One gated graph-convolution layer, forward (one fused launch; or two -- a feature-sliced aggregation into H and a
@@ -104,7 +120,7 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d,
                    const float *X, const float *W, const float *b, const float *wg, const float *cg,
                    float *Xn, float *Z, float *H, float *gate,
                    float dropout_p, const unsigned long long *rng_state, unsigned int stream_id,
-                   const float *H_in, float *colstats, const uint16_t *col16);
+                   const float *H_in, float *colstats, const cgcn_graph_aux *aux);
 
 /* Number of node tiles cgcn_layer_fwd(n, S, d) writes column statistics for (0 = unsupported shape);
  * *rows_per_tile = nodes per tile (the last tile may be shorter). */
@@ -198,7 +214,7 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d,
                    int accumulate, float in_dropout_p, const unsigned long long *rng_state,
                    unsigned int in_stream_id, const cgcn_head_grad *head,
                    void *workspace, size_t workspace_bytes, cgcn_stream_t aux_stream,
-                   const cgcn_sgd_fuse *sgd, const uint16_t *col16_t);
+                   const cgcn_sgd_fuse *sgd, const cgcn_graph_aux *aux_t);
 
 /*
  * Profiling hook: cgcn_layer_bwd one launch group at a time, so that each kernel can be bracketed with events on the
@@ -214,7 +230,7 @@ int cgcn_debug_layer_bwd_phases(cgcn_stream_t stream, int n, int S, int d,
                                 float *dX, float *dHs, float *dW, float *db, float *dwg, float *dcg,
                                 int accumulate, float in_dropout_p, const unsigned long long *rng_state,
                                 unsigned int in_stream_id, const cgcn_head_grad *head,
-                                void *workspace, size_t workspace_bytes, int phases, const uint16_t *col16_t);
+                                void *workspace, size_t workspace_bytes, int phases, const cgcn_graph_aux *aux_t);
 
 /* Bytes of scratch cgcn_head_fwd / cgcn_head_bwd need for (n, S, d, C).  0 on unsupported shapes. */
 size_t cgcn_head_workspace_bytes(int n, int S, int d, int C);

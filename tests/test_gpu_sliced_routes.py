@@ -67,7 +67,7 @@ def test_sliced_routes_agree_with_whole_row_routes(S, d):
 
 @pytest.mark.parametrize("S,d", [(2, 128), (1, 256)])
 def test_sixteen_bit_column_indices_give_bit_identical_results(S, d):
-    """graphs with at most 65 536 columns carry a uint16 copy of their column indices (graph.col16_ptr), which the
+    """graphs with at most 65 536 columns carry a uint16 copy of their column indices (graph.aux_ptr -> cgcn_graph_aux.col16), which the
     feature-sliced kernels walk instead of the int32 list: same neighbours in the same order -> identical bits, for the
     aggregation (cgcn_spmm's sliced route) and for the backward gather (cgcn_layer_bwd); hub rows included."""
     lib = _lib.load()
@@ -83,8 +83,8 @@ def test_sixteen_bit_column_indices_give_bit_identical_results(S, d):
         m = m + m.T
         m.data[:] = 1.0
         g = G.upload(G.normalize_graph("hic", m, n), DEV)
-        c16 = G.col16_ptr(g.col)
-        assert c16 is not None and g.val is None
+        c16 = G.aux_ptr(g.col)             # cgcn_graph_aux carrying the 16-bit copy
+        assert G.col16_ptr(g.col) is not None and g.val is None
         x = torch.randn(S, n, d, device=DEV)
         lib.cgcn_debug_set_fwd_split_bytes(0)       # the sliced route at every size
         try:
@@ -142,9 +142,16 @@ def test_super_hub_rows_and_skewed_waves(S, d, kind):
     lib.cgcn_debug_set_fwd_split_bytes(0)
     try:
         _lib.check(lib.cgcn_spmm(_lib.stream_ptr(), n, n, S, d, P(g.rowptr), P(g.col), None if g.val is None else P(g.val),
-                                 P(g.row_scale), P(x), P(y), G.col16_ptr(g.col)), "spmm")
+                                 P(g.row_scale), P(x), P(y), G.aux_ptr(g.col)), "spmm")
     finally:
         lib.cgcn_debug_set_fwd_split_bytes(-1)
+    # cgcn_graph_aux::max_row_len routes this graph through the sliced kernels without the debug hook, table size
+    # regardless (6 ... 12 MB here: S = 2, d = 128 is below the 8 MiB threshold): same bits as the forced route
+    assert G.max_row_len(g.col) == int(deg.max())
+    y2 = torch.empty_like(x)
+    _lib.check(lib.cgcn_spmm(_lib.stream_ptr(), n, n, S, d, P(g.rowptr), P(g.col), None if g.val is None else P(g.val),
+                             P(g.row_scale), P(x), P(y2), G.aux_ptr(g.col)), "spmm")
+    assert torch.equal(y, y2)
     A = sp.csr_matrix((np.ones(g.col.numel()) if g.val is None else g.val.cpu().numpy().astype(np.float64),
                        g.col.cpu().numpy(), g.rowptr.cpu().numpy()), shape=(n, n))
     rs = g.row_scale.cpu().numpy().astype(np.float64)

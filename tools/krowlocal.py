@@ -24,7 +24,7 @@ def main():
         P = _lib.ptr; st = _lib.stream_ptr
         def run(ph):
             return lambda: lib.cgcn_debug_layer_bwd_phases(st(), n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(z), P(h), P(gate), P(W), P(wg),
-                                                           P(dxn), None, P(dx), P(dhs), P(dW), P(db), P(dwg), P(dcg), 0, 0.0, None, 0, None, P(ws), wsb, ph, G.col16_ptr(g.col))
+                                                           P(dxn), None, P(dx), P(dhs), P(dW), P(db), P(dwg), P(dcg), 0, 0.0, None, 0, None, P(ws), wsb, ph, G.aux_ptr(g.col))
         assert run(3)() == 0
         torch.cuda.synchronize()
         mb = (5 * S * n * d * 4) / 1e6

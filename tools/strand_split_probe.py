@@ -24,7 +24,7 @@ def main():
         x = torch.randn(S, n, d, device=dev)
         W = torch.randn(d, d, device=dev) / d ** 0.5; b = torch.randn(d, device=dev) * 0.1
         wg = torch.randn(d, device=dev) / d ** 0.5; cg = torch.zeros(1, device=dev)
-        c16 = G.col16_ptr(g.col)
+        c16 = G.aux_ptr(g.col)
 
         def outs():
             return [torch.empty_like(x), torch.empty_like(x), torch.empty_like(x), torch.empty(S, n, device=dev)]
