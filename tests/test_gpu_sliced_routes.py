@@ -4,6 +4,8 @@ walk and the 512-neighbour one of the fused gather, empty-but-for-the-self-loop 
 binary and valued adjacency.  cgcn_spmm: the sliced route sums a row in list order like the whole-row kernel, so
 ordinary rows agree bitwise and hub rows to re-association; the gated layer (forward, every gradient): split route
 (k_aggregate_sliced + k_layer_dense, k_bwd_sliced) vs the fused forward, tolerance of fp32 re-association."""
+import ctypes
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -83,8 +85,9 @@ def test_sixteen_bit_column_indices_give_bit_identical_results(S, d):
         m = m + m.T
         m.data[:] = 1.0
         g = G.upload(G.normalize_graph("hic", m, n), DEV)
-        c16 = G.aux_ptr(g.col)             # cgcn_graph_aux carrying the 16-bit copy
         assert G.col16_ptr(g.col) is not None and g.val is None
+        aux16 = G.GraphAux(G.col16_ptr(g.col), 0)   # cgcn_graph_aux carrying the 16-bit copy and nothing else
+        c16 = ctypes.addressof(aux16)
         x = torch.randn(S, n, d, device=DEV)
         lib.cgcn_debug_set_fwd_split_bytes(0)       # the sliced route at every size
         try:
