@@ -52,9 +52,10 @@ CASES = [   # name, n, pairs, hic_like, adj_type, seed, d, layers, labels
     ("chr21_C256", synth.chrom_nodes("chr21"), 250000, False, "hic", 23, 128, 2, 256),
     ("d256_C256", synth.chrom_nodes("chr21"), 250000, False, "hic", 24, 256, 2, 256),
     ("chr1_C129", synth.chrom_nodes("chr1"), 250000, False, "hic", 25, 128, 2, 129),
-    # top-K-style graphs (synth "hub" generator: degrees 1 ... 10^4): the hub paths of every gather kernel at full size --
-    # chr21 size: fused forward with hub rows split over a workgroup (LONG_ROW), sliced backward with the cooperative
-    # walk (SLICED_HUB); chr1 size: both sliced kernels with hubs of up to 9 870 neighbours
+    # top-K-style graphs (synth "hub" generator: degrees 1 ... 10^4): the hub paths of the sliced gather kernels at full
+    # size (cooperative wave walk by cost model, rows > 768 neighbours walked by the whole workgroup); the graphs' longest
+    # row (cgcn_graph_aux::max_row_len > 2 048) sends chr21-size tables through the sliced forward too.  The fused
+    # forward's own hub path (LONG_ROW) meets the oracle in tests/test_gpu_parity.py (hubs of 600 ... 1 700 neighbours)
     ("chr21_hub", synth.chrom_nodes("chr21"), 250000, "hub", "hic", 26, 128, 2, NC),
     ("chr1_hub", synth.chrom_nodes("chr1"), 250000, "hub", "hic", 27, 128, 2, NC),
     ("chr21_hub_d256", synth.chrom_nodes("chr21"), 250000, "hub", "hic", 28, 256, 2, NC),

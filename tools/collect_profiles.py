@@ -30,7 +30,7 @@ def main():
         if lines:
             wl = os.path.basename(f)[len("bench_"):-len(".json")]
             open(os.path.join(prof, "%s_bench_line_%s.json" % (tag, wl)), "w").write(lines[-1] + "\n")
-    if "chr21_d256L4_d256" in traffic:   # bench.py keys its lookup by workload + width
+    if "chr21_d256L4_d256" in traffic:   # bench.py keys its lookup by workload (+ generator) + width
         traffic["chr21_d256"] = traffic.pop("chr21_d256L4_d256")
     note = traffic.pop("_note", None)
     out = dict(sorted(traffic.items()))
@@ -39,19 +39,26 @@ def main():
     json.dump(out, open(os.path.join(prof, "traffic.json"), "w"), indent=1)
     # the bench lines were printed before this traffic.json existed: their `roofline.traffic` is the stored value of the
     # previous profile run; point the copies at the values collected from THIS run's PMC passes
+    def lookup(key, kernel):
+        ent = out.get(key)
+        if not isinstance(ent, dict) or not kernel:
+            return None
+        base = kernel.split(":")[0].split("(")[0].strip()
+        for k, v in (ent.get("per_kernel") or {}).items():
+            if k.startswith("void " + base + "<") or k.startswith(base):
+                return v.get("bytes_per_launch")
+        return None
+
     for f in glob.glob(os.path.join(prof, "%s_bench_line_*.json" % tag)):
         d = json.loads(open(f).read())
-        r = d.get("roofline")
-        if not r:
-            continue
         wl = os.path.basename(f)[len(tag + "_bench_line_"):-len(".json")]
-        key = {"genome": "genome_d128", "genome_hic": "genome_hic_d128", "chr21": "chr21_d128", "chr21_hic": "chr21_hic_d128",
-               "chr1": "chr1_d128", "chr1_hic": "chr1_hic_d128", "chr21_d256L4": "chr21_d256"}.get(wl)
-        if key in out:
-            r["traffic"] = out[key]["bytes_per_launch"]
-            r["traffic_source"] = "stored profile value (profiles/traffic.json, tag %s: the PMC passes of the same run), not measured inside bench.py" % tag
-        else:
-            r["traffic"], r["traffic_source"] = None, None
+        key = "chr21_d256" if wl == "chr21_d256L4" else wl + "_d128"
+        src = "stored profile value (profiles/traffic.json, tag %s: the PMC passes of the same run; 2*FETCH_SIZE + WRITE_SIZE per launch, beyond-L2 bytes incl. Infinity-Cache hits), not measured inside bench.py" % tag
+        for r in [d.get("roofline")] + list(d.get("roofline_top3") or []):
+            if not r:
+                continue
+            t = lookup(key, r.get("kernel"))
+            r["traffic"], r["traffic_source"] = t, (src if t is not None else None)
         open(f, "w").write(json.dumps(d) + "\n")
     print("traffic keys:", [k for k in out if not k.startswith("_")])
 

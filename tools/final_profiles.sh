@@ -5,7 +5,11 @@ if [ -z "${SKIP_TESTS:-}" ]; then python -m pytest tests -m gpu -q > gpurun_out/
 python bench.py > gpurun_out/$T/bench_genome.json 2> gpurun_out/$T/bench_genome.err
 python bench.py --hic-like --no-cpu-baseline > gpurun_out/$T/bench_genome_hic.json 2>/dev/null
 for w in chr21 chr1 config1; do python bench.py --workload $w --no-cpu-baseline > gpurun_out/$T/bench_$w.json 2>/dev/null; python bench.py --workload $w --hic-like --no-cpu-baseline > gpurun_out/$T/bench_${w}_hic.json 2>/dev/null; done
+python bench.py --generator hub --no-cpu-baseline > gpurun_out/$T/bench_genome_hub.json 2>/dev/null
+for w in chr21 chr1; do python bench.py --workload $w --generator hub --no-cpu-baseline > gpurun_out/$T/bench_${w}_hub.json 2>/dev/null; done
 python bench.py --workload chr21 --d 256 --layers 4 --no-cpu-baseline > gpurun_out/$T/bench_chr21_d256L4.json 2>/dev/null
+python bench.py --d 256 --layers 4 --no-cpu-baseline > gpurun_out/$T/bench_genome_d256L4.json 2>/dev/null
+python bench.py --gpus 2 --backend gloo --share-gpu --no-cpu-baseline --no-extras > gpurun_out/$T/bench_genome_2ranks_one_gpu_gloo.json 2>/dev/null
 python bench.py --workload e2e > gpurun_out/$T/bench_e2e.json 2>/dev/null
 bash tools/profile_round.sh $T genome
 bash tools/profile_round.sh $T genome_hic --hic-like
@@ -14,6 +18,7 @@ bash tools/profile_round.sh $T chr21_hic --workload chr21 --hic-like
 bash tools/profile_round.sh $T chr1 --workload chr1
 bash tools/profile_round.sh $T chr1_hic --workload chr1 --hic-like
 bash tools/profile_round.sh $T chr21_d256L4 --workload chr21 --d 256 --layers 4
+bash tools/profile_round.sh $T genome_hub --generator hub
 for f in gpurun_out/$T/bench_*.json; do python - "$f" <<'PY'
 import json,sys
 try:
