@@ -581,7 +581,7 @@ def main():
                   "aggregations every step%s" %
                   (len(names), windows, min(s[2] for s in shapes), max(s[2] for s in shapes), args.d, args.layers,
                    synth.N_LABELS, args.dropout,
-                   "; chromosomes sharded over %d ranks (LPT), one flat-gradient all-reduce per step group (RCCL)" % world if world > 1 else ""))
+                   "; chromosomes sharded over %d ranks (LPT), one flat-gradient all-reduce per step group (%s)" % (world, "RCCL" if args.backend == "nccl" else args.backend) if world > 1 else ""))
         else:
             wl = ("%s-like synthetic Hi-C chromosome per rank: n=%d windows, %d contact pairs (nnz(A+I)=%d), d=%d, L=%d, "
                   "C=%d, dropout=%.2f, SGD lr .25 m .9 wd 1e-6; train step = f+r fwd, BCE, bwd incl. d/dx, optimizer step%s"

@@ -589,7 +589,9 @@ class GCNStage:
     def _alloc_flat_grad(self, total, dev):
         """the flat gradient arena: plain device memory, or (opt-in P2P all-reduce) symmetric memory every peer can read"""
         self._p2p = None
-        self.allreduce_kind = "rccl" if self.multi else "none"
+        # what carries the gradient all-reduce: "rccl" (torch backend nccl on ROCm), "gloo", ... or "p2p_one_shot" below
+        self.allreduce_kind = ({"nccl": "rccl"}.get(torch.distributed.get_backend(self.group), torch.distributed.get_backend(self.group))
+                               if self.multi else "none")
         if self.multi and self._p2p_opt and dev.type == "cuda" and torch.distributed.get_backend(self.group) == "nccl":
             try:   # collective: every rank takes this branch in the same call
                 import torch.distributed._symmetric_memory as symm
