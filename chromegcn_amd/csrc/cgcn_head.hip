@@ -111,56 +111,70 @@ __global__ __launch_bounds__(1024) void k_head_bn_finalize(int n, int S, int D, 
                                                            float* __restrict__ run_mean, float* __restrict__ run_var,
                                                            long long* __restrict__ nbt, float* __restrict__ save_mean,
                                                            float* __restrict__ save_invstd) {
+  // Two passes over the records, no division inside them: mean = sum_b n_b m_b / n, then
+  // M2 = sum_b [M2_b + n_b (m_b - mean)^2] (the exact identity Chan's pairwise formula telescopes to), everything in
+  // float64.  A thread keeps its first 16 records in registers between the passes (<= 1 024 records: every size the
+  // engine produces) and re-reads the rest.  Slices of one column: 4 per wave (lanes cl + 16 j) -> two DPP-free
+  // shuffles, then the 16 waves through LDS in wave order.  (Round 2's pairwise Chan merges cost ~32 dependent float64
+  // divisions per thread: 9-11 us per launch, now ~6.)
   constexpr int NSL = 1024 / COLS;          // slices
-  constexpr int G1 = (NSL == 64) ? 8 : 16;  // first merge step: NSL -> NSL / G1 (= G1 here), second: -> 1
-  static_assert(NSL == G1 * G1, "two equal merge steps");
-  __shared__ double sm[3][NSL + 1][COLS + 1];
-  const int cl = threadIdx.x % COLS, slice = threadIdx.x / COLS;
+  constexpr int SPW = 64 / COLS;            // slices inside one wave (lanes cl, cl + COLS, ...)
+  constexpr int NWV = 16;                   // waves
+  static_assert(COLS * SPW == 64 && NSL == SPW * NWV, "thread layout");
+  constexpr int KEEP = 16;
+  __shared__ double sm[2][NWV][COLS + 1];
+  __shared__ double stat[2][COLS + 1];      // mean, M2 of this workgroup's columns
+  const int cl = threadIdx.x % COLS, slice = threadIdx.x / COLS, wave = threadIdx.x >> 6;
   const int CPB = COLS / S;  // channels per workgroup (S is 1 or 2)
   const int s = cl / CPB, c = blockIdx.x * CPB + cl % CPB;
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += S;
   const int per = (nblk + NSL - 1) / NSL;
   const int b0 = slice * per, b1 = min(nblk, b0 + per);
-  double cnt = 0.0, mean = 0.0, m2 = 0.0;
+  auto rows_of = [&](int b) { return (double)max(0, min(n, (b + 1) * rows_per_blk) - b * rows_per_blk); };
+  auto wg_sum = [&](double v, int which) -> double {   // sum over the 64 slices of column cl; every thread gets it
+#pragma unroll
+    for (int o = COLS; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) < COLS) sm[which][wave][cl] = v;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) t += sm[which][w][cl];
+    return t;
+  };
+  float km[KEEP], k2[KEEP];
+  double s1 = 0.0;
   if (c < D) {
-    for (int b = b0; b < b1; b += 8) {
-      float pm[8], p2[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int bb = min(b + u, b1 - 1);
-        const float* p = part + (((size_t)bb * S + s) * D + c) * 2;
-        pm[u] = p[0];
-        p2[u] = p[1];
-      }
+    for (int u = 0; u < KEEP; ++u) {
+      const int bb = min(b0 + u, max(b1 - 1, 0));
+      const float* p = part + (((size_t)bb * S + s) * D + c) * 2;
+      km[u] = p[0];
+      k2[u] = p[1];
+    }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        if (b + u < b1) {
-          const double nb = (double)max(0, min(n, (b + u + 1) * rows_per_blk) - (b + u) * rows_per_blk);
-          chan_combine_d(cnt, mean, m2, nb, (double)pm[u], (double)p2[u]);
-        }
+    for (int u = 0; u < KEEP; ++u)
+      if (b0 + u < b1) s1 += rows_of(b0 + u) * (double)km[u];
+    for (int b = b0 + KEEP; b < b1; ++b) s1 += rows_of(b) * (double)part[(((size_t)b * S + s) * D + c) * 2];
+  }
+  const double mean = wg_sum(s1, 0) / (double)n;
+  double q = 0.0;
+  if (c < D) {
+#pragma unroll
+    for (int u = 0; u < KEEP; ++u)
+      if (b0 + u < b1) {
+        const double dm = (double)km[u] - mean;
+        q += (double)k2[u] + rows_of(b0 + u) * dm * dm;
       }
+    for (int b = b0 + KEEP; b < b1; ++b) {
+      const float* p = part + (((size_t)b * S + s) * D + c) * 2;
+      const double dm = (double)p[0] - mean;
+      q += (double)p[1] + rows_of(b) * dm * dm;
     }
   }
-  sm[0][slice][cl] = cnt;
-  sm[1][slice][cl] = mean;
-  sm[2][slice][cl] = m2;
-  __syncthreads();
-  if (slice < G1) {  // slices G1*slice .. G1*slice + G1-1
-    cnt = mean = m2 = 0.0;
-    for (int o = 0; o < G1; ++o) chan_combine_d(cnt, mean, m2, sm[0][slice * G1 + o][cl], sm[1][slice * G1 + o][cl], sm[2][slice * G1 + o][cl]);
-  }
-  __syncthreads();
-  if (slice < G1) {
-    sm[0][slice][cl] = cnt;
-    sm[1][slice][cl] = mean;
-    sm[2][slice][cl] = m2;
-  }
-  __syncthreads();
+  const double m2 = wg_sum(q, 1);
   if (slice == 0) {
-    cnt = mean = m2 = 0.0;
-    for (int o = 0; o < G1; ++o) chan_combine_d(cnt, mean, m2, sm[0][o][cl], sm[1][o][cl], sm[2][o][cl]);
-    sm[1][NSL][cl] = mean;
-    sm[2][NSL][cl] = m2;
+    stat[0][cl] = mean;
+    stat[1][cl] = m2;
     if (c < D) {
       save_mean[s * D + c] = (float)mean;
       save_invstd[s * D + c] = (float)(1.0 / sqrt(m2 / (double)n + (double)eps));
@@ -171,8 +185,8 @@ __global__ __launch_bounds__(1024) void k_head_bn_finalize(int n, int S, int D, 
   float rm = run_mean[c], rv = run_var[c];
   for (int st = 0; st < S; ++st) {
     // sequential update: the reference calls the model on the forward strand, then the reverse one
-    rm = (1.f - momentum) * rm + momentum * (float)sm[1][NSL][st * CPB + cl];
-    rv = (1.f - momentum) * rv + momentum * (float)(sm[2][NSL][st * CPB + cl] / (double)(n - 1));
+    rm = (1.f - momentum) * rm + momentum * (float)stat[0][st * CPB + cl];
+    rv = (1.f - momentum) * rv + momentum * (float)(stat[1][st * CPB + cl] / (double)(n - 1));
   }
   run_mean[c] = rm;
   run_var[c] = rv;
