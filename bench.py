@@ -65,6 +65,10 @@ def parse():
     ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses cuda:0")
     ap.add_argument("--p2p-allreduce", action="store_true",
                     help="N > 1: one-shot peer-to-peer gradient all-reduce over symmetric memory instead of RCCL's (SURVEY section 5)")
+    ap.add_argument("--gather", default="rank0", choices=["rank0", "all", "none"],
+                    help="N > 1: where an epoch's predictions are assembled -- rank0 (default; what nn.DataParallel does with "
+                         "the replicas' outputs, reference main.py:92-94: direct sends to rank 0), all (all-gather: every "
+                         "rank holds the whole split), none (each rank keeps its chromosomes' rows)")
     ap.add_argument("--no-group-graph", action="store_true",
                     help="N > 1: do not capture the collective + optimizer step into the step's HIP graph")
     ap.add_argument("--e2e-windows", type=int, default=4096, help="e2e: windows per chromosome pushed through the encoder")
@@ -424,7 +428,8 @@ def main():
     # skip the unobservable input gradient; measured separately below, never as `value`.)
     stage = GCNStage(model, opt, "hic", dev, hip_graphs=not args.no_hip_graph, input_grad=True,
                      group=dist.group.WORLD if world > 1 else None, cache_input_aggregation=False,
-                     group_graph=False if args.no_group_graph else None, p2p_allreduce=True if args.p2p_allreduce else None)
+                     group_graph=False if args.no_group_graph else None, p2p_allreduce=True if args.p2p_allreduce else None,
+                     prediction_gather=args.gather)
 
     if genome:
         names = genome_train_names()
@@ -599,7 +604,9 @@ def main():
                        "hip_graph": not args.no_hip_graph,
                        "parallelism": ("chromosomes sharded over %d rank(s)" % world) if genome else "chromosome-per-rank x%d" % world,
                        "allreduce": stage.allreduce_kind if world > 1 else None,
-                       "step_group_graph": bool(stage._group_graph_enabled()) if world > 1 else None},
+                       "step_group_graph": bool(stage._group_graph_enabled()) if world > 1 else None,
+                       "prediction_gather": (args.gather + (" (rows of every chromosome sent to rank 0 by its owner, asynchronously)" if args.gather == "rank0" else "")) if world > 1 and genome else None,
+                       "eager_collectives_on_own_communicator": (stage.aux_group is not stage.group) if world > 1 else None},
             "step_ms": {"median": float(np.median(per_ms)), "p10": float(np.percentile(per_ms, 10)),
                         "p90": float(np.percentile(per_ms, 90)), "n": len(per),
                         "note": "per-step host time on rank 0" + (" (each epoch ends with its own loss sync)" if genome else " (launch only: steps are asynchronous)")},

@@ -96,8 +96,16 @@ class GCNStage:
 
     def __init__(self, model, optimizer=None, adj_type: str = "hic", device="cuda", hip_graphs: bool = True,
                  input_grad: bool = False, group=None, fused_head: bool = True, cache_input_aggregation: bool = True,
-                 force_collectives: bool = False, group_graph: Optional[bool] = None, p2p_allreduce: Optional[bool] = None):
+                 force_collectives: bool = False, group_graph: Optional[bool] = None, p2p_allreduce: Optional[bool] = None,
+                 prediction_gather: str = "all", aux_group=None):
         self.model = model
+        # where a split's predictions are assembled in a multi-rank run: "all" = on every rank (every rank's run_split
+        # returns the whole split, like a single process), "rank0" = on rank 0 only, over direct point-to-point sends
+        # (what nn.DataParallel does with the replicas' outputs, main.py:92-94: gathered on device 0; the other ranks'
+        # run_split returns preds = None), "none" = nowhere (each rank keeps its chromosomes' rows in its arena)
+        if prediction_gather not in ("all", "rank0", "none"):
+            raise ValueError("prediction_gather must be 'all', 'rank0' or 'none'")
+        self.prediction_gather = prediction_gather
         # multi-rank step group as ONE HIP graph (fwd + bwd + gradient all-reduce + fused 1/k SGD step): needs a backend
         # whose collectives are stream-ordered device work (nccl = RCCL); None = on when possible, CGCN_GROUP_GRAPH=0 disables
         self._group_graph_opt = group_graph if group_graph is not None else os.environ.get("CGCN_GROUP_GRAPH", "1") != "0"
@@ -126,6 +134,16 @@ class GCNStage:
         if force_collectives and not (torch.distributed.is_available() and torch.distributed.is_initialized()):
             raise RuntimeError("force_collectives needs an initialised torch.distributed process group")
         self.multi = self.world > 1 or bool(force_collectives)
+        # Everything the split loop issues EAGERLY (asynchronous prediction gathers, the statistics / loss all-reduce)
+        # goes over a communicator of its own: the gradient all-reduce is replayed from inside captured HIP graphs, and
+        # one communicator must not carry a captured and an eager operation that may execute at the same time.
+        # aux_group: a second process group over the same ranks (bench.py creates it); None = created here when the
+        # stage spans the default group (new_group is collective over the default group: every rank builds its stage).
+        self.aux_group = aux_group if aux_group is not None else group
+        if (self.multi and aux_group is None and group in (None, getattr(torch.distributed.group, "WORLD", None))
+                and torch.distributed.is_available() and torch.distributed.is_initialized()
+                and os.environ.get("CGCN_AUX_GROUP", "1") != "0"):
+            self.aux_group = torch.distributed.new_group(backend=torch.distributed.get_backend(group))
         self.chroms: Dict[str, _Chrom] = {}
         self._pending: Dict[str, tuple] = {}   # chromosomes registered with defer=True: (feats, hic) on the host
         self._meta: Dict[str, tuple] = {}      # name -> (n, C, cost) of every registered chromosome, resident or not
@@ -544,6 +562,8 @@ class GCNStage:
             # the communicator's lazy initialisation must not happen under stream capture: one tiny eager collective
             # (every rank reaches its first train_group call in the same round)
             torch.distributed.all_reduce(torch.zeros(1, device=self.device), group=self.group)
+            if self.aux_group is not self.group:
+                torch.distributed.all_reduce(torch.zeros(1, device=self.device), group=self.aux_group)
             self._comm_warm = True
         if self._group_graph_enabled():
             try:
@@ -626,7 +646,7 @@ class GCNStage:
         if not parts:
             return extra
         flat = torch.cat(parts)
-        torch.distributed.all_reduce(flat, group=self.group)
+        torch.distributed.all_reduce(flat, group=self.aux_group)
         flat.div_(self.world)
         off = 0
         for b in bufs:
@@ -669,8 +689,13 @@ class GCNStage:
             preds = preds_dev.cpu()
         else:
             plan = plan_shards({nm: self._meta[nm][2] for nm in names}, self.world)
-            gp = self._gather_plan(names, plan, C)
-            nccl = torch.distributed.get_backend(self.group) == "nccl"
+            ag = self.aux_group
+            nccl = torch.distributed.get_backend(ag) == "nccl"
+            mode = self.prediction_gather
+            if mode == "rank0" and not nccl and self.device.type == "cuda":
+                mode = "all"   # gloo has no device-tensor send / recv (functional runs on a shared GPU): all-gather there
+            gp = self._gather_plan(names, plan, C, mode)
+            peer = (lambda r: r) if ag is None else (lambda r: torch.distributed.get_global_rank(ag, r))
             loss_sum = torch.zeros((), device=self.device)
             pending = []
             for r, group in enumerate(plan.rounds):
@@ -682,28 +707,54 @@ class GCNStage:
                     loss, p = self.eval_step(nm)
                 else:
                     loss = p = None
-                send, recv = gp["send"][r], gp["recv"][r]
                 if nm is not None:
-                    send[:p.shape[0]].copy_(p)            # this rank's slab of the round's gather
                     loss_sum += loss
-                # predictions of this round: ONE all-gather, issued asynchronously so that it travels (xGMI) while
-                # the next round computes; the split waits for all of them once, at the end
-                if nccl:
-                    pending.append(torch.distributed.all_gather_into_tensor(recv, send, group=self.group, async_op=True))
-                else:  # gloo (CPU tests, single-GPU functional runs): the list form is the one every backend implements
-                    pending.append(torch.distributed.all_gather(list(recv.view(self.world, -1, C).unbind(0)), send,
-                                                                group=self.group, async_op=True))
+                if mode == "all":
+                    send, recv = gp["send"][r], gp["recv"][r]
+                    if nm is not None:
+                        send[:p.shape[0]].copy_(p)            # this rank's slab of the round's gather
+                    # predictions of this round: ONE all-gather, issued asynchronously so that it travels (xGMI) while
+                    # the next round computes; the split waits for all of them once, at the end
+                    if nccl:
+                        pending.append(torch.distributed.all_gather_into_tensor(recv, send, group=ag, async_op=True))
+                    else:  # gloo (CPU tests, single-GPU functional runs): the list form is the one every backend implements
+                        pending.append(torch.distributed.all_gather(list(recv.view(self.world, -1, C).unbind(0)), send,
+                                                                    group=ag, async_op=True))
+                elif mode == "rank0":
+                    # every owner sends its chromosome's rows straight to rank 0 (one xGMI link each, unpadded); rank 0
+                    # posts the matching receives into its slice of the split buffer; asynchronous like the all-gather
+                    ops = []
+                    if self.rank == 0:
+                        for src, g in enumerate(group):
+                            if g is None:
+                                continue
+                            dst_rows = gp["rows"][g]
+                            if src == 0:
+                                dst_rows.copy_(p)
+                            else:
+                                ops.append(torch.distributed.P2POp(torch.distributed.irecv, dst_rows, peer(src), group=ag))
+                    elif nm is not None:
+                        ops.append(torch.distributed.P2POp(torch.distributed.isend, p, peer(0), group=ag))
+                    if ops:
+                        pending.extend(torch.distributed.batch_isend_irecv(ops))
             mine = sum(1 for nm in names if plan.owner[nm] == self.rank)
             S = 2   # strands per chromosome: forward + reverse complement (add_chromosome stacks both)
             if train:   # running statistics + the loss in one all-reduce; counters without communication
                 loss_sum = self.sync_running_stats(loss_sum, calls_total=S * len(names), calls_mine=S * mine)
             else:
-                torch.distributed.all_reduce(loss_sum, group=self.group)
+                torch.distributed.all_reduce(loss_sum, group=ag)
             for w in pending:
                 w.wait()
-            # one index_select puts the gathered rows into the reference's chromosome order (finetune.py:52)
-            preds_dev = gp["recv_all"].index_select(0, gp["index"]) if gp["total"] else gp["recv_all"][:0]
             total = float(loss_sum.item())
+            if mode == "all":
+                # one index_select puts the gathered rows into the reference's chromosome order (finetune.py:52)
+                preds_dev = gp["recv_all"].index_select(0, gp["index"]) if gp["total"] else gp["recv_all"][:0]
+            elif mode == "rank0":
+                preds_dev = gp["recv_all"] if self.rank == 0 else None   # received in the reference's order already
+            else:
+                preds_dev = None
+            if preds_dev is None:
+                return None, (self._split_targets_dev(names, C) if not to_cpu else None), total
             if not to_cpu:
                 return preds_dev, self._split_targets_dev(names, C), total
             preds = preds_dev.cpu()
@@ -724,16 +775,26 @@ class GCNStage:
         c = self.chroms.get(nm)
         return c.target if c is not None else self._pending[nm][0]["target"].to(torch.float32)
 
-    def _gather_plan(self, names, plan: ShardPlan, C: int):
+    def _gather_plan(self, names, plan: ShardPlan, C: int, mode: str = "all"):
         """Buffers and the row permutation of the prediction gathers, built once per (split, plan).  Round r of the
         plan gathers [world, max_r, C] rows (max_r = the round's largest chromosome; every rank sends one padded slab);
         the rounds' receive buffers are consecutive slices of ONE allocation, and `index` maps the reference's
         concatenation order (finetune.py:52, chromosome iteration order) onto its rows."""
-        key = (tuple(names), self.world, C)
+        key = (tuple(names), self.world, C, mode)
         gp = self._gather_plans.get(key)
         if gp is not None:
             return gp
         sizes = {nm: self._meta[nm][0] for nm in names}
+        if mode != "all":   # "rank0": one [sum n, C] buffer on rank 0 in the reference's order, a view per chromosome
+            gp = {"recv_all": None, "rows": {}, "total": sum(sizes.values())}
+            if mode == "rank0" and self.rank == 0:
+                gp["recv_all"] = torch.empty((gp["total"], C), device=self.device, dtype=torch.float32)
+                off = 0
+                for nm in names:
+                    gp["rows"][nm] = gp["recv_all"][off:off + sizes[nm]]
+                    off += sizes[nm]
+            self._gather_plans[key] = gp
+            return gp
         max_r = [max([sizes[g] for g in group if g is not None] + [0]) for group in plan.rounds]
         base_r, tot = [], 0
         for m in max_r:

@@ -80,7 +80,7 @@ def emulate(world, epochs):
     return {k: v.clone() for k, v in m.state_dict().items()}, tot, preds, ev
 
 
-def worker(rank, world, port, epochs, q):
+def worker(rank, world, port, epochs, q, gather="all"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
@@ -88,15 +88,27 @@ def worker(rank, world, port, epochs, q):
     feats, graphs = make_data()
     m = make_model()
     opt = O.make_sgd(m, 0.1)
-    stage = GCNStage(m, opt, "hic", "cpu", hip_graphs=False, group=dist.group.WORLD)
+    stage = GCNStage(m, opt, "hic", "cpu", hip_graphs=False, group=dist.group.WORLD, prediction_gather=gather)
+    assert stage.aux_group is not stage.group   # eager collectives travel on a communicator of their own
     stage.load(feats, graphs, defer=True)   # a rank materialises only the chromosomes the shard plan hands it
     tot = []
+    whole = gather == "all" or (gather == "rank0" and rank == 0)
     for _ in range(epochs):
         preds, targets, t = stage.run_split("train")
         tot.append(t)
-        assert preds.shape[0] == sum(SIZES.values()) and targets.shape == preds.shape
+        if whole:
+            assert preds.shape[0] == sum(SIZES.values()) and targets.shape == preds.shape
+        else:
+            assert preds is None
     preds, targets, ev = stage.run_split("valid")
-    q.put((rank, {k: v.numpy() for k, v in m.state_dict().items()}, tot, preds.numpy(), ev))
+    assert (preds is not None) == whole
+    if gather != "all":   # the same evaluation assembled on every rank: what rank 0 received point-to-point must equal it
+        stage.prediction_gather = "all"
+        preds_all, _, ev_all = stage.run_split("valid")
+        assert abs(ev_all - ev) < 1e-6
+        if whole:
+            assert torch.equal(preds_all, preds)
+    q.put((rank, {k: v.numpy() for k, v in m.state_dict().items()}, tot, preds.numpy() if whole else None, ev))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -120,12 +132,15 @@ def test_plan_shards_properties():
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_gloo_matches_single_process_emulation():
+@pytest.mark.parametrize("gather", ["all", "rank0", "none"])
+def test_two_rank_gloo_matches_single_process_emulation(gather):
+    """gather: where the split's predictions are assembled -- on every rank (all-gather per round), on rank 0 only (every
+    owner sends its rows straight to rank 0, like nn.DataParallel's output gather, main.py:92-94), or nowhere"""
     world, epochs = 2, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=worker, args=(r, world, port, epochs, q)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, epochs, q, gather)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=240) for _ in range(world)]
@@ -143,5 +158,6 @@ def test_two_rank_gloo_matches_single_process_emulation():
     # both ranks hold identical models (incl. the averaged BN buffers) and identical full predictions
     for k in results[0][1]:
         np.testing.assert_array_equal(results[0][1][k], results[1][1][k])
-    np.testing.assert_array_equal(results[0][3], results[1][3])
+    if gather == "all":
+        np.testing.assert_array_equal(results[0][3], results[1][3])
     assert abs(results[0][4] - results[1][4]) < 1e-6

@@ -35,8 +35,10 @@ def worker(port, q, group_graph=True):
     m = T.make_model(dev)
     opt = torch.optim.SGD(m.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-6)
     stage = GCNStage(m, opt, "hic", dev, hip_graphs=True, input_grad=True, group=dist.group.WORLD,
-                     cache_input_aggregation=False, force_collectives=True, group_graph=group_graph)
+                     cache_input_aggregation=False, force_collectives=True, group_graph=group_graph,
+                     prediction_gather="all" if group_graph else "rank0")
     assert stage.multi and stage.world == 1
+    assert stage.aux_group is not stage.group   # the eager gathers / statistics all-reduce run on a second RCCL communicator
     stage.load(feats, graphs, defer=True)      # registered only: uploaded when the shard plan hands them to this rank
     assert not stage.chroms and len(stage._meta) == len(feats)
     tot = []
