@@ -5,7 +5,7 @@ Splits the HIP-vs-float64 error of the last layer's bias-type sums into
                      inputs the kernel read (X, Z, gate, dXn) -- row math + summation inside k_bwd_rowlocal / reduce_slab
   (b) input error  : those float64-from-HIP-inputs sums  vs  the all-float64 oracle -- error the sums inherit from the
                      fp32 forward (activations, BatchNorm statistics, dL/dXn), amplified by the cancellation of the sum
-Usage (GPU box): python tools/bias_sum_probe.py [chr21|chr1]"""
+Usage (GPU box): python tests/probes/bias_sum_probe.py [chr21|chr1]"""
 import copy
 import os
 import sys
@@ -13,7 +13,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import chromegcn_amd as C  # noqa: E402
 from chromegcn_amd import graph as G, synth, torch_ops  # noqa: E402,F401
 from oracle import chromegcn_oracle as O  # noqa: E402  (checker)

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of the fused layer (forward + backward) against the oracle's numpy restatement: random
 sizes (1 .. 6000 nodes, ragged tiles), densities, adjacency types (implicit / explicit values), strands and widths.
-A one-off confidence tool for the GPU box (python tools/stress_parity.py [cases] [seed]); the fixed cases live in tests/."""
+A one-off confidence tool for the GPU box (python tests/probes/stress_parity.py [cases] [seed]); the fixed cases live in tests/."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

@@ -24,7 +24,7 @@ float64.  Bound: 1e-4 for EVERY tensor, the gate-bias gradients `W*.bias` includ
 sum of ~10^4-10^5 signed per-row terms that cancel to 0.17 % of their absolute sum -- and they amplify any error that is
 COHERENT over the rows by 600x: round 2's fp32 BatchNorm-backward column means (per-column constants in every row's
 dL/dXn) put dW2.bias at 2.2e-4; the float64 second stage of those sums (cgcn_common.hpp, head_stats_finalize) is what
-keeps it below the fp32 oracle's own error now (tools/bias_sum_probe.py separates the stages).  All measured figures
+keeps it below the fp32 oracle's own error now (tests/probes/bias_sum_probe.py separates the stages).  All measured figures
 (HIP and fp32 oracle, side by side) are printed."""
 import numpy as np
 import pytest
@@ -141,7 +141,7 @@ def _train_steps_case(name, n, pairs, hic_like, adj_type, seed, d, layers, label
     # itself is 1e-3 ... 1e-2 off the float64 truth at chr1 size (hubs of 10^4 neighbours: after the first optimizer
     # step the two fp32 paths hold the same fp32-rounded parameters and share that deviation digit for digit), and the
     # gate-bias sums cancel to 6e-4 of their absolute sum there, so ONE fp32 rounding (6e-8) of a per-column constant is
-    # already worth 1e-4 (tools/bias_sum_probe.py chr21 hub: every kernel stage is at 2e-7 ... 4e-6 on that graph).
+    # already worth 1e-4 (tests/probes/bias_sum_probe.py chr21 hub: every kernel stage is at 2e-7 ... 4e-6 on that graph).
     # Where the fp32 oracle is more than 2e-5 off the truth, the bound is therefore 10x the oracle's own error -- on the
     # hub cases only; every other case keeps 1e-4 for every tensor.
     hub = "hub" in name

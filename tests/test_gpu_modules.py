@@ -101,7 +101,7 @@ def test_chromegcn_forward_without_adjacency_matches_oracle(layers):
 
 
 def test_randomised_layer_sweep_matches_oracle():
-    """seeded, short version of tools/stress_parity.py: random sizes (ragged tiles, 1 .. 3000 nodes), densities,
+    """seeded, short version of tests/probes/stress_parity.py: random sizes (ragged tiles, 1 .. 3000 nodes), densities,
     adjacency kinds, strands, widths, hub rows; forward + every gradient of the fused layer vs the oracle's numpy math"""
     rng = np.random.RandomState(1234)
     for case in range(24):

@@ -23,7 +23,6 @@ def main():
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--epochs", type=int, default=3)
     ap.add_argument("--hic-like", action="store_true")
-    ap.add_argument("--sklearn", action="store_true", help="also time the oracle's sklearn metrics on the host")
     args = ap.parse_args()
     dev = torch.device("cuda")
     torch.manual_seed(0)
@@ -61,12 +60,6 @@ def main():
            "train_epoch_ms": tr * 1e3, "train_windows_per_s": n_train / tr,
            "eval_ms": ev * 1e3, "eval_windows_per_s": n_eval / ev,
            "metrics_3_splits_ms": me * 1e3, "train_loss": loss, "valid_meanAUC": mv["meanAUC"]}
-    if args.sklearn:
-        from oracle import chromegcn_oracle as O
-        t0 = time.perf_counter()
-        O.multilabel_metrics_np(tv.cpu().numpy().astype("float64"), pv.cpu().numpy())
-        out["sklearn_valid_split_s"] = time.perf_counter() - t0
-        out["valid_windows"] = int(tv.shape[0])
     print(json.dumps(out))
 
 
