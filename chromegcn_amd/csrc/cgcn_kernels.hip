@@ -851,6 +851,9 @@ __global__ __launch_bounds__(512) void k_dh_dense(int M, float* __restrict__ B, 
 // LDS row stride of the tiles = D + RL_LD_PAD floats.  Ht / Ut are read column-wise (dW = Ht^T Ut: lanes (q, r)
 // read row 4kk+q, column c0+r: conflict-free in a half-wave when the stride is 16 mod 32) and Ut also row-wise with
 // ds_read_b128 (dHs = Ut W^T); measured: 4 / 12 / 16 / 20 make no difference to the step.
+#ifndef RL_DH_EPILOGUE_FAST
+#define RL_DH_EPILOGUE_FAST 1
+#endif
 #ifndef RL_LD_PAD
 #define RL_LD_PAD 16
 #endif
@@ -894,7 +897,7 @@ __global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, i
   static_assert(TR % NW == 0 && TR % 16 == 0, "tile rows");
   __shared__ __attribute__((aligned(16))) float Ht[NBUF][TR * LD];
   __shared__ __attribute__((aligned(16))) float Ut[NBUF][TR * LD];
-  __shared__ float Sc[NBUF][TR];      // row_scale of the tile's rows (0 past the end)
+  __shared__ __attribute__((aligned(16))) float Sc[NBUF][TR];      // row_scale of the tile's rows (0 past the end)
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1062,6 +1065,27 @@ __global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, i
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) hacc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb][u], b[u], hacc[mb], 0, 0, 0);
     }
+#if RL_DH_EPILOGUE_FAST
+    // the four row scales of a row block in one 16-byte LDS read, and no per-element bound test on the tiles that lie
+    // inside the table (all but the last): eight stores back to back instead of eight read-wait-branch-store rounds,
+    // during which neither matrix wave of the SIMD issued an MFMA
+    f32x4 sc4[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) sc4[mb] = *(const f32x4*)&Sc[buf][mb * 16 + q * 4];
+    float* __restrict__ dst = dHs + (size_t)(tile * TR + q * 4) * D + own * 16 + r;
+    if (tile * TR + TR <= M) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[(size_t)(mb * 16 + e) * D] = hacc[mb][e] * sc4[mb][e];
+    } else {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (tile * TR + mb * 16 + q * 4 + e < M) dst[(size_t)(mb * 16 + e) * D] = hacc[mb][e] * sc4[mb][e];
+    }
+#else
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -1071,6 +1095,7 @@ __global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, i
         const float sc = Sc[buf][trow];
         if (m < M) dHs[(size_t)m * D + own * 16 + r] = hacc[mb][e] * sc;
       }
+#endif
 #endif
   };
 
