@@ -63,6 +63,10 @@ def parse():
     ap.add_argument("--backend", default=os.environ.get("CGCN_DIST_BACKEND", "nccl"),
                     help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU functional tests)")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses cuda:0")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="testing only: with ONE rank, still take the N > 1 code path -- process group (backend nccl = RCCL), shard "
+                         "plan, the step group captured with its all-reduce, prediction gather -- the only way to drive that "
+                         "path through RCCL on a one-GPU box")
     ap.add_argument("--p2p-allreduce", action="store_true",
                     help="N > 1: one-shot peer-to-peer gradient all-reduce over symmetric memory instead of RCCL's (SURVEY section 5)")
     ap.add_argument("--gather", default="rank0", choices=["rank0", "all", "none"],
@@ -115,6 +119,13 @@ def self_launch(args):
         sys.stderr.write("bench.py: the ranks exited 0 without printing a result line\n")
         rc = 1
     return rc
+
+
+def _one_rank_allreduce(dev):
+    """--force-collectives: the one-rank group's all-reduce of ones (= 1 when the backend is up)"""
+    t = torch.ones(1, device=dev, dtype=torch.float32)
+    dist.all_reduce(t)
+    return t.item()
 
 
 def ranks_seen(world, dev):
@@ -394,20 +405,26 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_collectives   # the N > 1 code path (one rank: --force-collectives, testing only)
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:   # one forced rank outside a launcher
+            import socket
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
-    seen = ranks_seen(world, dev)
+    seen = int(_one_rank_allreduce(dev)) if (multi and world == 1) else ranks_seen(world, dev)
     if args.workload == "e2e":
         from chromegcn_amd import e2e
         out = e2e.bench(args, dev, world, rank)
         if rank == 0:
             print(json.dumps(out))
             sys.stdout.flush()
-        if world > 1:
+        if multi:
             dist.barrier()
             dist.destroy_process_group()
         return out
@@ -427,16 +444,16 @@ def main():
     # reference.  (The engine's defaults cache A X of the first layer -- loop invariant, the features are fixed -- and
     # skip the unobservable input gradient; measured separately below, never as `value`.)
     stage = GCNStage(model, opt, "hic", dev, hip_graphs=not args.no_hip_graph, input_grad=True,
-                     group=dist.group.WORLD if world > 1 else None, cache_input_aggregation=False,
+                     group=dist.group.WORLD if multi else None, cache_input_aggregation=False,
                      group_graph=False if args.no_group_graph else None, p2p_allreduce=True if args.p2p_allreduce else None,
-                     prediction_gather=args.gather)
+                     prediction_gather=args.gather, force_collectives=bool(args.force_collectives))
 
     if genome:
         names = genome_train_names()
         shapes = []
         for nm in names:  # N > 1: registered only -- a rank normalises and uploads the chromosomes the shard plan gives it
             feats, hic = synth.synthetic_chromosome(nm, d=args.d, hic_like=args.hic_like)
-            stage.add_chromosome(nm, feats, hic, defer=world > 1)
+            stage.add_chromosome(nm, feats, hic, defer=multi)
             shapes.append((nm, feats["forward"].shape[0], int(hic.nnz) + feats["forward"].shape[0]))
         windows = sum(s[1] for s in shapes)
 
@@ -454,12 +471,12 @@ def main():
         windows = n * world
 
         def step():
-            if world > 1:
+            if multi:
                 return stage.train_group(name, world)
             return stage.train_step(name)
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -475,7 +492,7 @@ def main():
             per.append(time.perf_counter() - s0)
         fence()
         el = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             t = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
@@ -586,27 +603,27 @@ def main():
                   "aggregations every step%s" %
                   (len(names), windows, min(s[2] for s in shapes), max(s[2] for s in shapes), args.d, args.layers,
                    synth.N_LABELS, args.dropout,
-                   "; chromosomes sharded over %d ranks (LPT), one flat-gradient all-reduce per step group (%s)" % (world, "RCCL" if args.backend == "nccl" else args.backend) if world > 1 else ""))
+                   "; chromosomes sharded over %d ranks (LPT), one flat-gradient all-reduce per step group (%s)" % (world, "RCCL" if args.backend == "nccl" else args.backend) if multi else ""))
         else:
             wl = ("%s-like synthetic Hi-C chromosome per rank: n=%d windows, %d contact pairs (nnz(A+I)=%d), d=%d, L=%d, "
                   "C=%d, dropout=%.2f, SGD lr .25 m .9 wd 1e-6; train step = f+r fwd, BCE, bwd incl. d/dx, optimizer step%s"
                   % (args.workload, shapes[0][1], single_shape(args.workload)[2], shapes[0][2], args.d, args.layers,
-                     synth.N_LABELS, args.dropout, "; grad all-reduce over RCCL" if world > 1 else ""))
+                     synth.N_LABELS, args.dropout, "; grad all-reduce over RCCL" if multi else ""))
         out = {
             "metric": "GCN windows/sec (2-layer, d_model=128) on GM12878 Hi-C graph" if genome else
                       "GCN windows/sec (2-layer, d_model=128) train step, one chromosome",
             "value": windows * steps / elapsed, "unit": "windows/s",
-            "n_gpus": world, "ranks_seen_by_backend": seen, "backend": args.backend if world > 1 else None,
+            "n_gpus": world, "ranks_seen_by_backend": seen, "backend": args.backend if multi else None,
             "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if genome else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": wl, "generator": args.generator,
                        "hip_graph": not args.no_hip_graph,
                        "parallelism": ("chromosomes sharded over %d rank(s)" % world) if genome else "chromosome-per-rank x%d" % world,
-                       "allreduce": stage.allreduce_kind if world > 1 else None,
-                       "step_group_graph": bool(stage._group_graph_enabled()) if world > 1 else None,
-                       "prediction_gather": (args.gather + (" (rows of every chromosome sent to rank 0 by its owner, asynchronously)" if args.gather == "rank0" else "")) if world > 1 and genome else None,
-                       "eager_collectives_on_own_communicator": (stage.aux_group is not stage.group) if world > 1 else None},
+                       "allreduce": stage.allreduce_kind if multi else None,
+                       "step_group_graph": bool(stage._group_graph_enabled()) if multi else None,
+                       "prediction_gather": (args.gather + (" (rows of every chromosome sent to rank 0 by its owner, asynchronously)" if args.gather == "rank0" else "")) if multi and genome else None,
+                       "eager_collectives_on_own_communicator": (stage.aux_group is not stage.group) if multi else None},
             "step_ms": {"median": float(np.median(per_ms)), "p10": float(np.percentile(per_ms, 10)),
                         "p90": float(np.percentile(per_ms, 90)), "n": len(per),
                         "note": "per-step host time on rank 0" + (" (each epoch ends with its own loss sync)" if genome else " (launch only: steps are asynchronous)")},
@@ -616,7 +633,7 @@ def main():
         out.update(extras)
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     return out

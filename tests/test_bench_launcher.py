@@ -56,3 +56,26 @@ def test_self_launch_two_ranks_share_one_gpu_real_step():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["ranks_seen_by_backend"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gather", ["rank0", "all"])
+def test_n_gt_1_code_path_over_rccl_with_one_forced_rank(gather):
+    """bench.py's OWN multi-rank branch (process group with backend nccl = RCCL, deferred uploads, shard plan, the step
+    group captured as one HIP graph with its all-reduce, prediction gather on the second communicator, max-over-ranks
+    timing) on the one GPU a test box has: --force-collectives takes that branch with a one-rank group.  The loss after
+    the same number of epochs must be the plain single-process run's up to the order of the optimizer steps (the shard
+    plan walks the chromosomes largest first, the single process in the reference's order; a one-rank all-reduce is the
+    identity)."""
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-roofline"]
+    rc, lines, err = _run(["--force-collectives", "--gather", gather] + common, timeout=900)
+    assert rc == 0, err[-3000:]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert d["n_gpus"] == 1 and d["ranks_seen_by_backend"] == 1 and d["backend"] == "nccl"
+    assert c["allreduce"] == "rccl" and c["step_group_graph"] is True and c["eager_collectives_on_own_communicator"] is True
+    assert c["prediction_gather"].startswith(gather)
+    rc1, lines1, err1 = _run(common, timeout=900)
+    assert rc1 == 0, err1[-3000:]
+    assert abs(json.loads(lines1[0])["final_loss"] - d["final_loss"]) < 2e-3 * abs(d["final_loss"])
