@@ -545,6 +545,18 @@ class GCNStage:
             return loss, probs
         return self._eval(c)
 
+    def _warm_comms(self):
+        """One tiny eager all-reduce per communicator before anything else uses it: the lazy initialisation of a
+        communicator must not happen under stream capture, and the first operation on a group must be one EVERY rank takes
+        part in (a round's point-to-point sends involve only the ranks that own a chromosome in it).  Every rank reaches
+        its first train_group / multi-rank run_split call at the same point of the program."""
+        if not self.multi or self._comm_warm:
+            return
+        torch.distributed.all_reduce(torch.zeros(1, device=self.device), group=self.group)
+        if self.aux_group is not self.group:
+            torch.distributed.all_reduce(torch.zeros(1, device=self.device), group=self.aux_group)
+        self._comm_warm = True
+
     def train_group(self, name: Optional[str], group_size: int):
         """Multi-rank step group: every rank runs fwd+bwd on its own chromosome (or none), gradients are
         summed across ranks in ONE all-reduce of the flat buffer and divided by the number of chromosomes
@@ -558,13 +570,7 @@ class GCNStage:
         self._ensure_arena()
         c = self._resident(name) if name is not None else None
         scale = 1.0 / group_size if group_size > 1 else 1.0
-        if self.multi and not self._comm_warm:
-            # the communicator's lazy initialisation must not happen under stream capture: one tiny eager collective
-            # (every rank reaches its first train_group call in the same round)
-            torch.distributed.all_reduce(torch.zeros(1, device=self.device), group=self.group)
-            if self.aux_group is not self.group:
-                torch.distributed.all_reduce(torch.zeros(1, device=self.device), group=self.aux_group)
-            self._comm_warm = True
+        self._warm_comms()
         if self._group_graph_enabled():
             try:
                 return self._replay(c, "group", group_size)
@@ -688,6 +694,7 @@ class GCNStage:
                 return preds_dev, self._split_targets_dev(names, C), total
             preds = preds_dev.cpu()
         else:
+            self._warm_comms()
             plan = plan_shards({nm: self._meta[nm][2] for nm in names}, self.world)
             ag = self.aux_group
             nccl = torch.distributed.get_backend(ag) == "nccl"
