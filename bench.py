@@ -413,10 +413,14 @@ def main():
             with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
                 sk.bind(("127.0.0.1", 0))
                 os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        # a collective that does not complete within 4 minutes aborts the job with an error instead of hanging it (every
+        # collective of this benchmark moves at most a few tens of MB)
+        import datetime
+        tmo = datetime.timedelta(seconds=int(os.environ.get("CGCN_DIST_TIMEOUT_S", "240")))
         if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+            dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=tmo)
     seen = int(_one_rank_allreduce(dev)) if (multi and world == 1) else ranks_seen(world, dev)
     if args.workload == "e2e":
         from chromegcn_amd import e2e
