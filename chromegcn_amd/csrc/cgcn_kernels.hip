@@ -1749,21 +1749,30 @@ __device__ __forceinline__ f32x4 sliced_row_sum(const IT* __restrict__ col, cons
 #define SLICED_SUPER 768
 #endif
 struct SlicedTile {
-  int t0, t1;                 // lane l: neighbour range of row 64*tile + l (empty past n)
+  int t0, t1;                 // lane l: neighbour range of the tile's l-th row (empty past n)
   unsigned long long super;   // wave-uniform (and workgroup-uniform): rows of the tile with more than SLICED_SUPER neighbours
-  int k0, k1;                 // this lane's own row (row 8*wave + lane/8 of the tile)
+  int i;                      // this lane's own row: the (8*wave + lane/8)-th of the tile (n if past the end)
+  int k0, k1;                 // its neighbour range
 };
-__device__ __forceinline__ SlicedTile sliced_tile(const int* __restrict__ rowptr, int n, int tile, int wave, int lane) {
+// order (may be null): the rows in the order the tiles take them (cgcn_graph_aux::row_order): position p -> tile p / 64,
+// wave (p % 64) / 8.  The engine sorts the rows of every 64-row tile by length, so that the 8 rows a wave walks side by
+// side are about equally long (a wave steps until its longest row is done) while a tile keeps its rows.
+__device__ __forceinline__ SlicedTile sliced_tile(const int* __restrict__ rowptr, const int* __restrict__ order, int n,
+                                                  int tile, int wave, int lane) {
   SlicedTile t;
   const int r = tile * 64 + lane;
+  int row = n;
   t.t0 = t.t1 = 0;
   if (r < n) {
-    t.t0 = rowptr[r];
-    t.t1 = rowptr[r + 1];
+    row = order ? order[r] : r;
+    t.t0 = rowptr[row];
+    t.t1 = rowptr[row + 1];
   }
   t.super = __ballot(t.t1 - t.t0 > SLICED_SUPER);
-  t.k0 = __shfl(t.t0, wave * 8 + (lane >> 3), WAVE);
-  t.k1 = __shfl(t.t1, wave * 8 + (lane >> 3), WAVE);
+  const int mine = wave * 8 + (lane >> 3);
+  t.i = __shfl(row, mine, WAVE);
+  t.k0 = __shfl(t.t0, mine, WAVE);
+  t.k1 = __shfl(t.t1, mine, WAVE);
   return t;
 }
 // the tile's sums when it holds super rows (t.super != 0: every wave of the workgroup takes this branch)
@@ -1825,14 +1834,15 @@ __device__ __forceinline__ void sliced_block(int b, int tiles, int& slice, int& 
 template <int S, int D, bool HAS_VAL, typename IT = int>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HAS_VAL ? 6 : 8))) void k_aggregate_sliced(int n, const int* __restrict__ rowptr, const IT* __restrict__ col,
                                                           const float* __restrict__ val, const float* __restrict__ rs,
-                                                          const float* __restrict__ X, float* __restrict__ H) {
+                                                          const float* __restrict__ X, float* __restrict__ H,
+                                                          const int* __restrict__ order) {
   constexpr int NSL = S * D / 32, QPR = D / 32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int slice, tile;
   sliced_block<NSL>(blockIdx.x, (n + 63) / 64, slice, tile);
-  const int i = tile * 64 + wave * 8 + (lane >> 3);
   const size_t lane_el = (size_t)(slice / QPR) * n * D + (slice % QPR) * 32 + (lane & 7) * 4;
-  const SlicedTile t = sliced_tile(rowptr, n, tile, wave, lane);
+  const SlicedTile t = sliced_tile(rowptr, order, n, tile, wave, lane);
+  const int i = t.i;
   const float sc = (i < n && rs) ? rs[i] : 1.f;
   const unsigned lane_off = (unsigned)(lane_el * 4), rowsh = D == 128 ? 9u : 10u;
   const f32x4 acc = !t.super ? sliced_row_sum<HAS_VAL, IT>(col, val, t.k0, t.k1, (const char*)X, lane_off, rowsh, lane)
@@ -1854,7 +1864,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HAS_VAL ? 6
                                                     uint32_t stream_id, int gather_blocks, int P,
                                                     const float* __restrict__ part, float* __restrict__ dW,
                                                     float* __restrict__ db, float* __restrict__ dwg,
-                                                    float* __restrict__ dcg, int accumulate, SgdFuse sg, int reduce_slabs) {
+                                                    float* __restrict__ dcg, int accumulate, SgdFuse sg, int reduce_slabs,
+                                                    const int* __restrict__ order) {
   // Horizontal fusion: the workgroups past the gather tiles do the (independent) second-stage sum of the
   // row-local kernel's partials, so that reduction costs no launch of its own and overlaps the gather's tail.
   if ((int)blockIdx.x >= gather_blocks) {
@@ -1873,9 +1884,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HAS_VAL ? 6
   int slice, tile;
   sliced_block<NSL>(blockIdx.x, (n + 63) / 64, slice, tile);
   const int s = slice / QPR;
-  const int i = tile * 64 + wave * 8 + (lane >> 3);
   const size_t lane_el = (size_t)s * n * D + (slice % QPR) * 32 + (lane & 7) * 4;
-  const SlicedTile t = sliced_tile(rowptr, n, tile, wave, lane);
+  const SlicedTile t = sliced_tile(rowptr, order, n, tile, wave, lane);
+  const int i = t.i;
   const unsigned lane_off = (unsigned)(lane_el * 4), rowsh = D == 128 ? 9u : 10u;
   f32x4 res = (f32x4){0.f, 0.f, 0.f, 0.f}, acc;
   if (!t.super) {
@@ -2040,9 +2051,10 @@ static int dropout_args(float p, const unsigned long long* rng_state, float* kee
 
 // H = diag(rs) Ahat X, feature-sliced: int32 column indices, or the 16-bit copy when given (implicit values only)
 static void launch_aggregate_sliced(hipStream_t st, int gblocks, int n, int S, int d, const int32_t* rowptr, const int32_t* col,
-                                    const uint16_t* col16, const float* val, const float* rs, const float* X, float* H) {
+                                    const uint16_t* col16, const float* val, const float* rs, const float* X, float* H,
+                                    const int32_t* order) {
   if (col16) {
-#define CALL16(S_, D_) hipLaunchKernelGGL((k_aggregate_sliced<S_, D_, false, uint16_t>), dim3(gblocks), dim3(512), 0, st, n, rowptr, col16, val, rs, X, H)
+#define CALL16(S_, D_) hipLaunchKernelGGL((k_aggregate_sliced<S_, D_, false, uint16_t>), dim3(gblocks), dim3(512), 0, st, n, rowptr, col16, val, rs, X, H, order)
     if (S == 1 && d == 128) CALL16(1, 128);
     else if (S == 2 && d == 128) CALL16(2, 128);
     else if (S == 1 && d == 256) CALL16(1, 256);
@@ -2050,7 +2062,7 @@ static void launch_aggregate_sliced(hipStream_t st, int gblocks, int n, int S, i
 #undef CALL16
     return;
   }
-#define CALL(S_, D_, V_) hipLaunchKernelGGL((k_aggregate_sliced<S_, D_, V_, int>), dim3(gblocks), dim3(512), 0, st, n, rowptr, col, val, rs, X, H)
+#define CALL(S_, D_, V_) hipLaunchKernelGGL((k_aggregate_sliced<S_, D_, V_, int>), dim3(gblocks), dim3(512), 0, st, n, rowptr, col, val, rs, X, H, order)
   DISPATCH_SDV(S, d, val != nullptr, CALL);
 #undef CALL
 }
@@ -2096,6 +2108,7 @@ static inline const uint16_t* use_col16(const cgcn_graph_aux* aux, const float* 
 #define FWD_HUB_ROW 2048
 #endif
 static inline bool hub_graph(const cgcn_graph_aux* aux) { return aux && aux->max_row_len > FWD_HUB_ROW; }
+static inline const int32_t* row_order(const cgcn_graph_aux* aux) { return aux ? aux->row_order : nullptr; }
 
 int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d, const int32_t* rowptr, const int32_t* col,
               const float* val, const float* row_scale, const float* X, float* Y, const cgcn_graph_aux* aux) {
@@ -2117,7 +2130,7 @@ int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d, const 
   if (n_rows == n_cols && ((double)n_rows * S * d * 4.0 >= (double)g_fwd_split_bytes.load() || hub_graph(aux))) {
     // square operator on a table too large for the L2s: the feature-sliced aggregation (see k_aggregate_sliced)
     const int gblocks = (S * d / 32) * ((n_rows + 63) / 64);
-    launch_aggregate_sliced(st, gblocks, n_rows, S, d, rowptr, col, use_col16(aux, val, n_cols), val, row_scale, X, Y);
+    launch_aggregate_sliced(st, gblocks, n_rows, S, d, rowptr, col, use_col16(aux, val, n_cols), val, row_scale, X, Y, row_order(aux));
     return launch_status();
   }
   const int blocks = (n_rows + 3) / 4 < 4096 ? (n_rows + 3) / 4 : 4096;
@@ -2197,7 +2210,7 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   if (colstats && !split && !H_in && dense_stat_chunk(n, S, d) != 1) return CGCN_ERR_BAD_ARG;
   if (split) {
     const int gblocks = (S * d / 32) * ((n + 63) / 64);
-    launch_aggregate_sliced(st, gblocks, n, S, d, rowptr, col, use_col16(aux, val, n), val, row_scale, X, H);
+    launch_aggregate_sliced(st, gblocks, n, S, d, rowptr, col, use_col16(aux, val, n), val, row_scale, X, H, row_order(aux));
     if ((rc = launch_status())) return rc;
     H_in = H;
   }
@@ -2371,7 +2384,7 @@ static int layer_bwd_impl(cgcn_stream_t stream, int n, int S, int d, const int32
 #define CALL16(S_, D_)                                                                                               \
   hipLaunchKernelGGL((k_bwd_sliced<S_, D_, false, uint16_t>), dim3(blocks + (fuse_reduce ? slabs : 0) + sgd_blocks), dim3(512), 0, \
                      st, n, rowptr_t, col16_t, val_t, dHs, dXn, gate, dX, ks, th, rng_state, in_stream_id, blocks, P, \
-                     part, dW, db, dwg, dcg, accumulate, sg, fuse_reduce ? slabs : 0)
+                     part, dW, db, dwg, dcg, accumulate, sg, fuse_reduce ? slabs : 0, row_order(aux_t))
     if (S == 1 && d == 128) CALL16(1, 128);
     else if (S == 2 && d == 128) CALL16(2, 128);
     else if (S == 1 && d == 256) CALL16(1, 256);
@@ -2381,7 +2394,7 @@ static int layer_bwd_impl(cgcn_stream_t stream, int n, int S, int d, const int32
 #define CALL(S_, D_, V_)                                                                                             \
   hipLaunchKernelGGL((k_bwd_sliced<S_, D_, V_, int>), dim3(blocks + (fuse_reduce ? slabs : 0) + sgd_blocks), dim3(512), 0, \
                      st, n, rowptr_t, col_t, val_t, dHs, dXn, gate, dX, ks, th, rng_state, in_stream_id, blocks, P,  \
-                     part, dW, db, dwg, dcg, accumulate, sg, fuse_reduce ? slabs : 0)
+                     part, dW, db, dwg, dcg, accumulate, sg, fuse_reduce ? slabs : 0, row_order(aux_t))
     DISPATCH_SDV(S, d, val_t != nullptr, CALL);
 #undef CALL
   }

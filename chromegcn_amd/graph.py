@@ -8,6 +8,7 @@ chromosome (the reference rebuilds it every chromosome every epoch, finetune.py:
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass, field
 from typing import Dict, Optional
 
@@ -123,7 +124,26 @@ def host_csr_from_matrix(a: sp.spmatrix) -> HostCSR:
 # use may sit inside HIP-graph capture), found again by the address of the int32 array -- the registered operators
 # carry tensors, not graph objects.
 class GraphAux(ctypes.Structure):
-    _fields_ = [("col16", ctypes.c_void_p), ("max_row_len", ctypes.c_int32)]
+    _fields_ = [("col16", ctypes.c_void_p), ("row_order", ctypes.c_void_p), ("max_row_len", ctypes.c_int32)]
+
+
+def tile_sorted_rows(deg: torch.Tensor) -> torch.Tensor:
+    """cgcn_graph_aux::row_order of the engine: the rows of every 64-row tile of the feature-sliced kernels, longest
+    first (stable), tiles in place.  A wave walks 8 consecutive positions side by side until its longest row is done."""
+    n = int(deg.numel())
+    T = (n + 63) // 64
+    pad = torch.full((T * 64,), -1, dtype=torch.int64, device=deg.device)
+    pad[:n] = deg.to(torch.int64)
+    idx = torch.argsort(pad.view(T, 64), dim=1, descending=True, stable=True)
+    order = (idx + 64 * torch.arange(T, device=deg.device).view(T, 1)).reshape(-1)[:n]   # padding sorts last: dropped
+    return order.to(torch.int32).contiguous()
+
+
+def _wants_row_order(longest: int, n_rows: int, nnz: int) -> bool:
+    env = os.environ.get("CGCN_ROW_ORDER", "")
+    if env in ("0", "1"):
+        return env == "1"
+    return n_rows >= 128
 
 
 _AUX: Dict[int, tuple] = {}
@@ -136,15 +156,19 @@ def _register_aux(rowptr: torch.Tensor, col: torch.Tensor, n_cols: int):
     for k in [k for k, e in _AUX.items() if e[0]() is None]:
         del _AUX[k]
     c16 = col.to(torch.int16) if n_cols <= 65536 else None   # two's-complement truncation = the uint16 bits
-    longest = int((rowptr[1:] - rowptr[:-1]).max().item()) if rowptr.numel() > 1 else 0
-    _AUX[col.data_ptr()] = (weakref.ref(col), c16, GraphAux(None if c16 is None else c16.data_ptr(), longest))
+    n_rows = rowptr.numel() - 1
+    deg = rowptr[1:] - rowptr[:-1]
+    longest = int(deg.max().item()) if n_rows > 0 else 0
+    order = tile_sorted_rows(deg) if _wants_row_order(longest, n_rows, int(col.numel())) else None
+    _AUX[col.data_ptr()] = (weakref.ref(col), (c16, order), GraphAux(None if c16 is None else c16.data_ptr(),
+                                                                      None if order is None else order.data_ptr(), longest))
 
 
 def _aux_entry(col: Optional[torch.Tensor]):
     if col is None:
         return None
     ent = _AUX.get(col.data_ptr())
-    if ent is None or ent[0]() is None or (ent[1] is not None and ent[1].numel() != col.numel()):
+    if ent is None or ent[0]() is None or (ent[1][0] is not None and ent[1][0].numel() != col.numel()):
         return None
     return ent
 
@@ -159,7 +183,13 @@ def aux_ptr(col: Optional[torch.Tensor]):
 def col16_ptr(col: Optional[torch.Tensor]):
     """device pointer of the registered uint16 copy of `col` (None if there is none)"""
     ent = _aux_entry(col)
-    return None if ent is None or ent[1] is None else ent[1].data_ptr()
+    return None if ent is None or ent[1][0] is None else ent[1][0].data_ptr()
+
+
+def row_order(col: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """the registered row permutation of the graph (None = natural order)"""
+    ent = _aux_entry(col)
+    return None if ent is None else ent[1][1]
 
 
 def max_row_len(col: Optional[torch.Tensor]) -> int:

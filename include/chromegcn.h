@@ -50,7 +50,7 @@ extern "C" {
 #define CGCN_ERR_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after a launch      */
 #define CGCN_ERR_WORKSPACE (-4)   /* workspace too small (see cgcn_*_workspace_bytes)    */
 
-#define CGCN_ABI_VERSION 17
+#define CGCN_ABI_VERSION 18
 
 typedef void *cgcn_stream_t; /* hipStream_t */
 
@@ -65,10 +65,18 @@ typedef void *cgcn_stream_t; /* hipStream_t */
  *                 row is aggregated inside one workgroup by the fused forward (one CU's L1: ~65 us for 10 000
  *                 neighbours of 1 KiB); graphs whose longest row exceeds 2 048 entries therefore take the feature-sliced
  *                 route (8 ... 16 workgroups per row) at every table size.
- * For the backward (aux_t) both describe the CSR of Ahat^T.
+ *   row_order   : a permutation of 0 .. n_rows-1 (int32, device), or NULL = natural order: the order in which the
+ *                 feature-sliced kernels deal the rows to their 64-row tiles (position p -> tile p / 64, wave (p % 64) / 8;
+ *                 a wave walks its 8 rows side by side until the longest is done).  The engine passes the rows of every
+ *                 64-row tile sorted by length: a wave's 8 rows are then about equally long, and a tile still holds the
+ *                 same (neighbouring) rows.  Results are independent of the order up to fp32 re-association of a row's
+ *                 sum (a wave chooses how to walk its rows by their lengths).  Not checked: an array that is not a
+ *                 permutation leaves rows unwritten.
+ * For the backward (aux_t) all three describe the CSR of Ahat^T.
  */
 typedef struct cgcn_graph_aux {
   const uint16_t *col16;
+  const int32_t *row_order;
   int32_t max_row_len;
 } cgcn_graph_aux;
 

@@ -86,7 +86,7 @@ def test_sixteen_bit_column_indices_give_bit_identical_results(S, d):
         m.data[:] = 1.0
         g = G.upload(G.normalize_graph("hic", m, n), DEV)
         assert G.col16_ptr(g.col) is not None and g.val is None
-        aux16 = G.GraphAux(G.col16_ptr(g.col), 0)   # cgcn_graph_aux carrying the 16-bit copy and nothing else
+        aux16 = G.GraphAux(G.col16_ptr(g.col), None, 0)   # cgcn_graph_aux carrying the 16-bit copy and nothing else
         c16 = ctypes.addressof(aux16)
         x = torch.randn(S, n, d, device=DEV)
         lib.cgcn_debug_set_fwd_split_bytes(0)       # the sliced route at every size
@@ -167,3 +167,45 @@ def test_super_hub_rows_and_skewed_waves(S, d, kind):
     for nm, u, v in zip(["Xn", "gate", "spmm", "dX", "dW", "db", "dwg", "dcg"], a, b):
         err = float((u - v).abs().max()) / (float(u.abs().max()) + 1e-30)
         assert err < 2e-5, "%s: scale-relative difference %.2e" % (nm, err)
+
+
+def test_tile_sorted_row_order_is_a_tile_local_permutation_and_changes_nothing_but_summation_order():
+    """cgcn_graph_aux::row_order as the engine builds it (graph.tile_sorted_rows): the rows of every 64-row tile sorted by
+    length.  The sliced aggregation gives the same sums with and without it up to fp32 re-association (a wave that walks
+    its rows cooperatively adds a row's neighbours in butterfly order, and which waves do depends on their rows)."""
+    lib = _lib.load()
+    P = _lib.ptr
+    rng = np.random.RandomState(11)
+    for n in (130, 1000, 9000):
+        i = rng.randint(0, n, 20 * n); j = rng.randint(0, n, 20 * n)
+        for deg in (300, 900):
+            deg = min(deg, n - 1)
+            i = np.concatenate([i, np.full(deg, int(rng.randint(n)))]); j = np.concatenate([j, rng.choice(n, deg, replace=False)])
+        keep = i != j
+        m = sp.coo_matrix((np.ones(int(keep.sum()), dtype=np.float32), (i[keep], j[keep])), shape=(n, n)).tocsr()
+        m = m + m.T
+        m.data[:] = 1.0
+        g = G.upload(G.normalize_graph("hic", m, n), DEV)
+        order = G.row_order(g.col)
+        assert order is not None
+        o = order.cpu().numpy()
+        deg_rows = np.diff(g.rowptr.cpu().numpy())
+        assert sorted(o.tolist()) == list(range(n))
+        for t in range((n + 63) // 64):
+            seg = o[64 * t:64 * t + 64]
+            assert seg.min() >= 64 * t and seg.max() < min(n, 64 * t + 64)
+            assert np.all(np.diff(deg_rows[seg]) <= 0)
+        S, d = 2, 128
+        x = torch.randn(S, n, d, device=DEV)
+        plain = G.GraphAux(G.col16_ptr(g.col), None, G.max_row_len(g.col))
+        lib.cgcn_debug_set_fwd_split_bytes(0)
+        try:
+            ys = []
+            for aux in (ctypes.addressof(plain), G.aux_ptr(g.col)):
+                y = torch.empty_like(x)
+                _lib.check(lib.cgcn_spmm(_lib.stream_ptr(), n, n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(y), aux), "spmm")
+                ys.append(y)
+        finally:
+            lib.cgcn_debug_set_fwd_split_bytes(-1)
+        err = float((ys[0] - ys[1]).abs().max()) / float(ys[0].abs().max())
+        assert err < 2e-6, "n=%d: %.2e" % (n, err)
