@@ -24,6 +24,12 @@ int main(void) {
     /* argument checking happens before any launch: NULL pointers are rejected without touching a device */
     if (cgcn_spmm((cgcn_stream_t)0, 10, 10, 1, 128, NULL, NULL, NULL, NULL, NULL, NULL, NULL) != CGCN_ERR_BAD_ARG) return 7;
     if (cgcn_spmm((cgcn_stream_t)0, 10, 10, 1, 130, NULL, NULL, NULL, NULL, NULL, NULL, NULL) != CGCN_ERR_UNSUPPORTED) return 8;
+    {   /* the optional per-graph facts are a plain host struct: built in C, passed by address, argument checks unchanged */
+        cgcn_graph_aux aux = {NULL, NULL, 0};
+        aux.max_row_len = 5000;
+        if (cgcn_spmm((cgcn_stream_t)0, 10, 10, 1, 128, NULL, NULL, NULL, NULL, NULL, NULL, &aux) != CGCN_ERR_BAD_ARG) return 9;
+        if (sizeof(aux.col16) != sizeof(void *) || sizeof(aux.max_row_len) != 4) return 10;
+    }
     printf("c-abi ok v%d\n", cgcn_abi_version());
     return 0;
 }
