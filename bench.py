@@ -626,7 +626,8 @@ def main():
                        "parallelism": ("chromosomes sharded over %d rank(s)" % world) if genome else "chromosome-per-rank x%d" % world,
                        "allreduce": stage.allreduce_kind if multi else None,
                        "step_group_graph": bool(stage._group_graph_enabled()) if multi else None,
-                       "prediction_gather": (args.gather + (" (rows of every chromosome sent to rank 0 by its owner, asynchronously)" if args.gather == "rank0" else "")) if multi and genome else None,
+                       "prediction_gather": ((stage.prediction_gather_effective + (" (rows of every chromosome sent to rank 0 by its owner, asynchronously)" if stage.prediction_gather_effective == "rank0" else ""))
+                                             + ("" if stage.prediction_gather_effective == args.gather else " [asked for %s: the backend has no device-tensor send / recv]" % args.gather)) if multi and genome else None,
                        "eager_collectives_on_own_communicator": (stage.aux_group is not stage.group) if multi else None},
             "step_ms": {"median": float(np.median(per_ms)), "p10": float(np.percentile(per_ms, 10)),
                         "p90": float(np.percentile(per_ms, 90)), "n": len(per),

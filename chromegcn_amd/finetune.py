@@ -106,6 +106,7 @@ class GCNStage:
         if prediction_gather not in ("all", "rank0", "none"):
             raise ValueError("prediction_gather must be 'all', 'rank0' or 'none'")
         self.prediction_gather = prediction_gather
+        self.prediction_gather_effective = prediction_gather   # what the last multi-rank split actually did
         # multi-rank step group as ONE HIP graph (fwd + bwd + gradient all-reduce + fused 1/k SGD step): needs a backend
         # whose collectives are stream-ordered device work (nccl = RCCL); None = on when possible, CGCN_GROUP_GRAPH=0 disables
         self._group_graph_opt = group_graph if group_graph is not None else os.environ.get("CGCN_GROUP_GRAPH", "1") != "0"
@@ -701,6 +702,7 @@ class GCNStage:
             mode = self.prediction_gather
             if mode == "rank0" and not nccl and self.device.type == "cuda":
                 mode = "all"   # gloo has no device-tensor send / recv (functional runs on a shared GPU): all-gather there
+            self.prediction_gather_effective = mode
             gp = self._gather_plan(names, plan, C, mode)
             peer = (lambda r: r) if ag is None else (lambda r: torch.distributed.get_global_rank(ag, r))
             loss_sum = torch.zeros((), device=self.device)
