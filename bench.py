@@ -171,7 +171,8 @@ def kernel_costs(n, nnz, S, d, C, P_rl, P_head):
     t = S * 4 * n * d                      # one [S, n, d] tensor
     par = 4 * d * d + 8 * d + 4
     CP = 128 if C <= 128 else 256
-    return {
+    gat = 4.0 * nnz * S * d   # bytes of neighbour rows a gather kernel pulls through L2 / L1 (the L2-level traffic figure)
+    costs = {
         "k_aggregate_sliced": (csr + 2 * t, 2.0 * nnz * S * d),                               # X in, H out
         "k_layer_dense": (4 * t + S * 4 * n + par, 2.0 * S * n * d * d),                      # H, X in; X', Z out; gate
         "k_layer_fwd": (csr + 4 * t + S * 4 * n + par, 2.0 * nnz * S * d + 2.0 * S * n * d * d),   # X in; X', Z, H out
@@ -180,6 +181,7 @@ def kernel_costs(n, nnz, S, d, C, P_rl, P_head):
         "k_bwd_sliced": (4 * (n + 1) + 4 * nnz + 3 * t + S * 4 * n, 2.0 * nnz * S * d),      # dHs, dXn in; dX out
         "k_head_fused": (t + 2 * 4 * n * C + 4 * n * d + P_head * 4 * (CP * d + CP + 8 * d), 6.0 * n * d * C),   # X, targets in; probs, dym out
     }
+    return {k: (v[0], v[1], gat if k in ("k_aggregate_sliced", "k_layer_fwd", "k_bwd_sliced") else 0.0) for k, v in costs.items()}
 
 
 def time_kernels(stage, name, reps, dropout_p):
@@ -549,12 +551,13 @@ def main():
             costs = kernel_costs(n, stage.chroms[nm].graph.nnz, 2, args.d, synth.N_LABELS, p_rl, p_head)
             for k, (sec, per_step) in kt.items():
                 # (one kernel, two forms: k_bwd_rowlocal with the head prologue -- last layer -- and without)
-                e = agg.setdefault(k.split("(")[0], {"s": 0.0, "launches": 0, "bytes": 0.0, "flops": 0.0})
+                e = agg.setdefault(k.split("(")[0], {"s": 0.0, "launches": 0, "bytes": 0.0, "flops": 0.0, "gather": 0.0})
                 e["s"] += sec * per_step
                 e["launches"] += per_step
                 if k in costs:
                     e["bytes"] += costs[k][0] * per_step
                     e["flops"] += costs[k][1] * per_step
+                    e["gather"] += costs[k][2] * per_step
         wl_key = ("genome" if genome else args.workload) + {"uniform": "", "hic_like": "_hic", "hub": "_hub"}[args.generator] + "_d%d" % args.d
 
         def roof_entry(k, e):
@@ -571,7 +574,11 @@ def main():
                                       "beyond-L2 bytes incl. Infinity-Cache hits), not measured in this run" % ttag,
                     "algorithmic_bytes_per_launch": e["bytes"] / e["launches"], "flops_per_launch": e["flops"] / e["launches"],
                     "avg_kernel_us": us, "launches_per_step": e["launches"], "share_of_kernel_time": None,
-                    "hbm_GBps": gbps, "frac_hbm": fh, "mfma_f32_TFLOPs": tfl, "frac_mfma_f32": fm}
+                    "hbm_GBps": gbps, "frac_hbm": fh, "mfma_f32_TFLOPs": tfl, "frac_mfma_f32": fm,
+                    # gathered neighbour rows (4 nnz S d bytes per launch): served by the L2s / vector L1s, not by HBM -- the
+                    # table is cache resident -- so this rate may legitimately exceed the HBM peak
+                    "gathered_bytes_per_launch": (e["gather"] / e["launches"]) if e["gather"] else None,
+                    "gather_GBps": (e["gather"] / e["s"] / 1e9) if e["gather"] else None}
         tot_s = sum(e["s"] for e in agg.values())
         ranked = sorted(((k, e) for k, e in agg.items() if e["bytes"]), key=lambda kv: -kv[1]["s"])
         top3 = []
