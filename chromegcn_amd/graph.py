@@ -128,14 +128,23 @@ class GraphAux(ctypes.Structure):
 
 
 def tile_sorted_rows(deg: torch.Tensor) -> torch.Tensor:
-    """cgcn_graph_aux::row_order of the engine: the rows of every 64-row tile of the feature-sliced kernels, longest
-    first (stable), tiles in place.  A wave walks 8 consecutive positions side by side until its longest row is done."""
+    """cgcn_graph_aux::row_order of the engine for the feature-sliced kernels (position p -> tile p // 64, wave
+    (p % 64) // 8; a wave walks 8 consecutive positions side by side until its longest row is done):
+      * the rows of every 64-row group sorted longest first (stable): a wave's 8 rows are about equally long, and a tile
+        still holds 64 NEIGHBOURING rows (Hi-C neighbours share neighbours: L1 / L2 locality stays);
+      * the full groups dealt to the tiles heaviest first (total row length; stable), so the tiles that hold hub rows
+        start first instead of forming the launch's tail; the last, partial group stays last."""
     n = int(deg.numel())
     T = (n + 63) // 64
     pad = torch.full((T * 64,), -1, dtype=torch.int64, device=deg.device)
     pad[:n] = deg.to(torch.int64)
     idx = torch.argsort(pad.view(T, 64), dim=1, descending=True, stable=True)
-    order = (idx + 64 * torch.arange(T, device=deg.device).view(T, 1)).reshape(-1)[:n]   # padding sorts last: dropped
+    rows = idx + 64 * torch.arange(T, device=deg.device).view(T, 1)
+    full = n // 64
+    if full > 1:
+        w = pad.view(T, 64)[:full].sum(1)
+        rows = torch.cat([rows[:full][torch.argsort(w, descending=True, stable=True)], rows[full:]], 0)
+    order = rows.reshape(-1)[:n]   # the padding of the partial group sorts last: dropped
     return order.to(torch.int32).contiguous()
 
 

@@ -170,8 +170,8 @@ def test_super_hub_rows_and_skewed_waves(S, d, kind):
 
 
 def test_tile_sorted_row_order_is_a_tile_local_permutation_and_changes_nothing_but_summation_order():
-    """cgcn_graph_aux::row_order as the engine builds it (graph.tile_sorted_rows): the rows of every 64-row tile sorted by
-    length.  The sliced aggregation gives the same sums with and without it up to fp32 re-association (a wave that walks
+    """cgcn_graph_aux::row_order as the engine builds it (graph.tile_sorted_rows): the rows of every 64-row group sorted by
+    length, the groups dealt to the tiles heaviest first.  The sliced aggregation gives the same sums with and without it up to fp32 re-association (a wave that walks
     its rows cooperatively adds a row's neighbours in butterfly order, and which waves do depends on their rows)."""
     lib = _lib.load()
     P = _lib.ptr
@@ -191,10 +191,16 @@ def test_tile_sorted_row_order_is_a_tile_local_permutation_and_changes_nothing_b
         o = order.cpu().numpy()
         deg_rows = np.diff(g.rowptr.cpu().numpy())
         assert sorted(o.tolist()) == list(range(n))
+        weights = []
         for t in range((n + 63) // 64):
             seg = o[64 * t:64 * t + 64]
-            assert seg.min() >= 64 * t and seg.max() < min(n, 64 * t + 64)
-            assert np.all(np.diff(deg_rows[seg]) <= 0)
+            assert len(set((seg // 64).tolist())) == 1          # a tile holds ONE group of 64 neighbouring rows
+            assert np.all(np.diff(deg_rows[seg]) <= 0)           # longest first
+            weights.append(int(deg_rows[seg].sum()))
+        full = n // 64
+        assert np.all(np.diff(weights[:full]) <= 0)              # full tiles heaviest first
+        if n % 64:
+            assert o[64 * full] // 64 == full                    # the partial group stays last
         S, d = 2, 128
         x = torch.randn(S, n, d, device=DEV)
         plain = G.GraphAux(G.col16_ptr(g.col), None, G.max_row_len(g.col))
