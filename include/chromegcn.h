@@ -69,9 +69,9 @@ typedef void *cgcn_stream_t; /* hipStream_t */
  *                 feature-sliced kernels deal the rows to their 64-row tiles (position p -> tile p / 64, wave (p % 64) / 8;
  *                 a wave walks its 8 rows side by side until the longest is done).  The engine passes the rows of every
  *                 64-row group sorted by length (a wave's 8 rows are then about equally long, a tile still holds
- *                 neighbouring rows) and the groups heaviest first (tiles with hub rows start the launch).  Results are independent of the order up to fp32 re-association of a row's
- *                 sum (a wave chooses how to walk its rows by their lengths).  Not checked: an array that is not a
- *                 permutation leaves rows unwritten.
+ *                 neighbouring rows) and the groups heaviest first (tiles with hub rows start the launch).  Results are
+ *                 independent of the order up to fp32 re-association of a row's sum (a wave chooses how to walk its rows
+ *                 by their lengths).  Not checked: an array that is not a permutation leaves rows unwritten.
  * For the backward (aux_t) all three describe the CSR of Ahat^T.
  */
 typedef struct cgcn_graph_aux {
