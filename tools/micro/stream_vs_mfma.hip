@@ -8,11 +8,12 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
-template <bool STREAM, bool MFMA>
+template <bool STREAM, bool MFMA, int VALU>
 __global__ __launch_bounds__(1024) void k(const f32x4* __restrict__ src, f32x4* __restrict__ dst, size_t n4, int mfma_iters,
                                           float* out) {
   extern __shared__ float lds[];
@@ -25,7 +26,12 @@ __global__ __launch_bounds__(1024) void k(const f32x4* __restrict__ src, f32x4* 
     const size_t stride = (size_t)gridDim.x * 512;
     size_t i = (size_t)blockIdx.x * 512 + tid;
     for (; i + 3 * stride < n4; i += 4 * stride) {
-      const f32x4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+      f32x4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+      // VALU: vector instructions of "row math" per 16 bytes streamed (4 independent chains of packed-free FMAs per vector)
+#pragma unroll
+      for (int v = 0; v < VALU / 4; ++v) {
+        a = a * 1.0001f + 0.5f; b = b * 1.0001f + 0.5f; c = c * 1.0001f + 0.5f; d = d * 1.0001f + 0.5f;
+      }
       dst[i] = a * 1.5f; dst[i + stride] = b * 1.5f; dst[i + 2 * stride] = c * 1.5f; dst[i + 3 * stride] = d * 1.5f;
     }
     for (; i < n4; i += stride) dst[i] = src[i] * 1.5f;
@@ -82,13 +88,20 @@ int main() {
     CK(hipEventElapsedTime(&ms, e0, e1));
     return ms * 100.0;   // us per launch
   };
-  for (int iters : {30, 45, 60, 90}) {   // MFMA work per launch: iters x 32 MFMAs per wave, 8 waves per CU
-    const double flop = (double)iters * 32 * 2048 * 8 * 256;
-    const double t_s = timeit([&] { hipLaunchKernelGGL((k<true, false>), dim3(256), dim3(1024), lds_bytes, 0, src, dst, n4, iters, out); });
-    const double t_m = timeit([&] { hipLaunchKernelGGL((k<false, true>), dim3(256), dim3(1024), lds_bytes, 0, src, dst, n4, iters, out); });
-    const double t_b = timeit([&] { hipLaunchKernelGGL((k<true, true>), dim3(256), dim3(1024), lds_bytes, 0, src, dst, n4, iters, out); });
-    printf("MFMA work %.2f GFLOP: stream alone %6.1f us (%.2f TB/s) | MFMA alone %6.1f us (%.1f TF/s) | both %6.1f us (sum %.1f, max %.1f)\n",
-           flop / 1e9, t_s, 2.0 * bytes / (t_s * 1e-6) / 1e12, t_m, flop / (t_m * 1e-6) / 1e12, t_b, t_s + t_m, t_s > t_m ? t_s : t_m);
-  }
+  auto sweep = [&](auto tag, const char* name) {
+    constexpr int V = decltype(tag)::value;
+    for (int iters : {45, 60}) {   // MFMA work per launch: iters x 32 MFMAs per wave, 8 waves per CU
+      const double flop = (double)iters * 32 * 2048 * 8 * 256;
+      const double t_s = timeit([&] { hipLaunchKernelGGL((k<true, false, V>), dim3(256), dim3(1024), lds_bytes, 0, src, dst, n4, iters, out); });
+      const double t_m = timeit([&] { hipLaunchKernelGGL((k<false, true, V>), dim3(256), dim3(1024), lds_bytes, 0, src, dst, n4, iters, out); });
+      const double t_b = timeit([&] { hipLaunchKernelGGL((k<true, true, V>), dim3(256), dim3(1024), lds_bytes, 0, src, dst, n4, iters, out); });
+      printf("%-34s MFMA %.2f GFLOP: stream alone %6.1f us (%.2f TB/s) | MFMA alone %6.1f us (%.1f TF/s) | both %6.1f us (sum %.1f, max %.1f)\n",
+             name, flop / 1e9, t_s, 2.0 * bytes / (t_s * 1e-6) / 1e12, t_m, flop / (t_m * 1e-6) / 1e12, t_b, t_s + t_m, t_s > t_m ? t_s : t_m);
+    }
+  };
+  sweep(std::integral_constant<int, 0>{}, "stream waves: copy only");
+  sweep(std::integral_constant<int, 16>{}, "+ 16 x 4 FMAs per 16 B (64 VALU)");
+  sweep(std::integral_constant<int, 32>{}, "+ 32 x 4 FMAs per 16 B (128 VALU)");
+  sweep(std::integral_constant<int, 64>{}, "+ 64 x 4 FMAs per 16 B (256 VALU)");
   return 0;
 }
