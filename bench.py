@@ -507,10 +507,22 @@ def main():
     for _ in range(max(warmup, 1)):
         step()
     elapsed, per, last = timed(step, steps)
-    final_loss = float(last[2]) if genome else float(last[0].item())
+    final_loss = float(last[2]) if genome else float(last[0].item())   # (a deferred device loss is read here, after the timed region)
 
     extras = {}
     if not args.no_extras:
+        if genome and not multi:
+            # the same epochs with the loss left on the device (run_split(sync_loss=False)): no host wait per epoch, so
+            # the next epoch's launches are queued while this one still runs.  Reported beside the headline, which
+            # keeps one host sync per epoch (the reference waits for the device once per chromosome, finetune.py:51).
+            def step_nosync():
+                return stage.run_split("train", names, to_cpu=False, sync_loss=False)
+            step_nosync()
+            ns_el, _, ns_last = timed(step_nosync, steps)
+            extras["deferred_loss_sync_windows_per_s"] = windows * steps / ns_el
+            extras["deferred_loss_sync_ms_per_step"] = ns_el / steps * 1e3
+            extras["deferred_loss_sync_note"] = ("total loss returned as a device tensor and read after the timed region; "
+                                                 "not the headline")
         # inference: eval-mode forward of both strands over the same chromosomes
         if genome:
             def ev():

@@ -666,13 +666,16 @@ class GCNStage:
         return flat[n_stat:].view_as(extra) if extra is not None else None
 
     # ------------------------------------------------------------------ a whole split
-    def run_split(self, split: str, names: Optional[Sequence[str]] = None, to_cpu: bool = True):
+    def run_split(self, split: str, names: Optional[Sequence[str]] = None, to_cpu: bool = True, sync_loss: bool = True):
         """(all_preds, all_targets, total_loss) with finetune.py:67's meaning: sigmoid probabilities and
         targets concatenated in chromosome order, total_loss = sum of per-chromosome mean BCE.
         to_cpu=True returns CPU tensors like the reference (finetune.py:52-53 moves every chromosome's
         predictions to the host); to_cpu=False leaves them on the device for chromegcn_amd.metrics -- the
         predictions are then a view of the stage's output arena, valid until the next step on this stage.
-        Multi-rank: every rank returns the full concatenation."""
+        Multi-rank: every rank returns the full concatenation (prediction_gather="all").
+        sync_loss=False (with to_cpu=False): total_loss comes back as a 0-dim DEVICE tensor and the split does not wait for
+        the GPU at all -- a training loop that only logs the loss can read it an epoch late and keep the queue full
+        (finetune.py:51 waits for the device once per chromosome, sync_loss=True once per split)."""
         names = list(self._meta) if names is None else list(names)
         train = split == "train"
         C = next(iter(self._meta.values()))[1] if self._meta else 0
@@ -690,7 +693,7 @@ class GCNStage:
             else:
                 preds_dev = torch.empty((0, C), device=self.device)
                 loss_dev = torch.zeros((), device=self.device)
-            total = float(loss_dev.item())            # the one host sync of the split (finetune.py:51 syncs per chromosome)
+            total = float(loss_dev.item()) if (sync_loss or to_cpu) else loss_dev   # the one host sync of the split (finetune.py:51 syncs per chromosome)
             if not to_cpu:
                 return preds_dev, self._split_targets_dev(names, C), total
             preds = preds_dev.cpu()
