@@ -76,49 +76,237 @@ def parse():
     ap.add_argument("--no-group-graph", action="store_true",
                     help="N > 1: do not capture the collective + optimizer step into the step's HIP graph")
     ap.add_argument("--e2e-windows", type=int, default=4096, help="e2e: windows per chromosome pushed through the encoder")
+    ap.add_argument("--probe", action="store_true",
+                    help="internal (launch ladder): a short functional job -- the first two step groups of the epoch, one timed "
+                         "step, no extras -- whose only purpose is to come back")
+    ap.add_argument("--rung", type=int, default=None, help="internal (launch ladder): the rung this job runs on; no further probing")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous check only: every rank joins the process group, rank 0 prints one JSON line "
                          "(n_gpus, ranks_seen_by_backend) and nothing touches a GPU")
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# N > 1: the fallback ladder.  The first multi-GPU run on a node exercises code a one-GPU box cannot (RCCL with more
+# than one rank, the all-reduce captured into the step's HIP graph, point-to-point prediction sends), and a hang inside a
+# captured collective cannot be recovered from inside the process that issued it.  So before the measured job starts, a
+# process that has NOT touched a GPU -- the self-launching parent, or rank 0 of an external launcher's ranks -- runs a
+# short PROBE job per rung as a child (its own torch.distributed.run, same N, two step groups of the real epoch with
+# that rung's collectives) under a timeout, and the measured job runs with the first rung whose probe came back.  The
+# JSON line records which rung ran and why the earlier ones did not (`launch_ladder`).  Children only, never an exec.
+# ------------------------------------------------------------------------------------------------------------------
+LADDER = [
+    ("step group as one HIP graph (collective inside) + rows sent to rank 0", []),
+    ("captured fwd+bwd, eager all-reduce, all-gather of predictions", ["--no-group-graph", "--gather", "all"]),
+    ("no HIP graphs at all, eager all-reduce, all-gather of predictions", ["--no-group-graph", "--gather", "all", "--no-hip-graph"]),
+]
+_PASS_THROUGH = ("--backend", "--d", "--layers", "--dropout", "--generator", "--workload", "--e2e-windows")
+_PASS_FLAGS = ("--share-gpu", "--dry-run", "--hic-like", "--p2p-allreduce", "--no-hip-graph", "--no-group-graph")
+
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _child_job(gpus, argv, timeout_s, relay_stderr=True):
+    """Run `bench.py argv` as a child torch.distributed.run job of `gpus` ranks in a process group of its own; returns
+    (rc, rank 0's JSON line or None, seconds, why).  A job that outlives `timeout_s` is killed (the whole process group
+    we started, by its id) and reported as a timeout."""
+    import signal
+    import subprocess
+    import threading
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE",
+                        "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT",
+                        "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING",
+                        "TORCHELASTIC_ERROR_FILE")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    t0 = time.perf_counter()
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    got = {"line": None}
+
+    def pump():
+        for ln in proc.stdout:                 # rank 0's JSON line is the result; anything else goes to stderr
+            if ln.startswith("{"):
+                got["line"] = ln
+            elif relay_stderr:
+                sys.stderr.write(ln)
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+    why = None
+    try:
+        rc = proc.wait(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        why = "no result within %.0f s (killed)" % timeout_s
+        # torch.distributed.run puts every worker into a session of its own, so the job is not one process group: take
+        # the exact descendants of the launcher we started (by pid), ask the launcher to stop (SIGTERM: its agent
+        # terminates the workers), then kill whatever of them is still alive -- a rank stuck in a collective may
+        # ignore SIGTERM, and a rank left behind would keep its GPU
+        import psutil
+        try:
+            kids = psutil.Process(proc.pid).children(recursive=True)
+        except psutil.Error:
+            kids = []
+        proc.send_signal(signal.SIGTERM)
+        try:
+            proc.wait(timeout=float(os.environ.get("CGCN_BENCH_TERM_GRACE_S", "10")))
+        except subprocess.TimeoutExpired:
+            pass
+        for k in kids:
+            try:
+                k.kill()
+            except psutil.Error:
+                pass
+        if proc.poll() is None:
+            proc.kill()
+        rc = proc.wait()
+        psutil.wait_procs(kids, timeout=10)
+    th.join(5)
+    if why is None and rc != 0:
+        why = "exit code %d" % rc
+    if why is None and got["line"] is None:
+        why, rc = "exited 0 without a result line", 1
+    return rc, got["line"], time.perf_counter() - t0, why
+
+
+def _carried_args():
+    """the caller's arguments a probe / measured child must share (workload shape, backend, testing switches)"""
+    out, av, i = [], sys.argv[1:], 0
+    while i < len(av):
+        a = av[i]
+        if a in _PASS_THROUGH and i + 1 < len(av):
+            out += [a, av[i + 1]]
+            i += 2
+            continue
+        if a.split("=")[0] in _PASS_THROUGH or a in _PASS_FLAGS:
+            out.append(a)
+        i += 1
+    return out
+
+
+def choose_rung(args, first=0):
+    """Probe the ladder from rung `first`; returns (rung index or None, record for the JSON line)."""
+    probe_tmo = float(os.environ.get("CGCN_BENCH_PROBE_TIMEOUT_S", "150"))
+    rec = {"rungs": [r[0] for r in LADDER], "tried": []}
+    user = _carried_args()
+    for i in range(first, len(LADDER)):
+        flags = [f for f in LADDER[i][1] if f not in user or f in ("--gather", "all")]
+        argv = ["--gpus", str(args.gpus), "--probe", "--rung", str(i), "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+                "--no-extras", "--no-roofline"] + user + flags
+        rc, line, secs, why = _child_job(args.gpus, argv, probe_tmo)
+        rec["tried"].append({"rung": i, "probe_s": round(secs, 1), "ok": why is None, "why": why})
+        if why is None:
+            rec["rung"] = i
+            return i, rec
+    rec["rung"] = None
+    return None, rec
+
+
+def _rung_argv(args, rung):
+    """the measured job's arguments: the caller's, plus the rung's switches"""
+    av = [a for a in sys.argv[1:]]
+    for f in LADDER[rung][1]:
+        if f == "all":
+            continue
+        if f == "--gather":
+            if "--gather" in av:
+                k = av.index("--gather")
+                del av[k:k + 2]
+            av += ["--gather", "all"]
+        elif f not in av:
+            av.append(f)
+    return av + ["--rung", str(rung)]
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with N > 1 and no launcher environment (README.md:34 runs the reference with ONE
     command): start the N ranks ourselves -- `python -m torch.distributed.run`, one process per GPU, rendezvous on
     127.0.0.1 -- BEFORE anything in this process touches the GPU (a process that has initialised HIP must neither fork
-    GPU work nor exec), relay rank 0's JSON line and the job's exit code.  Under a launcher (WORLD_SIZE set) this is a
-    no-op and the process is one rank."""
+    GPU work nor exec), relay rank 0's JSON line and the job's exit code.  The measured job runs on the first rung of
+    LADDER whose probe job came back; if the measured job itself fails or hangs, the next rung is tried.  Under a
+    launcher (WORLD_SIZE set) this is a no-op and the process is one rank (see external_ladder)."""
     if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
         return None
-    import socket
-    import subprocess
     if not args.share_gpu and not args.dry_run:
         have = torch.cuda.device_count()   # counts devices without initialising the runtime
         if have < args.gpus:
             raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (use --share-gpu --backend gloo for a "
                              "single-GPU functional run)" % (args.gpus, have))
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    line = None
-    for ln in proc.stdout:                 # rank 0's JSON line goes to our stdout; anything else to stderr
-        if ln.startswith("{"):
-            line = ln
-            sys.stdout.write(ln)
+    job_tmo = float(os.environ.get("CGCN_BENCH_JOB_TIMEOUT_S", "1500"))
+    if os.environ.get("CGCN_BENCH_LADDER", "1") == "0" or args.rung is not None:
+        rc, line, _, why = _child_job(args.gpus, sys.argv[1:], job_tmo)
+        if line is not None:
+            sys.stdout.write(line)
             sys.stdout.flush()
-        else:
-            sys.stderr.write(ln)
-    rc = proc.wait()
-    if rc == 0 and line is None:
-        sys.stderr.write("bench.py: the ranks exited 0 without printing a result line\n")
-        rc = 1
-    return rc
+        if why:
+            sys.stderr.write("bench.py: the job failed: %s\n" % why)
+        return rc
+    first, history = 0, []
+    while first < len(LADDER):
+        rung, rec = choose_rung(args, first)
+        history += rec["tried"]
+        if rung is None:
+            break
+        rc, line, secs, why = _child_job(args.gpus, _rung_argv(args, rung), job_tmo)
+        if why is None:
+            d = json.loads(line)
+            d["launch_ladder"] = {"rung": rung, "ran": LADDER[rung][0], "tried": history, "measured_job_s": round(secs, 1),
+                                  "launcher": "bench.py (self-launched torch.distributed.run children)"}
+            sys.stdout.write(json.dumps(d) + "\n")
+            sys.stdout.flush()
+            return 0
+        history.append({"rung": rung, "measured_job": True, "ok": False, "why": why})
+        sys.stderr.write("bench.py: rung %d (%s) passed its probe but the measured job failed: %s; trying the next rung\n"
+                         % (rung, LADDER[rung][0], why))
+        first = rung + 1
+    sys.stderr.write("bench.py: no rung of the launch ladder produced a result: %s\n" % json.dumps(history))
+    return 1
+
+
+def external_ladder(args, world, rank):
+    """Under an external launcher (the driver's `python -m torch.distributed.run ... bench.py --gpus N`): the ranks
+    cannot be restarted, so the rung is chosen BEFORE any of them touches a GPU -- all ranks meet on a gloo group (CPU
+    only), rank 0 runs the probe jobs as children on the still untouched GPUs, the choice is broadcast, the gloo group
+    is torn down and the ranks go on to build the real (RCCL) group with the chosen switches.  CGCN_BENCH_LADDER=0
+    skips the probes: then the conservative form runs (eager all-reduce, all-gather) unless CGCN_GROUP_GRAPH=1."""
+    if world <= 1 or args.rung is not None or args.probe:
+        return None
+    if os.environ.get("CGCN_BENCH_LADDER", "1") == "0":
+        if os.environ.get("CGCN_GROUP_GRAPH") != "1":
+            args.no_group_graph = True
+            if "--gather" not in sys.argv:
+                args.gather = "all"
+        return {"rung": None, "ran": "no probes (CGCN_BENCH_LADDER=0): " + ("as asked" if os.environ.get("CGCN_GROUP_GRAPH") == "1" else LADDER[1][0]),
+                "launcher": "external"}
+    import datetime
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=1800))
+    box = [None]
+    if rank == 0:
+        rung, rec = choose_rung(args, 0)
+        box[0] = rec
+    dist.broadcast_object_list(box, src=0)
+    dist.barrier()
+    dist.destroy_process_group()
+    rec = box[0]
+    rung = rec.get("rung")
+    if rung is None:
+        raise SystemExit("bench.py: no rung of the launch ladder passed its probe: %s" % json.dumps(rec["tried"]))
+    for f in LADDER[rung][1]:
+        if f == "--no-group-graph":
+            args.no_group_graph = True
+        elif f == "--no-hip-graph":
+            args.no_hip_graph = True
+        elif f == "--gather":
+            args.gather = "all"
+    return {"rung": rung, "ran": LADDER[rung][0], "tried": rec["tried"],
+            "launcher": "external (rank 0 probed with child jobs before any rank touched a GPU)"}
 
 
 def _one_rank_allreduce(dev):
@@ -176,10 +364,13 @@ def kernel_costs(n, nnz, S, d, C, P_rl, P_head):
         "k_aggregate_sliced": (csr + 2 * t, 2.0 * nnz * S * d),                               # X in, H out
         "k_layer_dense": (4 * t + S * 4 * n + par, 2.0 * S * n * d * d),                      # H, X in; X', Z out; gate
         "k_layer_fwd": (csr + 4 * t + S * 4 * n + par, 2.0 * nnz * S * d + 2.0 * S * n * d * d),   # X in; X', Z, H out
-        "k_bwd_rowlocal": (5 * t + S * 4 * n + P_rl * (4 * d * d + 8 * d + 16), 4.0 * S * n * d * d),   # Z, X, H, dXn in; dHs out
-        "k_bwd_rowlocal(head)": (4 * t + 4 * n * d + t + S * 4 * n + P_rl * (4 * d * d + 8 * d + 16), 4.0 * S * n * d * d),   # dym [n,d] in, dL/dXn out
+        # (the per-workgroup partial records -- P_rl x (d^2 + 2d + 4) floats of dW / db / dwg / dcg, P_head x (CP d + CP + 8 d)
+        # of the head -- are what THIS implementation writes for its deterministic two-stage sums: implementation bytes,
+        # not algorithmic ones; the algorithm's own output there is one d x d (+ 2d + 1) / C x d (+ C + 4d) gradient)
+        "k_bwd_rowlocal": (5 * t + S * 4 * n + par + (4 * d * d + 8 * d + 4), 4.0 * S * n * d * d),   # Z, X, H, dXn, W in; dHs, dW/db/dwg/dcg out
+        "k_bwd_rowlocal(head)": (4 * t + 4 * n * d + t + S * 4 * n + par + (4 * d * d + 8 * d + 4), 4.0 * S * n * d * d),   # dym [n,d] in, dL/dXn out
         "k_bwd_sliced": (4 * (n + 1) + 4 * nnz + 3 * t + S * 4 * n, 2.0 * nnz * S * d),      # dHs, dXn in; dX out
-        "k_head_fused": (t + 2 * 4 * n * C + 4 * n * d + P_head * 4 * (CP * d + CP + 8 * d), 6.0 * n * d * C),   # X, targets in; probs, dym out
+        "k_head_fused": (t + 2 * 4 * n * C + 4 * n * d + 2 * 4 * (C * d + C) + 4 * 4 * d, 6.0 * n * d * C),   # X, targets, W_out in; probs, dym, dW_out/db_out/BN sums out
     }
     return {k: (v[0], v[1], gat if k in ("k_aggregate_sliced", "k_layer_fwd", "k_bwd_sliced") else 0.0) for k, v in costs.items()}
 
@@ -208,10 +399,12 @@ def time_kernels(stage, name, reps, dropout_p):
     colstats = torch.empty((tiles, S, d, 2), device=dev)
     L = m.n_layers
     gc1, w1, gcL, wL, bn, out = m.GC1, m.W1, getattr(m, "GC%d" % L), getattr(m, "W%d" % L), m.batch_norm, m.out
-    split = n * S * d * 4 >= (8 << 20) and S * d <= 256
     drop = dropout_p > 0
     from chromegcn_amd.graph import aux_ptr
     c16, c16t = aux_ptr(g.col), aux_ptr(g.col_t)   # the engine's own cgcn_graph_aux (16-bit indices, longest row)
+    # the route the LIBRARY takes for this graph (table size against the current threshold, hub-heavy graphs): asked,
+    # not re-derived here -- a hub graph on a small table runs k_aggregate_sliced + k_layer_dense, not k_layer_fwd
+    split = lib.cgcn_debug_layer_fwd_route(n, S, d, c16) == 1
 
     def ev_time(fn):
         for _ in range(3):
@@ -238,12 +431,13 @@ def time_kernels(stage, name, reps, dropout_p):
         t_agg = ev_time(lambda: lib.cgcn_spmm(st(), n, n, S, d, P(g.rowptr), P(g.col), P(g.val), P(g.row_scale), c.x.data_ptr(), h.data_ptr(), c16))
         t_d1 = ev_time(lambda: fwd(1, h, None, None))
         t_d2 = ev_time(lambda: fwd(L, h, None, colstats))
-        out_t["k_aggregate_sliced"] = (t_agg, 2)
-        out_t["k_layer_dense"] = ((t_d1 + t_d2) / 2, 2)
+        # L forward launches per step: L - 1 in the inter-layer-dropout form, the last with the column statistics
+        out_t["k_aggregate_sliced"] = (t_agg, L)
+        out_t["k_layer_dense"] = (((L - 1) * t_d1 + t_d2) / L, L)
     else:
         t_f1 = ev_time(lambda: fwd(1, None, h, None))
         t_f2 = ev_time(lambda: fwd(L, None, h, colstats))
-        out_t["k_layer_fwd"] = ((t_f1 + t_f2) / 2, 2)
+        out_t["k_layer_fwd"] = (((L - 1) * t_f1 + t_f2) / L, L)
     # ---- head: cgcn_head_train once in full (valid state for the phases and for the backward's head mode), then k_head_fused alone
     hws_b = lib.cgcn_head_workspace_bytes(n, S, d, C)
     hws = torch.empty(hws_b, dtype=torch.uint8, device=dev)
@@ -285,8 +479,9 @@ def time_kernels(stage, name, reps, dropout_p):
                                                P(rng) if drop else None, max(L - 1, 0) if head_mode else 0,
                                                ctypes.byref(hg) if head_mode else None, ws.data_ptr(), ws_b, ph, c16t)
     _lib.check(bwd(3, True), "bwd")
-    out_t["k_bwd_rowlocal(head)"] = (ev_time(lambda: bwd(1, True)), 1)
-    out_t["k_bwd_rowlocal"] = (ev_time(lambda: bwd(1, False)), max(L - 1, 0))
+    rl = "k_bwd_rowlocal_ring" if lib.cgcn_debug_layer_bwd_route(n, S, d) == 2 else "k_bwd_rowlocal"
+    out_t[rl + "(head)"] = (ev_time(lambda: bwd(1, True)), 1)
+    out_t[rl] = (ev_time(lambda: bwd(1, False)), max(L - 1, 0))
     _lib.check(bwd(3, False), "bwd")
     out_t["k_bwd_sliced"] = (ev_time(lambda: bwd(2, False)), L)
     torch.cuda.synchronize()
@@ -302,6 +497,11 @@ def stored_traffic(key, kernel=None):
         t = json.load(open(tpath))
     except Exception:
         return None, None
+    # the counters were collected on ONE build of the library: a stored value says nothing about kernels that have
+    # changed since, so it is only reported for the very sources it was measured on (content hash, _build.source_hash)
+    from chromegcn_amd import _build
+    if t.get("_src_hash") != _build.source_hash([]):
+        return None, "stale"
     ent = t.get(key)
     if not isinstance(ent, dict):
         return None, None
@@ -387,13 +587,25 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    # test hooks of the launch ladder (tests/test_bench_launcher.py): a rung that fails / hangs on purpose
+    if args.rung is not None:
+        def _in(var):
+            return str(args.rung) in [v for v in os.environ.get(var, "").split(",") if v]
+        if _in("CGCN_BENCH_FAIL_RUNGS") or (not args.probe and _in("CGCN_BENCH_FAIL_MEASURED_RUNGS")):
+            raise SystemExit("bench.py: rung %d told to fail (test hook)" % args.rung)
+        if args.probe and _in("CGCN_BENCH_HANG_RUNGS"):
+            time.sleep(3600)
+    ladder_rec = external_ladder(args, world, rank) if "WORLD_SIZE" in os.environ else None
     if args.dry_run:
         if world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group("gloo", rank=rank, world_size=world)
         seen = ranks_seen(world, torch.device("cpu"))
-        out = {"dry_run": True, "n_gpus": world, "ranks_seen_by_backend": seen, "backend": "gloo",
+        out = {"dry_run": True, "n_gpus": world, "ranks_seen_by_backend": seen, "backend": "gloo", "probe": bool(args.probe),
+               "rung": args.rung, "no_group_graph": bool(args.no_group_graph), "gather": args.gather, "hip_graph": not args.no_hip_graph,
                "launcher": "self (torch.distributed.run child)" if os.environ.get("TORCHELASTIC_RUN_ID") else "none"}
+        if ladder_rec is not None:
+            out["launch_ladder"] = ladder_rec
         if rank == 0:
             print(json.dumps(out))
             sys.stdout.flush()
@@ -456,6 +668,8 @@ def main():
 
     if genome:
         names = genome_train_names()
+        if args.probe:   # launch ladder: the first two step groups of the real epoch (its largest chromosomes), nothing more
+            names = sorted(names, key=lambda c: -synth.chrom_nodes(c))[:2 * world]
         shapes = []
         for nm in names:  # N > 1: registered only -- a rank normalises and uploads the chromosomes the shard plan gives it
             feats, hic = synth.synthetic_chromosome(nm, d=args.d, hic_like=args.hic_like)
@@ -523,6 +737,41 @@ def main():
             extras["deferred_loss_sync_ms_per_step"] = ns_el / steps * 1e3
             extras["deferred_loss_sync_note"] = ("total loss returned as a device tensor and read after the timed region; "
                                                  "not the headline")
+        if genome and not multi:
+            # the advertised drop-in: finetune()'s return value has the predictions on the HOST (finetune.py:52-53,67).
+            # run_split(to_cpu=True) sends every chromosome's rows to a pinned host arena on a copy stream behind its
+            # own step, under the next chromosome's kernels (finetune._HostArena); one sync at the end of the epoch.
+            def step_cpu():
+                return stage.run_split("train", names)
+            for _ in range(2):
+                step_cpu()
+            c_el, c_per, c_last = timed(step_cpu, steps)
+            extras["dropin_finetune_windows_per_s"] = windows * steps / c_el
+            extras["dropin_finetune_ms_per_step"] = c_el / steps * 1e3
+            extras["dropin_finetune_note"] = ("chromegcn_amd.finetune.finetune()'s epoch: the same train epoch returning CPU predictions "
+                                              "[%d x %d] fp32 (%.0f MB over PCIe per epoch, overlapped chromosome by chromosome), CPU targets "
+                                              "(cached) and the summed loss, like the reference; not the headline (inputs AND outputs resident)"
+                                              % (c_last[0].shape[0], c_last[0].shape[1], c_last[0].numel() * 4 / 1e6))
+            # the same epoch on the other two contact generators (real top-K Hi-C is between them: distance decay + hubs)
+            for gen in ("hic_like", "hub"):
+                if gen == args.generator:
+                    continue
+                torch.manual_seed(0)
+                m2 = C.ChromeGCN(args.d, args.d, synth.N_LABELS, args.dropout, True, args.layers).to(dev)
+                o2 = torch.optim.SGD(m2.parameters(), lr=0.25, momentum=0.9, weight_decay=1e-6)
+                s2 = GCNStage(m2, o2, "hic", dev, hip_graphs=not args.no_hip_graph, input_grad=True, cache_input_aggregation=False)
+                for nm in names:
+                    f2, h2 = synth.synthetic_chromosome(nm, d=args.d, hic_like=gen)
+                    s2.add_chromosome(nm, f2, h2)
+                for _ in range(3):
+                    s2.run_split("train", names, to_cpu=False)
+                g_el, _, _ = timed(lambda: s2.run_split("train", names, to_cpu=False), steps)
+                extras["%s_generator_ms_per_step" % gen] = g_el / steps * 1e3
+                extras["%s_generator_windows_per_s" % gen] = windows * steps / g_el
+                del s2, m2, o2
+            extras["generators_note"] = ("same genome shape and train epoch on synth.contact_graph's other generators: hic_like = "
+                                         "contact probability ~ 1 / distance, hub = top-K-style heavy-tailed degrees with 8 hubs of "
+                                         "2 000 - 10 000 neighbours per chromosome; `value` is the %s generator" % args.generator)
         # inference: eval-mode forward of both strands over the same chromosomes
         if genome:
             def ev():
@@ -566,10 +815,11 @@ def main():
                 e = agg.setdefault(k.split("(")[0], {"s": 0.0, "launches": 0, "bytes": 0.0, "flops": 0.0, "gather": 0.0})
                 e["s"] += sec * per_step
                 e["launches"] += per_step
-                if k in costs:
-                    e["bytes"] += costs[k][0] * per_step
-                    e["flops"] += costs[k][1] * per_step
-                    e["gather"] += costs[k][2] * per_step
+                ck = k.replace("k_bwd_rowlocal_ring", "k_bwd_rowlocal")   # same work, same algorithmic bytes / flops
+                if ck in costs:
+                    e["bytes"] += costs[ck][0] * per_step
+                    e["flops"] += costs[ck][1] * per_step
+                    e["gather"] += costs[ck][2] * per_step
         wl_key = ("genome" if genome else args.workload) + {"uniform": "", "hic_like": "_hic", "hub": "_hub"}[args.generator] + "_d%d" % args.d
 
         def roof_entry(k, e):
@@ -582,7 +832,9 @@ def main():
             return {"kernel": k, "bound": "hbm" if fh >= fm else "mfma",
                     "achieved": gbps if fh >= fm else tfl, "peak": HBM_PEAK_GBPS if fh >= fm else MFMA_F32_PEAK_TFLOPS,
                     "unit": "GB/s" if fh >= fm else "TFLOP/s", "frac": max(fh, fm), "traffic": traffic,
-                    "traffic_source": None if traffic is None else "stored profile value (profiles/traffic.json, tag %s; 2*FETCH_SIZE + WRITE_SIZE per launch, "
+                    "traffic_source": ("profiles/traffic.json was collected on other library sources than this build: no value"
+                                       if ttag == "stale" else None) if traffic is None else
+                                      "stored profile value (profiles/traffic.json, tag %s, same library sources; 2*FETCH_SIZE + WRITE_SIZE per launch, "
                                       "beyond-L2 bytes incl. Infinity-Cache hits), not measured in this run" % ttag,
                     "algorithmic_bytes_per_launch": e["bytes"] / e["launches"], "flops_per_launch": e["flops"] / e["launches"],
                     "avg_kernel_us": us, "launches_per_step": e["launches"], "share_of_kernel_time": None,
@@ -654,6 +906,10 @@ def main():
             "value_at_median": windows / (float(np.median(per_ms)) * 1e-3) if genome else None,
             "roofline": roof, "roofline_top3": top3 if roof else None, "cpu_baseline": cpu, "final_loss": final_loss,
         }
+        if args.probe:
+            out["probe"] = True
+        if ladder_rec is not None:
+            out["launch_ladder"] = ladder_rec
         out.update(extras)
         print(json.dumps(out))
         sys.stdout.flush()

@@ -24,6 +24,8 @@ _SIGNATURES = {
     "cgcn_layer_fwd": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 13 + [_c_float, _c_vp, _c_uint, _c_vp, _c_vp, _c_vp]),
     "cgcn_layer_fwd_colstats_tiles": (_c_int, [_c_int, _c_int, _c_int, _c_vp]),
     "cgcn_debug_set_fwd_split_bytes": (None, [ctypes.c_longlong]),
+    "cgcn_debug_layer_fwd_route": (_c_int, [_c_int, _c_int, _c_int, _c_vp]),
+    "cgcn_debug_layer_bwd_route": (_c_int, [_c_int, _c_int, _c_int]),
     "cgcn_layer_bwd_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
     "cgcn_layer_bwd": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 18 + [_c_int, _c_float, _c_vp, _c_uint, _c_vp, _c_vp, _c_sz, _c_vp, _c_vp, _c_vp]),
     "cgcn_debug_layer_bwd_phases": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 18 + [_c_int, _c_float, _c_vp, _c_uint, _c_vp, _c_vp, _c_sz, _c_int, _c_vp]),
@@ -44,7 +46,7 @@ _SIGNATURES = {
     "cgcn_multilabel_metrics": (_c_int, [_c_vp, ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_float, _c_vp, _c_vp, _c_sz]),
     "cgcn_sgd_step": (_c_int, [_c_vp, ctypes.c_longlong, _c_vp, _c_vp, _c_vp, _c_float, _c_float, _c_float, _c_int, _c_float, _c_vp]),
 }
-ABI_VERSION = 18
+ABI_VERSION = 19
 _lib = None
 
 
@@ -74,6 +76,13 @@ def load(build_if_missing=False):
         raise ChromeGCNLibraryError(
             "chromegcn_amd: %s is stale (sources changed since it was built) -- rebuild: "
             "python -m chromegcn_amd._build" % path)
+    _lib = open_library(path)
+    return _lib
+
+
+def open_library(path):
+    """ctypes handle of the library at `path` with every signature of include/chromegcn.h set (not cached: tuning
+    tools open a variant build beside the in-tree one)."""
     lib = ctypes.CDLL(path)
     for name, (res, args) in _SIGNATURES.items():
         try:
@@ -85,7 +94,6 @@ def load(build_if_missing=False):
     got = lib.cgcn_abi_version()
     if got != ABI_VERSION:
         raise ChromeGCNLibraryError("chromegcn_amd: ABI version %d != expected %d; rebuild" % (got, ABI_VERSION))
-    _lib = lib
     return lib
 
 

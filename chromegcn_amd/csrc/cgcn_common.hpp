@@ -119,16 +119,24 @@ __host__ __device__ __forceinline__ constexpr int head_part_stride(int CP, int D
 #define HEAD_STAT_COLS 16   // BatchNorm columns per workgroup of the statistics second stage
 
 // One 64-element slab of the head backward's second stage: elements [CP*D dW_out][CP db_out].
-template <int NT>
+// EXT: the staging buffer is the caller's LDS (`scratch`, NT floats) instead of a static array of this function -- a
+// kernel whose own tiles already fill the LDS lends them to its trailing workgroups.
+template <int NT, bool EXT = false>
 __device__ __forceinline__ void head_finalize_slab(int slab, int P, int D, int C, int CP,
                                                    const float* __restrict__ part, float* __restrict__ dWout,
                                                    float* __restrict__ dbout, int accumulate,
-                                                   const float* __restrict__ dloss) {
+                                                   const float* __restrict__ dloss, void* scratch = nullptr) {
   constexpr int NS = NT / 64;
   const float gl = dloss ? dloss[0] : 1.f;  // everything summed here is linear in the upstream d loss
   const int PS = head_part_stride(CP, D);
   const int total = CP * D + CP;
-  __shared__ __attribute__((aligned(16))) float hred[NS][64];
+  float (*hred)[64];
+  if constexpr (EXT) {
+    hred = (float (*)[64])scratch;
+  } else {
+    __shared__ __attribute__((aligned(16))) float hred_own[NS][64];
+    hred = hred_own;
+  }
   // lane = (el4, sub): 16 lanes x float4 cover the slab's 64 elements, the 4 sub-groups of a wave and the NS
   // waves each take a contiguous range of the P partials -> one or two batches of independent 16-byte loads
   // per thread instead of a long chain of 4-byte ones (the kernel is latency-, not bandwidth-limited).
@@ -177,13 +185,19 @@ __device__ __forceinline__ void head_finalize_slab(int slab, int P, int D, int C
 // (column, slice of the partial list); slices are merged through LDS in a fixed order => deterministic.
 // Writes d(bn bias) = sum dy, d(bn weight) = sum dy*xhat (both strands; scaled by the upstream d loss) and/or
 // bnc = the per-strand means for d loss = 1.
-template <int NT>
+template <int NT, bool EXT = false>
 __device__ __forceinline__ void head_stats_finalize(int blk, int P, int n, int S, int D, int CP,
                                                     const float* __restrict__ part, float* __restrict__ dbn_w,
                                                     float* __restrict__ dbn_b, float* __restrict__ bnc, int accumulate,
-                                                    const float* __restrict__ dloss) {
+                                                    const float* __restrict__ dloss, void* scratch = nullptr) {
   constexpr int NSL = NT / HEAD_STAT_COLS;
-  __shared__ double sred[4][NSL][HEAD_STAT_COLS + 1];
+  double (*sred)[NSL][HEAD_STAT_COLS + 1];   // EXT: 4 * NSL * 17 doubles of the caller's LDS (see head_finalize_slab)
+  if constexpr (EXT) {
+    sred = (double (*)[NSL][HEAD_STAT_COLS + 1])scratch;
+  } else {
+    __shared__ double sred_own[4][NSL][HEAD_STAT_COLS + 1];
+    sred = sred_own;
+  }
   const int cl = threadIdx.x % HEAD_STAT_COLS, slice = threadIdx.x / HEAD_STAT_COLS;
   const int c = blk * HEAD_STAT_COLS + cl;
   const int PS = head_part_stride(CP, D);

@@ -1182,79 +1182,138 @@ __global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, i
 }
 
 // ------------------------------------------------------------------------------------------
-// k_bwd_rowlocal_rs (D = 128): the same work as k_bwd_rowlocal<128, 32> with the 16 waves split by PIPE instead of by
-// product: waves 0-7 ("row team") stream the four row tensors and do all the row math on the vector pipe; waves 8-15
-// ("matrix team") do both MFMA products -- dW += Ht^T Ut (16 rows of dW each) and dHs = diag(rs) Ut W^T (16 columns
-// each) -- one tile behind, from the LDS tiles the row team left.  One barrier per 32-row tile.
-// Why: in k_bwd_rowlocal every wave alternates a row pass and a product, holds accumulators / W^T fragments AND one
-// tile of rows in 124 of 128 registers, and its loads have ONE phase of flight time: the stream (33 us alone at
-// n = 29 k) and the products (24 us floor) added up to 70 us.  The two teams run SEPARATE loops (each role's state on
-// its own path for the register allocator, like k_head_fused_rs): the row team has no accumulators, so it keeps TWO
-// tiles of rows in flight (64 registers); the matrix team has no rows, so both products' operands fit with a one-step
-// software pipeline of LDS reads.  Same results as k_bwd_rowlocal up to the order of the column sums.
+// k_bwd_rowlocal_ring (D = 128): the work of k_bwd_rowlocal<128, 32> as a PRODUCER / CONSUMER pair of wave teams that
+// meet only through a ring of LDS slots with counted flags -- no workgroup barrier between the first tile and the last.
+//   row team    (waves 0-7):  streams Z, X, H, dL/dXn (16 B per lane, one wave instruction = 2 rows), RING_PF slots of
+//                             rows in flight in registers, all the row math (head prologue, gate / tanh derivatives,
+//                             column sums), writes the H and dU operand tiles of a 16-row slot, then bumps FULL[slot];
+//   matrix team (waves 8-15): waits for FULL[slot], both fp32 MFMA products from the slot -- dW += H^T dU (16 rows of dW
+//                             per wave) and dHs = diag(row_scale) dU W^T (16 columns per wave, W^T fragments resident)
+//                             -- interleaved MFMA by MFMA (the single dHs accumulation chain never waits for its own
+//                             result), bumps FREE[slot] as soon as its last operand has left the LDS, stores dHs from
+//                             the accumulators.
+// Why (profiles/r03_stream_vs_mfma_microbench.txt, r03_rowlocal_rs_experiment.txt): a 5.5 TB/s stream and 120-130 TF/s
+// of LDS-fed fp32 MFMA share a CU at max(stream, MFMA) when they run in waves that never wait for one another; the
+// shipped kernel and three role-split versions of it with ONE workgroup barrier per tile all ran at stream + MFMA (47 %
+// of the wave-cycles parked at s_barrier / s_waitcnt): behind a barrier every interval lasts as long as the slowest of
+// 16 waves.  Here a wave only ever waits for the slot it needs: RING_SLOTS x 16 rows of slack between the teams.
+//   flags: FULL[s] / FREE[s] are monotonic arrival counters in LDS (8 arrivals per use of the slot); an arrival is
+//   s_waitcnt lgkmcnt(0) (the wave's own LDS writes / reads of the slot have completed) + one ds_add_u32 by lane 0; a
+//   wait is a ds_read_b32 poll with s_sleep.  The LDS is one coherent memory for the workgroup: no fence, no cache.
+//   slots: 16 rows x 128 floats, UNPADDED, 16-byte chunks XOR-swizzled by the row so that every access pattern is
+//   bank-conflict free: H chunk c of row k sits at c ^ 4(k & 1) (column-wise ds_read_b32 A operands), dU chunk c of row
+//   k at c ^ k (ds_read_b128 of 4 consecutive columns of row 4kk+q as B operands of four dW MFMAs -- the MFMA's column
+//   index r stands for column 64h + 4r + u, the partial is stored accordingly -- and ds_read_b128 of 4 consecutive K
+//   values of row r as A operands of four dHs MFMAs).
+//   work split: workgroup b owns the contiguous slots [b NST / P, (b + 1) NST / P): every workgroup within one 16-row
+//   slot of the mean (32-row tiles dealt round robin: 7.3 tiles per workgroup ran as 8 at chr1 size).
 //   partial layout per workgroup: [D*D dW][D db][D dwg][1 dcg][3 pad]   (as k_bwd_rowlocal)
+// Results equal k_bwd_rowlocal's up to the summation order inside a row and over the rows; bit-reproducible run to run
+// (every sum has a fixed order: no atomics on data).
 // ------------------------------------------------------------------------------------------
-#ifndef RL_RS
-#define RL_RS 0   // 1: the role-split kernel on the large tables (measured: no gain, profiles/r03_rowlocal_rs_experiment.txt)
+#ifndef RL_RING
+#define RL_RING 1
 #endif
+#ifndef RING_SLOTS
+#define RING_SLOTS 8
+#endif
+#ifndef RING_ROW_WAVES
+#define RING_ROW_WAVES 4 // 4: 12-wave workgroups, 3 waves per SIMD (1 row + 2 matrix), <= 168 registers; 8: 16 waves, <= 128
+#endif
+#define RING_THREADS ((RING_ROW_WAVES + 8) * 64)
+#ifndef RING_PF
+#define RING_PF 3        // slots of rows a row wave keeps in flight in registers
+#endif
+#ifndef RING_PF_HEAD
+#define RING_PF_HEAD 2   // ... in head mode (the head prologue needs ~25 more registers per row pair)
+#endif
+#ifndef RING_PRIO
+#define RING_PRIO 1      // s_setprio of the matrix team (measured: 0 -> 1: 51.3 -> 45.6 us at n = 29 910)
+#endif
+#ifndef RING_PRIME
+#define RING_PRIME 1     // matrix team: request the next slot's first operands under the current slot's last MFMAs
+#endif
+__device__ __forceinline__ void ring_wait(const unsigned* flag, unsigned target) {
+  while (true) {
+    const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    if ((int)(v - target) >= 0) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  asm volatile("" ::: "memory");   // nothing of the slot is read or written ahead of the poll
+}
+__device__ __forceinline__ void ring_arrive(unsigned* flag, int lane) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS accesses of the slot have completed
+  if (lane == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// Sum over each 32-lane half of the wave, the half's total in every lane of the half (all lanes active).
+__device__ __forceinline__ float half_sum(float v, bool upper) {
+  v += dpp_get<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+  v += dpp_get<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+  v += dpp_get<0x141, 0xF>(v);   // row_half_mirror
+  v += dpp_get<0x140, 0xF>(v);   // row_mirror: every lane holds its row's total
+  v += dpp_get<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3: they hold the totals of lanes 0-31 / 32-63
+  const float lo = rl_f(v, 31), hi = rl_f(v, 63);
+  return upper ? hi : lo;
+}
 // HEAD: the last layer (dL/dXn recomputed from the head's backward state, HeadApply); DROP: ... with the head's dropout
 template <bool HEAD, bool DROP>
-__global__ __launch_bounds__(1024) void k_bwd_rowlocal_rs(int M, int n, const float* __restrict__ dXn,
-                                                          const float* __restrict__ Z, const float* __restrict__ X,
-                                                          const float* __restrict__ gate, const float* __restrict__ dgate,
-                                                          const float* __restrict__ H, const float* __restrict__ wg,
-                                                          const float* __restrict__ rs, float* __restrict__ dHs,
-                                                          float* __restrict__ part, HeadApply hp,
-                                                          float* __restrict__ dxn_store, int row_blocks, int head_slabs,
-                                                          const float* __restrict__ W) {
-  constexpr int D = 128, TR = 32, NW = 16, EPL = 2, JB = D / 16;
-  if ((int)blockIdx.x >= row_blocks) {   // extra workgroups: the head's deferred second stage (see k_bwd_rowlocal)
-    const int extra = (int)blockIdx.x - row_blocks;
+__global__ __launch_bounds__(RING_THREADS) void k_bwd_rowlocal_ring(int M, int n, const float* __restrict__ dXn,
+                                                            const float* __restrict__ Z, const float* __restrict__ X,
+                                                            const float* __restrict__ gate, const float* __restrict__ dgate,
+                                                            const float* __restrict__ H, const float* __restrict__ wg,
+                                                            const float* __restrict__ rs, float* __restrict__ dHs,
+                                                            float* __restrict__ part, HeadApply hp,
+                                                            float* __restrict__ dxn_store, int row_blocks, int head_slabs,
+                                                            const float* __restrict__ W) {
+  constexpr int D = 128, SR = 16, NSL = RING_SLOTS, PF = HEAD ? RING_PF_HEAD : RING_PF;
+  constexpr int NRW = RING_ROW_WAVES;          // row-team waves (the matrix team always has 8: one per 16 rows of dW)
+  constexpr int NT = RING_THREADS;
+  constexpr int RT = SR / (2 * NRW);           // row PAIRS (one wave instruction = 2 rows) per row wave per slot
+  static_assert(NRW * 2 * RT == SR && (NRW == 4 || NRW == 8), "row-team geometry");
+  constexpr int PSTRIDE = D * D + 2 * D + 4;
+  constexpr int RS = 2 * D + 4;
+  __shared__ __attribute__((aligned(16))) float Hs[NSL][SR * D];
+  if ((int)blockIdx.x >= row_blocks) {   // extra workgroups: the head's deferred second stage (see k_bwd_rowlocal); they
+    const int extra = (int)blockIdx.x - row_blocks;      // stage through the (here unused) ring memory
     const int wslabs = (hp.hf_CP * D + hp.hf_CP) / 64;
+    static_assert(sizeof(Hs) >= 4 * (NT / HEAD_STAT_COLS) * (HEAD_STAT_COLS + 1) * sizeof(double), "finalize staging fits the H ring");
     if (extra < wslabs)
-      head_finalize_slab<NW * 64>(extra, hp.hf_P, D, hp.hf_C, hp.hf_CP, hp.hf_part, hp.hf_dWout, hp.hf_dbout,
-                                  hp.hf_accumulate, hp.dloss);
+      head_finalize_slab<NT, true>(extra, hp.hf_P, D, hp.hf_C, hp.hf_CP, hp.hf_part, hp.hf_dWout, hp.hf_dbout,
+                                   hp.hf_accumulate, hp.dloss, &Hs[0][0]);
     else
-      head_stats_finalize<NW * 64>(extra - wslabs, hp.hf_P, n, hp.S, D, hp.hf_CP, hp.hf_part, hp.hf_dbn_w, hp.hf_dbn_b,
-                                   nullptr, hp.hf_accumulate, hp.dloss);
+      head_stats_finalize<NT, true>(extra - wslabs, hp.hf_P, n, hp.S, D, hp.hf_CP, hp.hf_part, hp.hf_dbn_w, hp.hf_dbn_b,
+                                    nullptr, hp.hf_accumulate, hp.dloss, &Hs[0][0]);
     return;
   }
-  constexpr int LD = D + RL_LD_PAD;
-  constexpr int PSTRIDE = D * D + 2 * D + 4;
-  constexpr int RPW = TR / 8;          // rows per row-team wave per tile
-  __shared__ __attribute__((aligned(16))) float Ht[2][TR * LD];
-  __shared__ __attribute__((aligned(16))) float Ut[2][TR * LD];
-  __shared__ float Sc[2][TR];          // row_scale of the tile's rows (0 past the end)
+  __shared__ __attribute__((aligned(16))) float Us[NSL][SR * D];
+  __shared__ __attribute__((aligned(16))) float Sc[NSL][SR];   // row_scale of the slot's rows (0 past the end)
   __shared__ __attribute__((aligned(16))) float Hc[HEAD ? 9 * D : 4];   // head mode: BatchNorm constants (row team)
+  __shared__ __attribute__((aligned(16))) float red[NRW][RS];  // column sums of the row waves
+  __shared__ unsigned flg[2 * NSL + 1];                        // FULL[0..NSL), FREE[NSL..2 NSL), DONE (row team's column sums)
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int own = wave & 7;
-  const int ntiles = (M + TR - 1) / TR;
-  const int tile0 = blockIdx.x;
-  const int nt = tile0 < ntiles ? (ntiles - 1 - tile0) / row_blocks + 1 : 0;   // tiles of this workgroup
+  const int NST = (M + SR - 1) / SR;
+  const int s_begin = (int)((long long)blockIdx.x * NST / row_blocks);
+  const int ns = (int)((long long)(blockIdx.x + 1) * NST / row_blocks) - s_begin;   // slots of this workgroup
   float* P = part + (size_t)blockIdx.x * PSTRIDE;
-  KT_STAMP_NW(4, 0, true);
-#define OPAQUE_LANE(r_, q_, l_)          \
-  int l_ = lane;                         \
-  asm volatile("" : "+v"(l_));           \
-  const int r_ = l_ & 15, q_ = l_ >> 4
+  if (threadIdx.x < 2 * NSL + 1) flg[threadIdx.x] = 0u;
+  unsigned* const FULL = flg;
+  unsigned* const FREE = flg + NSL;
+  unsigned* const DONE = flg + 2 * NSL;
 
-  if (wave < 8) {
+  if (wave < NRW) {
     // =============================================================== row team
-    float wgl[EPL], db_acc[EPL], dwg_acc[EPL];
+    const bool upper = lane >= 32;
+    const int l = lane & 31;
+    const int row0 = 2 * wave + (upper ? 1 : 0);   // this half-wave's rows inside a slot: row0 + 2 NRW t, t < RT
+    const f32x4 wgl = *(const f32x4*)&wg[4 * l];
+    f32x4 db_acc = {0.f, 0.f, 0.f, 0.f}, dwg_acc = {0.f, 0.f, 0.f, 0.f};
     float dcg_acc = 0.f;
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-      wgl[e] = wg[lane * EPL + e];
-      db_acc[e] = dwg_acc[e] = 0.f;
-    }
     const uint32_t hkey = (HEAD && DROP) ? dropout_key(hp.rng_state, HEAD_STREAM_ID) : 0u;
     const float hgl = (HEAD && hp.dloss) ? hp.dloss[0] : 1.f;
-    // head mode: the per-column BatchNorm constants of both strands in LDS (a row's strand is m >= n): [s][invstd, mean,
-    // c0, c1][D] and bn weight; staged by this team before its first row pass (the first workgroup barrier orders it)
-    if (HEAD) {
-      for (int i = threadIdx.x; i < 2 * D; i += 512) {
+    if (HEAD) {   // per-column BatchNorm constants of both strands: [s][invstd, mean, c0, c1][D], then bn weight
+      for (int i = threadIdx.x; i < 2 * D; i += NRW * 64) {
         const int s = i / D, c = i % D, ss = s < hp.S ? s : 0;
         Hc[(s * 4 + 0) * D + c] = hp.invstd[ss * D + c];
         Hc[(s * 4 + 1) * D + c] = hp.mean[ss * D + c];
@@ -1262,265 +1321,227 @@ __global__ __launch_bounds__(1024) void k_bwd_rowlocal_rs(int M, int n, const fl
         Hc[(s * 4 + 3) * D + c] = hp.bnc[(ss * 2 + 1) * D + c];
         if (s == 0) Hc[8 * D + c] = hp.bn_w[c];
       }
-      __syncthreads();   // (matched by the matrix team)
     }
-    // two register sets of rows: tile it is consumed from set it & 1 while the loads of tile it + 1 are in flight in the
-    // other set and those of tile it + 2 are issued into this one right after its row pass
-    float gupA[RPW][EPL], zA[RPW][EPL], xA[RPW][EPL], hA[RPW][EPL], gtA[RPW];
-    float gupB[RPW][EPL], zB[RPW][EPL], xB[RPW][EPL], hB[RPW][EPL], gtB[RPW];
-    auto load_tile = [&](int tile, float (&gup)[RPW][EPL], float (&z)[RPW][EPL], float (&x)[RPW][EPL], float (&h)[RPW][EPL],
-                         float (&gt)[RPW]) {
+    struct Rows { f32x4 z[RT], x[RT], h[RT], g[RT]; float gt[RT], sc[RT]; };
+    Rows R_[PF];
+    auto load_slot = [&](int it, Rows& w) {
 #pragma unroll
-      for (int t = 0; t < RPW; ++t) {
-        const int m = tile * TR + own + t * 8;
-        const bool ok = m < M;
-        const unsigned off = (unsigned)(m * D + lane * EPL);
-#ifdef RLRS_SKIP_LOADS
-        if (false) {
+      for (int t = 0; t < RT; ++t) {
+        const int m = (s_begin + it) * SR + row0 + 2 * NRW * t;
+#ifdef RING_SKIP_LOADS
+        const bool ok = false;
 #else
-        if (ok) {
+        const bool ok = m < M;
 #endif
-          ld_row<EPL>(z[t], &Z[off]);
-          ld_row<EPL>(x[t], &X[off]);
-          ld_row<EPL>(h[t], &H[off]);
-          ld_row<EPL>(gup[t], HEAD ? &hp.dym[(unsigned)((m >= n ? m - n : m) * D + lane * EPL)] : &dXn[off]);  // S <= 2
-        } else {
-          zero_row<EPL>(z[t]);
-          zero_row<EPL>(x[t]);
-          zero_row<EPL>(h[t]);
-          zero_row<EPL>(gup[t]);
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        w.z[t] = w.x[t] = w.h[t] = w.g[t] = zero;
+        w.gt[t] = 0.f;
+        w.sc[t] = 0.f;
+        if (ok) {
+          const unsigned off = (unsigned)(m * D + 4 * l);
+          const int mi = m >= n ? m - n : m;   // S <= 2
+          w.z[t] = *(const f32x4*)&Z[off];
+          w.x[t] = *(const f32x4*)&X[off];
+          w.h[t] = *(const f32x4*)&H[off];
+          w.g[t] = HEAD ? *(const f32x4*)&hp.dym[(unsigned)(mi * D + 4 * l)] : *(const f32x4*)&dXn[off];
+          w.gt[t] = gate[m];
+          w.sc[t] = rs ? rs[mi] : 1.f;
         }
-        gt[t] = ok ? gate[m] : 0.f;
       }
     };
-    // row math of the loaded tile -> H and dU tiles (and the row scales) in LDS buffer `buf` (k_bwd_rowlocal::row_pass,
-    // written without a branch per row: with one, the RPW rows of a wave ran as RPW serial chains; rows past M were
-    // loaded as zeros -- gate 0, so gamma = dU = 0 -- and only their stores are predicated)
-    auto row_pass = [&](int tile, int buf, float (&gup)[RPW][EPL], float (&z)[RPW][EPL], float (&x)[RPW][EPL],
-                        float (&h)[RPW][EPL], float (&gt)[RPW]) {
-      int lane_ = lane;
-      asm volatile("" : "+v"(lane_));
-      float dg[RPW];
+    auto row_pass = [&](int it, Rows& w) {
+      f32x4 du[RT];
 #pragma unroll
-      for (int t = 0; t < RPW; ++t) {
-        const int m = tile * TR + own + t * 8;
-        const unsigned off = (unsigned)(m * D + lane_ * EPL);
-        const float g = gt[t];
+      for (int t = 0; t < RT; ++t) {
+        const int m = (s_begin + it) * SR + row0 + 2 * NRW * t;
+        const unsigned off = (unsigned)(m * D + 4 * l);
+        const float g = w.gt[t];
+        f32x4 gup = w.g[t];
         if (HEAD) {   // dL/dXn of the last layer from the head's backward state (see HeadApply)
           const int s = m >= n ? 1 : 0;   // S <= 2
           const float invS = 1.f / (float)hp.S;
-          const float* __restrict__ hc = Hc + s * 4 * D + lane_ * EPL;
-          const f32x2 is2 = *(const f32x2*)&hc[0], mu2 = *(const f32x2*)&hc[D], c02 = *(const f32x2*)&hc[2 * D], c12 = *(const f32x2*)&hc[3 * D];
-          const f32x2 bw2 = *(const f32x2*)&Hc[8 * D + lane_ * EPL];
+          const float* __restrict__ hc = Hc + s * 4 * D + 4 * l;
+          const f32x4 is4 = *(const f32x4*)&hc[0], mu4 = *(const f32x4*)&hc[D], c04 = *(const f32x4*)&hc[2 * D], c14 = *(const f32x4*)&hc[3 * D];
+          const f32x4 bw4 = *(const f32x4*)&Hc[8 * D + 4 * l];
 #pragma unroll
-          for (int e = 0; e < EPL; ++e) {
-            const float is = is2[e], mu = mu2[e], c0 = c02[e], c1 = c12[e];
-            const float xn = (1.f - g) * x[t][e] + g * z[t][e];
-            float dy = gup[t][e] * invS * hgl;
+          for (int e = 0; e < 4; ++e) {
+            const float xn = (1.f - g) * w.x[t][e] + g * w.z[t][e];
+            float dy = gup[e] * invS * hgl;
             if (DROP) dy = dropout_keep(hkey, (uint32_t)(off + e), hp.thresh) ? dy * hp.keep_scale : 0.f;
-            const float xh = (fmaxf(xn, 0.f) - mu) * is;
-            const float dr = bw2[e] * is * (dy - hgl * c0 - xh * (hgl * c1));
-            gup[t][e] = xn > 0.f ? dr : 0.f;
+            const float xh = (fmaxf(xn, 0.f) - mu4[e]) * is4[e];
+            const float dr = bw4[e] * is4[e] * (dy - hgl * c04[e] - xh * (hgl * c14[e]));
+            gup[e] = xn > 0.f ? dr : 0.f;
           }
-          if (dxn_store && m < M) st_row<EPL>(&dxn_store[off], gup[t]);  // k_bwd_sliced reads it back as dL/dXn for the (1-g) dXn term
+          if (dxn_store && m < M) *(f32x4*)&dxn_store[off] = gup;   // k_bwd_sliced reads it back as dL/dXn for the (1-g) dXn term
         }
         float a = 0.f;
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) a += gup[t][e] * (z[t][e] - x[t][e]);
-        dg[t] = a;
-      }
+        for (int e = 0; e < 4; ++e) a += gup[e] * (w.z[t][e] - w.x[t][e]);
+        float dg = half_sum(a, upper);
+        if (dgate) dg += m < M ? dgate[m] : 0.f;   // an upstream gradient on the gate output itself: rare, read in place
+        const float gamma = g * (1.f - g) * dg;
 #pragma unroll
-      for (int t = 0; t < RPW; ++t) dg[t] = wave_sum(dg[t]);   // RPW independent DPP chains
-      if (dgate) {   // an upstream gradient on the gate output itself (return_gate consumers): rare, read in place
-#pragma unroll
-        for (int t = 0; t < RPW; ++t) {
-          const int m = tile * TR + own + t * 8;
-          dg[t] += m < M ? dgate[m] : 0.f;
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < RPW; ++t) {
-        const int trow = own + t * 8;
-        const int m = tile * TR + trow;
-        const float g = gt[t];
-        const float gamma = g * (1.f - g) * dg[t];
-        float du[EPL];
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-          const float dz = g * gup[t][e] + gamma * wgl[e];
-          du[e] = dz * (1.f - z[t][e] * z[t][e]);
-          db_acc[e] += du[e];
-          dwg_acc[e] += gamma * z[t][e];
+        for (int e = 0; e < 4; ++e) {
+          const float dz = g * gup[e] + gamma * wgl[e];
+          du[t][e] = dz * (1.f - w.z[t][e] * w.z[t][e]);
+          db_acc[e] += du[t][e];
+          dwg_acc[e] += gamma * w.z[t][e];
         }
         dcg_acc += gamma;
-        const int mi = m < M ? (m >= n ? m - n : m) : 0;
-        const float sc = m < M ? (rs ? rs[mi] : 1.f) : 0.f;
-        if (lane_ == 0) Sc[buf][trow] = sc;
-        *(f32x2*)&Ht[buf][trow * LD + lane_ * EPL] = (f32x2){h[t][0], h[t][1]};
-        *(f32x2*)&Ut[buf][trow * LD + lane_ * EPL] = (f32x2){du[0], du[1]};
       }
-    };
-    if (nt > 0) load_tile(tile0, gupA, zA, xA, hA, gtA);
-    if (nt > 1) load_tile(tile0 + row_blocks, gupB, zB, xB, hB, gtB);
-    for (int it = 0; it <= nt; it += 2) {   // two periods per trip: register set A, then B (static register indexing)
-      KT_STAMP_NW(0, 0, it == KT_PERIOD);
-#ifdef RLRS_SKIP_ROWTEAM
-      if (false) {
-#else
-      if (it < nt) {
-#endif
-        row_pass(tile0 + it * row_blocks, 0, gupA, zA, xA, hA, gtA);
-        KT_STAMP_NW(1, 0, it == KT_PERIOD);
-        if (it + 2 < nt) load_tile(tile0 + (it + 2) * row_blocks, gupA, zA, xA, hA, gtA);
-      }
-      KT_STAMP_NW(2, 0, it == KT_PERIOD);
-      __syncthreads();
-      KT_STAMP_NW(3, 0, it == KT_PERIOD);
-      if (it + 1 > nt) break;
-#ifdef RLRS_SKIP_ROWTEAM
-      if (false) {
-#else
-      if (it + 1 < nt) {
-#endif
-        row_pass(tile0 + (it + 1) * row_blocks, 1, gupB, zB, xB, hB, gtB);
-        if (it + 3 < nt) load_tile(tile0 + (it + 3) * row_blocks, gupB, zB, xB, hB, gtB);
-      }
-      __syncthreads();
-    }
-    // column sums: combine the 8 row waves through LDS in a fixed order (the tile buffers are idle now)
-    __syncthreads();   // (the matrix team's last products are done)
-    float* red = Ht[0];  // [8][2*D + 1]
-    constexpr int RS = 2 * D + 1;
+      const int slot = it % NSL;
+      if (it >= NSL) ring_wait(&FREE[slot], 8u * (unsigned)(it / NSL));   // the matrix team is done with the slot's last use
+#ifndef RING_SKIP_MFMA
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-      red[own * RS + lane * EPL + e] = db_acc[e];
-      red[own * RS + D + lane * EPL + e] = dwg_acc[e];
-    }
-    if (lane == 0) red[own * RS + 2 * D] = dcg_acc;
+      for (int t = 0; t < RT; ++t) {   // swizzled chunk positions (see the header)
+        const int rowi = row0 + 2 * NRW * t;
+        *(f32x4*)&Hs[slot][rowi * D + ((l ^ ((rowi & 1) << 2)) << 2)] = w.h[t];
+        *(f32x4*)&Us[slot][rowi * D + ((l ^ rowi) << 2)] = du[t];
+        if (l == 0) Sc[slot][rowi] = w.sc[t];
+      }
+#endif
+      ring_arrive(&FULL[slot], lane);
+    };
+#ifdef RING_SKIP_ROWTEAM
     __syncthreads();
-    for (int c = threadIdx.x; c < RS; c += 512) {
+    for (int it = 0; it < ns; ++it) {
+      if (it >= NSL) ring_wait(&FREE[it % NSL], 8u * (unsigned)(it / NSL));
+      ring_arrive(&FULL[it % NSL], lane);
+    }
+#else
+#pragma unroll
+    for (int j = 0; j < PF; ++j)
+      if (j < ns) load_slot(j, R_[j]);
+    __syncthreads();   // flags zeroed, head constants staged (matched by the matrix team): THE barrier of this kernel; the
+                       // first slots' rows are already on their way
+    for (int it0 = 0; it0 < ns; it0 += PF) {   // PF slots per trip: static register-set indexing
+#pragma unroll
+      for (int j = 0; j < PF; ++j) {
+        const int it = it0 + j;
+        if (it < ns) {
+          row_pass(it, R_[j]);
+          if (it + PF < ns) load_slot(it + PF, R_[j]);
+        }
+      }
+    }
+#endif
+    // column sums: the two halves of a wave hold the same columns; combine them, then the row waves through LDS in a fixed order
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      db_acc[e] += __shfl_xor(db_acc[e], 32);
+      dwg_acc[e] += __shfl_xor(dwg_acc[e], 32);
+    }
+    dcg_acc += __shfl_xor(dcg_acc, 32);
+    if (!upper) {
+      *(f32x4*)&red[wave][4 * l] = db_acc;
+      *(f32x4*)&red[wave][D + 4 * l] = dwg_acc;
+      if (l == 0) red[wave][2 * D] = dcg_acc;
+    }
+    ring_arrive(DONE, lane);   // among the row waves only: the matrix team is still on its last slots
+    ring_wait(DONE, (unsigned)NRW);
+    for (int c = threadIdx.x; c < 2 * D + 1; c += NRW * 64) {
       float sacc = 0.f;
-      for (int w = 0; w < 8; ++w) sacc += red[w * RS + c];
+#pragma unroll
+      for (int w = 0; w < NRW; ++w) sacc += red[w][c];
       P[D * D + c] = sacc;
     }
-    KT_STAMP_NW(5, 0, true);
   } else {
-    // =============================================================== matrix team, one tile behind
-    f32x4 accW[JB], WT[JB];
+    // =============================================================== matrix team
+    const int own = wave - NRW;   // 16 rows of dW / 16 columns of dHs
+    int lq = lane;
+    asm volatile("" : "+v"(lq));
+    const int r = lq & 15, q = lq >> 4;
+    f32x4 accW[8], WT[8];
 #pragma unroll
-    for (int jb = 0; jb < JB; ++jb) accW[jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    {
-      const int r = lane & 15, q = lane >> 4;
-      // W^T fragments of this wave's 16 output columns of dHs: B operand of k-step (t, u) = W[16 own + r][16 t + 4 q + u]
+    for (int i = 0; i < 8; ++i) accW[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // W^T fragments of this wave's 16 output columns of dHs: B operand of k-step (t, u) = W[16 own + r][16 t + 4 q + u]
 #pragma unroll
-      for (int t = 0; t < JB; ++t) WT[t] = dHs ? *(const f32x4*)&W[(size_t)(16 * own + r) * D + 16 * t + 4 * q] : (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    if (HEAD) __syncthreads();   // the row team's staging of the head constants
-#ifndef RLRS_PRIO
-#define RLRS_PRIO 0
-#endif
-    // the matrix waves issue ahead of the (older) row waves that share their SIMDs: an MFMA takes the issue port for a
-    // quarter of its 32 cycles and the row math fills the rest, but not the other way round
-    if (RLRS_PRIO) __builtin_amdgcn_s_setprio(RLRS_PRIO);
-    for (int it = 0; it <= nt; ++it) {
-      KT_STAMP_NW(8, 512, it == KT_PERIOD);
-#ifdef RLRS_SKIP_MFMA
-      if (false) {
-#else
-      if (it >= 1) {
-#endif
-        const int buf = (it - 1) & 1;
-        const int tile = tile0 + (it - 1) * row_blocks;
-        OPAQUE_LANE(r, q, lq);
-        {   // dW += Ht^T Ut  (K = TR rows): this wave's 16 rows of dW (H columns 16 own ..), all 8 column blocks; the
-            // operands of k-step kk + 1 are read under the MFMAs of step kk
-          const float* __restrict__ Ha = Ht[buf] + q * LD + own * 16 + r;
-          const float* __restrict__ Ua = Ut[buf] + q * LD + r;
-          float a0, a1, b0[JB], b1[JB];
-          a0 = Ha[0];
+    for (int t = 0; t < 8; ++t) WT[t] = dHs ? *(const f32x4*)&W[(size_t)(16 * own + r) * D + 16 * t + 4 * q] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();   // flags zeroed (and the row team's staging of the head constants)
+    if (RING_PRIO) __builtin_amdgcn_s_setprio(RING_PRIO);
+    // operand offsets inside a slot (floats), see the header for the swizzles
+    //   dW A: H[4 kk + q][16 own + r]            -> + kk * 4 D
+    const int ha_off = q * D + (((4 * own + (r >> 2)) ^ ((q & 1) << 2)) << 2) + (r & 3);
+    //   dW B: dU[4 kk + q][64 h + 4 r .. + 3]    -> chunk (16 h + r) ^ (4 kk + q) = 16 h + 4 ((r >> 2) ^ kk) + ((r & 3) ^ q)
+    const int ub_lo = q * D + (((r & 3) ^ q) << 2);
+    //   dHs A: dU[r][16 t + 4 q .. + 3]          -> chunk (4 t + q) ^ r = 4 (t ^ (r >> 2)) + (q ^ (r & 3))
+    const int ua_lo = r * D + ((q ^ (r & 3)) << 2);
+    const int rq = r >> 2;
+    const unsigned dh_lane = (unsigned)(4 * q * D + own * 16 + r);   // this lane's element of a slot's dHs rows
+    // Software pipeline across slots: under the last MFMA step of a slot the next slot's FULL flag is looked at (not
+    // waited for) and, if it is up, its first operand set is requested, so a slot whose rows are ready starts without
+    // an LDS round trip; otherwise the wave polls at the top of the next trip.
+    float av[4];
+    f32x4 bv[3], uv[3];
+    bool primed = false;
+    auto rd = [&](const float* __restrict__ Hb, const float* __restrict__ Ub, int s) {
+      const int kk = s >> 1, h = s & 1;
+      if (h == 0) av[kk] = Hb[ha_off + kk * 4 * D];
+      bv[s % 3] = *(const f32x4*)&Ub[ub_lo + kk * 4 * D + 64 * h + ((rq ^ kk) << 4)];
+      uv[s % 3] = *(const f32x4*)&Ub[ua_lo + (((s & 3) ^ rq) << 4) + (s & 4) * 16];
+    };
+    for (int it = 0; it < ns; ++it) {
+      const int slot = it % NSL;
+#ifndef RING_SKIP_MFMA
+      const float* __restrict__ Hb = Hs[slot];
+      const float* __restrict__ Ub = Us[slot];
+      if (!primed) {
+        ring_wait(&FULL[slot], (unsigned)NRW * (unsigned)(it / NSL + 1));
+        rd(Hb, Ub, 0);
+      }
+      rd(Hb, Ub, 1);
+      const f32x4 sc_cur = *(const f32x4*)&Sc[slot][4 * q];
+      primed = false;
+      const int nslot = (it + 1) % NSL;
+      unsigned nflag = 0u;
+      f32x4 hacc = {0.f, 0.f, 0.f, 0.f};
+      // step s = (kk, h) = (s >> 1, s & 1) of the dW product and k-step block t = s of the dHs product; operands of step
+      // s + 2 are requested before the MFMAs of step s
 #pragma unroll
-          for (int jb = 0; jb < JB; ++jb) b0[jb] = Ua[jb * 16];
-#pragma unroll
-          for (int kk = 0; kk < TR / 4; kk += 2) {
-            a1 = Ha[(kk + 1) * 4 * LD];
-#pragma unroll
-            for (int jb = 0; jb < JB; ++jb) b1[jb] = Ua[(kk + 1) * 4 * LD + jb * 16];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int jb = 0; jb < JB; ++jb) accW[jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[jb], accW[jb], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kk + 2 < TR / 4) {
-              a0 = Ha[(kk + 2) * 4 * LD];
-#pragma unroll
-              for (int jb = 0; jb < JB; ++jb) b0[jb] = Ua[(kk + 2) * 4 * LD + jb * 16];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int jb = 0; jb < JB; ++jb) accW[jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[jb], accW[jb], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-          }
+      for (int s = 0; s < 8; ++s) {
+        if (s + 2 < 8) rd(Hb, Ub, s + 2);
+        if (s == 5 && RING_PRIME) nflag = __hip_atomic_load(&FULL[nslot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (s == 6) ring_arrive(&FREE[slot], lane);   // every operand of the slot is in registers (step 5's MFMAs covered the reads)
+        if (s == 7 && RING_PRIME && it + 1 < ns &&
+            (int)(__builtin_amdgcn_readfirstlane(nflag) - (unsigned)NRW * (unsigned)((it + 1) / NSL + 1)) >= 0) {
+          asm volatile("" ::: "memory");
+          primed = true;
+          rd(Hs[nslot], Us[nslot], 0);
         }
-        KT_STAMP_NW(9, 512, it == KT_PERIOD);
-        if (dHs) {   // dHs = diag(row_scale) Ut W^T: this wave's 16 output columns, both row blocks of the tile
-          const float* __restrict__ Ua = Ut[buf] + r * LD + 4 * q;
-#ifndef RLRS_DH_CHAINS
-#define RLRS_DH_CHAINS 2   // accumulation chains per row block (K split into halves by parity of the step), summed at the end
-#endif
-          f32x4 hacc[2 * RLRS_DH_CHAINS];
+        __builtin_amdgcn_sched_barrier(0);
+        const int kk = s >> 1, h = s & 1;
 #pragma unroll
-          for (int i = 0; i < 2 * RLRS_DH_CHAINS; ++i) hacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          f32x4 ua[2][2];
-          ua[0][0] = *(const f32x4*)&Ua[0];
-          ua[0][1] = *(const f32x4*)&Ua[16 * LD];
+        for (int u = 0; u < 4; ++u) {
+          accW[h * 4 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bv[s % 3][u], accW[h * 4 + u], 0, 0, 0);
+          hacc = __builtin_amdgcn_mfma_f32_16x16x4f32(uv[s % 3][u], WT[s][u], hacc, 0, 0, 0);
+          if (u < 3) __builtin_amdgcn_sched_barrier(0);   // keep the alternation: two links of the dHs chain are 64 cycles apart
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (dHs) {   // 64-byte row segments straight from the accumulators (32-bit offsets from the uniform base)
+        const int m0 = (s_begin + it) * SR + 4 * q;
+        const unsigned o = (unsigned)((s_begin + it) * SR * D) + dh_lane;
+        if ((s_begin + it) * SR + SR <= M) {
 #pragma unroll
-          for (int t = 0; t < JB; ++t) {
-            if (t + 1 < JB) {
-              ua[(t + 1) & 1][0] = *(const f32x4*)&Ua[16 * (t + 1)];
-              ua[(t + 1) & 1][1] = *(const f32x4*)&Ua[16 * LD + 16 * (t + 1)];
-            }
-            __builtin_amdgcn_sched_barrier(0);
+          for (int e = 0; e < 4; ++e) dHs[o + e * D] = hacc[e] * sc_cur[e];
+        } else {
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-              for (int mb = 0; mb < 2; ++mb) {
-                f32x4& h4 = hacc[mb + 2 * (u % RLRS_DH_CHAINS)];
-                h4 = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[t & 1][mb][u], WT[t][u], h4, 0, 0, 0);
-              }
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          if (RLRS_DH_CHAINS == 2) { hacc[0] += hacc[2]; hacc[1] += hacc[3]; }
-          if (RLRS_DH_CHAINS == 4) { hacc[0] += hacc[2]; hacc[1] += hacc[3]; hacc[4] += hacc[6]; hacc[5] += hacc[7]; hacc[0] += hacc[4]; hacc[1] += hacc[5]; }
-#pragma unroll
-          for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int trow = mb * 16 + q * 4 + e;
-              const int m = tile * TR + trow;
-              const float sc = Sc[buf][trow];
-#ifdef RLRS_SKIP_DHS_STORE
-              if (m < M && sc == 12345.f) dHs[(unsigned)(m * D + own * 16 + r)] = hacc[mb][e] * sc;
-#else
-              if (m < M) dHs[(unsigned)(m * D + own * 16 + r)] = hacc[mb][e] * sc;   // 64-byte row segments
-#endif
-            }
+          for (int e = 0; e < 4; ++e)
+            if (m0 + e < M) dHs[o + e * D] = hacc[e] * sc_cur[e];
         }
       }
-      KT_STAMP_NW(10, 512, it == KT_PERIOD);
-      __syncthreads();
-      KT_STAMP_NW(11, 512, it == KT_PERIOD);
+#else
+      ring_wait(&FULL[slot], (unsigned)NRW * (unsigned)(it / NSL + 1));
+      ring_arrive(&FREE[slot], lane);
+#endif
     }
-    // ---- this workgroup's dW partial
-    {
-      const int r = lane & 15, q = lane >> 4;
+    // ---- this workgroup's dW partial: accW[4 h + u][e] = dW[16 own + 4 q + e][64 h + 4 r + u]
 #pragma unroll
-      for (int jb = 0; jb < JB; ++jb)
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) P[(own * 16 + q * 4 + e) * D + jb * 16 + r] = accW[jb][e];
-    }
-    __syncthreads();   // the row team's column-sum staging
-    __syncthreads();
+      for (int e = 0; e < 4; ++e)
+        *(f32x4*)&P[(own * 16 + q * 4 + e) * D + 64 * h + 4 * r] = (f32x4){accW[h * 4 + 0][e], accW[h * 4 + 1][e], accW[h * 4 + 2][e], accW[h * 4 + 3][e]};
   }
-#undef OPAQUE_LANE
 }
 
 // Fused optimizer step (cgcn_sgd_fuse): torch.optim.SGD on the flat arenas, element `idx`, given its final gradient g.
@@ -2185,6 +2206,12 @@ int cgcn_layer_fwd_colstats_tiles(int n, int S, int d, int* rows_per_tile) {
   return (n + tn - 1) / tn;
 }
 
+int cgcn_debug_layer_fwd_route(int n, int S, int d, const cgcn_graph_aux* aux) {
+  const int rc = check_shape(n, S, d);
+  if (rc) return rc;
+  return (fwd_split_shape(n, S, d) || hub_graph(aux)) ? 1 : 0;
+}
+
 int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* rowptr, const int32_t* col, const float* val,
                    const float* row_scale, const float* X, const float* W, const float* b, const float* wg,
                    const float* cg, float* Xn, float* Z, float* H, float* gate, float dropout_p,
@@ -2256,12 +2283,29 @@ static int bwd_tile_rows(int n, int S, int d) {
   return (M > 32 * BWD_MAX_PARTIALS && M <= 48 * BWD_MAX_PARTIALS) ? 48 : 32;
 }
 
+// d = 128 above RING_MIN_ROWS rows: k_bwd_rowlocal_ring (16-row slots dealt in contiguous, balanced ranges)
+#ifndef RING_MIN_ROWS
+#define RING_MIN_ROWS 0
+#endif
+static bool bwd_ring(int n, int S, int d) { return RL_RING && d == 128 && (long long)n * S >= RING_MIN_ROWS; }
+
 static int bwd_partials(int n, int S, int d) {
   const int M = n * S;
+  if (bwd_ring(n, S, d)) {
+    const int nst = (M + 15) / 16;
+    return nst < 1 ? 1 : (nst < BWD_MAX_PARTIALS ? nst : BWD_MAX_PARTIALS);
+  }
   const int tr = bwd_tile_rows(n, S, d);
   const int ntiles = (M + tr - 1) / tr;
   int P = ntiles < BWD_MAX_PARTIALS ? ntiles : BWD_MAX_PARTIALS;
   return P < 1 ? 1 : P;
+}
+
+int cgcn_debug_layer_bwd_route(int n, int S, int d) {
+  const int rc = check_shape(n, S, d);
+  if (rc) return rc;
+  if (bwd_ring(n, S, d)) return 2;
+  return bwd_tile_rows(n, S, d) == 48 ? 1 : 0;
 }
 
 size_t cgcn_layer_bwd_workspace_bytes(int n, int S, int d) {
@@ -2330,14 +2374,14 @@ static int layer_bwd_impl(cgcn_stream_t stream, int n, int S, int d, const int32
   const int M = n * S;
   if (!(phases & 1)) {
     // profiling only: the partials / dHs / dL/dXn of an earlier full call are still in place
-  } else if (d == 128 && bwd_tile_rows(n, S, d) == 48)
+  } else if (d == 128 && !bwd_ring(n, S, d) && bwd_tile_rows(n, S, d) == 48)
     hipLaunchKernelGGL((k_bwd_rowlocal<128, 48>), dim3(P + head_slabs), dim3(1024), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, P, head_slabs, W);
-  else if (d == 128 && RL_RS) {
-#define RLRS(H_, D_) hipLaunchKernelGGL((k_bwd_rowlocal_rs<H_, D_>), dim3(P + head_slabs), dim3(1024), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, P, head_slabs, W)
-    if (!head) RLRS(false, false);
-    else if (hp.thresh) RLRS(true, true);
-    else RLRS(true, false);
-#undef RLRS
+  else if (bwd_ring(n, S, d)) {
+#define RING(H_, D_) hipLaunchKernelGGL((k_bwd_rowlocal_ring<H_, D_>), dim3(P + head_slabs), dim3(RING_THREADS), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, P, head_slabs, W)
+    if (!head) RING(false, false);
+    else if (hp.thresh) RING(true, true);
+    else RING(true, false);
+#undef RING
   }
   else if (d == 128)
     hipLaunchKernelGGL((k_bwd_rowlocal<128, 32>), dim3(P + head_slabs), dim3(1024), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, P, head_slabs, W);

@@ -80,6 +80,53 @@ class _SourceKey:
         return self.hic_sig == (getattr(hic, "nnz", None), getattr(hic, "shape", None))
 
 
+class _HostArena:
+    """Pinned host mirror of the stage's [sum n, C] prediction arena, for callers that want the reference's return value
+    (CPU predictions, finetune.py:52-53,67).  The reference copies every chromosome's predictions to the host
+    synchronously inside its loop; here chromosome c's rows travel on a COPY stream as soon as c's step is enqueued --
+    an event after the step orders the copy behind it -- so the PCIe transfer (100 MB per train epoch of the GM12878-
+    shaped genome, ~2 ms at 50 GB/s) runs under the next chromosome's kernels and only the last chromosome's rows are
+    exposed.  Two pinned buffers alternate: the tensor a split returns stays valid until the call AFTER the next one
+    on the same stage (the reference returns fresh tensors; a caller that keeps predictions longer must clone them)."""
+
+    def __init__(self, rows: int, C: int, device):
+        self.device = device
+        self.bufs = []
+        for _ in range(2):
+            try:
+                self.bufs.append(torch.empty((rows, C), dtype=torch.float32, pin_memory=True))
+            except RuntimeError:   # no pinned memory to be had: pageable (the copies then serialise with the host)
+                self.bufs.append(torch.empty((rows, C), dtype=torch.float32))
+        self.turn = 0
+        self.stream = torch.cuda.Stream(device=device)
+        self.events: List[torch.cuda.Event] = []
+        self.used = 0
+
+    def begin(self):
+        self.turn ^= 1
+        self.used = 0
+
+    def fetch(self, rows, probs_dev):
+        """enqueue the copy of arena rows [r0, r1) behind everything the current stream holds so far"""
+        if self.used == len(self.events):
+            self.events.append(torch.cuda.Event())
+        ev = self.events[self.used]
+        self.used += 1
+        ev.record(torch.cuda.current_stream(self.device))
+        self.stream.wait_event(ev)
+        r0, r1 = rows
+        with torch.cuda.stream(self.stream):
+            self.bufs[self.turn][r0:r1].copy_(probs_dev[r0:r1], non_blocking=True)
+
+    def finish(self, span, rows_list):
+        """wait for the copies; the split's rows as ONE host tensor (a view when the split is a contiguous run of the arena)"""
+        self.stream.synchronize()
+        buf = self.bufs[self.turn]
+        if span is not None:
+            return buf[span[0]:span[1]]
+        return torch.cat([buf[r0:r1] for r0, r1 in rows_list], 0)
+
+
 class GCNStage:
     """Device-resident state + step engine of the GCN stage for one split-independent model.
 
@@ -174,28 +221,47 @@ class GCNStage:
         same on every rank -- and keep the host tensors; the graph is normalised and everything uploaded when THIS rank
         first runs the chromosome (run_split's shard plan), so a rank holds the chromosomes it owns, not the genome."""
         n = feats["forward"].shape[0]
+        # shard-plan cost: ONE formula from the caller's inputs alone (never from the normalised graph, whose nnz a
+        # rank only knows once it has built it): plan_shards must see identical costs on every rank whether a rank
+        # registered the chromosome deferred, uploaded it at once, or held it from an earlier split
+        cost = self._cost_estimate(hic, n, feats["forward"].shape[1])
         if defer:
-            d = feats["forward"].shape[1]
-            nnz_est = (int(hic.nnz) if hic is not None and hasattr(hic, "nnz") else 0) + n   # nnz(A + I) up to duplicates
             self._pending[name] = (feats, hic)
-            self._meta[name] = (n, feats["target"].shape[1], float(nnz_est) * d + 3.0 * n * d * d / 16.0)
+            self._meta[name] = (n, feats["target"].shape[1], cost)
             self.chroms.pop(name, None)
             self._invalidate_layout(name)
             return
-        self._pending.pop(name, None)
+        pend = self._pending.pop(name, None)
+        materialising = pend is not None and pend[0] is feats and pend[1] is hic   # same data as registered
         h = G.normalize_graph(self.adj_type, hic, n)
         g = G.upload(h, self.device)
         x = torch.stack([feats["forward"], feats["backward"]]).to(self.device, torch.float32).contiguous()
         t = feats["target"].to(self.device, torch.float32).contiguous()
-        d = x.shape[2]
-        cost = float(h.nnz) * d + 3.0 * n * d * d / 16.0
         known = self._meta.get(name)
-        self.chroms[name] = _Chrom(name, n, g, x, t, known[2] if known else cost, _SourceKey(feats, hic))
+        self.chroms[name] = _Chrom(name, n, g, x, t, cost, _SourceKey(feats, hic))
         if known is None or known[:2] != (n, t.shape[1]):
             self._meta[name] = (n, t.shape[1], cost)
             self._invalidate_layout(name)
-        else:   # a deferred chromosome materialising: the arena / gather layout already accounts for it
+        else:
+            # same (n, C): the arena / gather layout already accounts for the chromosome; its captured graphs read the
+            # old device tensors and go.  The cached target concatenations are COPIES of target data: they survive only
+            # when a deferred chromosome materialises from the very tensors it was registered with, and are rebuilt
+            # when the caller handed in new (or edited) targets of the same shape.
+            self._meta[name] = (n, t.shape[1], cost)
             self._graphs = {k: v for k, v in self._graphs.items() if k[0] != name}
+            if not materialising:
+                self._targets_cpu.clear()
+                self._targets_dev.clear()
+
+    def _cost_estimate(self, hic, n: int, d: int) -> float:
+        """LPT cost of a chromosome (dist.plan_shards): gather work ~ nnz(A + I) d, dense work ~ 3 n d^2 / 16, with
+        nnz estimated from the raw inputs (duplicates / band overlaps not removed)."""
+        nnz = n
+        if self.adj_type in ("hic", "both") and hic is not None and hasattr(hic, "nnz"):
+            nnz += int(hic.nnz)
+        if self.adj_type in ("constant", "both"):
+            nnz += 14 * n
+        return float(nnz) * d + 3.0 * n * d * d / 16.0
 
     def _invalidate_layout(self, name):
         self._targets_cpu.clear()
@@ -681,8 +747,13 @@ class GCNStage:
         C = next(iter(self._meta.values()))[1] if self._meta else 0
         if not self.multi:
             self._ensure_arena()
+            # to_cpu (the reference's return value, finetune.py:52-53): every chromosome's rows leave for a pinned host
+            # arena on a copy stream right behind its own step, while the next chromosome computes (_HostArena)
+            host = self._host_arena(C) if (to_cpu and names and self.device.type == "cuda") else None
             for nm in names:
                 self.train_step(nm) if train else self.eval_step(nm)   # results land in the arena: nothing to copy or add
+                if host is not None:
+                    host.fetch(self._arena["rows"][nm], self._arena["probs"])
             span = self._arena_span(names)
             if span is not None:   # the usual case: the split is the stage's chromosomes in order -> views, no copy
                 preds_dev = self._arena["probs"][span[0]:span[1]]
@@ -696,7 +767,10 @@ class GCNStage:
             total = float(loss_dev.item()) if (sync_loss or to_cpu) else loss_dev   # the one host sync of the split (finetune.py:51 syncs per chromosome)
             if not to_cpu:
                 return preds_dev, self._split_targets_dev(names, C), total
-            preds = preds_dev.cpu()
+            if host is not None:
+                preds = host.finish(span, [self._arena["rows"][nm] for nm in names])
+            else:
+                preds = preds_dev.cpu()
         else:
             self._warm_comms()
             plan = plan_shards({nm: self._meta[nm][2] for nm in names}, self.world)
@@ -774,6 +848,14 @@ class GCNStage:
         if key not in self._targets_cpu:  # targets never change: one D2H per split, not one per epoch
             self._targets_cpu[key] = torch.cat([self._target_of(nm).cpu() for nm in names], 0) if names else torch.empty(0, C)
         return preds, self._targets_cpu[key], total
+
+    def _host_arena(self, C):
+        """the pinned mirror of the output arena (built with it, dropped with it)"""
+        ha = self._arena.get("host")
+        if ha is None:
+            ha = self._arena["host"] = _HostArena(self._arena["probs"].shape[0], C, self.device)
+        ha.begin()
+        return ha
 
     def _split_targets_dev(self, names, C):
         key = tuple(names)

@@ -50,7 +50,7 @@ extern "C" {
 #define CGCN_ERR_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after a launch      */
 #define CGCN_ERR_WORKSPACE (-4)   /* workspace too small (see cgcn_*_workspace_bytes)    */
 
-#define CGCN_ABI_VERSION 18
+#define CGCN_ABI_VERSION 19
 
 typedef void *cgcn_stream_t; /* hipStream_t */
 
@@ -137,6 +137,16 @@ int cgcn_layer_fwd_colstats_tiles(int n, int S, int d, int *rows_per_tile);
 /* Test / tuning hook: feature-table size in bytes from which cgcn_layer_fwd takes the two-launch route when H is
  * given (0 = always, negative = restore the built-in default).  Process-wide. */
 void cgcn_debug_set_fwd_split_bytes(long long bytes);
+
+/* Which kernels a call WOULD launch, so that a profiler prices the kernel that actually runs (bench.py's roofline);
+ * nothing is launched, no GPU is needed.
+ *   cgcn_debug_layer_fwd_route: the training forward (H given, no H_in) on this graph, under the current split
+ *     threshold: 0 = the fused k_layer_fwd, 1 = k_aggregate_sliced + k_layer_dense (large tables, hub-heavy graphs).
+ *   cgcn_debug_layer_bwd_route: the row-local launch of cgcn_layer_bwd: 0 = k_bwd_rowlocal with 32-row tiles,
+ *     1 = with 48-row tiles, 2 = k_bwd_rowlocal_ring (d = 128: row / matrix wave teams over a flag-synchronised LDS ring).
+ * Negative = error code (unsupported shape). */
+int cgcn_debug_layer_fwd_route(int n, int S, int d, const cgcn_graph_aux *aux);
+int cgcn_debug_layer_bwd_route(int n, int S, int d);
 
 /*
  * State the fused head's backward leaves for the LAST gated layer's backward (cgcn_head_bwd with

@@ -79,3 +79,67 @@ def test_n_gt_1_code_path_over_rccl_with_one_forced_rank(gather):
     rc1, lines1, err1 = _run(common, timeout=900)
     assert rc1 == 0, err1[-3000:]
     assert abs(json.loads(lines1[0])["final_loss"] - d["final_loss"]) < 2e-3 * abs(d["final_loss"])
+
+
+# ---- the launch ladder: a rung that fails or hangs must cost a probe, not the run ---------------------
+def test_ladder_first_rung_fails_second_runs():
+    rc, lines, err = _run(["--gpus", "2", "--dry-run"], {"CGCN_BENCH_FAIL_RUNGS": "0"})
+    assert rc == 0, err[-3000:]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    lad = d["launch_ladder"]
+    assert lad["rung"] == 1 and d["rung"] == 1
+    assert [t["ok"] for t in lad["tried"]] == [False, True] and "exit code" in lad["tried"][0]["why"]
+    # the measured job ran with the second rung's switches: eager all-reduce, predictions all-gathered
+    assert d["no_group_graph"] is True and d["gather"] == "all" and d["hip_graph"] is True and d["probe"] is False
+
+
+def test_ladder_hanging_probe_is_killed_and_the_next_rung_runs():
+    rc, lines, err = _run(["--gpus", "2", "--dry-run"], {"CGCN_BENCH_HANG_RUNGS": "0,1", "CGCN_BENCH_PROBE_TIMEOUT_S": "20"}, timeout=300)
+    assert rc == 0, err[-3000:]
+    d = json.loads(lines[0])
+    lad = d["launch_ladder"]
+    assert lad["rung"] == 2 and [t["ok"] for t in lad["tried"]] == [False, False, True]
+    assert "killed" in lad["tried"][0]["why"]
+    assert d["no_group_graph"] is True and d["gather"] == "all" and d["hip_graph"] is False
+
+
+def test_ladder_measured_job_failure_falls_through_to_the_next_rung():
+    rc, lines, err = _run(["--gpus", "2", "--dry-run"], {"CGCN_BENCH_FAIL_MEASURED_RUNGS": "0"})
+    assert rc == 0, err[-3000:]
+    lad = json.loads(lines[0])["launch_ladder"]
+    assert lad["rung"] == 1 and any(t.get("measured_job") and not t["ok"] for t in lad["tried"])
+
+
+def test_ladder_every_rung_failing_is_an_error_with_the_history():
+    rc, lines, err = _run(["--gpus", "2", "--dry-run"], {"CGCN_BENCH_FAIL_RUNGS": "0,1,2"})
+    assert rc != 0 and not lines and "no rung of the launch ladder" in err
+
+
+def test_external_launcher_probes_before_any_rank_touches_a_gpu():
+    """the driver's form: `python -m torch.distributed.run ... bench.py --gpus N`.  Rank 0 probes with child jobs while
+    all ranks wait on a gloo group; every rank then runs with the chosen rung's switches."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["CGCN_BENCH_FAIL_RUNGS"] = "0"
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen_by_backend"] == 2
+    lad = d["launch_ladder"]
+    assert lad["rung"] == 1 and lad["launcher"].startswith("external")
+    assert d["no_group_graph"] is True and d["gather"] == "all"
+
+
+def test_external_launcher_without_probes_runs_the_conservative_form():
+    env = {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "CGCN_BENCH_LADDER": "0"}
+    rc, lines, err = _run(["--gpus", "1", "--dry-run"], env)
+    assert rc == 0, err[-2000:]
+    assert "launch_ladder" not in json.loads(lines[0])   # one rank: nothing to choose

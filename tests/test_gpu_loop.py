@@ -160,3 +160,37 @@ def test_cached_input_aggregation_is_bitwise_identical(golden):
     assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
     for a, b in zip(outs[0][3], outs[1][3]):
         assert torch.equal(a, b)
+
+
+def test_cpu_predictions_of_the_drop_in_equal_the_device_arena_bitwise(golden):
+    """finetune() returns CPU predictions like the reference (finetune.py:52-53,67).  They leave the device chromosome by
+    chromosome on a copy stream behind each step (pinned host arena): what arrives must be the device arena bit for bit,
+    in the reference's chromosome order, for a split that is the whole stage and for a subset in another order; the
+    tensor of one call must survive the next call (two host buffers alternate)."""
+    z = golden("g4_finetune_loop.npz")
+    chroms, feats, graphs = _load(z)
+    init = state_from(z, "init")
+    m = C.ChromeGCN(128, 128, init["out.weight"].shape[0], 0.2, True, 2)
+    m.load_state_dict(init); m.to(DEV)
+    optim = torch.optim.SGD(m.parameters(), lr=0.05, weight_decay=1e-6, momentum=0.9)
+    st = GCNStage(m, optim, "hic", DEV, hip_graphs=True)
+    st.load(feats, graphs)
+    kept = []
+    for e in range(3):
+        preds, targets, total = st.run_split("train", chroms)           # to_cpu=True is the default
+        torch.cuda.synchronize()
+        assert preds.device.type == "cpu" and preds.is_pinned()
+        assert torch.equal(preds, st._arena["probs"].cpu())
+        dev_preds, dev_targets, dev_total = st.run_split("valid", chroms, to_cpu=False)
+        assert torch.equal(targets, dev_targets.cpu())
+        kept.append((preds, preds.clone()))
+        if e >= 1:   # the tensor returned one call ago is still intact
+            assert torch.equal(kept[e - 1][0], kept[e - 1][1])
+    assert not torch.equal(kept[0][1], kept[2][1])                      # (the model did train in between)
+    # a subset in another order: not a contiguous run of the arena -> concatenated from the host arena
+    sub = [chroms[2], chroms[0]]
+    preds, targets, total = st.run_split("valid", sub)
+    rows = st._arena["rows"]
+    want = torch.cat([st._arena["probs"][rows[c][0]:rows[c][1]] for c in sub]).cpu()
+    assert torch.equal(preds, want)
+    assert torch.equal(targets, torch.cat([feats[c]["target"] for c in sub]))

@@ -36,6 +36,10 @@ def main():
     out = dict(sorted(traffic.items()))
     if note:
         out["_note"] = note
+    # the library sources these counters were measured on: bench.py reports a stored value only for the same sources
+    sys.path.insert(0, ROOT)
+    from chromegcn_amd import _build
+    out["_src_hash"] = _build.source_hash([])
     json.dump(out, open(os.path.join(prof, "traffic.json"), "w"), indent=1)
     # the bench lines were printed before this traffic.json existed: their `roofline.traffic` is the stored value of the
     # previous profile run; point the copies at the values collected from THIS run's PMC passes
@@ -60,7 +64,7 @@ def main():
             t = lookup(key, r.get("kernel"))
             r["traffic"], r["traffic_source"] = t, (src if t is not None else None)
         open(f, "w").write(json.dumps(d) + "\n")
-    print("traffic keys:", [k for k in out if not k.startswith("_")])
+    print("traffic keys:", [k for k in out if not k.startswith("_")], "src_hash", out["_src_hash"][:16])
 
 
 if __name__ == "__main__":
