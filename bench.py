@@ -804,7 +804,7 @@ def main():
         # ABI / its profiling hooks on the chromosomes this rank holds); the DOMINANT kernel = the largest share of the
         # epoch's summed kernel time; roofline_top3 = the three largest, each against both roofs
         reps = 20 if genome else 100
-        agg = {}
+        agg, forms = {}, {}
         for nm, n, nnz in shapes:
             if nm not in stage.chroms or args.no_roofline:
                 continue
@@ -813,6 +813,10 @@ def main():
             for k, (sec, per_step) in kt.items():
                 # (one kernel, two forms: k_bwd_rowlocal with the head prologue -- last layer -- and without)
                 e = agg.setdefault(k.split("(")[0], {"s": 0.0, "launches": 0, "bytes": 0.0, "flops": 0.0, "gather": 0.0})
+                if per_step:
+                    f = forms.setdefault(k, [0.0, 0])
+                    f[0] += sec * per_step
+                    f[1] += per_step
                 e["s"] += sec * per_step
                 e["launches"] += per_step
                 ck = k.replace("k_bwd_rowlocal_ring", "k_bwd_rowlocal")   # same work, same algorithmic bytes / flops
@@ -860,6 +864,8 @@ def main():
                                top3[0]["launches_per_step"]))
             roof["sum_kernel_ms_per_step"] = tot_s * 1e3
             roof["all_kernels_us"] = {k: round(e["s"] / max(e["launches"], 1) * 1e6, 2) for k, e in agg.items()}
+            # (the row-local backward in its two forms: "(head)" = last layer, the head's backward recomputed in its prologue)
+            roof["all_kernels_us"].update({k: round(f[0] / f[1] * 1e6, 2) for k, f in forms.items() if "(" in k})
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # the host baseline is reported at N=1 only
             if genome:  # bounded sample of the same genome: its smallest, a middle and its largest train chromosome

@@ -205,11 +205,23 @@ __device__ __forceinline__ void head_stats_finalize(int blk, int P, int n, int S
   const int p0 = slice * per, p1 = min(P, p0 + per);
   double a[4] = {0.0, 0.0, 0.0, 0.0};
   if (c < D) {
-#pragma unroll 2
-    for (int p = p0; p < p1; ++p) {
-      const double* st = (const double*)(part + (size_t)p * PS + CP * D + CP);
+    // batches of 8 records: all 32 loads of a batch are issued before the first add (the kernel is a latency chain:
+    // with two records per trip the 8 records of a 256-partial launch were four dependent round trips); same
+    // summation order as a plain loop
+    for (int p = p0; p < p1; p += 8) {
+      double t[8][4];
 #pragma unroll
-      for (int qd = 0; qd < 4; ++qd) a[qd] += st[qd * D + c];
+      for (int u = 0; u < 8; ++u) {
+        const double* st = (const double*)(part + (size_t)min(p + u, p1 - 1) * PS + CP * D + CP);
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) t[u][qd] = st[qd * D + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (p + u < p1) {
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) a[qd] += t[u][qd];
+        }
     }
   }
 #pragma unroll

@@ -9,7 +9,9 @@
 //   k_aggregate_sliced<S,D> the same aggregation, feature-sliced: one 128-byte column slice per XCD (large tables)
 //   k_layer_fwd<S,D>        fused layer forward: gather -> LDS tile -> fp32 MFMA (x W) -> bias/tanh/gate/mix epilogue
 //   k_layer_dense<S,D>      the row-local half of the layer forward on an H that is in memory (after k_aggregate_sliced)
-//   k_bwd_rowlocal<D>       per-row gate/tanh derivative, H^T dU and dHs = diag(rs) dU W^T on fp32 MFMA (persistent)
+//   k_bwd_rowlocal_ring     (d = 128) per-row gate/tanh derivative by a row team, H^T dU and dHs = diag(rs) dU W^T on fp32 MFMA by a
+//                           matrix team, the teams meeting through a flag-synchronised ring of LDS slots (no per-tile barrier)
+//   k_bwd_rowlocal256, k_dh_dense<256>   the same work at d = 256: row pass + H^T dU per tile, dHs in a second launch
 //   k_reduce_partials       deterministic second stage of the column / dW sums
 //   k_bwd_sliced<S,D>       dX = mask ((1-g) dXn + Ahat^T dHs): feature-sliced gather + element-wise epilogue
 //
@@ -831,46 +833,30 @@ __global__ __launch_bounds__(512) void k_dh_dense(int M, float* __restrict__ B, 
 }
 
 // ------------------------------------------------------------------------------------------
-// k_bwd_rowlocal: everything in the layer backward that is local to a (strand,node) row, plus the two dense
+// The row-local launch of the layer backward: everything that is local to a (strand, node) row, plus the two dense
 // products on MFMA:  dW = H^T dU  and  dHs = diag(row_scale) dU W^T  (dL/dH, pre-scaled: the operand of the gather
-// over Ahat^T that follows in k_bwd_sliced).  Persistent: each workgroup walks row tiles and keeps its D x D slice of
-// dW in accumulators, then writes one partial.  Rows are the flattened [S*n] axis.
+// over Ahat^T that follows in k_bwd_sliced).  Rows are the flattened [S*n] axis; every workgroup keeps its share of dW
+// in accumulators and writes one partial:
 //   partial layout per workgroup: [D*D dW][D db][D dwg][1 dcg][3 pad]
-// The two products are 4 M D^2 flop on the fp32 matrix pipe (157 TFLOP/s) -- about as long as streaming the five row
-// tensors takes -- so the kernel is arranged to keep that pipe busy.
-// D = 128: one workgroup of 16 waves per CU.  All 16 do the row pass (TR/16 rows each).  Waves 0-7 own 16 rows of dW
-// each (8 accumulator blocks), waves 8-15 own 16 output columns of dHs each, their W^T fragments resident in the SAME
-// 32 registers the other half uses as accumulators (R below): 64 KB of accumulators + 64 KB of weights per workgroup
-// in 32 registers per thread, which is what lets 16 waves (<= 128 VGPRs) live on one CU.  The H / dU tiles are double
-// buffered in LDS and the two halves run each step in OPPOSITE order -- dW waves: matrix product on tile t, then the
-// row pass of tile t+1; dHs waves: row pass of tile t+1, then the product on tile t -- so on every SIMD two waves
-// occupy the matrix pipe while the other two do the row math, and swap.  One barrier per tile.
-// D = 256: 8 waves, every wave owns 32 rows of dW (128 accumulator registers: no room for W^T fragments), single-buffered,
-// row pass and dW product in turn; the rows of diag(row_scale) dU go to memory and k_dh_dense turns them into dHs.
+// d = 128: k_bwd_rowlocal_ring (below).  d = 256: k_bwd_rowlocal256 + k_dh_dense<256>.
+//
+// k_bwd_rowlocal256: 8 waves, persistent over 32-row tiles (one workgroup per CU at most), every wave owns 32 rows of dW
+// (128 accumulator registers: no room for W^T fragments), single-buffered tile, row pass and dW product in turn; the
+// rows of diag(row_scale) dU go to memory and k_dh_dense<256> turns them into dHs in place.  (Until round 4 this was
+// the D = 256 instantiation of a template that also served d = 128; that kernel -- 16 waves, role-split by product,
+// one workgroup barrier per tile -- is in the history at the round-3 tag and in profiles/r04_rowlocal_ring_experiment.txt.)
+// LDS row stride of the tiles = D + 16 floats (Ht / Ut are read column-wise: lanes (q, r) read row 4kk+q, column c0+r:
+// conflict-free in a half-wave when the stride is 16 mod 32).
 // ------------------------------------------------------------------------------------------
-// LDS row stride of the tiles = D + RL_LD_PAD floats.  Ht / Ut are read column-wise (dW = Ht^T Ut: lanes (q, r)
-// read row 4kk+q, column c0+r: conflict-free in a half-wave when the stride is 16 mod 32) and Ut also row-wise with
-// ds_read_b128 (dHs = Ut W^T); measured: 4 / 12 / 16 / 20 make no difference to the step.
-#ifndef RL_DH_EPILOGUE_FAST
-#define RL_DH_EPILOGUE_FAST 1
-#endif
-#ifndef RL_LD_PAD
-#define RL_LD_PAD 16
-#endif
-#ifndef RL_ANTIPHASE
-#define RL_ANTIPHASE 1
-#endif
-template <int D, int TR>
-__global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, int n, const float* __restrict__ dXn,
-                                                      const float* __restrict__ Z, const float* __restrict__ X,
-                                                      const float* __restrict__ gate, const float* __restrict__ dgate,
-                                                      const float* __restrict__ H, const float* __restrict__ wg,
-                                                      const float* __restrict__ rs, float* __restrict__ dHs,
-                                                      float* __restrict__ part, HeadApply hp,
-                                                      float* __restrict__ dxn_store, int row_blocks, int head_slabs,
-                                                      const float* __restrict__ W) {
-  constexpr bool SPLIT = (D == 128);  // role-split, double-buffered (see above)
-  constexpr int NW = SPLIT ? 16 : 8;
+template <int TR>
+__global__ __launch_bounds__(512) void k_bwd_rowlocal256(int M, int n, const float* __restrict__ dXn,
+                                                         const float* __restrict__ Z, const float* __restrict__ X,
+                                                         const float* __restrict__ gate, const float* __restrict__ dgate,
+                                                         const float* __restrict__ H, const float* __restrict__ wg,
+                                                         const float* __restrict__ rs, float* __restrict__ dHs,
+                                                         float* __restrict__ part, HeadApply hp,
+                                                         float* __restrict__ dxn_store, int row_blocks, int head_slabs) {
+  constexpr int D = 256, NW = 8;
   // extra workgroups past the row tiles: the head's deferred dW_out / db_out second stage (independent work,
   // fused "horizontally" so it costs no launch of its own)
   if ((int)blockIdx.x >= row_blocks) {
@@ -884,27 +870,19 @@ __global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, i
                                    nullptr, hp.hf_accumulate, hp.dloss);
     return;
   }
-  KT_STAMP(0);
-  constexpr int IBW = SPLIT ? 1 : D / 128;  // 16-row blocks of dW / 16-column blocks of dHs owned by one wave
-  constexpr int LD = D + RL_LD_PAD;
+  constexpr int IBW = D / 128;        // 16-row blocks of dW owned by one wave
+  constexpr int LD = D + 16;
   constexpr int EPL = D / 64;
   constexpr int JB = D / 16;
-  constexpr int MB = TR / 16;
   constexpr int RPW = TR / NW;        // rows per wave per tile
-  constexpr bool DB = SPLIT && TR == 32;  // double-buffered tiles, halves in opposite order (48-row tiles: one tile per workgroup)
-  constexpr int NBUF = DB ? 2 : 1;
   constexpr int PSTRIDE = D * D + 2 * D + 4;
   static_assert(TR % NW == 0 && TR % 16 == 0, "tile rows");
-  __shared__ __attribute__((aligned(16))) float Ht[NBUF][TR * LD];
-  __shared__ __attribute__((aligned(16))) float Ut[NBUF][TR * LD];
-  __shared__ __attribute__((aligned(16))) float Sc[NBUF][TR];      // row_scale of the tile's rows (0 past the end)
+  __shared__ __attribute__((aligned(16))) float Ht[TR * LD];
+  __shared__ __attribute__((aligned(16))) float Ut[TR * LD];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, q = lane >> 4;
-  const bool dw_wave = !SPLIT || wave < 8;
-  const bool dh_wave = dHs && SPLIT && wave >= 8;   // d = 256: no registers left for W^T fragments -> k_dh_dense afterwards
-  const int own = SPLIT ? (wave & 7) : wave;  // first 16-row block of dW / 16-column block of dHs of this wave: own * IBW
 
   float wgl[EPL], db_acc[EPL], dwg_acc[EPL];
   float dcg_acc = 0.f;
@@ -914,21 +892,14 @@ __global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, i
     db_acc[e] = 0.f;
     dwg_acc[e] = 0.f;
   }
-  // R: dW accumulators acc[ib][jb] of a dW wave; with SPLIT, the W^T fragments of a dHs wave instead:
-  // R[0][t][u] = W[(16 * own + r) * D + 16 t + 4 q + u]  (B operand of k-step (t, u), as load_wfrag<.., true>)
-  f32x4 R[IBW][JB];
+  f32x4 R[IBW][JB];   // dW accumulators acc[ib][jb]
 #pragma unroll
   for (int ib = 0; ib < IBW; ++ib)
 #pragma unroll
     for (int jb = 0; jb < JB; ++jb) R[ib][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (SPLIT && dh_wave) {
-#pragma unroll
-    for (int t = 0; t < JB; ++t) R[0][t] = *(const f32x4*)&W[(size_t)(16 * own + r) * D + 16 * t + 4 * q];
-  }
   const uint32_t hkey = (hp.dym && hp.thresh) ? dropout_key(hp.rng_state, HEAD_STREAM_ID) : 0u;
   const float hgl = (hp.dym && hp.dloss) ? hp.dloss[0] : 1.f;
 
-  KT_STAMP(1);
   const int ntiles = (M + TR - 1) / TR;
   // The wave's RPW rows of a tile are loaded into registers in one go (all loads issued before the first use); the
   // loads of the tile after it are issued right after its row pass, a whole tile time before they are needed.
@@ -939,11 +910,7 @@ __global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, i
       const int m = tile * TR + wave + t * NW;
       const bool ok = m < M;
       const size_t off = (size_t)m * D + lane * EPL;
-#ifdef RL_SKIP_LOADS
-      if (false) {
-#else
       if (ok) {
-#endif
         ld_row<EPL>(z[t], &Z[off]);
         ld_row<EPL>(x[t], &X[off]);
         ld_row<EPL>(h[t], &H[off]);
@@ -958,8 +925,8 @@ __global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, i
       dgt[t] = (ok && dgate) ? dgate[m] : 0.f;
     }
   };
-  // row math of the loaded tile -> H and dU tiles (and the row scales) in LDS buffer `buf`
-  auto row_pass = [&](int tile, int buf) {
+  // row math of the loaded tile -> H and dU tiles in LDS
+  auto row_pass = [&](int tile) {
 #pragma unroll
     for (int t = 0; t < RPW; ++t) {
       const int trow = wave + t * NW;
@@ -1003,9 +970,8 @@ __global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, i
           dwg_acc[e] += gamma * z[t][e];
         }
         dcg_acc += gamma;
-        const float sc = rs ? rs[m >= n ? m - n : m] : 1.f;
-        if (lane == 0) Sc[buf][trow] = sc;
-        if (!SPLIT && dHs) {   // diag(row_scale) dU; k_dh_dense multiplies it by W^T in place
+        if (dHs) {   // diag(row_scale) dU; k_dh_dense multiplies it by W^T in place
+          const float sc = rs ? rs[m >= n ? m - n : m] : 1.f;
           float dus[EPL];
 #pragma unroll
           for (int e = 0; e < EPL; ++e) dus[e] = du[e] * sc;
@@ -1014,156 +980,55 @@ __global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, i
       } else {
 #pragma unroll
         for (int e = 0; e < EPL; ++e) du[e] = 0.f;
-        if (lane == 0) Sc[buf][trow] = 0.f;
       }
-#ifndef RL_SKIP_MFMA
 #pragma unroll
       for (int e = 0; e < EPL; ++e) {
-        Ht[buf][trow * LD + lane * EPL + e] = h[t][e];
-        Ut[buf][trow * LD + lane * EPL + e] = du[e];
+        Ht[trow * LD + lane * EPL + e] = h[t][e];
+        Ut[trow * LD + lane * EPL + e] = du[e];
       }
-#endif
     }
   };
   // dW += Ht^T Ut  (K = TR rows)
-  auto mma_dw = [&](int buf) {
-#ifndef RL_SKIP_MFMA
-    const float* __restrict__ Hb = Ht[buf];
-    const float* __restrict__ Ub = Ut[buf];
+  auto mma_dw = [&]() {
 #pragma unroll
     for (int kk = 0; kk < TR / 4; ++kk) {
       const int k = 4 * kk + q;
       float a[IBW];
 #pragma unroll
-      for (int ib = 0; ib < IBW; ++ib) a[ib] = Hb[k * LD + (IBW * own + ib) * 16 + r];
+      for (int ib = 0; ib < IBW; ++ib) a[ib] = Ht[k * LD + (IBW * wave + ib) * 16 + r];
 #pragma unroll
       for (int jb = 0; jb < JB; ++jb) {
-        const float b = Ub[k * LD + jb * 16 + r];
+        const float b = Ut[k * LD + jb * 16 + r];
 #pragma unroll
         for (int ib = 0; ib < IBW; ++ib) R[ib][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ib], b, R[ib][jb], 0, 0, 0);
       }
     }
-#endif
-  };
-  // dHs = diag(row_scale) Ut W^T (d = 128 only): this wave's 16 output columns, all row blocks of the tile at once
-  // (independent accumulation chains), straight from the accumulators (64-byte row segments; the other column blocks
-  // of the same rows are written by the neighbouring waves)
-  auto mma_dh = [&](int tile, int buf) {
-#ifndef RL_SKIP_MFMA
-    const float* __restrict__ Ub = Ut[buf];
-    f32x4 hacc[MB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) hacc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < JB; ++t) {
-      f32x4 a[MB];
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) a[mb] = *(const f32x4*)&Ub[(mb * 16 + r) * LD + 16 * t + 4 * q];
-      const f32x4 b = R[0][t];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) hacc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb][u], b[u], hacc[mb], 0, 0, 0);
-    }
-#if RL_DH_EPILOGUE_FAST
-    // the four row scales of a row block in one 16-byte LDS read, and no per-element bound test on the tiles that lie
-    // inside the table (all but the last): eight stores back to back instead of eight read-wait-branch-store rounds,
-    // during which neither matrix wave of the SIMD issued an MFMA
-    f32x4 sc4[MB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) sc4[mb] = *(const f32x4*)&Sc[buf][mb * 16 + q * 4];
-    float* __restrict__ dst = dHs + (size_t)(tile * TR + q * 4) * D + own * 16 + r;
-    if (tile * TR + TR <= M) {
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dst[(size_t)(mb * 16 + e) * D] = hacc[mb][e] * sc4[mb][e];
-    } else {
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (tile * TR + mb * 16 + q * 4 + e < M) dst[(size_t)(mb * 16 + e) * D] = hacc[mb][e] * sc4[mb][e];
-    }
-#else
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int trow = mb * 16 + q * 4 + e;
-        const int m = tile * TR + trow;
-        const float sc = Sc[buf][trow];
-        if (m < M) dHs[(size_t)m * D + own * 16 + r] = hacc[mb][e] * sc;
-      }
-#endif
-#endif
   };
 
   const int tile0 = blockIdx.x;
-  if (DB) {
-    if (tile0 < ntiles) {
-      load_tile(tile0);
-      row_pass(tile0, 0);
-      if (tile0 + row_blocks < ntiles) load_tile(tile0 + row_blocks);
-    }
+  if (tile0 < ntiles) load_tile(tile0);
+  for (int tile = tile0; tile < ntiles; tile += row_blocks) {
+    row_pass(tile);
+    if (tile + row_blocks < ntiles) load_tile(tile + row_blocks);  // in flight during the barrier + MFMA phase
     __syncthreads();
-    int buf = 0;
-    for (int tile = tile0; tile < ntiles; tile += row_blocks, buf ^= 1) {
-      const int next = tile + row_blocks;
-      if (tile == tile0 + 3 * row_blocks) KT_STAMP(2);
-      if (RL_ANTIPHASE && !dw_wave) {   // dHs waves: rows first, matrix pipe second
-        if (tile == tile0 + 3 * row_blocks) KT_STAMP_T(8, 512);
-        if (next < ntiles) {
-          row_pass(next, buf ^ 1);
-          if (next + row_blocks < ntiles) load_tile(next + row_blocks);
-        }
-        if (tile == tile0 + 3 * row_blocks) KT_STAMP_T(9, 512);
-        if (dh_wave) mma_dh(tile, buf);
-        if (tile == tile0 + 3 * row_blocks) KT_STAMP_T(10, 512);
-      } else {                          // dW waves: matrix pipe first, rows second
-        if (dw_wave) mma_dw(buf);
-        else if (dh_wave) mma_dh(tile, buf);
-        if (tile == tile0 + 3 * row_blocks) KT_STAMP(3);
-        if (next < ntiles) {
-          row_pass(next, buf ^ 1);
-          if (next + row_blocks < ntiles) load_tile(next + row_blocks);
-        }
-      }
-      if (tile == tile0 + 3 * row_blocks) KT_STAMP(4);
-      __syncthreads();
-      if (tile == tile0 + 3 * row_blocks) KT_STAMP(5);
-    }
-  } else {
-    if (tile0 < ntiles) load_tile(tile0);
-    for (int tile = tile0; tile < ntiles; tile += row_blocks) {
-      row_pass(tile, 0);
-      if (tile + row_blocks < ntiles) load_tile(tile + row_blocks);  // in flight during the barrier + MFMA phase
-      __syncthreads();
-      if (dw_wave) mma_dw(0);
-      if (dh_wave) mma_dh(tile, 0);
-      __syncthreads();
-    }
+    mma_dw();
+    __syncthreads();
   }
 
   // ---- write this workgroup's partial
   float* P = part + (size_t)blockIdx.x * PSTRIDE;
-#ifndef RL_SKIP_MFMA
-  if (dw_wave) {
 #pragma unroll
-    for (int ib = 0; ib < IBW; ++ib)
+  for (int ib = 0; ib < IBW; ++ib)
 #pragma unroll
-      for (int jb = 0; jb < JB; ++jb)
+    for (int jb = 0; jb < JB; ++jb)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int i = (IBW * own + ib) * 16 + q * 4 + e;
-          const int j = jb * 16 + r;
-          P[i * D + j] = R[ib][jb][e];
-        }
-  }
-#endif
-  KT_STAMP(6);
+      for (int e = 0; e < 4; ++e) {
+        const int i = (IBW * wave + ib) * 16 + q * 4 + e;
+        const int j = jb * 16 + r;
+        P[i * D + j] = R[ib][jb][e];
+      }
   // column sums: combine the NW waves through LDS in a fixed order (the tile buffers are idle after the last barrier)
-  float* red = Ht[0];  // [NW][2*D + 1]
+  float* red = Ht;  // [NW][2*D + 1]
   constexpr int RS = 2 * D + 1;
   static_assert(NW * RS <= TR * LD, "column-sum staging fits the H tile");
 #pragma unroll
@@ -1178,7 +1043,6 @@ __global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, i
     for (int w = 0; w < NW; ++w) s += red[w * RS + c];
     P[D * D + c] = s;
   }
-  KT_STAMP(7);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1211,18 +1075,15 @@ __global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, i
 // Results equal k_bwd_rowlocal's up to the summation order inside a row and over the rows; bit-reproducible run to run
 // (every sum has a fixed order: no atomics on data).
 // ------------------------------------------------------------------------------------------
-#ifndef RL_RING
-#define RL_RING 1
-#endif
 #ifndef RING_SLOTS
 #define RING_SLOTS 8
 #endif
 #ifndef RING_ROW_WAVES
-#define RING_ROW_WAVES 4 // 4: 12-wave workgroups, 3 waves per SIMD (1 row + 2 matrix), <= 168 registers; 8: 16 waves, <= 128
-#endif
+#define RING_ROW_WAVES 8 // 8: 16-wave workgroups, 2 row + 2 matrix waves per SIMD, <= 128 registers (needs RING_OPBUF 2, RING_PRIME 0);
+#endif                   // 4: 12 waves, 1 row + 2 matrix per SIMD, <= 168.  Measured (profiles/r04_rowlocal_ring_experiment.txt): 8 wins
 #define RING_THREADS ((RING_ROW_WAVES + 8) * 64)
 #ifndef RING_PF
-#define RING_PF 3        // slots of rows a row wave keeps in flight in registers
+#define RING_PF 2        // slots of rows a row wave keeps in flight in registers (3: 4.65 vs 4.63 ms genome epoch)
 #endif
 #ifndef RING_PF_HEAD
 #define RING_PF_HEAD 2   // ... in head mode (the head prologue needs ~25 more registers per row pair)
@@ -1230,10 +1091,19 @@ __global__ __launch_bounds__(D == 128 ? 1024 : 512) void k_bwd_rowlocal(int M, i
 #ifndef RING_PRIO
 #define RING_PRIO 1      // s_setprio of the matrix team (measured: 0 -> 1: 51.3 -> 45.6 us at n = 29 910)
 #endif
+#ifndef RING_OPBUF
+#define RING_OPBUF 2     // matrix team: operand sets in flight (3: two steps ahead, 2: one step ahead, 8 registers fewer)
+#endif
+#ifndef RING_EARLY_FLAG
+#define RING_EARLY_FLAG 1 // matrix team: read the next slot's FULL flag under the current slot's MFMAs; poll only if it was not up yet
+#endif
 #ifndef RING_PRIME
-#define RING_PRIME 1     // matrix team: request the next slot's first operands under the current slot's last MFMAs
+#define RING_PRIME 0     // matrix team: request the next slot's first operands under the current slot's last MFMAs (measured: no gain)
 #endif
 __device__ __forceinline__ void ring_wait(const unsigned* flag, unsigned target) {
+#ifdef RING_NO_WAIT   // experiment only (results are garbage): the two teams run free of each other -> their pure interference
+  return;
+#endif
   while (true) {
     const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
     if ((int)(v - target) >= 0) break;
@@ -1254,6 +1124,26 @@ __device__ __forceinline__ float half_sum(float v, bool upper) {
   v += dpp_get<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3: they hold the totals of lanes 0-31 / 32-63
   const float lo = rl_f(v, 31), hi = rl_f(v, 63);
   return upper ? hi : lo;
+}
+// ... of N independent values at once, step by step: a DPP instruction needs two wait states behind the instruction that
+// wrote its source, and the other values' steps are exactly that (one value alone: an s_nop per step)
+template <int N>
+__device__ __forceinline__ void half_sum_n(float (&v)[N], bool upper) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_get<0xB1, 0xF>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_get<0x4E, 0xF>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_get<0x141, 0xF>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_get<0x140, 0xF>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_get<0x142, 0xA>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const float lo = rl_f(v[i], 31), hi = rl_f(v[i], 63);
+    v[i] = upper ? hi : lo;
+  }
 }
 // HEAD: the last layer (dL/dXn recomputed from the head's backward state, HeadApply); DROP: ... with the head's dropout
 template <bool HEAD, bool DROP>
@@ -1294,8 +1184,9 @@ __global__ __launch_bounds__(RING_THREADS) void k_bwd_rowlocal_ring(int M, int n
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int NST = (M + SR - 1) / SR;
-  const int s_begin = (int)((long long)blockIdx.x * NST / row_blocks);
-  const int ns = (int)((long long)(blockIdx.x + 1) * NST / row_blocks) - s_begin;   // slots of this workgroup
+  // (the 64-bit divisions run on the vector unit: tell the compiler their results are uniform)
+  const int s_begin = __builtin_amdgcn_readfirstlane((int)((long long)blockIdx.x * NST / row_blocks));
+  const int ns = __builtin_amdgcn_readfirstlane((int)((long long)(blockIdx.x + 1) * NST / row_blocks)) - s_begin;   // slots of this workgroup
   float* P = part + (size_t)blockIdx.x * PSTRIDE;
   if (threadIdx.x < 2 * NSL + 1) flg[threadIdx.x] = 0u;
   unsigned* const FULL = flg;
@@ -1324,10 +1215,41 @@ __global__ __launch_bounds__(RING_THREADS) void k_bwd_rowlocal_ring(int M, int n
     }
     struct Rows { f32x4 z[RT], x[RT], h[RT], g[RT]; float gt[RT], sc[RT]; };
     Rows R_[PF];
+    // this lane's element of a slot's rows, as 32-bit offsets from UNIFORM per-slot bases (scalar base + vector offset
+    // addressing: no 64-bit vector address arithmetic per load)
+    const unsigned lane_el = (unsigned)(row0 * D + 4 * l);
     auto load_slot = [&](int it, Rows& w) {
+      const int m0 = (s_begin + it) * SR;   // first row of the slot (uniform)
+#ifdef RING_SKIP_LOADS
+      if (false) {
+#else
+      if (m0 + SR <= M && (m0 >= n || m0 + SR <= n)) {
+#endif
+        // the whole slot lies inside the table and inside one strand (all but two slots of a launch): no predicates
+        const int mi0 = m0 >= n ? m0 - n : m0;   // S <= 2
+        const float* __restrict__ Zb = Z + (size_t)m0 * D;
+        const float* __restrict__ Xb = X + (size_t)m0 * D;
+        const float* __restrict__ Hb = H + (size_t)m0 * D;
+        const float* __restrict__ Gb = HEAD ? hp.dym + (size_t)mi0 * D : dXn + (size_t)m0 * D;
+        const float* __restrict__ gb = gate + m0;
+        const float* __restrict__ rb = rs ? rs + mi0 : nullptr;
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {   // BYTE offsets: base + zero-extended 32-bit vector offset is one addressing mode
+          unsigned ob = 4u * lane_el + (unsigned)(2 * NRW * t * D * 4);
+          unsigned rb4 = 4u * (unsigned)(row0 + 2 * NRW * t);
+          asm volatile("" : "+v"(ob), "+v"(rb4));   // keep the zero-extension next to the loads (a hoisted 64-bit offset defeats the mode)
+          w.z[t] = *(const f32x4*)((const char*)Zb + ob);
+          w.x[t] = *(const f32x4*)((const char*)Xb + ob);
+          w.h[t] = *(const f32x4*)((const char*)Hb + ob);
+          w.g[t] = *(const f32x4*)((const char*)Gb + ob);
+          w.gt[t] = *(const float*)((const char*)gb + rb4);
+          w.sc[t] = rb ? *(const float*)((const char*)rb + rb4) : 1.f;
+        }
+        return;
+      }
 #pragma unroll
       for (int t = 0; t < RT; ++t) {
-        const int m = (s_begin + it) * SR + row0 + 2 * NRW * t;
+        const int m = m0 + row0 + 2 * NRW * t;
 #ifdef RING_SKIP_LOADS
         const bool ok = false;
 #else
@@ -1350,7 +1272,8 @@ __global__ __launch_bounds__(RING_THREADS) void k_bwd_rowlocal_ring(int M, int n
       }
     };
     auto row_pass = [&](int it, Rows& w) {
-      f32x4 du[RT];
+      f32x4 du[RT], gupv[RT];
+      float dgv[RT];
 #pragma unroll
       for (int t = 0; t < RT; ++t) {
         const int m = (s_begin + it) * SR + row0 + 2 * NRW * t;
@@ -1377,12 +1300,20 @@ __global__ __launch_bounds__(RING_THREADS) void k_bwd_rowlocal_ring(int M, int n
         float a = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) a += gup[e] * (w.z[t][e] - w.x[t][e]);
-        float dg = half_sum(a, upper);
+        dgv[t] = a;
+        gupv[t] = gup;
+      }
+      half_sum_n<RT>(dgv, upper);   // the RT rows' reductions side by side
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        const int m = (s_begin + it) * SR + row0 + 2 * NRW * t;
+        const float g = w.gt[t];
+        float dg = dgv[t];
         if (dgate) dg += m < M ? dgate[m] : 0.f;   // an upstream gradient on the gate output itself: rare, read in place
         const float gamma = g * (1.f - g) * dg;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float dz = g * gup[e] + gamma * wgl[e];
+          const float dz = g * gupv[t][e] + gamma * wgl[e];
           du[t][e] = dz * (1.f - w.z[t][e] * w.z[t][e]);
           db_acc[e] += du[t][e];
           dwg_acc[e] += gamma * w.z[t][e];
@@ -1471,14 +1402,15 @@ __global__ __launch_bounds__(RING_THREADS) void k_bwd_rowlocal_ring(int M, int n
     // Software pipeline across slots: under the last MFMA step of a slot the next slot's FULL flag is looked at (not
     // waited for) and, if it is up, its first operand set is requested, so a slot whose rows are ready starts without
     // an LDS round trip; otherwise the wave polls at the top of the next trip.
+    constexpr int OB = RING_OPBUF;   // operand sets in flight: step s + OB - 1 is requested before the MFMAs of step s
     float av[4];
-    f32x4 bv[3], uv[3];
-    bool primed = false;
+    f32x4 bv[OB], uv[OB];
+    bool primed = false, next_full = false;
     auto rd = [&](const float* __restrict__ Hb, const float* __restrict__ Ub, int s) {
       const int kk = s >> 1, h = s & 1;
       if (h == 0) av[kk] = Hb[ha_off + kk * 4 * D];
-      bv[s % 3] = *(const f32x4*)&Ub[ub_lo + kk * 4 * D + 64 * h + ((rq ^ kk) << 4)];
-      uv[s % 3] = *(const f32x4*)&Ub[ua_lo + (((s & 3) ^ rq) << 4) + (s & 4) * 16];
+      bv[s % OB] = *(const f32x4*)&Ub[ub_lo + kk * 4 * D + 64 * h + ((rq ^ kk) << 4)];
+      uv[s % OB] = *(const f32x4*)&Ub[ua_lo + (((s & 3) ^ rq) << 4) + (s & 4) * 16];
     };
     for (int it = 0; it < ns; ++it) {
       const int slot = it % NSL;
@@ -1486,11 +1418,11 @@ __global__ __launch_bounds__(RING_THREADS) void k_bwd_rowlocal_ring(int M, int n
       const float* __restrict__ Hb = Hs[slot];
       const float* __restrict__ Ub = Us[slot];
       if (!primed) {
-        ring_wait(&FULL[slot], (unsigned)NRW * (unsigned)(it / NSL + 1));
+        if (!(RING_EARLY_FLAG && next_full)) ring_wait(&FULL[slot], (unsigned)NRW * (unsigned)(it / NSL + 1));
         rd(Hb, Ub, 0);
       }
-      rd(Hb, Ub, 1);
-      const f32x4 sc_cur = *(const f32x4*)&Sc[slot][4 * q];
+      if (OB == 3) rd(Hb, Ub, 1);
+      f32x4 sc_cur;
       primed = false;
       const int nslot = (it + 1) % NSL;
       unsigned nflag = 0u;
@@ -1499,9 +1431,14 @@ __global__ __launch_bounds__(RING_THREADS) void k_bwd_rowlocal_ring(int M, int n
       // s + 2 are requested before the MFMAs of step s
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
-        if (s + 2 < 8) rd(Hb, Ub, s + 2);
-        if (s == 5 && RING_PRIME) nflag = __hip_atomic_load(&FULL[nslot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (s == 6) ring_arrive(&FREE[slot], lane);   // every operand of the slot is in registers (step 5's MFMAs covered the reads)
+        if (s + OB - 1 < 8) rd(Hb, Ub, s + OB - 1);
+        if (s == 5 && (RING_PRIME || RING_EARLY_FLAG)) nflag = __hip_atomic_load(&FULL[nslot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (s == 7) sc_cur = *(const f32x4*)&Sc[slot][4 * q];   // (requested here, not at the top: four registers less through the loop)
+        if (s == 7 && RING_EARLY_FLAG) {   // the next slot's flag was looked at two steps ago: usually up already -> no poll,
+          next_full = it + 1 < ns &&       // no exposed LDS round trip at the top of the next trip
+                      (int)(__builtin_amdgcn_readfirstlane(nflag) - (unsigned)NRW * (unsigned)((it + 1) / NSL + 1)) >= 0;
+          asm volatile("" ::: "memory");
+        }
         if (s == 7 && RING_PRIME && it + 1 < ns &&
             (int)(__builtin_amdgcn_readfirstlane(nflag) - (unsigned)NRW * (unsigned)((it + 1) / NSL + 1)) >= 0) {
           asm volatile("" ::: "memory");
@@ -1512,12 +1449,13 @@ __global__ __launch_bounds__(RING_THREADS) void k_bwd_rowlocal_ring(int M, int n
         const int kk = s >> 1, h = s & 1;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          accW[h * 4 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bv[s % 3][u], accW[h * 4 + u], 0, 0, 0);
-          hacc = __builtin_amdgcn_mfma_f32_16x16x4f32(uv[s % 3][u], WT[s][u], hacc, 0, 0, 0);
+          accW[h * 4 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bv[s % OB][u], accW[h * 4 + u], 0, 0, 0);
+          hacc = __builtin_amdgcn_mfma_f32_16x16x4f32(uv[s % OB][u], WT[s][u], hacc, 0, 0, 0);
           if (u < 3) __builtin_amdgcn_sched_barrier(0);   // keep the alternation: two links of the dHs chain are 64 cycles apart
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      ring_arrive(&FREE[slot], lane);   // every operand of the slot is in registers (the last step's MFMAs covered the reads)
       if (dHs) {   // 64-byte row segments straight from the accumulators (32-bit offsets from the uniform base)
         const int m0 = (s_begin + it) * SR + 4 * q;
         const unsigned o = (unsigned)((s_begin + it) * SR * D) + dh_lane;
@@ -1839,6 +1777,16 @@ __device__ __forceinline__ f32x4 sliced_super_sum(const IT* __restrict__ col, co
 // workgroup b -> (column slice, 64-row tile).  Up to 8 slices: slice = b mod NSL, so XCD x (workgroups b = x mod 8) owns
 // slice x.  16 slices (S*D = 512 floats): two passes over the tiles, XCD x works on slice x in the first half of the
 // grid and on slice x + 8 in the second, so that one slice (not two) is hot in its L2 at a time.
+// Tuning: non-temporal accesses on the sliced kernels' once-touched streams, so that they compete less
+// with the L2-resident slice of the gathered table.  Bit 0: H store of k_aggregate_sliced; bit 1: the (1-g) dXn operand
+// of k_bwd_sliced; bit 2: its dX store.
+#ifndef SLICED_NT
+#define SLICED_NT 0
+#endif
+__device__ __forceinline__ f32x4 ld_stream4(const float* p) {
+  if (SLICED_NT & 2) return __builtin_nontemporal_load((const f32x4*)p);
+  return *(const f32x4*)p;
+}
 template <int NSL>
 __device__ __forceinline__ void sliced_block(int b, int tiles, int& slice, int& tile) {
   if (NSL <= 8) {
@@ -1868,7 +1816,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HAS_VAL ? 6
   const unsigned lane_off = (unsigned)(lane_el * 4), rowsh = D == 128 ? 9u : 10u;
   const f32x4 acc = !t.super ? sliced_row_sum<HAS_VAL, IT>(col, val, t.k0, t.k1, (const char*)X, lane_off, rowsh, lane)
                              : sliced_super_sum<HAS_VAL, IT>(col, val, t, (const char*)X, lane_off, rowsh, lane, wave);
-  if (i < n) *(f32x4*)&H[lane_el + (size_t)i * D] = acc * sc;
+  if (i < n) {
+    if (SLICED_NT & 1) __builtin_nontemporal_store(acc * sc, (f32x4*)&H[lane_el + (size_t)i * D]);
+    else *(f32x4*)&H[lane_el + (size_t)i * D] = acc * sc;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1912,11 +1863,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HAS_VAL ? 6
   f32x4 res = (f32x4){0.f, 0.f, 0.f, 0.f}, acc;
   if (!t.super) {
     // the (1-g) dXn term first: its loads are in flight during the walk
-    if (i < n) res = *(const f32x4*)&dXn[lane_el + (size_t)i * D] * (1.f - gate[(size_t)s * n + i]);
+    if (i < n) res = ld_stream4(&dXn[lane_el + (size_t)i * D]) * (1.f - gate[(size_t)s * n + i]);
     acc = sliced_row_sum<HAS_VAL, IT>(col, val, t.k0, t.k1, (const char*)dHs, lane_off, rowsh, lane);
   } else {
     acc = sliced_super_sum<HAS_VAL, IT>(col, val, t, (const char*)dHs, lane_off, rowsh, lane, wave);
-    if (i < n) res = *(const f32x4*)&dXn[lane_el + (size_t)i * D] * (1.f - gate[(size_t)s * n + i]);
+    if (i < n) res = ld_stream4(&dXn[lane_el + (size_t)i * D]) * (1.f - gate[(size_t)s * n + i]);
   }
   if (i >= n) return;
   const size_t g_off = lane_el + (size_t)i * D;
@@ -1926,7 +1877,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HAS_VAL ? 6
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = dropout_keep(key, (uint32_t)(g_off + e), thresh) ? o[e] * keep_scale : 0.f;
   }
-  *(f32x4*)&dX[g_off] = o;
+  if (SLICED_NT & 4) __builtin_nontemporal_store(o, (f32x4*)&dX[g_off]);
+  else *(f32x4*)&dX[g_off] = o;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2273,39 +2225,20 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   return launch_status();
 }
 
-// Row-tile height and workgroup count of k_bwd_rowlocal: one persistent workgroup per CU at most (BWD_MAX_PARTIALS).
-// d = 128: 48-row tiles while that gives every tile its own workgroup (chr21-size graphs: 241 workgroups of one tile
-// instead of 256 of which 105 walk two 32-row tiles; single-buffered), 32-row tiles (double-buffered, <= 128 registers
-// for 16 waves) above.  d = 256: 32 rows (registers).
-static int bwd_tile_rows(int n, int S, int d) {
-  if (d != 128) return 32;
-  const int M = n * S;
-  return (M > 32 * BWD_MAX_PARTIALS && M <= 48 * BWD_MAX_PARTIALS) ? 48 : 32;
-}
-
-// d = 128 above RING_MIN_ROWS rows: k_bwd_rowlocal_ring (16-row slots dealt in contiguous, balanced ranges)
-#ifndef RING_MIN_ROWS
-#define RING_MIN_ROWS 0
-#endif
-static bool bwd_ring(int n, int S, int d) { return RL_RING && d == 128 && (long long)n * S >= RING_MIN_ROWS; }
-
+// Workgroups (= partial records) of the row-local launch: one persistent workgroup per CU at most (BWD_MAX_PARTIALS).
+// d = 128: k_bwd_rowlocal_ring, 16-row slots dealt in contiguous, balanced ranges; d = 256: k_bwd_rowlocal256, 32-row tiles.
 static int bwd_partials(int n, int S, int d) {
   const int M = n * S;
-  if (bwd_ring(n, S, d)) {
-    const int nst = (M + 15) / 16;
-    return nst < 1 ? 1 : (nst < BWD_MAX_PARTIALS ? nst : BWD_MAX_PARTIALS);
-  }
-  const int tr = bwd_tile_rows(n, S, d);
+  const int tr = d == 128 ? 16 : 32;
   const int ntiles = (M + tr - 1) / tr;
-  int P = ntiles < BWD_MAX_PARTIALS ? ntiles : BWD_MAX_PARTIALS;
+  const int P = ntiles < BWD_MAX_PARTIALS ? ntiles : BWD_MAX_PARTIALS;
   return P < 1 ? 1 : P;
 }
 
 int cgcn_debug_layer_bwd_route(int n, int S, int d) {
   const int rc = check_shape(n, S, d);
   if (rc) return rc;
-  if (bwd_ring(n, S, d)) return 2;
-  return bwd_tile_rows(n, S, d) == 48 ? 1 : 0;
+  return d == 128 ? 2 : 0;
 }
 
 size_t cgcn_layer_bwd_workspace_bytes(int n, int S, int d) {
@@ -2374,19 +2307,14 @@ static int layer_bwd_impl(cgcn_stream_t stream, int n, int S, int d, const int32
   const int M = n * S;
   if (!(phases & 1)) {
     // profiling only: the partials / dHs / dL/dXn of an earlier full call are still in place
-  } else if (d == 128 && !bwd_ring(n, S, d) && bwd_tile_rows(n, S, d) == 48)
-    hipLaunchKernelGGL((k_bwd_rowlocal<128, 48>), dim3(P + head_slabs), dim3(1024), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, P, head_slabs, W);
-  else if (bwd_ring(n, S, d)) {
+  } else if (d == 128) {
 #define RING(H_, D_) hipLaunchKernelGGL((k_bwd_rowlocal_ring<H_, D_>), dim3(P + head_slabs), dim3(RING_THREADS), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, P, head_slabs, W)
     if (!head) RING(false, false);
     else if (hp.thresh) RING(true, true);
     else RING(true, false);
 #undef RING
-  }
-  else if (d == 128)
-    hipLaunchKernelGGL((k_bwd_rowlocal<128, 32>), dim3(P + head_slabs), dim3(1024), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, P, head_slabs, W);
-  else
-    hipLaunchKernelGGL((k_bwd_rowlocal<256, 32>), dim3(P + head_slabs), dim3(512), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, P, head_slabs, W);
+  } else
+    hipLaunchKernelGGL((k_bwd_rowlocal256<32>), dim3(P + head_slabs), dim3(512), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, P, head_slabs);
   if ((rc = launch_status())) return rc;
   if ((phases & 1) && d == 256 && dHs && M > 0) {   // dHs = (diag(row_scale) dU) W^T: d = 128 did it inside the row-local kernel
     const int dh_tiles = (M + 16 * DH_MB - 1) / (16 * DH_MB);

@@ -25,13 +25,27 @@ from .layers import ChromeGCN
 E2E_CHROMS = ("chr19", "chr20", "chr22")
 
 
+def windows_per_chrom(chroms, windows):
+    """{chrom: window count}: `windows` is one count for every chromosome, a {chrom: count} dict, or "full" = the
+    chromosome's real size in the synthetic genome (synth.chrom_nodes: chr21 = 5 776 windows with peaks)"""
+    if isinstance(windows, str):
+        if windows != "full":
+            raise ValueError("windows must be an int, a dict or 'full'")
+        return {c: synth.chrom_nodes(c) for c in chroms}
+    if isinstance(windows, dict):
+        return {c: int(windows[c]) for c in chroms}
+    return {c: int(windows) for c in chroms}
+
+
 def synthetic_windows(chroms, windows, seq_length, n_labels, seed=0):
     """tokens [N, L] int64 in {0..4}, targets [N, C], locs [(chrom, start, end)] in file order (chromosome by
     chromosome, ascending start: data/5merge_seqs_and_labels.py:70)"""
+    per = windows_per_chrom(chroms, windows)
+    total = sum(per.values())
     g = torch.Generator().manual_seed(seed)
-    tokens = torch.randint(0, 5, (len(chroms) * windows, seq_length), generator=g)
-    targets = (torch.rand(len(chroms) * windows, n_labels, generator=g) < 0.05).float()
-    locs = [(c, 1000 * i, 1000 * i + 1000) for c in chroms for i in range(windows)]
+    tokens = torch.randint(0, 5, (total, seq_length), generator=g)
+    targets = (torch.rand(total, n_labels, generator=g) < 0.05).float()
+    locs = [(c, 1000 * i, 1000 * i + 1000) for c in chroms for i in range(per[c])]
     return tokens, targets, locs
 
 
@@ -59,10 +73,11 @@ def run_pipeline(dev, windows=4096, seq_length=2000, d=128, layers=2, dropout=0.
         model.out.load_state_dict(enc.model.classifier.state_dict())
         model.batch_norm.load_state_dict(enc.model.batch_norm.state_dict())
     opt = torch.optim.SGD(model.parameters(), lr=0.25, momentum=0.9, weight_decay=1e-6)
+    wpc = windows_per_chrom(chroms, windows)
     graphs = {}
-    for c in chroms:
-        pairs = max(1, int(round(synth.PAIRS_PER_CHROM * windows / synth.chrom_nodes(c))))
-        graphs[c] = synth.contact_graph(windows, pairs, synth.chrom_seed(c), hic_like)
+    for c in chroms:   # the chromosome's own contact budget, scaled with the share of its windows that is used
+        pairs = max(1, int(round(synth.PAIRS_PER_CHROM * wpc[c] / synth.chrom_nodes(c))))
+        graphs[c] = synth.contact_graph(wpc[c], pairs, synth.chrom_seed(c), hic_like)
     stage = GCNStage(model, opt, "hic", dev, hip_graphs=hip_graphs, input_grad=True, cache_input_aggregation=False,
                      group=group)
     # ---- who encodes what: the stage's own shard plan (every rank registers every chromosome -- size, labels, cost --
@@ -116,8 +131,8 @@ def run_pipeline(dev, windows=4096, seq_length=2000, d=128, layers=2, dropout=0.
         t0 = time.perf_counter()
         _, _, loss = stage.run_split("train", names, to_cpu=False)
         per.append(time.perf_counter() - t0)
-    n_win = len(chroms) * windows
-    out = {"windows": n_win, "encoder_s": t_enc, "regroup_s": t_regroup, "stage_load_s": t_load,
+    n_win = sum(wpc.values())
+    out = {"windows": n_win, "windows_per_chrom": wpc, "encoder_s": t_enc, "regroup_s": t_regroup, "stage_load_s": t_load,
            "gcn_epoch_s": float(np.median(per)), "gcn_epoch_p10_s": float(np.percentile(per, 10)),
            "gcn_epoch_p90_s": float(np.percentile(per, 90)), "epochs": epochs, "final_loss": loss,
            "feat_device": str(feats[mine[0]]["forward"].device) if mine else str(dev), "owned": mine,
@@ -134,7 +149,11 @@ def bench(args, dev, world, rank):
     # 8 ranks want at least 8 chromosomes: the 3 smallest train chromosomes at N = 1 (the round-2 line), the 8 smallest beyond
     chroms = E2E_CHROMS if world <= 3 else tuple(sorted((c for c in synth.HG19_LEN if synth.split_of(c) == "train"),
                                                          key=synth.chrom_nodes)[:max(8, world)])
-    t, stage, names = run_pipeline(dev, windows=args.e2e_windows, d=args.d, layers=args.layers, dropout=args.dropout,
+    full = args.e2e_windows <= 0   # --e2e-windows 0: REAL chromosome sizes -- chr21 (5 776 windows x 2 000 tokens, its own
+    if full:                       # 250 000 contact pairs) on one rank, the `world` smallest train chromosomes beyond
+        chroms = ("chr21",) if world == 1 else tuple(sorted((c for c in synth.HG19_LEN if synth.split_of(c) == "train"),
+                                                            key=synth.chrom_nodes)[:world])
+    t, stage, names = run_pipeline(dev, windows="full" if full else args.e2e_windows, d=args.d, layers=args.layers, dropout=args.dropout,
                                    epochs=steps, warmup=warmup, hic_like=args.hic_like, hip_graphs=not args.no_hip_graph,
                                    chroms=chroms, group=dist.group.WORLD if world > 1 else None)
     n = t["windows"]
@@ -145,9 +164,12 @@ def bench(args, dev, world, rank):
         "value": n / total, "unit": "windows/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": t["gcn_epoch_s"] * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "config 5 scaled down: %d chromosomes x %d windows (tokens in {0..4}, length 2000, encoder batch 64), "
+        "config": {"workload": ("config 5 at real chromosome size: %s (tokens in {0..4}, length 2000, encoder batch 64), " % ", ".join(
+                                   "%s = %d windows" % (c, k) for c, k in t["windows_per_chrom"].items()) if full else
+                                "config 5 scaled down: %d chromosomes x %d windows (tokens in {0..4}, length 2000, encoder batch 64), "
+                                % (len(names), args.e2e_windows)) +
                                "features f/r handed to the GCN stage on the device; GCN stage = train epoch in reference "
-                               "semantics, d=%d, L=%d, C=%d" % (len(names), args.e2e_windows, args.d, args.layers, synth.N_LABELS),
+                               "semantics, d=%d, L=%d, C=%d" % (args.d, args.layers, synth.N_LABELS),
                    "generator": getattr(args, "generator", "hic_like" if args.hic_like else "uniform"),
                    "parallelism": "chromosomes sharded over %d rank(s): each rank encodes and trains the chromosomes it owns" % world},
         "encoder_windows_per_s": enc_rate, "gcn_windows_per_s": gcn_rate,

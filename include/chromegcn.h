@@ -142,8 +142,9 @@ void cgcn_debug_set_fwd_split_bytes(long long bytes);
  * nothing is launched, no GPU is needed.
  *   cgcn_debug_layer_fwd_route: the training forward (H given, no H_in) on this graph, under the current split
  *     threshold: 0 = the fused k_layer_fwd, 1 = k_aggregate_sliced + k_layer_dense (large tables, hub-heavy graphs).
- *   cgcn_debug_layer_bwd_route: the row-local launch of cgcn_layer_bwd: 0 = k_bwd_rowlocal with 32-row tiles,
- *     1 = with 48-row tiles, 2 = k_bwd_rowlocal_ring (d = 128: row / matrix wave teams over a flag-synchronised LDS ring).
+ *   cgcn_debug_layer_bwd_route: the row-local launch of cgcn_layer_bwd: 0 = k_bwd_rowlocal256 (d = 256: 32-row tiles,
+ *     dHs by a second launch), 2 = k_bwd_rowlocal_ring (d = 128: row / matrix wave teams over a flag-synchronised LDS
+ *     ring).  (1 was the 48-row-tile kernel of ABI <= 18: no longer returned.)
  * Negative = error code (unsupported shape). */
 int cgcn_debug_layer_fwd_route(int n, int S, int d, const cgcn_graph_aux *aux);
 int cgcn_debug_layer_bwd_route(int n, int S, int d);

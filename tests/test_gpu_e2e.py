@@ -175,3 +175,53 @@ def test_e2e_pipeline_at_full_sequence_length():
     assert t["windows"] == 4096 and names == ["chr22"] and stage.chroms["chr22"].n == 4096
     assert stage.chroms["chr22"].x.shape == (2, 4096, 128) and np.isfinite(t["final_loss"])
     assert t["encoder_s"] > 0 and t["gcn_epoch_s"] > 0
+
+
+@pytest.mark.timeout(900)
+def test_e2e_at_one_real_chromosome(tmp_path):
+    """BASELINE.json configs[4] at ONE REAL chromosome's size: chr21 of the synthetic genome -- 5 776 windows
+    with peaks x 2 000 tokens (pretrain.py:24-63 pushes them through the encoder in batches of 64), its own 250 000 contact
+    pairs -- encoder -> device hand-off -> GCN stage -> multi-label metrics, nothing scaled down.  The device hand-off must
+    be the reference's `.pt` round trip (utils/util_methods.py:183-199 writes, main.py:30-32 reads) bit for bit at this
+    size too, and the stage fed either way must train to identical parameters."""
+    from chromegcn_amd import metrics
+    dev = torch.device(DEV)
+    n = synth.chrom_nodes("chr21")
+    t, stage, names = e2e.run_pipeline(dev, windows="full", seq_length=2000, dropout=0.0, epochs=2, warmup=1, chroms=("chr21",),
+                                       batch_size=64, return_feats=True)
+    assert names == ["chr21"] and t["windows"] == n == 5776 and t["windows_per_chrom"] == {"chr21": n}
+    c = stage.chroms["chr21"]
+    assert c.n == n and c.x.shape == (2, n, 128) and c.graph.nnz > 2 * 200000   # the full contact budget (+ diagonal)
+    assert t["encoder_s"] > 0 and t["gcn_epoch_s"] > 0 and np.isfinite(t["final_loss"])
+    feats_dev = t["feats"]
+    assert feats_dev["chr21"]["forward"].is_cuda and feats_dev["chr21"]["forward"].shape == (n, 128)
+    # ---- the reference's artefact at this size: written from the same collector contents, read back on the host
+    col = FeatureCollector()
+    col.add([("chr21", 1000 * i, 1000 * i + 1000) for i in range(n)], feats_dev["chr21"]["forward"],
+            feats_dev["chr21"]["backward"], feats_dev["chr21"]["target"])
+    path = col.save(str(tmp_path / "run.finetune.x"), "train")
+    feats_pt = torch.load(path)
+    for k in ("forward", "backward", "target"):
+        assert feats_pt["chr21"][k].device.type == "cpu" and torch.equal(feats_pt["chr21"][k], feats_dev["chr21"][k].cpu()), k
+    # ---- the stage fed from the file trains to the same parameters as the stage fed on the device (run_pipeline's)
+    hic = synth.contact_graph(n, synth.PAIRS_PER_CHROM, synth.chrom_seed("chr21"))
+    torch.manual_seed(0)
+    enc = StrandPair(WindowEncoder(synth.N_LABELS, 2000)).to(dev)   # the same seed as run_pipeline: the same head init
+    m = C.ChromeGCN(128, 128, synth.N_LABELS, 0.0, True, 2).to(dev)
+    with torch.no_grad():
+        m.out.load_state_dict(enc.model.classifier.state_dict())
+        m.batch_norm.load_state_dict(enc.model.batch_norm.state_dict())
+    del enc
+    opt = torch.optim.SGD(m.parameters(), lr=0.25, momentum=0.9, weight_decay=1e-6)
+    st = GCNStage(m, opt, "hic", dev, hip_graphs=True, input_grad=True, cache_input_aggregation=False)
+    st.load(feats_pt, {"chr21": hic})
+    for _ in range(3):   # warmup 1 + epochs 2
+        st.run_split("train", names, to_cpu=False)
+    for k, v in stage.model.state_dict().items():
+        assert torch.equal(v, m.state_dict()[k]), k
+    # ---- and the metrics stage on the full chromosome's predictions (runner.py:41)
+    preds, targets, loss = stage.run_split("valid", names, to_cpu=False)
+    res = metrics.compute_metrics(preds, targets, loss)
+    assert preds.shape == (n, synth.N_LABELS) and np.isfinite(loss)
+    assert all(np.isfinite(res[k]) for k in ("mAP", "meanAUC", "meanAUPR", "meanFDR", "loss"))
+    assert len(res["allAUC"]) == synth.N_LABELS   # 5 776 windows at 5 % positives: every label has both classes

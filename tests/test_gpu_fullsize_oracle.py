@@ -59,15 +59,19 @@ CASES = [   # name, n, pairs, hic_like, adj_type, seed, d, layers, labels
     ("chr21_hub", synth.chrom_nodes("chr21"), 250000, "hub", "hic", 26, 128, 2, NC),
     ("chr1_hub", synth.chrom_nodes("chr1"), 250000, "hub", "hic", 27, 128, 2, NC),
     ("chr21_hub_d256", synth.chrom_nodes("chr21"), 250000, "hub", "hic", 28, 256, 2, NC),
+    # the same hub graphs with a CONDITIONED model (GC weights x 8 instead of x 40: tanh and the gates leave their linear
+    # range without saturating the hub windows): these hold the plain 1e-4 bound against float64, no relaxation
+    ("chr21_hub_w8", synth.chrom_nodes("chr21"), 250000, "hub", "hic", 26, 128, 2, NC),
+    ("chr1_hub_w8", synth.chrom_nodes("chr1"), 250000, "hub", "hic", 27, 128, 2, NC),
 ]
 
 
-def _scaled_oracle(seed, d=D, layers=2, labels=NC):
+def _scaled_oracle(seed, d=D, layers=2, labels=NC, gain=40.0):
     torch.manual_seed(seed)
     orc = O.GatedGCNOracle(d, labels, 0.0, layers)
     with torch.no_grad():  # the reference init (gain 0.02) leaves tanh / gates in their linear range: scale up
         for k in range(1, layers + 1):
-            getattr(orc, "GC%d" % k).weight.mul_(40 * (128.0 / d) ** 0.5)
+            getattr(orc, "GC%d" % k).weight.mul_(gain * (128.0 / d) ** 0.5)
             getattr(orc, "W%d" % k).weight.mul_(3)
     return orc
 
@@ -82,16 +86,22 @@ def test_train_steps_match_oracle_at_full_size(case):
     name, n, pairs, hic_like, adj_type, seed, d, layers, labels = case
     from chromegcn_amd import _lib
     _lib.load().cgcn_debug_set_fwd_split_bytes(0 if name.endswith("forced_split") else -1)
+    # The host oracle's fp32 sums depend on torch's thread count (another test module pins it to 1 at import, i.e. for a
+    # whole `pytest tests` session but not for this file alone: sequential sums over a hub's 10^4 neighbours are 100x less
+    # accurate than the chunked ones).  Fix it here, so that the oracle is the same oracle in every session.
+    threads = torch.get_num_threads()
+    torch.set_num_threads(8)
     try:
         _train_steps_case(name, n, pairs, hic_like, adj_type, seed, d, layers, labels)
     finally:
+        torch.set_num_threads(threads)
         _lib.load().cgcn_debug_set_fwd_split_bytes(-1)
 
 
 def _train_steps_case(name, n, pairs, hic_like, adj_type, seed, d, layers, labels):
     feats = synth.chrom_features(n, d, labels, 1000 + seed)
     hic = synth.contact_graph(n, pairs, seed, hic_like)
-    orc = _scaled_oracle(seed, d, layers, labels)
+    orc = _scaled_oracle(seed, d, layers, labels, gain=8.0 if name.endswith("_w8") else 40.0)
     model = C.ChromeGCN(d, d, labels, 0.0, True, layers)
     model.load_state_dict(orc.state_dict())
     model.to(DEV)
@@ -104,8 +114,11 @@ def _train_steps_case(name, n, pairs, hic_like, adj_type, seed, d, layers, label
     oopt64 = O.make_sgd(orc64, 0.25)
     feats64 = {k: v.double() for k, v in feats.items()}
     cache, cache64 = {}, {}
-    worst, worst32 = {}, {}
+    worst, worst32, worst_hip32 = {}, {}, {}
     for step in range(2):
+        # the float64 truth starts EVERY step from the parameters (and BatchNorm statistics) the two fp32 paths hold: what
+        # is compared is the arithmetic of one step on identical inputs, not two optimisation trajectories drifting apart
+        orc64.load_state_dict({k: (v.double() if v.dtype.is_floating_point else v.clone()) for k, v in orc.state_dict().items()})
         loss, probs, dx = stage.train_step(name)
         torch.cuda.synchronize()
         grads_hip = {k: p.grad.detach().cpu().numpy().copy() for k, p in model.named_parameters()}
@@ -123,20 +136,22 @@ def _train_steps_case(name, n, pairs, hic_like, adj_type, seed, d, layers, label
         dx64 = np.stack([ig64[name][0].numpy(), ig64[name][1].numpy()])
         worst["dx"] = max(worst.get("dx", 0.0), _rel(dx.cpu().numpy(), dx64))
         worst32["dx"] = max(worst32.get("dx", 0.0), _rel(dxo, dx64))
+        worst_hip32["dx"] = max(worst_hip32.get("dx", 0.0), _rel(dx.cpu().numpy(), dxo))
         # every parameter gradient (the oracle's .grad survives its optimizer.step())
         g64 = {k: p.grad.numpy() for k, p in orc64.named_parameters()}
         for k, p in orc.named_parameters():
             np.testing.assert_allclose(grads_hip[k], p.grad.numpy(), atol=1e-4, rtol=1e-4, err_msg=k)
             worst["d" + k] = max(worst.get("d" + k, 0.0), _rel(grads_hip[k], g64[k]))
             worst32["d" + k] = max(worst32.get("d" + k, 0.0), _rel(p.grad.numpy(), g64[k]))
+            worst_hip32["d" + k] = max(worst_hip32.get("d" + k, 0.0), _rel(grads_hip[k], p.grad.numpy()))
         # parameters after the SGD step + BatchNorm running statistics
         osd = orc.state_dict()
         for k, v in model.state_dict().items():
             tol = 1e-5 if "running" in k else 1e-4
             np.testing.assert_allclose(v.cpu().numpy(), osd[k].numpy(), atol=tol, rtol=tol, err_msg="%s after step %d" % (k, step))
-    print("\n[%s] scale-relative max error vs the float64 oracle: HIP / fp32 oracle" % name)
+    print("\n[%s] scale-relative max error vs the float64 oracle: HIP / fp32 oracle   |   HIP vs the fp32 oracle" % name)
     for k in sorted(worst):
-        print("   %-22s %.2e / %.2e" % (k, worst[k], worst32[k]))
+        print("   %-22s %.2e / %.2e   |   %.2e" % (k, worst[k], worst32[k], worst_hip32[k]))
     # Bound: 1e-4.  On the top-K-style (hub) graphs some of these quantities are ill-conditioned AT fp32: the fp32 oracle
     # itself is 1e-3 ... 1e-2 off the float64 truth at chr1 size (hubs of 10^4 neighbours: after the first optimizer
     # step the two fp32 paths hold the same fp32-rounded parameters and share that deviation digit for digit), and the
@@ -144,11 +159,18 @@ def _train_steps_case(name, n, pairs, hic_like, adj_type, seed, d, layers, label
     # already worth 1e-4 (tests/probes/bias_sum_probe.py chr21 hub: every kernel stage is at 2e-7 ... 4e-6 on that graph).
     # Where the fp32 oracle is more than 2e-5 off the truth, the bound is therefore 10x the oracle's own error -- on the
     # hub cases only; every other case keeps 1e-4 for every tensor.
-    hub = "hub" in name
-    def bound(k):
-        return 10.0 * worst32[k] if (hub and worst32[k] > 2e-5) else 1e-4
-    bad = {k: (v, worst32[k]) for k, v in worst.items() if v > bound(k)}
-    assert not bad, "scale-relative gradient error above its bound (HIP, fp32 oracle): %s" % bad
+    hub = "hub" in name and not name.endswith("_w8")   # (the conditioned hub cases keep the plain bound)
+    lim = float(__import__("os").environ.get("CGCN_HUB_FP32_AGREEMENT", "1e-4"))
+    def ok(k):
+        if worst[k] <= 1e-4:
+            return True          # accurate against float64 outright
+        # Only on the ill-conditioned hub cases, and only for what fp32 arithmetic itself cannot hold: the relaxed bound
+        # (10x the fp32 oracle's own error) AND -- what that relaxation rests on, asserted -- the HIP path must agree with
+        # the plain-fp32 oracle scale-relatively: the deviation from float64 is then fp32's, shared digit for digit by
+        # both fp32 paths, not the kernels'.
+        return hub and worst32[k] > 2e-5 and worst[k] <= 10.0 * worst32[k] and worst_hip32[k] <= lim
+    bad = {k: (worst[k], worst32[k], worst_hip32[k]) for k in worst if not ok(k)}
+    assert not bad, "scale-relative gradient error above its bound (HIP vs float64, fp32 oracle vs float64, HIP vs fp32 oracle): %s" % bad
 
 
 def test_eval_forward_matches_oracle_at_chr1_size():
