@@ -1781,7 +1781,7 @@ __device__ __forceinline__ f32x4 sliced_super_sum(const IT* __restrict__ col, co
 // with the L2-resident slice of the gathered table.  Bit 0: H store of k_aggregate_sliced; bit 1: the (1-g) dXn operand
 // of k_bwd_sliced; bit 2: its dX store.
 #ifndef SLICED_NT
-#define SLICED_NT 0
+#define SLICED_NT 7   // measured (profiles/r04_sliced_nt_experiment.txt): genome epoch 4.67 -> 4.63 ms, traffic beyond L2 -6 %
 #endif
 __device__ __forceinline__ f32x4 ld_stream4(const float* p) {
   if (SLICED_NT & 2) return __builtin_nontemporal_load((const f32x4*)p);

@@ -152,24 +152,18 @@ def _train_steps_case(name, n, pairs, hic_like, adj_type, seed, d, layers, label
     print("\n[%s] scale-relative max error vs the float64 oracle: HIP / fp32 oracle   |   HIP vs the fp32 oracle" % name)
     for k in sorted(worst):
         print("   %-22s %.2e / %.2e   |   %.2e" % (k, worst[k], worst32[k], worst_hip32[k]))
-    # Bound: 1e-4.  On the top-K-style (hub) graphs some of these quantities are ill-conditioned AT fp32: the fp32 oracle
-    # itself is 1e-3 ... 1e-2 off the float64 truth at chr1 size (hubs of 10^4 neighbours: after the first optimizer
-    # step the two fp32 paths hold the same fp32-rounded parameters and share that deviation digit for digit), and the
-    # gate-bias sums cancel to 6e-4 of their absolute sum there, so ONE fp32 rounding (6e-8) of a per-column constant is
-    # already worth 1e-4 (tests/probes/bias_sum_probe.py chr21 hub: every kernel stage is at 2e-7 ... 4e-6 on that graph).
-    # Where the fp32 oracle is more than 2e-5 off the truth, the bound is therefore 10x the oracle's own error -- on the
-    # hub cases only; every other case keeps 1e-4 for every tensor.
-    hub = "hub" in name and not name.endswith("_w8")   # (the conditioned hub cases keep the plain bound)
-    lim = float(__import__("os").environ.get("CGCN_HUB_FP32_AGREEMENT", "1e-4"))
-    def ok(k):
-        if worst[k] <= 1e-4:
-            return True          # accurate against float64 outright
-        # Only on the ill-conditioned hub cases, and only for what fp32 arithmetic itself cannot hold: the relaxed bound
-        # (10x the fp32 oracle's own error) AND -- what that relaxation rests on, asserted -- the HIP path must agree with
-        # the plain-fp32 oracle scale-relatively: the deviation from float64 is then fp32's, shared digit for digit by
-        # both fp32 paths, not the kernels'.
-        return hub and worst32[k] > 2e-5 and worst[k] <= 10.0 * worst32[k] and worst_hip32[k] <= lim
-    bad = {k: (worst[k], worst32[k], worst_hip32[k]) for k in worst if not ok(k)}
+    # Bound: 1e-4 against float64.  On the top-K-style (hub) graphs with the x40 test weights a few bias-type sums are
+    # ill-conditioned AT fp32 (hubs of 10^4 neighbours saturate tanh, the sums cancel to 6e-4 of their absolute sum): ANY
+    # fp32 evaluation order is ~1e-3 off the float64 truth there -- the host oracle's own fp32 run is (`fp32 oracle` column),
+    # the HIP path is, and the two fp32 paths differ from EACH OTHER by as much (third column: 3e-4 ... 1.4e-3 measured,
+    # depending on the oracle's thread count; round 3's "same digits" reading of one run does not hold in general and is not
+    # asserted).  For those tensors the bound is 10x the fp32 oracle's own error -- on the x40 hub cases only, and only where
+    # the oracle is more than 2e-5 off the truth.  What carries the strict claim for hub graphs are the conditioned cases
+    # (*_w8: the same graphs, GC weights x8): 1e-4 against float64 for every tensor, no relaxation, like every other case.
+    hub = "hub" in name and not name.endswith("_w8")
+    def bound(k):
+        return 10.0 * worst32[k] if (hub and worst32[k] > 2e-5) else 1e-4
+    bad = {k: (worst[k], worst32[k], worst_hip32[k]) for k in worst if worst[k] > bound(k)}
     assert not bad, "scale-relative gradient error above its bound (HIP vs float64, fp32 oracle vs float64, HIP vs fp32 oracle): %s" % bad
 
 
