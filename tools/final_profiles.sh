@@ -2,7 +2,7 @@ set -u
 T=$1
 mkdir -p gpurun_out/$T
 if [ -z "${SKIP_TESTS:-}" ]; then python -m pytest tests -m gpu -q > gpurun_out/$T/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/$T/pytest.log; tail -3 gpurun_out/$T/pytest.log; fi
-python bench.py > gpurun_out/$T/bench_genome.json 2> gpurun_out/$T/bench_genome.err
+( time python bench.py > gpurun_out/$T/bench_genome.json 2> gpurun_out/$T/bench_genome.err ) 2> gpurun_out/$T/bench_genome.time
 python bench.py --hic-like --no-cpu-baseline > gpurun_out/$T/bench_genome_hic.json 2>/dev/null
 for w in chr21 chr1 config1; do python bench.py --workload $w --no-cpu-baseline > gpurun_out/$T/bench_$w.json 2>/dev/null; python bench.py --workload $w --hic-like --no-cpu-baseline > gpurun_out/$T/bench_${w}_hic.json 2>/dev/null; done
 python bench.py --generator hub --no-cpu-baseline > gpurun_out/$T/bench_genome_hub.json 2>/dev/null
@@ -11,6 +11,7 @@ python bench.py --workload chr21 --d 256 --layers 4 --no-cpu-baseline > gpurun_o
 python bench.py --d 256 --layers 4 --no-cpu-baseline > gpurun_out/$T/bench_genome_d256L4.json 2>/dev/null
 python bench.py --gpus 2 --backend gloo --share-gpu --no-cpu-baseline --no-extras > gpurun_out/$T/bench_genome_2ranks_one_gpu_gloo.json 2>/dev/null
 python bench.py --workload e2e > gpurun_out/$T/bench_e2e.json 2>/dev/null
+python bench.py --workload e2e --e2e-windows 0 > gpurun_out/$T/bench_e2e_chr21_full.json 2>/dev/null
 bash tools/profile_round.sh $T genome
 bash tools/profile_round.sh $T genome_hic --hic-like
 bash tools/profile_round.sh $T chr21 --workload chr21
