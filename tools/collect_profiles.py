@@ -37,9 +37,16 @@ def main():
     if note:
         out["_note"] = note
     # the library sources these counters were measured on: bench.py reports a stored value only for the same sources
-    sys.path.insert(0, ROOT)
-    from chromegcn_amd import _build
-    out["_src_hash"] = _build.source_hash([])
+    # (recorded on the GPU box from the very snapshot that was profiled: tools/final_profiles.sh; an argument overrides it)
+    hfile = os.path.join(ROOT, "gpurun_out", tag, "src_hash.txt")
+    if len(sys.argv) > 3:
+        out["_src_hash"] = sys.argv[3]
+    elif os.path.exists(hfile):
+        out["_src_hash"] = open(hfile).read().strip()
+    else:
+        sys.path.insert(0, ROOT)
+        from chromegcn_amd import _build
+        out["_src_hash"] = _build.source_hash([])
     json.dump(out, open(os.path.join(prof, "traffic.json"), "w"), indent=1)
     # the bench lines were printed before this traffic.json existed: their `roofline.traffic` is the stored value of the
     # previous profile run; point the copies at the values collected from THIS run's PMC passes

@@ -1,6 +1,7 @@
 set -u
 T=$1
 mkdir -p gpurun_out/$T
+python -c "from chromegcn_amd import _build; print(_build.source_hash([]))" > gpurun_out/$T/src_hash.txt
 if [ -z "${SKIP_TESTS:-}" ]; then python -m pytest tests -m gpu -q > gpurun_out/$T/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/$T/pytest.log; tail -3 gpurun_out/$T/pytest.log; fi
 ( time python bench.py > gpurun_out/$T/bench_genome.json 2> gpurun_out/$T/bench_genome.err ) 2> gpurun_out/$T/bench_genome.time
 python bench.py --hic-like --no-cpu-baseline > gpurun_out/$T/bench_genome_hic.json 2>/dev/null
