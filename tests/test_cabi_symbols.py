@@ -34,3 +34,32 @@ def test_library_builds_loads_and_exports_everything():
     assert lib.cgcn_spmm(None, 10, 10, 3, 128, None, None, None, None, None, None, None) == -2   # strands
     assert lib.cgcn_spmm(None, 10, 10, 1, 100, None, None, None, None, None, None, None) == -1   # any width % 4: null pointers
     assert lib.cgcn_spmm(None, 10, 10, 1, 128, None, None, None, None, None, None, None) == -1
+
+
+def test_route_queries_are_pure_host_logic():
+    """cgcn_debug_layer_{fwd,bwd}_route (ABI v19): which kernels a call would launch; nothing is launched, no GPU needed."""
+    import ctypes
+    lib = _lib.load()
+    # forward: fused below the split threshold (8 MiB of feature table), two launches above, or for a hub-heavy graph
+    assert lib.cgcn_debug_layer_fwd_route(5776, 2, 128, None) == 0       # 5.9 MB
+    assert lib.cgcn_debug_layer_fwd_route(29910, 2, 128, None) == 1      # 30.6 MB
+    assert lib.cgcn_debug_layer_fwd_route(5776, 2, 256, None) == 0       # d = 256, both strands: the fused kernel at every size
+    assert lib.cgcn_debug_layer_fwd_route(29910, 2, 256, None) == 0
+
+    class Aux(ctypes.Structure):
+        _fields_ = [("col16", ctypes.c_void_p), ("row_order", ctypes.c_void_p), ("max_row_len", ctypes.c_int32)]
+    hub = Aux(None, None, 9000)
+    assert lib.cgcn_debug_layer_fwd_route(5776, 2, 128, ctypes.byref(hub)) == 1
+    lib.cgcn_debug_set_fwd_split_bytes(0)
+    try:
+        assert lib.cgcn_debug_layer_fwd_route(64, 1, 128, None) == 1     # the test hook forces the split at every size
+    finally:
+        lib.cgcn_debug_set_fwd_split_bytes(-1)
+    # backward: the ring kernel at d = 128, the 32-row-tile kernel + k_dh_dense at d = 256
+    assert lib.cgcn_debug_layer_bwd_route(5776, 2, 128) == 2 and lib.cgcn_debug_layer_bwd_route(29910, 1, 128) == 2
+    assert lib.cgcn_debug_layer_bwd_route(5776, 2, 256) == 0
+    assert lib.cgcn_debug_layer_bwd_route(5776, 3, 128) == -2 and lib.cgcn_debug_layer_fwd_route(5776, 2, 100, None) == -2
+    # one partial record per workgroup of the row-local launch: at most one per CU, 16-row slots at d = 128
+    rec = (128 * 128 + 2 * 128 + 4) * 4
+    assert lib.cgcn_layer_bwd_workspace_bytes(5776, 2, 128) == 256 * rec
+    assert lib.cgcn_layer_bwd_workspace_bytes(40, 2, 128) == 5 * rec

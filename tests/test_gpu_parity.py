@@ -120,6 +120,38 @@ def test_gated_layer_forward_backward_matches_oracle(S, d, split_forward):
         np.testing.assert_allclose(t["cg"].grad.cpu().numpy().ravel()[0], acc["dcg"], err_msg=name + " dcg", **TOL)
 
 
+def test_ring_backward_over_many_slot_generations():
+    """k_bwd_rowlocal_ring walks an 8-slot LDS ring with monotonic FULL / FREE counters: a workgroup of the 256 reuses every
+    slot once per 8 x 16 rows.  n = 70 000 windows x 2 strands = 8 750 slots = 34 per workgroup: more than four trips
+    round the ring (the full-size oracle cases reach two), a last slot that is not full, and a row range that crosses the
+    strand boundary inside a slot.  Identity adjacency ('none', utils/util_methods.py:173-174) keeps the host oracle
+    cheap; the row-local kernel does not look at the graph."""
+    n, S, d = 70003, 2, 128
+    h = G.normalize_graph("none", None, n)
+    g = G.upload(h, DEV)
+    rng = np.random.RandomState(31)
+    W, b, wg, cg = _layer_params(d, 32)
+    x = rng.randn(S, n, d).astype(np.float32)
+    gup = (rng.randn(S, n, d) * 0.1).astype(np.float32)
+    t = {k: dev(v).requires_grad_(True) for k, v in dict(x=x, W=W, b=b, wg=wg.reshape(1, d), cg=np.array([cg])).items()}
+    xn, gate = ops.gated_layer(t["x"], t["W"], t["b"], t["wg"], t["cg"], g)
+    (xn * dev(gup)).sum().backward()
+    a = h.to_scipy()
+    acc = {k: 0.0 for k in ["dW", "db", "dwg", "dcg"]}
+    for s in range(S):
+        f = O.layer_forward_np(a, x[s].astype(np.float64), W.astype(np.float64), b.astype(np.float64), wg.astype(np.float64), float(cg))
+        bw = O.layer_backward_np(a, x[s].astype(np.float64), W.astype(np.float64), wg.astype(np.float64), f["Z"], f["g"],
+                                 gup[s].astype(np.float64), np.zeros(n))
+        np.testing.assert_allclose(t["x"].grad[s].cpu().numpy(), bw["dX"], err_msg="dX strand %d" % s, **TOL)
+        for k in acc:
+            acc[k] = acc[k] + bw[k]
+    rel = lambda got, want: float(np.abs(got - want).max() / np.abs(want).max())
+    assert rel(t["W"].grad.cpu().numpy(), acc["dW"]) < 1e-4
+    assert rel(t["b"].grad.cpu().numpy(), acc["db"]) < 1e-4
+    assert rel(t["wg"].grad.cpu().numpy().ravel(), acc["dwg"]) < 1e-4
+    assert abs(t["cg"].grad.cpu().numpy().ravel()[0] - acc["dcg"]) < 1e-4 * max(1.0, abs(acc["dcg"]))
+
+
 def test_gated_layer_against_reference_golden(golden):
     """G2: values recorded from the reference's own GraphConvolution + gate math."""
     z = golden("g2_gated_layer.npz")
