@@ -18,6 +18,7 @@
 // Reference semantics: models/SubLayers.py:42-52, models/ChromeModels.py:34-46 (forward);
 // SURVEY.md Appendix A (backward).
 #include <atomic>
+#include <type_traits>
 #include <cstdlib>
 
 #include "cgcn_common.hpp"
@@ -1406,73 +1407,82 @@ __global__ __launch_bounds__(RING_THREADS) void k_bwd_rowlocal_ring(int M, int n
     float av[4];
     f32x4 bv[OB], uv[OB];
     bool primed = false, next_full = false;
-    auto rd = [&](const float* __restrict__ Hb, const float* __restrict__ Ub, int s) {
-      const int kk = s >> 1, h = s & 1;
-      if (h == 0) av[kk] = Hb[ha_off + kk * 4 * D];
-      bv[s % OB] = *(const f32x4*)&Ub[ub_lo + kk * 4 * D + 64 * h + ((rq ^ kk) << 4)];
-      uv[s % OB] = *(const f32x4*)&Ub[ua_lo + (((s & 3) ^ rq) << 4) + (s & 4) * 16];
-    };
-    for (int it = 0; it < ns; ++it) {
-      const int slot = it % NSL;
-#ifndef RING_SKIP_MFMA
-      const float* __restrict__ Hb = Hs[slot];
-      const float* __restrict__ Ub = Us[slot];
-      if (!primed) {
-        if (!(RING_EARLY_FLAG && next_full)) ring_wait(&FULL[slot], (unsigned)NRW * (unsigned)(it / NSL + 1));
-        rd(Hb, Ub, 0);
-      }
-      if (OB == 3) rd(Hb, Ub, 1);
-      f32x4 sc_cur;
-      primed = false;
-      const int nslot = (it + 1) % NSL;
-      unsigned nflag = 0u;
-      f32x4 hacc = {0.f, 0.f, 0.f, 0.f};
-      // step s = (kk, h) = (s >> 1, s & 1) of the dW product and k-step block t = s of the dHs product; operands of step
-      // s + 2 are requested before the MFMAs of step s
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        if (s + OB - 1 < 8) rd(Hb, Ub, s + OB - 1);
-        if (s == 5 && (RING_PRIME || RING_EARLY_FLAG)) nflag = __hip_atomic_load(&FULL[nslot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (s == 7) sc_cur = *(const f32x4*)&Sc[slot][4 * q];   // (requested here, not at the top: four registers less through the loop)
-        if (s == 7 && RING_EARLY_FLAG) {   // the next slot's flag was looked at two steps ago: usually up already -> no poll,
-          next_full = it + 1 < ns &&       // no exposed LDS round trip at the top of the next trip
-                      (int)(__builtin_amdgcn_readfirstlane(nflag) - (unsigned)NRW * (unsigned)((it + 1) / NSL + 1)) >= 0;
-          asm volatile("" ::: "memory");
-        }
-        if (s == 7 && RING_PRIME && it + 1 < ns &&
-            (int)(__builtin_amdgcn_readfirstlane(nflag) - (unsigned)NRW * (unsigned)((it + 1) / NSL + 1)) >= 0) {
-          asm volatile("" ::: "memory");
-          primed = true;
-          rd(Hs[nslot], Us[nslot], 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+    // DH: with the dHs product (a gather over Ahat^T follows) or without (dHs == NULL: the layer's input is a leaf nobody
+    // differentiates -- the engine's default for the first layer -- so the matrix team runs the dW product alone: half its MFMAs)
+    auto slot_loop = [&](auto DH_) {
+      constexpr bool DH = decltype(DH_)::value;
+      auto rd = [&](const float* __restrict__ Hb, const float* __restrict__ Ub, int s) {
         const int kk = s >> 1, h = s & 1;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          accW[h * 4 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bv[s % OB][u], accW[h * 4 + u], 0, 0, 0);
-          hacc = __builtin_amdgcn_mfma_f32_16x16x4f32(uv[s % OB][u], WT[s][u], hacc, 0, 0, 0);
-          if (u < 3) __builtin_amdgcn_sched_barrier(0);   // keep the alternation: two links of the dHs chain are 64 cycles apart
+        if (h == 0) av[kk] = Hb[ha_off + kk * 4 * D];
+        bv[s % OB] = *(const f32x4*)&Ub[ub_lo + kk * 4 * D + 64 * h + ((rq ^ kk) << 4)];
+        if (DH) uv[s % OB] = *(const f32x4*)&Ub[ua_lo + (((s & 3) ^ rq) << 4) + (s & 4) * 16];
+      };
+      for (int it = 0; it < ns; ++it) {
+        const int slot = it % NSL;
+#ifndef RING_SKIP_MFMA
+        const float* __restrict__ Hb = Hs[slot];
+        const float* __restrict__ Ub = Us[slot];
+        if (!primed) {
+          if (!(RING_EARLY_FLAG && next_full)) ring_wait(&FULL[slot], (unsigned)NRW * (unsigned)(it / NSL + 1));
+          rd(Hb, Ub, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      ring_arrive(&FREE[slot], lane);   // every operand of the slot is in registers (the last step's MFMAs covered the reads)
-      if (dHs) {   // 64-byte row segments straight from the accumulators (32-bit offsets from the uniform base)
-        const int m0 = (s_begin + it) * SR + 4 * q;
-        const unsigned o = (unsigned)((s_begin + it) * SR * D) + dh_lane;
-        if ((s_begin + it) * SR + SR <= M) {
+        if (OB == 3) rd(Hb, Ub, 1);
+        f32x4 sc_cur;
+        primed = false;
+        const int nslot = (it + 1) % NSL;
+        unsigned nflag = 0u;
+        f32x4 hacc = {0.f, 0.f, 0.f, 0.f};
+        // step s = (kk, h) = (s >> 1, s & 1) of the dW product and k-step block t = s of the dHs product; operands of step
+        // s + OB - 1 are requested before the MFMAs of step s
 #pragma unroll
-          for (int e = 0; e < 4; ++e) dHs[o + e * D] = hacc[e] * sc_cur[e];
-        } else {
+        for (int s = 0; s < 8; ++s) {
+          if (s + OB - 1 < 8) rd(Hb, Ub, s + OB - 1);
+          if (s == 5 && (RING_PRIME || RING_EARLY_FLAG)) nflag = __hip_atomic_load(&FULL[nslot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (DH && s == 7) sc_cur = *(const f32x4*)&Sc[slot][4 * q];   // (requested here, not at the top: four registers less through the loop)
+          if (s == 7 && RING_EARLY_FLAG) {   // the next slot's flag was looked at two steps ago: usually up already -> no poll,
+            next_full = it + 1 < ns &&       // no exposed LDS round trip at the top of the next trip
+                        (int)(__builtin_amdgcn_readfirstlane(nflag) - (unsigned)NRW * (unsigned)((it + 1) / NSL + 1)) >= 0;
+            asm volatile("" ::: "memory");
+          }
+          if (s == 7 && RING_PRIME && it + 1 < ns &&
+              (int)(__builtin_amdgcn_readfirstlane(nflag) - (unsigned)NRW * (unsigned)((it + 1) / NSL + 1)) >= 0) {
+            asm volatile("" ::: "memory");
+            primed = true;
+            rd(Hs[nslot], Us[nslot], 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          const int kk = s >> 1, h = s & 1;
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (m0 + e < M) dHs[o + e * D] = hacc[e] * sc_cur[e];
+          for (int u = 0; u < 4; ++u) {
+            accW[h * 4 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bv[s % OB][u], accW[h * 4 + u], 0, 0, 0);
+            if (DH) {
+              hacc = __builtin_amdgcn_mfma_f32_16x16x4f32(uv[s % OB][u], WT[s][u], hacc, 0, 0, 0);
+              if (u < 3) __builtin_amdgcn_sched_barrier(0);   // keep the alternation: two links of the dHs chain are 64 cycles apart
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
-      }
+        ring_arrive(&FREE[slot], lane);   // every operand of the slot is in registers (the last step's MFMAs covered the reads)
+        if (DH) {   // 64-byte row segments straight from the accumulators (32-bit offsets from the uniform base)
+          const int m0 = (s_begin + it) * SR + 4 * q;
+          const unsigned o = (unsigned)((s_begin + it) * SR * D) + dh_lane;
+          if ((s_begin + it) * SR + SR <= M) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dHs[o + e * D] = hacc[e] * sc_cur[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (m0 + e < M) dHs[o + e * D] = hacc[e] * sc_cur[e];
+          }
+        }
 #else
-      ring_wait(&FULL[slot], (unsigned)NRW * (unsigned)(it / NSL + 1));
-      ring_arrive(&FREE[slot], lane);
+        ring_wait(&FULL[slot], (unsigned)NRW * (unsigned)(it / NSL + 1));
+        ring_arrive(&FREE[slot], lane);
 #endif
-    }
+      }
+    };
+    if (dHs) slot_loop(std::true_type{});
+    else slot_loop(std::false_type{});
     // ---- this workgroup's dW partial: accW[4 h + u][e] = dW[16 own + 4 q + e][64 h + 4 r + u]
 #pragma unroll
     for (int h = 0; h < 2; ++h)

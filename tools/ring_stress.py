@@ -30,12 +30,17 @@ def main():
         dW = torch.zeros_like(W); db = torch.zeros(d, device=dev); dwg = torch.zeros(d, device=dev); dcg = torch.zeros(1, device=dev)
         wsb = lib.cgcn_layer_bwd_workspace_bytes(n, S, d); ws = torch.zeros(wsb, dtype=torch.uint8, device=dev)
 
-        def run(ph):   # dX == NULL: the row-local launch + the second-stage sum only (no gather)
+        def run(ph, with_dhs=True):   # dX == NULL: the row-local launch + the second-stage sum only (no gather)
             return lib.cgcn_debug_layer_bwd_phases(st(), n, S, d, P(g.rowptr), P(g.col), None, P(rs), P(x), P(z), P(h), P(gate), P(W), P(wg),
-                                                   P(dxn), None, None, P(dhs), P(dW), P(db), P(dwg), P(dcg), 0, 0.0, None, 0, None, P(ws), wsb, ph, None)
+                                                   P(dxn), None, None, P(dhs) if with_dhs else None, P(dW), P(db), P(dwg), P(dcg), 0, 0.0, None, 0,
+                                                   None, P(ws), wsb, ph, None)
         assert run(3) == 0
         torch.cuda.synchronize()
         first = [t.clone() for t in (dhs, dW, db, dwg, dcg)]
+        # the form without the dHs product (dHs == NULL: nobody differentiates the layer's input) must give the same sums
+        assert run(3, with_dhs=False) == 0
+        torch.cuda.synchronize()
+        same_without = all(torch.equal(a, b) for a, b in zip(first[1:], (dW, db, dwg, dcg)))
         # float64 restatement
         X, Z, Hh, Gu = (t.double().reshape(S * n, d) for t in (x, z, h, dxn))
         gt = gate.double().reshape(S * n)
@@ -53,9 +58,10 @@ def main():
                 torch.cuda.synchronize()
                 if not all(torch.equal(a, b) for a, b in zip(first, (dhs, dW, db, dwg, dcg))):
                     diff += 1
-        ok = diff == 0 and max(err.values()) < 2e-5
+        ok = diff == 0 and same_without and max(err.values()) < 2e-5
         bad += 0 if ok else 1
-        print("S=%d n=%6d  launches %d  differing checks %d  rel err vs float64 %s  %s" % (S, n, reps, diff, {k: "%.1e" % v for k, v in err.items()}, "ok" if ok else "FAIL"))
+        print("S=%d n=%6d  launches %d  differing checks %d  dW-only form identical %s  rel err vs float64 %s  %s"
+              % (S, n, reps, diff, same_without, {k: "%.1e" % v for k, v in err.items()}, "ok" if ok else "FAIL"))
         sys.stdout.flush()
     print("RING STRESS", "ok" if bad == 0 else "FAILED (%d sizes)" % bad)
     sys.exit(1 if bad else 0)
