@@ -143,3 +143,26 @@ def test_external_launcher_without_probes_runs_the_conservative_form():
     rc, lines, err = _run(["--gpus", "1", "--dry-run"], env)
     assert rc == 0, err[-2000:]
     assert "launch_ladder" not in json.loads(lines[0])   # one rank: nothing to choose
+
+
+@pytest.mark.gpu
+def test_external_launcher_on_the_gpu_box_probes_then_runs():
+    """The driver's own form on real hardware: `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`, here
+    with two gloo ranks sharing the one GPU a test box has.  Rank 0 must run the probe job(s) as children BEFORE either
+    rank touches the GPU, both ranks must then run the measured job with the chosen switches, and the line must say so."""
+    import socket
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
+                        "--workload", "chr21", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-roofline"],
+                       env=env, capture_output=True, text=True, timeout=1200)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    lad = d["launch_ladder"]
+    assert d["n_gpus"] == 2 and d["ranks_seen_by_backend"] == 2 and d["value"] > 0
+    assert lad["launcher"].startswith("external") and lad["rung"] == 0 and lad["tried"][0]["ok"] is True
