@@ -201,6 +201,11 @@ def choose_rung(args, first=0):
                 "--no-extras", "--no-roofline"] + user + flags
         rc, line, secs, why = _child_job(args.gpus, argv, probe_tmo)
         rec["tried"].append({"rung": i, "probe_s": round(secs, 1), "ok": why is None, "why": why})
+        if why is not None and "killed" not in why and secs < 45.0:
+            # a probe that DIES quickly (not one that hangs) may have lost a race for its rendezvous port or met a
+            # transient start-up error: the same rung once more, on a fresh port, before the configuration is given up
+            rc, line, secs, why = _child_job(args.gpus, argv, probe_tmo)
+            rec["tried"].append({"rung": i, "probe_s": round(secs, 1), "ok": why is None, "why": why, "retry": True})
         if why is None:
             rec["rung"] = i
             return i, rec

@@ -1105,9 +1105,12 @@ __device__ __forceinline__ void ring_wait(const unsigned* flag, unsigned target)
 #ifdef RING_NO_WAIT   // experiment only (results are garbage): the two teams run free of each other -> their pure interference
   return;
 #endif
-  while (true) {
+  // Every spin is bounded: a poll is ~200 cycles, a launch lasts ~10^5, so 2^22 polls (~0.4 s) can only mean a broken
+  // protocol -- trap (the launch fails with an error) instead of hanging the device.
+  for (unsigned spins = 0;; ++spins) {
     const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
     if ((int)(v - target) >= 0) break;
+    if (spins > (1u << 22)) __builtin_trap();
     __builtin_amdgcn_s_sleep(1);
   }
   asm volatile("" ::: "memory");   // nothing of the slot is read or written ahead of the poll
