@@ -43,6 +43,37 @@ __device__ __forceinline__ float wave_sum(float v) {
   return rl_f(v, 63);
 }
 
+// Sum over each 32-lane half of the wave, the half's total in every lane of the half (all lanes active).
+__device__ __forceinline__ float half_sum(float v, bool upper) {
+  v += dpp_get<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+  v += dpp_get<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+  v += dpp_get<0x141, 0xF>(v);   // row_half_mirror
+  v += dpp_get<0x140, 0xF>(v);   // row_mirror: every lane holds its row's total
+  v += dpp_get<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3: they hold the totals of lanes 0-31 / 32-63
+  const float lo = rl_f(v, 31), hi = rl_f(v, 63);
+  return upper ? hi : lo;
+}
+// ... of N independent values at once, step by step: a DPP instruction needs two wait states behind the instruction that
+// wrote its source, and the other values' steps are exactly that (one value alone: an s_nop per step)
+template <int N>
+__device__ __forceinline__ void half_sum_n(float (&v)[N], bool upper) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_get<0xB1, 0xF>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_get<0x4E, 0xF>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_get<0x141, 0xF>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_get<0x140, 0xF>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_get<0x142, 0xA>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const float lo = rl_f(v[i], 31), hi = rl_f(v[i], 63);
+    v[i] = upper ? hi : lo;
+  }
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // Chan's exact merge of two (count, mean, sum of squared deviations) summaries: A <- A u B

@@ -628,6 +628,9 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512, FWD_WAVES_PE
 #ifndef DENSE_WAVES_PER_SIMD
 #define DENSE_WAVES_PER_SIMD 4
 #endif
+#ifndef DENSE_HALF_WAVE_ROWS
+#define DENSE_HALF_WAVE_ROWS 1
+#endif
 template <int S, int D, int MB>
 __global__ __launch_bounds__(512, DENSE_WAVES_PER_SIMD) void k_layer_dense(int n, int ntiles, const float* __restrict__ Hin,
                                                     const float* __restrict__ X, const float* __restrict__ W,
@@ -659,6 +662,22 @@ __global__ __launch_bounds__(512, DENSE_WAVES_PER_SIMD) void k_layer_dense(int n
   ld_row<EPL>(wgl, &wg[lane * EPL]);
   const float c0 = cg[0];
   const uint32_t key = thresh ? dropout_key(rng_state, stream_id) : 0u;
+  // D = 128 (round 4): the row-wise passes take a row per HALF-wave, 16 bytes per lane -- one wave instruction moves two
+  // rows (k_bwd_rowlocal_ring's row team streams the same rows at 6.5 TB/s that way against 5.3 with 8 bytes per lane
+  // and a row per wave): half the loads / stores / LDS accesses, one DPP reduction for two rows.  The wave's two rows of
+  // a 16-row tile are 2 wave + {0, 1}.
+  constexpr bool HW = (D == 128 && MB == 1 && DENSE_HALF_WAVE_ROWS);
+  const bool upper = lane >= 32;
+  const int l4 = (lane & 31) * 4;
+  const int hm = 2 * wave + (upper ? 1 : 0);            // this half-wave's row of the tile
+  const int hs = hm / R, hr = hm % R;                   // its strand and its node inside the tile
+  const f32x4 wgl4 = HW ? *(const f32x4*)&wg[l4] : (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 hrow4 = {0.f, 0.f, 0.f, 0.f}, xres4 = hrow4, xnext4 = hrow4;
+  auto load_rows4 = [&](f32x4& dst, const float* __restrict__ src, int tile) {
+    const int i = tile * R + hr;
+    dst = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (i < n) dst = *(const f32x4*)&src[((size_t)hs * n + i) * D + l4];
+  };
 
   // rows of the tile this wave streams in / finishes: m = wave + t * NW  ->  (strand m / R, node node0 + m % R).
   // Both input streams run one whole tile ahead: the loads of tile t+1 are issued at the top of tile t, so every
@@ -682,22 +701,36 @@ __global__ __launch_bounds__(512, DENSE_WAVES_PER_SIMD) void k_layer_dense(int n
   const int tend = colstats ? min(ntiles, tfirst + stat_chunk) : ntiles;
   float st_cnt = 0.f, st_mean = 0.f, st_m2 = 0.f;   // running statistics of this thread's (strand, column)
   if (tfirst < tend) {
-    load_rows(hrow, Hin, tfirst);
-    load_rows(xnext, X, tfirst);
+    if (HW) {
+      load_rows4(hrow4, Hin, tfirst);
+      load_rows4(xnext4, X, tfirst);
+    } else {
+      load_rows(hrow, Hin, tfirst);
+      load_rows(xnext, X, tfirst);
+    }
   }
   KT_STAMP(9);
   for (int tile = tfirst; tile < tend; tile += tstep) {
     const int node0 = tile * R;
     KT_STAMP(10);
+    if (HW) {
+      *(f32x4*)&T[hm * LD + l4] = hrow4;
+      xres4 = xnext4;
+      if (tile + tstep < tend) {
+        load_rows4(hrow4, Hin, tile + tstep);
+        load_rows4(xnext4, X, tile + tstep);
+      }
+    } else {
 #pragma unroll
-    for (int t = 0; t < RPW; ++t) {
-      st_row<EPL>(&T[(wave + t * NW) * LD + lane * EPL], hrow[t]);
+      for (int t = 0; t < RPW; ++t) {
+        st_row<EPL>(&T[(wave + t * NW) * LD + lane * EPL], hrow[t]);
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) xres[t][e] = xnext[t][e];
-    }
-    if (tile + tstep < tend) {
-      load_rows(hrow, Hin, tile + tstep);
-      load_rows(xnext, X, tile + tstep);
+        for (int e = 0; e < EPL; ++e) xres[t][e] = xnext[t][e];
+      }
+      if (tile + tstep < tend) {
+        load_rows(hrow, Hin, tile + tstep);
+        load_rows(xnext, X, tile + tstep);
+      }
     }
     __syncthreads();
     KT_STAMP(11);
@@ -721,6 +754,26 @@ __global__ __launch_bounds__(512, DENSE_WAVES_PER_SIMD) void k_layer_dense(int n
     __syncthreads();
     KT_STAMP(13);
     // ---- row-wise gate + residual mix, coalesced stores
+    if (HW) {
+      const int i = node0 + hr;
+      const f32x4 z4 = *(const f32x4*)&T[hm * LD + l4];
+      float dot = z4[0] * wgl4[0] + z4[1] * wgl4[1] + z4[2] * wgl4[2] + z4[3] * wgl4[3];
+      dot = half_sum(dot, upper);
+      const float g = sigmoidf_(dot + c0);
+      if (i < n) {
+        const size_t g_off = ((size_t)hs * n + i) * D + l4;
+        f32x4 xo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xo[e] = (1.f - g) * xres4[e] + g * z4[e];
+          if (thresh) xo[e] = dropout_keep(key, (uint32_t)(g_off + e), thresh) ? xo[e] * keep_scale : 0.f;
+        }
+        if (colstats) *(f32x4*)&T[hm * LD + l4] = (f32x4){fmaxf(xo[0], 0.f), fmaxf(xo[1], 0.f), fmaxf(xo[2], 0.f), fmaxf(xo[3], 0.f)};  // own row, already consumed above
+        *(f32x4*)&Xn[g_off] = xo;
+        if (Zout) *(f32x4*)&Zout[g_off] = z4;
+        if ((lane & 31) == 0) gate[(size_t)hs * n + i] = g;
+      }
+    } else
 #pragma unroll
     for (int t = 0; t < RPW; ++t) {
       const int m = wave + t * NW;
@@ -1118,36 +1171,6 @@ __device__ __forceinline__ void ring_wait(const unsigned* flag, unsigned target)
 __device__ __forceinline__ void ring_arrive(unsigned* flag, int lane) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS accesses of the slot have completed
   if (lane == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-// Sum over each 32-lane half of the wave, the half's total in every lane of the half (all lanes active).
-__device__ __forceinline__ float half_sum(float v, bool upper) {
-  v += dpp_get<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
-  v += dpp_get<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
-  v += dpp_get<0x141, 0xF>(v);   // row_half_mirror
-  v += dpp_get<0x140, 0xF>(v);   // row_mirror: every lane holds its row's total
-  v += dpp_get<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3: they hold the totals of lanes 0-31 / 32-63
-  const float lo = rl_f(v, 31), hi = rl_f(v, 63);
-  return upper ? hi : lo;
-}
-// ... of N independent values at once, step by step: a DPP instruction needs two wait states behind the instruction that
-// wrote its source, and the other values' steps are exactly that (one value alone: an s_nop per step)
-template <int N>
-__device__ __forceinline__ void half_sum_n(float (&v)[N], bool upper) {
-#pragma unroll
-  for (int i = 0; i < N; ++i) v[i] += dpp_get<0xB1, 0xF>(v[i]);
-#pragma unroll
-  for (int i = 0; i < N; ++i) v[i] += dpp_get<0x4E, 0xF>(v[i]);
-#pragma unroll
-  for (int i = 0; i < N; ++i) v[i] += dpp_get<0x141, 0xF>(v[i]);
-#pragma unroll
-  for (int i = 0; i < N; ++i) v[i] += dpp_get<0x140, 0xF>(v[i]);
-#pragma unroll
-  for (int i = 0; i < N; ++i) v[i] += dpp_get<0x142, 0xA>(v[i]);
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    const float lo = rl_f(v[i], 31), hi = rl_f(v[i], 63);
-    v[i] = upper ? hi : lo;
-  }
 }
 // HEAD: the last layer (dL/dXn recomputed from the head's backward state, HeadApply); DROP: ... with the head's dropout
 template <bool HEAD, bool DROP>
