@@ -437,6 +437,12 @@ __device__ __forceinline__ void tile_mfma(const float* __restrict__ T, const flo
 // 8 waves per SIMD (<= 64 VGPRs; the two-strand 16-row variants need 62-66 as it is): four workgroups per CU
 // resident.  Measured with it: chr10-like layer forward 73.4 -> 68.9 us, chr1-like 92.5 -> 87.3 us, chr21-like
 // unchanged.  Not for the single-strand geometry (deeper batches, more registers: 25.4 us free vs 29.2 us forced).
+#ifndef DENSE_HALF_WAVE_ROWS
+#define DENSE_HALF_WAVE_ROWS 1   // d = 128: the row-wise passes of k_layer_fwd / k_layer_dense take a row per half-wave, 16 B per lane
+#endif
+#ifndef FWD_HALF_WAVE_ROWS
+#define FWD_HALF_WAVE_ROWS 1
+#endif
 #ifndef FWD_WAVES_PER_SIMD
 #define FWD_WAVES_PER_SIMD(S_, D_) (((S_) * (D_) == 128) ? 1 : 8)
 #endif
@@ -521,13 +527,25 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512, FWD_WAVES_PE
   if (PRE) load_wfrag<D, CBW, false>(W, wave, lane, bw);
   KT_STAMP(10);
   // prefetch the residual rows this wave will mix in phase 3 (latency hides behind the MFMA phase)
+  // D = 128: the row-wise epilogue takes a row per HALF-wave, 16 bytes per lane (see k_layer_dense): the wave's two rows
+  // of the 16-row tile are 2 wave + {0, 1}
+  constexpr bool HW = (D == 128 && MB == 1 && NW == 8 && FWD_HALF_WAVE_ROWS);
+  const bool upper = lane >= 32;
+  const int l4 = (lane & 31) * 4;
+  const int hm = 2 * wave + (upper ? 1 : 0);
+  const int hs = hm / R, hr = hm % R;
+  f32x4 xres4 = {0.f, 0.f, 0.f, 0.f};
   float xres[RPW][EPL];
+  if (HW) {
+    if (node0 + hr < n) xres4 = *(const f32x4*)&X[((size_t)hs * n + node0 + hr) * D + l4];
+  } else {
 #pragma unroll
-  for (int t = 0; t < RPW; ++t) {
-    const int m = wave + t * NW;
-    const int i = node0 + (m % R);
-    if (m < ROWS && i < n) ld_row<EPL>(xres[t], &X[((size_t)(m / R) * n + i) * D + lane * EPL]);
-    else zero_row<EPL>(xres[t]);
+    for (int t = 0; t < RPW; ++t) {
+      const int m = wave + t * NW;
+      const int i = node0 + (m % R);
+      if (m < ROWS && i < n) ld_row<EPL>(xres[t], &X[((size_t)(m / R) * n + i) * D + lane * EPL]);
+      else zero_row<EPL>(xres[t]);
+    }
   }
   // the epilogue's small operands too (bias of this lane's columns, gate weights): their latency would otherwise sit
   // between the MFMA phase and the tanh
@@ -547,6 +565,9 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512, FWD_WAVES_PE
 
   KT_STAMP(12);
   // ---- phase 3a: Z = tanh(U + b) back into the tile
+  // (the gate weights of the half-wave form are requested here, behind the products: they would cost four registers
+  // through the gather and the MFMA phase -- two spilled ones in the deep-batch instantiations at the 64-register cap)
+  const f32x4 wgl4 = HW ? *(const f32x4*)&wg[l4] : (f32x4){0.f, 0.f, 0.f, 0.f};
   {
     const int r = lane & 15, q = lane >> 4;
 #pragma unroll
@@ -563,6 +584,26 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512, FWD_WAVES_PE
 
   KT_STAMP(13);
   // ---- phase 3b: row-wise gate + residual mix, coalesced stores
+  if (HW) {
+    const int i = node0 + hr;
+    const f32x4 z4 = *(const f32x4*)&T[hm * LD + l4];
+    float dot = z4[0] * wgl4[0] + z4[1] * wgl4[1] + z4[2] * wgl4[2] + z4[3] * wgl4[3];
+    dot = half_sum(dot, upper);
+    const float g = sigmoidf_(dot + c0);
+    if (i < n) {
+      const size_t g_off = ((size_t)hs * n + i) * D + l4;
+      f32x4 xo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xo[e] = (1.f - g) * xres4[e] + g * z4[e];
+        if (thresh) xo[e] = dropout_keep(key, (uint32_t)(g_off + e), thresh) ? xo[e] * keep_scale : 0.f;
+      }
+      if (colstats) *(f32x4*)&T[hm * LD + l4] = (f32x4){fmaxf(xo[0], 0.f), fmaxf(xo[1], 0.f), fmaxf(xo[2], 0.f), fmaxf(xo[3], 0.f)};  // own row, already consumed above
+      *(f32x4*)&Xn[g_off] = xo;
+      if (Zout) *(f32x4*)&Zout[g_off] = z4;
+      if ((lane & 31) == 0) gate[(size_t)hs * n + i] = g;
+    }
+  } else
 #pragma unroll
   for (int t = 0; t < RPW; ++t) {
     const int m = wave + t * NW;
@@ -628,9 +669,7 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512, FWD_WAVES_PE
 #ifndef DENSE_WAVES_PER_SIMD
 #define DENSE_WAVES_PER_SIMD 4
 #endif
-#ifndef DENSE_HALF_WAVE_ROWS
-#define DENSE_HALF_WAVE_ROWS 1
-#endif
+
 template <int S, int D, int MB>
 __global__ __launch_bounds__(512, DENSE_WAVES_PER_SIMD) void k_layer_dense(int n, int ntiles, const float* __restrict__ Hin,
                                                     const float* __restrict__ X, const float* __restrict__ W,
