@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--dropout", type=float, default=0.2)
     ap.add_argument("--no-hip-graph", action="store_true")
+    ap.add_argument("--no-epoch-graph", action="store_true", help="A/B: one HIP graph launch per chromosome instead of one per epoch (single rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (profiling runs)")
     ap.add_argument("--no-roofline", action="store_true", help="tuning runs only: skip the isolated layer-forward timing (roofline = null)")
@@ -669,7 +670,8 @@ def main():
     stage = GCNStage(model, opt, "hic", dev, hip_graphs=not args.no_hip_graph, input_grad=True,
                      group=dist.group.WORLD if multi else None, cache_input_aggregation=False,
                      group_graph=False if args.no_group_graph else None, p2p_allreduce=True if args.p2p_allreduce else None,
-                     prediction_gather=args.gather, force_collectives=bool(args.force_collectives))
+                     prediction_gather=args.gather, force_collectives=bool(args.force_collectives),
+                     epoch_graph=False if args.no_epoch_graph else None)
 
     if genome:
         names = genome_train_names()
@@ -904,7 +906,7 @@ def main():
             "higher_is_better": True, "scaling": "strong" if genome else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": wl, "generator": args.generator,
-                       "hip_graph": not args.no_hip_graph,
+                       "hip_graph": not args.no_hip_graph, "epoch_graph": bool(stage.epoch_graph and not args.no_hip_graph and not multi),
                        "parallelism": ("chromosomes sharded over %d rank(s)" % world) if genome else "chromosome-per-rank x%d" % world,
                        "allreduce": stage.allreduce_kind if multi else None,
                        "step_group_graph": bool(stage._group_graph_enabled()) if multi else None,

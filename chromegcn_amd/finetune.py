@@ -80,6 +80,11 @@ class _SourceKey:
         return self.hic_sig == (getattr(hic, "nnz", None), getattr(hic, "shape", None))
 
 
+def _graph_uses(key, name) -> bool:
+    """does the captured graph stored under `key` touch chromosome `name`?  (key[0]: a name, None, or -- the epoch graph -- a tuple of names)"""
+    return key[0] == name or (isinstance(key[0], tuple) and name in key[0])
+
+
 class _HostArena:
     """Pinned host mirror of the stage's [sum n, C] prediction arena, for callers that want the reference's return value
     (CPU predictions, finetune.py:52-53,67).  The reference copies every chromosome's predictions to the host
@@ -106,17 +111,24 @@ class _HostArena:
         self.turn ^= 1
         self.used = 0
 
-    def fetch(self, rows, probs_dev):
-        """enqueue the copy of arena rows [r0, r1) behind everything the current stream holds so far"""
+    def fetch(self, rows_list, probs_dev):
+        """enqueue the copies of the arena row ranges [r0, r1) behind everything the current stream holds so far
+        (adjacent ranges travel as one copy)"""
         if self.used == len(self.events):
             self.events.append(torch.cuda.Event())
         ev = self.events[self.used]
         self.used += 1
         ev.record(torch.cuda.current_stream(self.device))
         self.stream.wait_event(ev)
-        r0, r1 = rows
+        runs = []
+        for r0, r1 in rows_list:
+            if runs and runs[-1][1] == r0:
+                runs[-1][1] = r1
+            else:
+                runs.append([r0, r1])
         with torch.cuda.stream(self.stream):
-            self.bufs[self.turn][r0:r1].copy_(probs_dev[r0:r1], non_blocking=True)
+            for r0, r1 in runs:
+                self.bufs[self.turn][r0:r1].copy_(probs_dev[r0:r1], non_blocking=True)
 
     def finish(self, span, rows_list):
         """wait for the copies; the split's rows as ONE host tensor (a view when the split is a contiguous run of the arena)"""
@@ -144,8 +156,12 @@ class GCNStage:
     def __init__(self, model, optimizer=None, adj_type: str = "hic", device="cuda", hip_graphs: bool = True,
                  input_grad: bool = False, group=None, fused_head: bool = True, cache_input_aggregation: bool = True,
                  force_collectives: bool = False, group_graph: Optional[bool] = None, p2p_allreduce: Optional[bool] = None,
-                 prediction_gather: str = "all", aux_group=None):
+                 prediction_gather: str = "all", aux_group=None, epoch_graph: Optional[bool] = None):
         self.model = model
+        # one HIP graph for a whole single-rank split (every chromosome's step, back to back) instead of one graph launch
+        # per chromosome, when the predictions stay on the device; CGCN_EPOCH_GRAPH=0 / epoch_graph=False = one graph per
+        # chromosome (profiles/r04_epoch_graph_experiment.txt)
+        self.epoch_graph = epoch_graph if epoch_graph is not None else os.environ.get("CGCN_EPOCH_GRAPH", "1") != "0"
         # where a split's predictions are assembled in a multi-rank run: "all" = on every rank (every rank's run_split
         # returns the whole split, like a single process), "rank0" = on rank 0 only, over direct point-to-point sends
         # (what nn.DataParallel does with the replicas' outputs, main.py:92-94: gathered on device 0; the other ranks'
@@ -248,7 +264,7 @@ class GCNStage:
             # when a deferred chromosome materialises from the very tensors it was registered with, and are rebuilt
             # when the caller handed in new (or edited) targets of the same shape.
             self._meta[name] = (n, t.shape[1], cost)
-            self._graphs = {k: v for k, v in self._graphs.items() if k[0] != name}
+            self._graphs = {k: v for k, v in self._graphs.items() if not _graph_uses(k, name)}
             if not materialising:
                 self._targets_cpu.clear()
                 self._targets_dev.clear()
@@ -268,7 +284,7 @@ class GCNStage:
         self._targets_dev.clear()
         self._gather_plans.clear()
         self._arena = None   # the output arena is laid out over the chromosome set: rebuilt (and graphs dropped) lazily
-        self._graphs = {k: v for k, v in self._graphs.items() if k[0] != name}
+        self._graphs = {k: v for k, v in self._graphs.items() if not _graph_uses(k, name)}
         if not self._graphs:
             self._pool = None
 
@@ -304,7 +320,7 @@ class GCNStage:
             self.chroms.pop(nm, None)
             self._pending.pop(nm, None)
             self._meta.pop(nm, None)
-            self._graphs = {k: v for k, v in self._graphs.items() if k[0] != nm}
+            self._graphs = {k: v for k, v in self._graphs.items() if not _graph_uses(k, nm)}
         if not self._graphs:
             self._pool = None
         self._targets_cpu.clear()
@@ -518,10 +534,15 @@ class GCNStage:
         """kind: 'train' (zero_grad+fwd+bwd+step), 'fwdbwd' (no optimizer step: multi-rank), 'eval', 'group' (multi-rank:
         fwd+bwd of `c` -- or a zeroed gradient when this rank sits the round out --, all-reduce, fused 1/k step)."""
         was_training = self.model.training
-        self.model.train(kind != "eval")
+        self.model.train(kind not in ("eval", "epoch_eval"))
         snap = self._snapshot()
 
         def body(collective=True):
+            if kind in ("epoch", "epoch_eval"):   # c: the split's chromosomes; their steps one after the other in ONE graph
+                out = None
+                for cc in c:
+                    out = self._fwd_bwd_step(cc) if kind == "epoch" else self._eval(cc) + (None,)
+                return out
             if kind == "eval":
                 loss, probs = self._eval(c)
                 return loss, probs, None
@@ -539,7 +560,7 @@ class GCNStage:
                 return out
             return self._fwd_bwd(c)
 
-        if kind == "train" and not self._fused_sgd:
+        if kind in ("train", "epoch") and not self._fused_sgd:
             # torch optimizers are not capturable by default (Adam.step raises under capture): callers replay
             # 'fwdbwd' and step eagerly instead (train_step)
             raise RuntimeError("only the fused SGD step can be captured; use kind='fwdbwd' + an eager optimizer.step()")
@@ -584,6 +605,53 @@ class GCNStage:
             ent = self._graphs[key] = self._capture(c, kind, group_size)
         ent["graph"].replay()
         return ent["loss"], ent["probs"], ent["dx"]
+
+    def _replay_epoch(self, names, train: bool) -> bool:
+        """The chromosomes `names` of a split as ONE captured graph (single rank; training needs the fused SGD): one graph
+        launch instead of one per chromosome -- the launches' gaps were 3 % of the genome epoch
+        (profiles/r04_epoch_graph_experiment.txt).  False = not applicable, the caller steps chromosome by chromosome."""
+        if not (self.epoch_graph and self.hip_graphs and len(names) > 1):
+            return False
+        if train:
+            self.model.train()
+            self._ensure_flat_grad()
+            if not self._fused_sgd:
+                return False
+        else:
+            self.model.eval()
+        self._ensure_arena()
+        cs = tuple(self._resident(nm) for nm in names)
+        if self._captured_lr != self._lr_signature():
+            self._drop_graphs()  # the learning rate is baked into the captured optimizer kernels
+            self._captured_lr = self._lr_signature()
+        kind = "epoch" if train else "epoch_eval"
+        key = (tuple(names), kind)
+        ent = self._graphs.get(key)
+        if ent is None:
+            ent = self._graphs[key] = self._capture(cs, kind)
+        ent["graph"].replay()
+        return True
+
+    def _copy_groups(self, names):
+        """A to_cpu split as a few graphs instead of one: the host copies of a group's rows are ordered behind the group's
+        graph by an event and run under the NEXT group's kernels (inside one graph neither memcpy nodes nor a copy kernel
+        on a forked branch overlapped: 6.7 / 6.55 ms per epoch instead of 4.9).  Every group holds at least half of the
+        rows still to come, so the copies keep up (PCIe moves a row 2-3x faster than the GPU computes one) and what is
+        exposed at the end is the last chromosome's copy alone: 16 chromosomes -> groups of 7, 6, 2, 1."""
+        if not (self.epoch_graph and self.hip_graphs):
+            return [[nm] for nm in names]
+        left = sum(self._meta[nm][0] for nm in names)
+        groups, cur, rows = [], [], 0
+        for nm in names:
+            cur.append(nm)
+            rows += self._meta[nm][0]
+            if 2 * rows >= left:
+                groups.append(cur)
+                left -= rows
+                cur, rows = [], 0
+        if cur:
+            groups.append(cur)
+        return groups
 
     # ------------------------------------------------------------------ public steps
     def train_step(self, name: str):
@@ -750,10 +818,12 @@ class GCNStage:
             # to_cpu (the reference's return value, finetune.py:52-53): every chromosome's rows leave for a pinned host
             # arena on a copy stream right behind its own step, while the next chromosome computes (_HostArena)
             host = self._host_arena(C) if (to_cpu and names and self.device.type == "cuda") else None
-            for nm in names:
-                self.train_step(nm) if train else self.eval_step(nm)   # results land in the arena: nothing to copy or add
+            for grp in ([names] if host is None else self._copy_groups(names)):
+                if not self._replay_epoch(grp, train):
+                    for nm in grp:
+                        self.train_step(nm) if train else self.eval_step(nm)   # results land in the arena: nothing to copy or add
                 if host is not None:
-                    host.fetch(self._arena["rows"][nm], self._arena["probs"])
+                    host.fetch([self._arena["rows"][nm] for nm in grp], self._arena["probs"])
             span = self._arena_span(names)
             if span is not None:   # the usual case: the split is the stage's chromosomes in order -> views, no copy
                 preds_dev = self._arena["probs"][span[0]:span[1]]

@@ -194,3 +194,44 @@ def test_cpu_predictions_of_the_drop_in_equal_the_device_arena_bitwise(golden):
     want = torch.cat([st._arena["probs"][rows[c][0]:rows[c][1]] for c in sub]).cpu()
     assert torch.equal(preds, want)
     assert torch.equal(targets, torch.cat([feats[c]["target"] for c in sub]))
+
+
+def test_one_graph_per_split_equals_one_graph_per_chromosome_bitwise(golden):
+    """run_split(to_cpu=False) on one rank replays ONE graph for the whole split (GCNStage(epoch_graph=True), the default).
+    Same kernels in the same order as one graph per chromosome: parameters, momentum, dropout state, losses and predictions
+    must agree bit for bit over several epochs (dropout on), for train and eval splits, for a subset in another order, across
+    a learning-rate change (the rate is baked into the captured optimizer kernels) and after a chromosome is reloaded."""
+    z = golden("g4_finetune_loop.npz")
+    chroms, feats, graphs = _load(z)
+    init = state_from(z, "init")
+    runs = []
+    for whole in (False, True):
+        m = C.ChromeGCN(128, 128, init["out.weight"].shape[0], 0.2, True, 2)
+        m.load_state_dict(init); m.to(DEV)
+        optim = torch.optim.SGD(m.parameters(), lr=0.05, weight_decay=1e-6, momentum=0.9)
+        st = GCNStage(m, optim, "hic", DEV, hip_graphs=True, epoch_graph=whole)
+        st.load(feats, graphs)
+        log = []
+        for e in range(4):
+            if e == 2:
+                optim.param_groups[0]["lr"] = 0.01
+            if e == 3:   # new data for one chromosome: every graph that touches it must be re-captured
+                c0 = chroms[0]
+                st.add_chromosome(c0, {"forward": feats[c0]["forward"] * 0.5, "backward": feats[c0]["backward"] * 0.5,
+                                       "target": 1.0 - feats[c0]["target"]}, graphs[c0])
+            p, t, loss = st.run_split("train", chroms, to_cpu=False, sync_loss=False)
+            log.append((p.clone(), loss.clone()))
+            p, t, loss = st.run_split("valid", chroms, to_cpu=False)
+            log.append((p.clone(), torch.tensor(loss)))
+            p, t, loss = st.run_split("train", [chroms[-1], chroms[0]], to_cpu=False)
+            log.append((p.clone(), torch.tensor(loss)))
+        keys = [k for k in st._graphs]
+        assert any(isinstance(k[0], tuple) for k in keys) == whole, keys
+        runs.append((log, {k: v.clone() for k, v in m.state_dict().items()},
+                     [optim.state[p_]["momentum_buffer"].clone() for p_ in m.parameters() if p_ in optim.state and "momentum_buffer" in optim.state[p_]]))
+    for (pa, la), (pb, lb) in zip(runs[0][0], runs[1][0]):
+        assert torch.equal(pa, pb) and torch.equal(la.cpu(), lb.cpu())
+    for k in runs[0][1]:
+        assert torch.equal(runs[0][1][k], runs[1][1][k]), k
+    for a, b in zip(runs[0][2], runs[1][2]):
+        assert torch.equal(a, b)
