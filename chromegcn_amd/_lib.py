@@ -34,6 +34,7 @@ _SIGNATURES = {
     "cgcn_head_bwd_partials": (_c_int, [_c_int]),
     "cgcn_head_fwd": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp] * 6 + [_c_float, _c_float, _c_int] + [_c_vp] * 3
                       + [_c_float] + [_c_vp] * 7 + [_c_sz]),
+    "cgcn_head_logits": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp] * 5 + [_c_float] + [_c_vp] * 3),
     "cgcn_head_train": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp] * 6 + [_c_float, _c_float] + [_c_vp] * 3 + [_c_float]
                         + [_c_vp] * 6 + [_c_int, _c_int, _c_vp, _c_sz]),
     "cgcn_debug_head_train_phases": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp] * 6 + [_c_float, _c_float] + [_c_vp] * 3 + [_c_float]
@@ -46,7 +47,7 @@ _SIGNATURES = {
     "cgcn_multilabel_metrics": (_c_int, [_c_vp, ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_float, _c_vp, _c_vp, _c_sz]),
     "cgcn_sgd_step": (_c_int, [_c_vp, ctypes.c_longlong, _c_vp, _c_vp, _c_vp, _c_float, _c_float, _c_float, _c_int, _c_float, _c_vp]),
 }
-ABI_VERSION = 19
+ABI_VERSION = 20
 _lib = None
 
 

@@ -128,6 +128,9 @@ __global__ __launch_bounds__(1024) void k_head_bn_finalize(int n, int S, int D, 
   const int CPB = COLS / S;  // channels per workgroup (S is 1 or 2)
   const int s = cl / CPB, c = blockIdx.x * CPB + cl % CPB;
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += S;
+  // the running statistics the tail updates: fetched now, under the record loads (they were a second dependent round trip)
+  float rm = 0.f, rv = 0.f;
+  if (slice == 0 && s == 0 && c < D) { rm = run_mean[c]; rv = run_var[c]; }
   const int per = (nblk + NSL - 1) / NSL;
   const int b0 = slice * per, b1 = min(nblk, b0 + per);
   auto rows_of = [&](int b) { return (double)max(0, min(n, (b + 1) * rows_per_blk) - b * rows_per_blk); };
@@ -182,7 +185,6 @@ __global__ __launch_bounds__(1024) void k_head_bn_finalize(int n, int S, int D, 
   }
   __syncthreads();
   if (slice != 0 || s != 0 || c >= D) return;
-  float rm = run_mean[c], rv = run_var[c];
   for (int st = 0; st < S; ++st) {
     // sequential update: the reference calls the model on the forward strand, then the reverse one
     rm = (1.f - momentum) * rm + momentum * (float)stat[0][st * CPB + cl];
@@ -250,7 +252,8 @@ __global__ __launch_bounds__(512) void k_head_fwd(int n, int S, int C, const flo
                                                   float keep_scale, uint32_t thresh,
                                                   const unsigned long long* __restrict__ rng_state, float inv_count,
                                                   float* __restrict__ probs, float* __restrict__ dpred,
-                                                  float* __restrict__ loss_part) {
+                                                  float* __restrict__ loss_part, float* __restrict__ logits) {
+  // logits != NULL (cgcn_head_logits): pred is the output; target, probs, dpred and loss_part are then NULL.
   // 8 waves; wave w owns label blocks w, w+8 (NCBW of them; C <= 128*NCBW) and rows w, w+8 of the 16-node tile.
   constexpr int R = HEAD_TILE, LD = D + 4, EPL = D / 64, NW = 8, KQ = D / 4, RPW = R / NW;
   constexpr bool PRE = (D == 128);
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(512) void k_head_fwd(int n, int S, int C, const flo
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int i = node0 + q * 4 + e;
-      tgv[cbi][e] = (i < n && j < C) ? target[(size_t)i * C + j] : 0.f;
+      tgv[cbi][e] = (target && i < n && j < C) ? target[(size_t)i * C + j] : 0.f;
     }
   }
   __syncthreads();
@@ -374,6 +377,10 @@ __global__ __launch_bounds__(512) void k_head_fwd(int n, int S, int C, const flo
         const int i = node0 + q * 4 + e;
         if (i < n) {
           const float pred = acc[cbi][e] + bjv[cbi];
+          if (logits) {
+            logits[(size_t)i * C + j] = pred;
+            continue;
+          }
           const float en = __expf(-fabsf(pred));            // exp(-|x|) in (0,1]
           const float inv = 1.f / (1.f + en);
           const float p = pred >= 0.f ? inv : en * inv;      // sigmoid(x), no overflow
@@ -384,6 +391,7 @@ __global__ __launch_bounds__(512) void k_head_fwd(int n, int S, int C, const flo
       }
     }
   }
+  if (logits) return;
   lacc = wave_sum(lacc);
   if (lane == 0) lsum[wave] = lacc;
   __syncthreads();
@@ -1619,13 +1627,39 @@ int cgcn_head_fwd(cgcn_stream_t stream, int n, int S, int d, int C, const float*
 #define HF(D_, NC_)                                                                                                   \
   hipLaunchKernelGGL((k_head_fwd<D_, NC_>), dim3(blocks), dim3(512), 0, st, n, S, C, X, bn_w, bn_b, mean, vr,         \
                      training ? 0 : 1, eps, Wout, bout, target, keep_scale, thresh, rng_state, inv_count, probs,      \
-                     training ? dpred : nullptr, w_loss)
+                     training ? dpred : nullptr, w_loss, nullptr)
   if (d == 128) { if (C <= 128) HF(128, 1); else HF(128, 2); }
   else { if (C <= 128) HF(256, 1); else HF(256, 2); }
 #undef HF
   if ((rc = launch_status())) return rc;
   hipLaunchKernelGGL(k_sum_scale, dim3(1), dim3(256), 0, st, blocks, w_loss, inv_count, loss);
   return launch_status();
+}
+
+// The eval-mode head of ONE ChromeGCN.forward call per strand (models/ChromeModels.py:48-51 with the module in eval
+// mode: running statistics, dropout off): logits[s] = BatchNorm1d(relu(X[s])) W_out^T + b_out.  No strand mean, no loss.
+int cgcn_head_logits(cgcn_stream_t stream, int n, int S, int d, int C, const float* X, const float* bn_w,
+                     const float* bn_b, const float* run_mean, const float* run_var, float eps, const float* Wout,
+                     const float* bout, float* logits) {
+  int rc = head_check(n, S, d, C);
+  if (rc) return rc;
+  if (!X || !bn_w || !bn_b || !run_mean || !run_var || !Wout || !bout || !logits) return CGCN_ERR_BAD_ARG;
+  if (misaligned16(Wout) || misaligned16(X)) return CGCN_ERR_BAD_ARG;  // vector row accesses
+  if (n == 0) return CGCN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = (n + HEAD_TILE - 1) / HEAD_TILE;
+  for (int s = 0; s < S; ++s) {
+    const float* Xs = X + (size_t)s * n * d;
+    float* Ls = logits + (size_t)s * n * C;
+#define HF(D_, NC_)                                                                                                   \
+  hipLaunchKernelGGL((k_head_fwd<D_, NC_>), dim3(blocks), dim3(512), 0, st, n, 1, C, Xs, bn_w, bn_b, run_mean, run_var, \
+                     1, eps, Wout, bout, nullptr, 1.f, 0u, nullptr, 0.f, nullptr, nullptr, nullptr, Ls)
+    if (d == 128) { if (C <= 128) HF(128, 1); else HF(128, 2); }
+    else { if (C <= 128) HF(256, 1); else HF(256, 2); }
+#undef HF
+    if ((rc = launch_status())) return rc;
+  }
+  return CGCN_OK;
 }
 
 }  // extern "C"

@@ -143,6 +143,11 @@ class ChromeGCN(nn.Module):
         """relu -> BatchNorm1d over the node axis -> dropout -> Linear (ChromeModels.py:48-51).
         x: [S, n, d]; strands go through BatchNorm one after the other, as the reference's two
         forward calls do (running statistics are updated forward strand first)."""
+        bn, out = self.batch_norm, self.out
+        if (not self.training and not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in
+                (bn.weight, bn.bias, out.weight, out.bias)))) and bn.track_running_stats and bn.affine
+                and x.shape[-1] in (128, 256) and out.weight.shape[0] <= 256 and out.bias is not None):
+            return ops.head_logits(x, bn, out)   # eval, nothing to differentiate: one fused kernel per strand
         x = F.relu(x)
         x = torch.stack([self.batch_norm(x[s]) for s in range(x.shape[0])], 0)
         x = F.dropout(x, self.dropout, training=self.training)

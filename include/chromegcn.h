@@ -50,7 +50,7 @@ extern "C" {
 #define CGCN_ERR_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after a launch      */
 #define CGCN_ERR_WORKSPACE (-4)   /* workspace too small (see cgcn_*_workspace_bytes)    */
 
-#define CGCN_ABI_VERSION 19
+#define CGCN_ABI_VERSION 20
 
 typedef void *cgcn_stream_t; /* hipStream_t */
 
@@ -282,6 +282,15 @@ int cgcn_head_fwd(cgcn_stream_t stream, int n, int S, int d, int C, const float 
                   const float *target, float dropout_p, const unsigned long long *rng_state,
                   float *probs, float *loss, float *dpred, float *save_mean, float *save_invstd,
                   void *workspace, size_t workspace_bytes);
+
+/*
+ * The eval-mode classifier head of ONE ChromeGCN.forward call per strand (models/ChromeModels.py:48-51 with the module in
+ * eval mode, what `model(x, adj)` returns as its second value): logits[s] = BatchNorm1d(relu(X[s])) W_out^T + b_out with
+ * the RUNNING statistics, dropout off -- no strand mean, no sigmoid, no loss, nothing updated.  X: [S,n,d] -> logits: [S,n,C].
+ */
+int cgcn_head_logits(cgcn_stream_t stream, int n, int S, int d, int C, const float *X, const float *bn_w,
+                     const float *bn_b, const float *run_mean, const float *run_var, float eps, const float *W_out,
+                     const float *b_out, float *logits);
 
 /*
  * Training-mode head forward fused with the tile-local half of its backward (one pass over X): same outputs as

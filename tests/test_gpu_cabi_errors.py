@@ -141,3 +141,25 @@ def test_fused_sgd_rejects_input_dropout_with_an_input_gradient(env):
     assert bwd(0.0, P(dx)) == OK
     torch.cuda.synchronize()
     assert int(rng[1].item()) == 1
+
+
+def test_head_logits_argument_checks(env):
+    """cgcn_head_logits: unsupported widths / label counts and NULL pointers come back as error codes, n = 0 launches nothing."""
+    lib, P, st = env["lib"], _lib.ptr, _lib.stream_ptr
+    n, d, C = 64, 128, 7
+    x = torch.randn(1, n, d, device="cuda")
+    v = torch.ones(d, device="cuda")
+    W = torch.randn(C, d, device="cuda"); b = torch.zeros(C, device="cuda")
+    out = torch.full((1, n, C), 7.0, device="cuda")
+    ok = lambda **k: lib.cgcn_head_logits(st(), k.get("n", n), k.get("S", 1), k.get("d", d), k.get("C", C), P(x), P(v), P(v), P(v),
+                                         k.get("rv", P(v)), 1e-5, P(W), P(b), k.get("out", P(out)))
+    assert ok() == OK
+    torch.cuda.synchronize()
+    want = (torch.relu(x[0]) - 1) / (1 + 1e-5) ** 0.5 + 1   # BatchNorm with mean = var = weight = bias = 1
+    assert torch.allclose(out[0], want @ W.t() + b, atol=1e-4, rtol=1e-4)
+    assert ok(d=96) == UNSUPPORTED and ok(C=257) == UNSUPPORTED and ok(S=3) == UNSUPPORTED
+    assert ok(rv=None) == BAD_ARG and ok(out=None) == BAD_ARG and ok(n=-1) == BAD_ARG
+    out.fill_(7.0)
+    assert ok(n=0) == OK
+    torch.cuda.synchronize()
+    assert bool((out == 7.0).all())

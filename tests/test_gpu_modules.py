@@ -244,3 +244,45 @@ def test_batchnorm_training_needs_two_rows():
     with pytest.raises(RuntimeError, match="bad argument"):
         m.forward_loss(x, g, torch.zeros(1, 5, device=DEV))
     assert torch.isfinite(m.batch_norm.running_var).all()
+
+
+@pytest.mark.parametrize("d,c,layers", [(128, 103, 2), (128, 164, 2), (256, 256, 4), (128, 1, 1)])
+def test_module_forward_in_eval_under_no_grad_runs_the_fused_head_and_matches_oracle(d, c, layers, monkeypatch):
+    """model.eval(); with torch.no_grad(): model(x, adj) -- how the reference's evaluation and visualisation code calls the
+    module (finetune.py:41-42 under the valid / test splits) -- goes through cgcn_head_logits (relu -> BatchNorm with the
+    running statistics -> Linear, one kernel); with gradients enabled the same call takes the differentiable torch ops.
+    Both must match the oracle module; forward_strands likewise for both strands at once."""
+    n = 777
+    torch.manual_seed(11)
+    orc = O.GatedGCNOracle(d, c, 0.3, layers)
+    with torch.no_grad():
+        orc.batch_norm.running_mean.normal_(0.1, 0.3)
+        orc.batch_norm.running_var.uniform_(0.4, 2.0)
+        orc.batch_norm.weight.uniform_(0.5, 1.5)
+        orc.batch_norm.bias.normal_(0, 0.2)
+    m = C.ChromeGCN(d, d, c, 0.3, True, layers)
+    m.load_state_dict(orc.state_dict())
+    m.to(DEV)
+    adj = synth.contact_graph(n, 4000, 3)
+    g = G.upload(G.normalize_graph("hic", adj, n), DEV)
+    adj_o = O.process_graph("hic", {"c": adj}, n, "c")
+    xf, xr = torch.randn(n, d), torch.randn(n, d)
+    orc.eval(); m.eval()
+    calls = []
+    real = ops.head_logits
+    monkeypatch.setattr(ops, "head_logits", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    with torch.no_grad():
+        want_f = orc(xf, adj_o, None)[1].numpy()
+        want_r = orc(xr, adj_o, None)[1].numpy()
+        got_f = m(xf.to(DEV), g)[1]
+        assert len(calls) == 1 and tuple(got_f.shape) == (n, c)
+        both = m.forward_strands(torch.stack([xf, xr]).to(DEV), g)[0]
+        assert len(calls) == 2 and tuple(both.shape) == (2, n, c)
+    np.testing.assert_allclose(got_f.cpu().numpy(), want_f, **TOL)
+    np.testing.assert_allclose(both[0].cpu().numpy(), want_f, **TOL)
+    np.testing.assert_allclose(both[1].cpu().numpy(), want_r, **TOL)
+    rm = m.batch_norm.running_mean.clone()
+    got_grad = m(xf.to(DEV), g)[1]                 # gradients enabled: the torch ops (differentiable), same numbers
+    assert len(calls) == 2 and got_grad.requires_grad
+    np.testing.assert_allclose(got_grad.detach().cpu().numpy(), got_f.cpu().numpy(), atol=2e-5, rtol=1e-5)
+    assert torch.equal(rm, m.batch_norm.running_mean)
