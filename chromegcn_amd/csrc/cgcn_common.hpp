@@ -216,7 +216,7 @@ __device__ __forceinline__ void head_finalize_slab(int slab, int P, int D, int C
 // (column, slice of the partial list); slices are merged through LDS in a fixed order => deterministic.
 // Writes d(bn bias) = sum dy, d(bn weight) = sum dy*xhat (both strands; scaled by the upstream d loss) and/or
 // bnc = the per-strand means for d loss = 1.
-template <int NT, bool EXT = false>
+template <int NT, bool EXT = false, int BATCH = 8>
 __device__ __forceinline__ void head_stats_finalize(int blk, int P, int n, int S, int D, int CP,
                                                     const float* __restrict__ part, float* __restrict__ dbn_w,
                                                     float* __restrict__ dbn_b, float* __restrict__ bnc, int accumulate,
@@ -239,16 +239,16 @@ __device__ __forceinline__ void head_stats_finalize(int blk, int P, int n, int S
     // batches of 8 records: all 32 loads of a batch are issued before the first add (the kernel is a latency chain:
     // with two records per trip the 8 records of a 256-partial launch were four dependent round trips); same
     // summation order as a plain loop
-    for (int p = p0; p < p1; p += 8) {
-      double t[8][4];
+    for (int p = p0; p < p1; p += BATCH) {   // (BATCH = 4 inside kernels that live on 64 registers: same summation order)
+      double t[BATCH][4];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < BATCH; ++u) {
         const double* st = (const double*)(part + (size_t)min(p + u, p1 - 1) * PS + CP * D + CP);
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) t[u][qd] = st[qd * D + c];
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < BATCH; ++u)
         if (p + u < p1) {
 #pragma unroll
           for (int qd = 0; qd < 4; ++qd) a[qd] += t[u][qd];

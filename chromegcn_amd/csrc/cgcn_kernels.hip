@@ -1912,18 +1912,31 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HAS_VAL ? 6
                                                     const float* __restrict__ part, float* __restrict__ dW,
                                                     float* __restrict__ db, float* __restrict__ dwg,
                                                     float* __restrict__ dcg, int accumulate, SgdFuse sg, int reduce_slabs,
-                                                    const int* __restrict__ order) {
+                                                    const int* __restrict__ order, HeadApply hp, int head_slabs) {
   // Horizontal fusion: the workgroups past the gather tiles do the (independent) second-stage sum of the
   // row-local kernel's partials, so that reduction costs no launch of its own and overlaps the gather's tail.
   if ((int)blockIdx.x >= gather_blocks) {
-    const int extra = (int)blockIdx.x - gather_blocks;
+    int extra = (int)blockIdx.x - gather_blocks;
     if (extra < reduce_slabs) {
       reduce_slab<512>(extra, P, D, part, dW, db, dwg, dcg, accumulate, sg);
       return;
     }
+    extra -= reduce_slabs;
+    if (extra < head_slabs) {
+      // the head's deferred second stage (dW_out / db_out slabs, BatchNorm column sums): the row-local launch of the last
+      // layer used to carry these 266 workgroups, but every workgroup of that kernel needs the whole LDS of a CU, so they
+      // ran as a second wave behind the 256 resident ones (+5 us); here they share CUs with the gather workgroups
+      const int wslabs = (hp.hf_CP * D + hp.hf_CP) / 64;
+      if (extra < wslabs)
+        head_finalize_slab<512>(extra, hp.hf_P, D, hp.hf_C, hp.hf_CP, hp.hf_part, hp.hf_dWout, hp.hf_dbout, hp.hf_accumulate, hp.dloss);
+      else
+        head_stats_finalize<512, false, 4>(extra - wslabs, hp.hf_P, n, S, D, hp.hf_CP, hp.hf_part, hp.hf_dbn_w, hp.hf_dbn_b, nullptr,
+                                           hp.hf_accumulate, hp.dloss);
+      return;
+    }
     // fused optimizer step (cgcn_sgd_fuse) for every arena element whose gradient an EARLIER launch finished: all but
     // this layer's own dW / db / dwg / dcg, which the slabs above step as they finish them
-    sgd_other_elements(sg, extra - reduce_slabs, D, dW, db, dwg, dcg);
+    sgd_other_elements(sg, extra - head_slabs, D, dW, db, dwg, dcg);
     return;
   }
   constexpr int NSL = S * D / 32, QPR = D / 32;
@@ -2371,6 +2384,13 @@ static int layer_bwd_impl(cgcn_stream_t stream, int n, int S, int d, const int32
     // dW_out / db_out slabs, plus the BatchNorm-column slabs when their parameter gradients are still to be summed
     head_slabs = (CP * d + CP) / 64 + (head->dbn_w ? d / HEAD_STAT_COLS : 0);
   }
+  // the head's second-stage workgroups ride in the gather launch when there is one on this stream and it does not carry
+  // the optimizer step (whose workgroups would step the head's gradients while these finish them); else in the row-local one
+#ifndef HEAD_SLABS_IN_GATHER
+#define HEAD_SLABS_IN_GATHER 1   // 0: A/B, round 3's placement (profiles/r04_head_slabs_in_gather.txt)
+#endif
+  const bool head_in_gather = HEAD_SLABS_IN_GATHER && head_slabs > 0 && n > 0 && dX != nullptr && !sg.param && !(aux_stream && aux_stream != stream);
+  const int head_slabs_rl = head_in_gather ? 0 : head_slabs, head_slabs_g = head_in_gather ? head_slabs : 0;
   if (!workspace || workspace_bytes < cgcn_layer_bwd_workspace_bytes(n, S, d)) return CGCN_ERR_WORKSPACE;
   if (misaligned16(workspace)) return CGCN_ERR_BAD_ARG;
   float ks;
@@ -2383,13 +2403,13 @@ static int layer_bwd_impl(cgcn_stream_t stream, int n, int S, int d, const int32
   if (!(phases & 1)) {
     // profiling only: the partials / dHs / dL/dXn of an earlier full call are still in place
   } else if (d == 128) {
-#define RING(H_, D_) hipLaunchKernelGGL((k_bwd_rowlocal_ring<H_, D_>), dim3(P + head_slabs), dim3(RING_THREADS), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, P, head_slabs, W)
+#define RING(H_, D_) hipLaunchKernelGGL((k_bwd_rowlocal_ring<H_, D_>), dim3(P + head_slabs_rl), dim3(RING_THREADS), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, P, head_slabs_rl, W)
     if (!head) RING(false, false);
     else if (hp.thresh) RING(true, true);
     else RING(true, false);
 #undef RING
   } else
-    hipLaunchKernelGGL((k_bwd_rowlocal256<32>), dim3(P + head_slabs), dim3(512), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, P, head_slabs);
+    hipLaunchKernelGGL((k_bwd_rowlocal256<32>), dim3(P + head_slabs_rl), dim3(512), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, P, head_slabs_rl);
   if ((rc = launch_status())) return rc;
   if ((phases & 1) && d == 256 && dHs && M > 0) {   // dHs = (diag(row_scale) dU) W^T: d = 128 did it inside the row-local kernel
     const int dh_tiles = (M + 16 * DH_MB - 1) / (16 * DH_MB);
@@ -2429,9 +2449,9 @@ static int layer_bwd_impl(cgcn_stream_t stream, int n, int S, int d, const int32
   const int sgd_blocks = sg.param ? (sg.count + 511) / 512 : 0;
   if (const uint16_t* col16_t = use_col16(aux_t, val_t, n)) {
 #define CALL16(S_, D_)                                                                                               \
-  hipLaunchKernelGGL((k_bwd_sliced<S_, D_, false, uint16_t>), dim3(blocks + (fuse_reduce ? slabs : 0) + sgd_blocks), dim3(512), 0, \
+  hipLaunchKernelGGL((k_bwd_sliced<S_, D_, false, uint16_t>), dim3(blocks + (fuse_reduce ? slabs : 0) + head_slabs_g + sgd_blocks), dim3(512), 0, \
                      st, n, rowptr_t, col16_t, val_t, dHs, dXn, gate, dX, ks, th, rng_state, in_stream_id, blocks, P, \
-                     part, dW, db, dwg, dcg, accumulate, sg, fuse_reduce ? slabs : 0, row_order(aux_t))
+                     part, dW, db, dwg, dcg, accumulate, sg, fuse_reduce ? slabs : 0, row_order(aux_t), hp, head_slabs_g)
     if (S == 1 && d == 128) CALL16(1, 128);
     else if (S == 2 && d == 128) CALL16(2, 128);
     else if (S == 1 && d == 256) CALL16(1, 256);
@@ -2439,9 +2459,9 @@ static int layer_bwd_impl(cgcn_stream_t stream, int n, int S, int d, const int32
 #undef CALL16
   } else {
 #define CALL(S_, D_, V_)                                                                                             \
-  hipLaunchKernelGGL((k_bwd_sliced<S_, D_, V_, int>), dim3(blocks + (fuse_reduce ? slabs : 0) + sgd_blocks), dim3(512), 0, \
+  hipLaunchKernelGGL((k_bwd_sliced<S_, D_, V_, int>), dim3(blocks + (fuse_reduce ? slabs : 0) + head_slabs_g + sgd_blocks), dim3(512), 0, \
                      st, n, rowptr_t, col_t, val_t, dHs, dXn, gate, dX, ks, th, rng_state, in_stream_id, blocks, P,  \
-                     part, dW, db, dwg, dcg, accumulate, sg, fuse_reduce ? slabs : 0, row_order(aux_t))
+                     part, dW, db, dwg, dcg, accumulate, sg, fuse_reduce ? slabs : 0, row_order(aux_t), hp, head_slabs_g)
     DISPATCH_SDV(S, d, val_t != nullptr, CALL);
 #undef CALL
   }
