@@ -1279,6 +1279,10 @@ __global__ __launch_bounds__(RING_THREADS) void k_bwd_rowlocal_ring(int M, int n
         if (s == 0) Hc[8 * D + c] = hp.bn_w[c];
       }
     }
+#ifndef RING_NT_LOADS
+#define RING_NT_LOADS 0   // bit mask of row streams loaded non-temporally (every one is a last use): 1 Z, 2 X, 4 H, 8 dXn, 16 dym
+#endif
+#define RING_LD(bit, p) ((RING_NT_LOADS & (bit)) ? __builtin_nontemporal_load((const f32x4*)(p)) : *(const f32x4*)(p))
     struct Rows { f32x4 z[RT], x[RT], h[RT], g[RT]; float gt[RT], sc[RT]; };
     Rows R_[PF];
     // this lane's element of a slot's rows, as 32-bit offsets from UNIFORM per-slot bases (scalar base + vector offset
@@ -1304,10 +1308,10 @@ __global__ __launch_bounds__(RING_THREADS) void k_bwd_rowlocal_ring(int M, int n
           unsigned ob = 4u * lane_el + (unsigned)(2 * NRW * t * D * 4);
           unsigned rb4 = 4u * (unsigned)(row0 + 2 * NRW * t);
           asm volatile("" : "+v"(ob), "+v"(rb4));   // keep the zero-extension next to the loads (a hoisted 64-bit offset defeats the mode)
-          w.z[t] = *(const f32x4*)((const char*)Zb + ob);
-          w.x[t] = *(const f32x4*)((const char*)Xb + ob);
-          w.h[t] = *(const f32x4*)((const char*)Hb + ob);
-          w.g[t] = *(const f32x4*)((const char*)Gb + ob);
+          w.z[t] = RING_LD(1, (const char*)Zb + ob);
+          w.x[t] = RING_LD(2, (const char*)Xb + ob);
+          w.h[t] = RING_LD(4, (const char*)Hb + ob);
+          w.g[t] = RING_LD(HEAD ? 16 : 8, (const char*)Gb + ob);
           w.gt[t] = *(const float*)((const char*)gb + rb4);
           w.sc[t] = rb ? *(const float*)((const char*)rb + rb4) : 1.f;
         }
