@@ -476,19 +476,12 @@ def head_loss(x, bn: torch.nn.BatchNorm1d, out: torch.nn.Linear, target, trainin
 
 def head_logits(x, bn: torch.nn.BatchNorm1d, out: torch.nn.Linear):
     """The eval-mode head of ChromeGCN.forward per strand (models/ChromeModels.py:48-51 with running statistics and
-    dropout off): relu -> BatchNorm1d -> Linear in one kernel (cgcn_head_logits).  x: [S, n, d] -> logits [S, n, C].
-    No autograd: callers use it when nothing needs a gradient (layers.ChromeGCN._head)."""
+    dropout off): relu -> BatchNorm1d -> Linear in one kernel (torch.ops.chromegcn.head_logits -> cgcn_head_logits).
+    x: [S, n, d] -> logits [S, n, C].  No autograd: callers use it when nothing needs a gradient (layers.ChromeGCN._head)."""
     _require_cuda(x, "x")
-    x = _dense(x)
-    S, n, d = x.shape
-    C = out.weight.shape[0]
-    logits = torch.empty((S, n, C), dtype=torch.float32, device=x.device)
-    lib = _lib.load()
-    P = lambda t: _dense(t.detach()).data_ptr()
-    _lib.check(lib.cgcn_head_logits(_lib.stream_ptr(), n, S, d, C, x.data_ptr(), P(bn.weight), P(bn.bias), P(bn.running_mean),
-                                    P(bn.running_var), float(bn.eps), P(out.weight), P(out.bias), logits.data_ptr()),
-               "cgcn_head_logits")
-    return logits
+    from . import torch_ops  # noqa: F401  (registers the ops)
+    return torch.ops.chromegcn.head_logits(x.detach(), bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                                           float(bn.eps), out.weight.detach(), out.bias.detach())
 
 
 def sgd_step(flat_param, flat_grad, flat_mom, lr, momentum, weight_decay, nesterov, rng_state=None, grad_scale=1.0):

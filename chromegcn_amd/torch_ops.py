@@ -5,6 +5,7 @@
     torch.ops.chromegcn.gated_layer_backward  its backward
     torch.ops.chromegcn.head_loss             relu/BatchNorm/dropout/Linear/BCE        models/ChromeModels.py:48-51, finetune.py:43-45,52
     torch.ops.chromegcn.head_loss_backward
+    torch.ops.chromegcn.head_logits           eval-mode relu/BatchNorm/Linear per strand   models/ChromeModels.py:48-51 (model.eval())
     torch.ops.chromegcn.sgd_step              SGD(momentum, weight decay) in place     utils/util_methods.py:14-19
 
 Pure-tensor signatures (the graph is passed as its CSR tensors), fake/meta implementations, and `register_autograd`
@@ -288,6 +289,32 @@ def _head_backward(ctx, dloss, dprobs, dsm, dsi, ddpred, drm, drv):
 
 
 head_loss.register_autograd(_head_backward, setup_context=_head_setup)
+
+
+@torch.library.custom_op("chromegcn::head_logits", mutates_args=(), device_types="cuda")
+def head_logits(x: Tensor, bn_w: Tensor, bn_b: Tensor, run_mean: Tensor, run_var: Tensor, eps: float, w_out: Tensor,
+                b_out: Tensor) -> Tensor:
+    """logits[s] = BatchNorm1d(relu(x[s]); running statistics) W_out^T + b_out -- the head of ChromeGCN.forward with the
+    module in eval mode, per strand, one kernel each (cgcn_head_logits).  x: [S, n, d] -> [S, n, C].  No autograd formula:
+    layers.ChromeGCN._head takes it only when nothing needs a gradient."""
+    for t, nm in ((x, "x"), (bn_w, "bn weight"), (bn_b, "bn bias"), (run_mean, "running_mean"), (run_var, "running_var"),
+                  (w_out, "out.weight"), (b_out, "out.bias")):
+        _cuda_f32(t, nm)
+    if x.dim() != 3:
+        raise RuntimeError("chromegcn::head_logits: x must be [S, n, d], got %s" % (tuple(x.shape),))
+    x = _dense(x)
+    S, n, d = x.shape
+    C = w_out.shape[0]
+    logits = torch.empty((S, n, C), dtype=torch.float32, device=x.device)
+    D = lambda t: _dense(t).data_ptr()
+    _lib.check(_lib.load().cgcn_head_logits(_lib.stream_ptr(), n, S, d, C, x.data_ptr(), D(bn_w), D(bn_b), D(run_mean), D(run_var),
+                                            float(eps), D(w_out), D(b_out), logits.data_ptr()), "cgcn_head_logits")
+    return logits
+
+
+@head_logits.register_fake
+def _(x, bn_w, bn_b, run_mean, run_var, eps, w_out, b_out):
+    return x.new_empty((x.shape[0], x.shape[1], w_out.shape[0]))
 
 
 def head_loss_module(x: Tensor, bn: torch.nn.BatchNorm1d, out: torch.nn.Linear, target: Tensor, training: bool,

@@ -72,6 +72,19 @@ def test_opcheck_head_loss(training, p):
         torch.library.opcheck(torch.ops.chromegcn.head_loss_backward.default, bargs)
 
 
+def test_opcheck_head_logits():
+    S, n, d, Cn = 2, 200, 128, 13
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    x = torch.randn(S, n, d, device=DEV, generator=gen)
+    bw, bb = 1 + 0.1 * torch.randn(d, device=DEV, generator=gen), 0.1 * torch.randn(d, device=DEV, generator=gen)
+    rm, rv = 0.2 * torch.randn(d, device=DEV, generator=gen), 0.5 + torch.rand(d, device=DEV, generator=gen)
+    Wo, bo = torch.randn(Cn, d, device=DEV, generator=gen) / d ** 0.5, 0.1 * torch.randn(Cn, device=DEV, generator=gen)
+    args = (x, bw, bb, rm, rv, 1e-5, Wo, bo)
+    torch.library.opcheck(torch.ops.chromegcn.head_logits.default, args)
+    want = torch.nn.functional.linear(torch.nn.functional.batch_norm(torch.relu(x).reshape(S * n, d), rm, rv, bw, bb, False, 0.0, 1e-5), Wo, bo)
+    assert torch.allclose(torch.ops.chromegcn.head_logits(*args).reshape(S * n, Cn), want, atol=2e-5, rtol=1e-5)
+
+
 def test_opcheck_and_values_of_sgd_step():
     n = 5000
     p = torch.randn(n, device=DEV); g = torch.randn(n, device=DEV); m = torch.randn(n, device=DEV)

@@ -8,7 +8,7 @@ from chromegcn_amd import torch_ops  # noqa: F401  (registers the operators)
 
 def test_operators_are_registered_with_functional_schemas():
     ops = torch.ops.chromegcn
-    for name in ("spmm", "gated_layer", "gated_layer_backward", "head_loss", "head_loss_backward", "sgd_step"):
+    for name in ("spmm", "gated_layer", "gated_layer_backward", "head_loss", "head_loss_backward", "head_logits", "sgd_step"):
         assert hasattr(ops, name), name
     assert "Tensor(a" not in str(ops.gated_layer.default._schema)       # functional: autograd formulas are registered
     assert "Tensor(a" not in str(ops.head_loss.default._schema)
@@ -40,6 +40,7 @@ def test_fake_implementations_propagate_shapes():
         Wo, bo = torch.empty(C, d, device=dev), torch.empty(C, device=dev)
         rm, rv = torch.empty(d, device=dev), torch.empty(d, device=dev)
         tgt = torch.empty(n, C, device=dev)
+        assert tuple(torch.ops.chromegcn.head_logits(xn, bw, bb, rm, rv, 1e-5, Wo, bo).shape) == (S, n, C)
         for training in (True, False):
             loss, probs, sm, si, dp, nrm, nrv = torch.ops.chromegcn.head_loss(xn, bw, bb, Wo, bo, tgt, rm, rv, 0.1, 1e-5,
                                                                               training, 0.0, None)
