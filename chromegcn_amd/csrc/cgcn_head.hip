@@ -1097,7 +1097,7 @@ extern "C" int cgcn_debug_rs_stamps(unsigned long long* out) {
 // past the pass's labels hold zeros in Pt / W_out's LDS copy, so walking them is only wasted work).  A compile-time
 // count keeps the product loops free of branches: with `if (ib < CB)` inside them every MFMA sat behind its own
 // ds_read + lgkmcnt(0).
-template <bool MULTI, int NB, bool DROP>
+template <bool MULTI, int NB, bool DROP, int NRB = 2>
 __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, const float* __restrict__ X,
                                                         const float* __restrict__ bn_w, const float* __restrict__ bn_b,
                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -1107,7 +1107,7 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
                                                         float* __restrict__ probs, float* __restrict__ loss_part,
                                                         float* __restrict__ dym, float* __restrict__ part,
                                                         int c0, int Cp, int CPT, int first_, int last_) {
-  constexpr int D = 128, TR = HEADB_TILE, EPL = 2, RPW = TR / 8, KQ = D / 4;
+  constexpr int D = 128, TR = 16 * NRB, EPL = 2, RPW = TR / 8, KQ = D / 4;   // NRB: 16-row MFMA blocks per tile (2 = HEADB_TILE)
   constexpr int CP = 128, CBMAX = 8;
   constexpr int LDP = CP + 18, LDY = D + 16, LDW = D + 16;
   __shared__ __attribute__((aligned(16))) float Wl[NB * 16 * LDW];   // W_out rows c0 .. c0 + 16 NB (zeros past Cp)
@@ -1146,7 +1146,7 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
 
   if (wave < 8) {
     // =============================================================== P: pred team
-    float xv[RPW][2][EPL], tgv[2][4], mu[2][EPL], is[2][EPL], gw[EPL], gb[EPL];
+    float xv[RPW][2][EPL], tgv[NRB][4], mu[2][EPL], is[2][EPL], gw[EPL], gb[EPL];
     float dbo = 0.f, lacc = 0.f;
     const float bj = own * 16 + (lane & 15) < Cp ? bout[c0 + own * 16 + (lane & 15)] : 0.f;
 #pragma unroll
@@ -1178,7 +1178,7 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
       const int node0 = tile * TR;
       const int j = own * 16 + (lane & 15), q = lane >> 4;
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb)
+      for (int mb = 0; mb < NRB; ++mb)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int i = node0 + mb * 16 + q * 4 + e;
@@ -1224,7 +1224,9 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
       __syncthreads();
       // ---- S2: pred = ym W_out^T (M = 32 rows, K = D permuted, N = this wave's label block)   (matrix; Q: its epilogue)
       RS_STAMP(2);
-      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      f32x4 acc[NRB];
+#pragma unroll
+      for (int mb = 0; mb < NRB; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (k < mt) {
         if (k + 1 < mt) load_rows(tile + G);   // the rows were consumed in S1
         if (own < NB) {
@@ -1234,13 +1236,14 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
           const float* __restrict__ Wa = Wl + (own * 16 + r) * LDW + 4 * q;
 #pragma unroll
           for (int t = 0; t < KQ / 4; ++t) {
-            const f32x4 a0 = *(const f32x4*)&Ya[16 * t], a1 = *(const f32x4*)&Ya[16 * LDY + 16 * t];
+            f32x4 a[NRB];
+#pragma unroll
+            for (int mb = 0; mb < NRB; ++mb) a[mb] = *(const f32x4*)&Ya[mb * 16 * LDY + 16 * t];
             const f32x4 b = *(const f32x4*)&Wa[16 * t];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], b[u], acc[0], 0, 0, 0);
-              acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u], b[u], acc[1], 0, 0, 0);
-            }
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int mb = 0; mb < NRB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb][u], b[u], acc[mb], 0, 0, 0);
           }
           __builtin_amdgcn_s_setprio(0);
         }
@@ -1254,7 +1257,7 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
         OPAQUE_LANE(r, q, lq);
         const int j = own * 16 + r;
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+        for (int mb = 0; mb < NRB; ++mb)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {   // branch-free but for the predicated store (see S1)
             const int row = mb * 16 + q * 4 + e;
@@ -1304,14 +1307,14 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
     // X of this lane's (row, column) elements of a tile, for the BatchNorm sums of its epilogue: requested a whole matrix
     // product before they are used -- the rows have left the L2 since P read them (a 30 MB table), and their latency was
     // all of the epilogue's time when they were requested there
-    float xq[2][2][4];
+    float xq[2][NRB][4];
     auto load_xq = [&](int tile) {
       OPAQUE_LANE(r, q, lq);
       const int node0 = tile * TR, c = own * 16 + r;
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+        for (int mb = 0; mb < NRB; ++mb)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int i = node0 + mb * 16 + q * 4 + e;
@@ -1320,7 +1323,9 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
     };
     for (int k = 0; k <= mt; ++k) {
       const int node0 = ((int)blockIdx.x + (k - 1) * G) * TR;   // tile k-1
-      f32x4 accY[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      f32x4 accY[NRB];
+#pragma unroll
+      for (int mb = 0; mb < NRB; ++mb) accY[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
       // ---- S1: dym tile = Pt W_out of tile k-1 (M = TR rows, K = labels, N = this wave's 16 columns)   (matrix; P: ym rows)
       RS_STAMP(0);
       if (k >= 1) {
@@ -1329,7 +1334,7 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
         if (MULTI && !first) {   // the earlier label passes' share of dym seeds the accumulators
           const int c = own * 16 + r;
 #pragma unroll
-          for (int mb = 0; mb < 2; ++mb)
+          for (int mb = 0; mb < NRB; ++mb)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int i = node0 + mb * 16 + q * 4 + e;
@@ -1340,12 +1345,12 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
         __builtin_amdgcn_s_setprio(HEAD_RS_PRIO);
         const float* __restrict__ Pa = Pb + r * LDP + q;
         const float* __restrict__ Wa = Wl + q * LDW + own * 16 + r;
-        float pa[2][8], wb[2][4];
+        float pa[2][4 * NRB], wb[2][4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           wb[0][u] = Wa[4 * u * LDW];
 #pragma unroll
-          for (int mb = 0; mb < 2; ++mb) pa[0][u * 2 + mb] = Pa[mb * 16 * LDP + 4 * u];
+          for (int mb = 0; mb < NRB; ++mb) pa[0][u * NRB + mb] = Pa[mb * 16 * LDP + 4 * u];
         }
 #pragma unroll
         for (int g = 0; g < NB; ++g) {
@@ -1354,14 +1359,14 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
             for (int u = 0; u < 4; ++u) {
               wb[(g + 1) & 1][u] = Wa[4 * (4 * (g + 1) + u) * LDW];
 #pragma unroll
-              for (int mb = 0; mb < 2; ++mb) pa[(g + 1) & 1][u * 2 + mb] = Pa[mb * 16 * LDP + 4 * (4 * (g + 1) + u)];
+              for (int mb = 0; mb < NRB; ++mb) pa[(g + 1) & 1][u * NRB + mb] = Pa[mb * 16 * LDP + 4 * (4 * (g + 1) + u)];
             }
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) accY[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[g & 1][u * 2 + mb], wb[g & 1][u], accY[mb], 0, 0, 0);
+            for (int mb = 0; mb < NRB; ++mb) accY[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[g & 1][u * NRB + mb], wb[g & 1][u], accY[mb], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_setprio(0);
@@ -1374,7 +1379,7 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
         OPAQUE_LANE(r, q, lq);
         const int c = own * 16 + r;
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+        for (int mb = 0; mb < NRB; ++mb)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {   // branch-free but for the predicated store: rows past n have d loss / d pred = 0,
             const int i = node0 + mb * 16 + q * 4 + e;   // hence dym = 0 and contribute nothing to the sums
@@ -1548,7 +1553,8 @@ static inline int head_stat_blocks(int n, int* rows_per_blk) {
 // Workgroups (= partials) of k_head_fused / k_head_bwd: one 32-node tile each up to HEAD_MAX_PARTIALS (one per CU),
 // persistent beyond.  Measured alternatives: twice as many workgroups for large chromosomes (the kernel needs 206
 // VGPRs, so they do not co-reside: 81 vs 75 us at chr1 size); 16-node tiles for small ones (more, shorter chains but
-// twice the partials: chr21 step 0.234 vs 0.221 ms).
+// twice the partials: chr21 step 0.234 vs 0.221 ms).  k_head_fused_rs keeps this workgroup count at either tile height
+// (it picks 16- or 32-row tiles per launch, cgcn_head_train).
 static inline int head_bwd_partials(int n) {
   int t = (n + HEADB_TILE - 1) / HEADB_TILE;
   if (t > HEAD_MAX_PARTIALS) t = HEAD_MAX_PARTIALS;
@@ -1721,18 +1727,27 @@ static int head_train_impl(cgcn_stream_t stream, int n, int S, int d, int C, con
                        CP, first, last)
     if (d == 128 && HEAD_RS) {
       const bool nb7 = Cp > 96 && Cp <= 112;
+      // Tile height.  A launch lasts (tiles per workgroup + 1) periods -- the Q team runs one tile behind the P team --,
+      // so 1.1 tiles per workgroup cost 3 periods of 32-row tiles; 16-row tiles cost HEAD_TR16_COST_PCT % of a 32-row
+      // period each (their products reuse every W_out operand half as often) but quantise the work twice as finely.
+#ifndef HEAD_TR16_COST_PCT
+#define HEAD_TR16_COST_PCT 55   // measured 55 < 60 < 75 = off (0: 32-row tiles always); profiles/r04_head_tile_height.txt
+#endif
+      auto periods = [&](int tr) { return (((n + tr - 1) / tr) + P - 1) / P + 1; };
+      const bool tr16 = HEAD_TR16_COST_PCT > 0 && periods(16) * HEAD_TR16_COST_PCT < periods(32) * 100;
+#define HRS2(M_, NB_, DR_, NRB_)                                                                                       \
+        hipLaunchKernelGGL((k_head_fused_rs<M_, NB_, DR_, NRB_>), dim3(P), dim3(1024), 0, st, n, S, C, X, bn_w, bn_b, save_mean, save_invstd, \
+                         Wout, bout, target, keep_scale, thresh, rng_state, inv_count, probs, w_loss, w_dym, w_part, c0, Cp, \
+                         CP, first, last)
 #define HRS(M_, NB_)                                                                                                   \
       do {                                                                                                             \
-        if (thresh) hipLaunchKernelGGL((k_head_fused_rs<M_, NB_, true>), dim3(P), dim3(1024), 0, st, n, S, C, X, bn_w, bn_b, save_mean, save_invstd, \
-                         Wout, bout, target, keep_scale, thresh, rng_state, inv_count, probs, w_loss, w_dym, w_part, c0, Cp, \
-                         CP, first, last);                                                                             \
-        else hipLaunchKernelGGL((k_head_fused_rs<M_, NB_, false>), dim3(P), dim3(1024), 0, st, n, S, C, X, bn_w, bn_b, save_mean, save_invstd, \
-                         Wout, bout, target, keep_scale, thresh, rng_state, inv_count, probs, w_loss, w_dym, w_part, c0, Cp, \
-                         CP, first, last);                                                                             \
+        if (thresh) { if (tr16) HRS2(M_, NB_, true, 1); else HRS2(M_, NB_, true, 2); }                                  \
+        else { if (tr16) HRS2(M_, NB_, false, 1); else HRS2(M_, NB_, false, 2); }                                       \
       } while (0)
       if (C <= 128) { if (nb7) HRS(false, 7); else HRS(false, 8); }
       else { if (nb7) HRS(true, 7); else HRS(true, 8); }
 #undef HRS
+#undef HRS2
     }
     else if (d == 128) HFU(128);
     else HFU(256);
