@@ -853,7 +853,11 @@ def main():
                     # gathered neighbour rows (4 nnz S d bytes per launch): served by the L2s / vector L1s, not by HBM -- the
                     # table is cache resident -- so this rate may legitimately exceed the HBM peak
                     "gathered_bytes_per_launch": (e["gather"] / e["launches"]) if e["gather"] else None,
-                    "gather_GBps": (e["gather"] / e["s"] / 1e9) if e["gather"] else None}
+                    "gather_GBps": (e["gather"] / e["s"] / 1e9) if e["gather"] else None,
+                    # what actually bounds a gather kernel: MI355X_MICROARCH.md measures 16.8-18.8 TB/s for row gathers out
+                    # of the XCD L2s (L2 -> vector L1 line rate); `frac` above prices the compulsory HBM bytes only
+                    "gather_ceiling_GBps": [16800.0, 18800.0] if e["gather"] else None,
+                    "frac_of_gather_ceiling": (e["gather"] / e["s"] / 1e9 / 18800.0) if e["gather"] else None}
         tot_s = sum(e["s"] for e in agg.values())
         ranked = sorted(((k, e) for k, e in agg.items() if e["bytes"]), key=lambda kv: -kv[1]["s"])
         top3 = []
