@@ -637,7 +637,7 @@ class GCNStage:
         graph by an event and run under the NEXT group's kernels (inside one graph neither memcpy nodes nor a copy kernel
         on a forked branch overlapped: 6.7 / 6.55 ms per epoch instead of 4.9).  Every group holds at least half of the
         rows still to come, so the copies keep up (PCIe moves a row 2-3x faster than the GPU computes one) and what is
-        exposed at the end is the last chromosome's copy alone: 16 chromosomes -> groups of 7, 6, 2, 1."""
+        exposed at the end is the last chromosome's copy alone: 16 chromosomes -> groups of 6, 4, 3, 2, 1."""
         if not (self.epoch_graph and self.hip_graphs):
             return [[nm] for nm in names]
         left = sum(self._meta[nm][0] for nm in names)

@@ -64,3 +64,27 @@ def test_genome_plan_is_balanced_at_eight_ranks():
     # each round synchronises at its all-reduce: the round's span is its slowest member
     span = sum(max(cost[g] for g in r) for r in plan.rounds)
     assert span / (sum(cost.values()) / 8) < 1.35
+
+
+def test_copy_groups_of_a_to_cpu_split_keep_the_copies_ahead_of_the_compute():
+    """GCNStage._copy_groups (host logic, no device): a split that returns CPU predictions is replayed as a few graphs, each
+    followed by one copy of its rows.  Every group must hold at least half of the rows still to come (so the PCIe copies,
+    2-3x faster per row than the compute, never fall behind), the groups must partition the names in order, and without
+    epoch graphs every chromosome is its own group."""
+    from chromegcn_amd import synth
+    from chromegcn_amd.finetune import GCNStage
+    st = GCNStage.__new__(GCNStage)
+    names = [c for c in synth.HG19_LEN if synth.split_of(c) == "train"]
+    st._meta = {c: (synth.chrom_nodes(c), 103, 1.0) for c in names}
+    st.epoch_graph, st.hip_graphs = True, True
+    groups = st._copy_groups(names)
+    assert [c for g in groups for c in g] == names and [len(g) for g in groups] == [6, 4, 3, 2, 1]
+    left = sum(st._meta[c][0] for c in names)
+    for g in groups:
+        rows = sum(st._meta[c][0] for c in g)
+        assert 2 * rows >= left
+        left -= rows
+    assert left == 0
+    assert st._copy_groups(names[:1]) == [names[:1]] and st._copy_groups([]) == []
+    st.epoch_graph = False
+    assert st._copy_groups(names) == [[c] for c in names]
