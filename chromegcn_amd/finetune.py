@@ -88,10 +88,10 @@ def _graph_uses(key, name) -> bool:
 class _HostArena:
     """Pinned host mirror of the stage's [sum n, C] prediction arena, for callers that want the reference's return value
     (CPU predictions, finetune.py:52-53,67).  The reference copies every chromosome's predictions to the host
-    synchronously inside its loop; here chromosome c's rows travel on a COPY stream as soon as c's step is enqueued --
-    an event after the step orders the copy behind it -- so the PCIe transfer (100 MB per train epoch of the GM12878-
-    shaped genome, ~2 ms at 50 GB/s) runs under the next chromosome's kernels and only the last chromosome's rows are
-    exposed.  Two pinned buffers alternate: the tensor a split returns stays valid until the call AFTER the next one
+    synchronously inside its loop; here the rows of a group of chromosomes (GCNStage._copy_groups; one chromosome without
+    epoch graphs) travel on a COPY stream as soon as the group's steps are enqueued -- an event after them orders the copy
+    behind them -- so the PCIe transfer (100 MB per train epoch of the GM12878-shaped genome, ~2 ms at 50 GB/s) runs under
+    the following kernels and only the last chromosome's rows are exposed.  Two pinned buffers alternate: the tensor a split returns stays valid until the call AFTER the next one
     on the same stage (the reference returns fresh tensors; a caller that keeps predictions longer must clone them)."""
 
     def __init__(self, rows: int, C: int, device):
@@ -815,8 +815,8 @@ class GCNStage:
         C = next(iter(self._meta.values()))[1] if self._meta else 0
         if not self.multi:
             self._ensure_arena()
-            # to_cpu (the reference's return value, finetune.py:52-53): every chromosome's rows leave for a pinned host
-            # arena on a copy stream right behind its own step, while the next chromosome computes (_HostArena)
+            # to_cpu (the reference's return value, finetune.py:52-53): the rows of every group of chromosomes leave for a
+            # pinned host arena on a copy stream right behind the group's graph, while the next group computes (_HostArena)
             host = self._host_arena(C) if (to_cpu and names and self.device.type == "cuda") else None
             for grp in ([names] if host is None else self._copy_groups(names)):
                 if not self._replay_epoch(grp, train):
