@@ -25,6 +25,14 @@ __global__ void k_dirty(float* p, size_t n4) {
   for (size_t k = i; k < n4; k += stride) q[k] = make_float4(1.f, 2.f, 3.f, 4.f);
 }
 
+__global__ void k_nt(float* p, size_t n4) {   // non-temporal stores
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4* q = (f32x4*)p;
+  for (size_t k = i; k < n4; k += stride) __builtin_nontemporal_store((f32x4){1.f, 2.f, 3.f, 4.f}, &q[k]);
+}
+
 __global__ void k_dirty2(float* p, size_t n4) {   // the same work as k_dirty under another name
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -97,6 +105,18 @@ int main() {
       hipLaunchKernelGGL(k_empty<0>, dim3(16), dim3(1024), 0, st, buf, 0);
     }, nodes / 2, reps) * 2.f;
     printf("  writer of %2zu MB: %6.2f us per launch back to back; writer + empty 16 x 1024 kernel: %6.2f us per pair (the empty one adds %5.2f)\n", mb, w, p, p - w);
+  }
+  {   // does the ORDER matter?  W = 32 MB of plain stores (k_layer_dense-like), N = 16 MB of non-temporal stores (k_aggregate_sliced-
+      // like), E = empty 16 x 1024 (k_head_bn_finalize-like).  Per triple: W E N (today's order) against W N E.
+    const size_t w4 = (32u << 20) / 16, n4 = (16u << 20) / 16;
+    float* buf2 = buf + (32u << 20) / 4;
+    auto W = [&](hipStream_t st) { hipLaunchKernelGGL(k_dirty, dim3(1024), dim3(256), 0, st, buf, w4); };
+    auto N = [&](hipStream_t st) { hipLaunchKernelGGL(k_nt, dim3(1024), dim3(256), 0, st, buf2, n4); };
+    auto E = [&](hipStream_t st) { hipLaunchKernelGGL(k_empty<0>, dim3(16), dim3(1024), 0, st, buf, 0); };
+    const float wen = graph_us_per_node([&](hipStream_t st) { W(st); E(st); N(st); }, 60, reps) * 3.f;
+    const float wne = graph_us_per_node([&](hipStream_t st) { W(st); N(st); E(st); }, 60, reps) * 3.f;
+    const float wn = graph_us_per_node([&](hipStream_t st) { W(st); N(st); }, 60, reps) * 2.f;
+    printf("  per triple: W E N %6.2f us, W N E %6.2f us (W N alone %6.2f)\n", wen, wne, wn);
   }
   // eager (no graph) for comparison
   {
