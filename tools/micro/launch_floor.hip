@@ -33,6 +33,17 @@ __global__ void k_nt(float* p, size_t n4) {   // non-temporal stores
   for (size_t k = i; k < n4; k += stride) __builtin_nontemporal_store((f32x4){1.f, 2.f, 3.f, 4.f}, &q[k]);
 }
 
+__global__ void k_read(const float* p, size_t n4, float* out) {   // workgroups >= 16 stream n4 float4 and keep a sum
+  if (blockIdx.x < 16) return;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const size_t i = (size_t)(blockIdx.x - 16) * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)(gridDim.x - 16) * blockDim.x;
+  const f32x4* q = (const f32x4*)p;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  for (size_t k = i; k < n4; k += stride) a += __builtin_nontemporal_load(&q[k]);
+  if (a[0] + a[1] + a[2] + a[3] == 12345.678f) out[0] = 1.f;
+}
+
 __global__ void k_dirty2(float* p, size_t n4) {   // the same work as k_dirty under another name
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -117,6 +128,19 @@ int main() {
     const float wne = graph_us_per_node([&](hipStream_t st) { W(st); N(st); E(st); }, 60, reps) * 3.f;
     const float wn = graph_us_per_node([&](hipStream_t st) { W(st); N(st); }, 60, reps) * 2.f;
     printf("  per triple: W E N %6.2f us, W N E %6.2f us (W N alone %6.2f)\n", wen, wne, wn);
+  }
+  {   // is work that rides in the tiny kernel's launch free while the predecessor drains?  R(B) = a kernel whose workgroups
+      // stream B bytes of reads (a stand-in for a share of another chromosome's aggregation) + the 16 empty workgroups
+    const size_t w4 = (32u << 20) / 16;
+    float* src = buf + (32u << 20) / 4;   // the other half of the buffer
+    auto W = [&](hipStream_t st) { hipLaunchKernelGGL(k_dirty, dim3(1024), dim3(256), 0, st, buf, w4); };
+    for (size_t mb : {0u, 4u, 8u, 16u, 32u}) {
+      const size_t n4 = (mb << 20) / 16;
+      auto R = [&](hipStream_t st) { hipLaunchKernelGGL(k_read, dim3(16 + (mb ? 1024 : 0)), dim3(256), 0, st, src, n4, buf + (60u << 20) / 4); };
+      const float wr = graph_us_per_node([&](hipStream_t st) { W(st); R(st); }, 100, reps) * 2.f;
+      const float rr = graph_us_per_node([&](hipStream_t st) { R(st); }, 100, reps);
+      printf("  W(32 MB) then [16 empty workgroups + reads of %2zu MB]: %6.2f us per pair; the read kernel alone, back to back: %6.2f us\n", mb, wr, rr);
+    }
   }
   // eager (no graph) for comparison
   {
