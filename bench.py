@@ -275,6 +275,36 @@ def self_launch(args):
     return 1
 
 
+_JOB_STORE = [None]
+
+
+def job_store(rank, world):
+    """The ONE c10d store of this process: a client of the launcher's TCP store (torch.distributed.run hosts it in its
+    agent: TORCHELASTIC_USE_AGENT_STORE=True), or -- ranks started by hand with MASTER_ADDR / MASTER_PORT -- hosted by
+    rank 0.  The launch ladder hands its choice over it and init_group builds the process group on a prefix of it."""
+    if _JOB_STORE[0] is None:
+        import datetime
+        agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") == "True"
+        _JOB_STORE[0] = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ["MASTER_PORT"]), world,
+                                      is_master=(rank == 0 and not agent), timeout=datetime.timedelta(seconds=1800),
+                                      wait_for_workers=False, multi_tenant=True)
+    return _JOB_STORE[0]
+
+
+def init_group(backend, rank, world, dev=None, timeout_s=None):
+    """The default process group, initialised ONCE per process, on a prefix of the job's store."""
+    import datetime
+    if dist.is_initialized():
+        raise RuntimeError("bench.py: the default process group is initialised once per process")
+    k = int(os.environ.get("CGCN_BENCH_TEST_SKEW_RANK", "-1"))   # test hook: one rank arrives late at the rendezvous
+    if k == rank:
+        time.sleep(float(os.environ.get("CGCN_BENCH_TEST_SKEW_S", "3")))
+    kw = {"timeout": datetime.timedelta(seconds=timeout_s)} if timeout_s else {}
+    if backend == "nccl":
+        kw["device_id"] = dev
+    dist.init_process_group(backend, store=dist.PrefixStore("cgcn_pg", job_store(rank, world)), rank=rank, world_size=world, **kw)
+
+
 def external_ladder(args, world, rank):
     """Under an external launcher (the driver's `python -m torch.distributed.run ... bench.py --gpus N`): the ranks
     cannot be restarted, so the rung is chosen BEFORE any of them touches a GPU -- all ranks meet on a gloo group (CPU
@@ -290,17 +320,19 @@ def external_ladder(args, world, rank):
                 args.gather = "all"
         return {"rung": None, "ran": "no probes (CGCN_BENCH_LADDER=0): " + ("as asked" if os.environ.get("CGCN_GROUP_GRAPH") == "1" else LADDER[1][0]),
                 "launcher": "external"}
-    import datetime
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=1800))
-    box = [None]
+    # The rung travels over the job's c10d STORE, not over a process group: the default group is initialised exactly once
+    # per process (init_group below).  [Round 4 met on a gloo group, destroyed it and initialised the default group again
+    # on the same store: destroy_process_group resets the group counter, the second group reused the first one's store
+    # prefix and a rank that arrived early read its peer's dead gloo address -- VERDICT r4.]
+    store = job_store(rank, world)
+    key = "cgcn/ladder/%s" % os.environ.get("TORCHELASTIC_RUN_ID", "job")
     if rank == 0:
         rung, rec = choose_rung(args, 0)
-        box[0] = rec
-    dist.broadcast_object_list(box, src=0)
-    dist.barrier()
-    dist.destroy_process_group()
-    rec = box[0]
+        store.set(key, json.dumps(rec))
+    else:
+        import datetime
+        store.wait([key], datetime.timedelta(seconds=float(os.environ.get("CGCN_BENCH_LADDER_WAIT_S", "3600"))))
+    rec = json.loads(store.get(key).decode())
     rung = rec.get("rung")
     if rung is None:
         raise SystemExit("bench.py: no rung of the launch ladder passed its probe: %s" % json.dumps(rec["tried"]))
@@ -605,7 +637,7 @@ def main():
     if args.dry_run:
         if world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            init_group("gloo", rank, world)
         seen = ranks_seen(world, torch.device("cpu"))
         out = {"dry_run": True, "n_gpus": world, "ranks_seen_by_backend": seen, "backend": "gloo", "probe": bool(args.probe),
                "rung": args.rung, "no_group_graph": bool(args.no_group_graph), "gather": args.gather, "hip_graph": not args.no_hip_graph,
@@ -635,12 +667,7 @@ def main():
                 os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         # a collective that does not complete within 4 minutes aborts the job with an error instead of hanging it (every
         # collective of this benchmark moves at most a few tens of MB)
-        import datetime
-        tmo = datetime.timedelta(seconds=int(os.environ.get("CGCN_DIST_TIMEOUT_S", "240")))
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=tmo)
+        init_group(args.backend, rank, world, dev, int(os.environ.get("CGCN_DIST_TIMEOUT_S", "240")))
     seen = int(_one_rank_allreduce(dev)) if (multi and world == 1) else ranks_seen(world, dev)
     if args.workload == "e2e":
         from chromegcn_amd import e2e

@@ -263,6 +263,8 @@ class GCNStage:
             # old device tensors and go.  The cached target concatenations are COPIES of target data: they survive only
             # when a deferred chromosome materialises from the very tensors it was registered with, and are rebuilt
             # when the caller handed in new (or edited) targets of the same shape.
+            if known[2] != cost:          # another graph: the shard plan (rounds, send / recv layout) may change with it
+                self._gather_plans.clear()
             self._meta[name] = (n, t.shape[1], cost)
             self._graphs = {k: v for k, v in self._graphs.items() if not _graph_uses(k, name)}
             if not materialising:

@@ -306,9 +306,12 @@ def head_logits(x: Tensor, bn_w: Tensor, bn_b: Tensor, run_mean: Tensor, run_var
     S, n, d = x.shape
     C = w_out.shape[0]
     logits = torch.empty((S, n, C), dtype=torch.float32, device=x.device)
-    D = lambda t: _dense(t).data_ptr()
-    _lib.check(_lib.load().cgcn_head_logits(_lib.stream_ptr(), n, S, d, C, x.data_ptr(), D(bn_w), D(bn_b), D(run_mean), D(run_var),
-                                            float(eps), D(w_out), D(b_out), logits.data_ptr()), "cgcn_head_logits")
+    # the dense copies (if any were needed) stay bound to names until the launch is enqueued: a temporary dropped
+    # earlier hands its block back to the caching allocator, and the next copy of the same size would alias it
+    bn_w, bn_b, run_mean, run_var, w_out, b_out = map(_dense, (bn_w, bn_b, run_mean, run_var, w_out, b_out))
+    _lib.check(_lib.load().cgcn_head_logits(_lib.stream_ptr(), n, S, d, C, x.data_ptr(), bn_w.data_ptr(), bn_b.data_ptr(),
+                                            run_mean.data_ptr(), run_var.data_ptr(), float(eps), w_out.data_ptr(),
+                                            b_out.data_ptr(), logits.data_ptr()), "cgcn_head_logits")
     return logits
 
 

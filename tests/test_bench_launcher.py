@@ -19,6 +19,40 @@ def _run(args, env_extra=None, timeout=600):
     return p.returncode, lines, p.stderr
 
 
+def _torchrun(bench_args, env_extra=None, timeout=600, nproc=2):
+    """The driver's form: `python -m torch.distributed.run --nproc-per-node N bench.py ...`, with every rank's stdout /
+    stderr redirected to files of its own (--redirects 3 --tee 3 --log-dir), so that a failure is reported with the
+    traceback of the rank that failed FIRST -- torchrun's own summary (all that `stderr[-3000:]` of the launcher shows) names
+    the rank but cuts its traceback.  Returns (rc, JSON lines of the launcher's stdout, failure report)."""
+    import glob
+    import socket
+    import tempfile
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    with tempfile.TemporaryDirectory(prefix="cgcn_launch_") as logs:
+        p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+                            "--master-addr", "127.0.0.1", "--master-port", str(port), "--redirects", "3", "--tee", "3",
+                            "--log-dir", logs, os.path.join(ROOT, "bench.py")] + bench_args,
+                           env=env, capture_output=True, text=True, timeout=timeout)
+        report = ""
+        if p.returncode != 0:
+            per_rank = []
+            for f in sorted(glob.glob(os.path.join(logs, "**", "stderr.log"), recursive=True)):
+                txt = open(f, errors="replace").read()
+                first = txt.find("Traceback")
+                per_rank.append((os.path.getmtime(f) if first >= 0 else float("inf"), f, txt[first:] if first >= 0 else txt[-1500:]))
+            per_rank.sort(key=lambda t: t[0])
+            report = "\n".join("==== %s ====\n%s" % (f[len(logs):], t[-4000:]) for _, f, t in per_rank)
+            report += "\n==== launcher ====\n" + p.stderr[-1500:]
+    # with --tee the ranks' stdout lines arrive prefixed "[default0]:"
+    lines = [l[l.index("{"):] for l in p.stdout.splitlines() if "{" in l and l.lstrip().startswith(("{", "[default"))]
+    lines = [l for l in lines if l.startswith('{"')]
+    return p.returncode, lines, report
+
+
 def test_self_launch_two_ranks_dry_run_prints_one_line():
     rc, lines, err = _run(["--gpus", "2", "--dry-run"])
     assert rc == 0, err[-2000:]
@@ -119,24 +153,47 @@ def test_ladder_every_rung_failing_is_an_error_with_the_history():
 
 def test_external_launcher_probes_before_any_rank_touches_a_gpu():
     """the driver's form: `python -m torch.distributed.run ... bench.py --gpus N`.  Rank 0 probes with child jobs while
-    all ranks wait on a gloo group; every rank then runs with the chosen rung's switches."""
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env["CGCN_BENCH_FAIL_RUNGS"] = "0"
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
-                       env=env, capture_output=True, text=True, timeout=600)
-    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    assert p.returncode == 0, p.stderr[-3000:]
+    the other ranks wait on the job's c10d store; every rank then runs with the chosen rung's switches."""
+    rc, lines, report = _torchrun(["--gpus", "2", "--dry-run"], {"CGCN_BENCH_FAIL_RUNGS": "0"})
+    assert rc == 0, report
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["ranks_seen_by_backend"] == 2
     lad = d["launch_ladder"]
     assert lad["rung"] == 1 and lad["launcher"].startswith("external")
     assert d["no_group_graph"] is True and d["gather"] == "all"
+
+
+@pytest.mark.parametrize("late_rank", [0, 1])
+def test_external_launcher_ranks_out_of_lockstep(late_rank):
+    """round 4 initialised the default process group twice on the launcher's store (gloo meeting for the ladder,
+    destroy, then the real group); whichever rank reached the second rendezvous first read its peer's stale address, so
+    the run failed about half the time once the ranks were >= 1 s apart -- and passed whenever they were in lockstep,
+    which is all the old test saw.  The skew is injected here: one rank sleeps 3 s between the ladder hand-off and the
+    group's rendezvous; repeated (CGCN_TEST_SKEW_REPEATS, default 2; the old code failed 3 of 4 such runs)."""
+    for rep in range(int(os.environ.get("CGCN_TEST_SKEW_REPEATS", "2"))):
+        rc, lines, report = _torchrun(["--gpus", "2", "--dry-run"],
+                                      {"CGCN_BENCH_TEST_SKEW_RANK": str(late_rank), "CGCN_BENCH_TEST_SKEW_S": "3"})
+        assert rc == 0, "repeat %d\n%s" % (rep, report)
+        assert len(lines) == 1, lines
+        d = json.loads(lines[0])
+        assert d["ranks_seen_by_backend"] == 2 and d["launch_ladder"]["rung"] == 0
+
+
+def test_default_process_group_is_initialised_once_per_process():
+    """the invariant behind the fix, checked on the source: bench.py reaches init_process_group through init_group only,
+    and never destroys a group before the end of the job"""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.count("dist.init_process_group(") == 1
+    body = src[src.index("def external_ladder("):src.index("def _one_rank_allreduce(")]
+    assert "dist.init_process_group(" not in body and "dist.destroy_process_group(" not in body and " init_group(" not in body
+
+
+def test_failing_rank_traceback_is_reported():
+    """a launcher-test failure must show the failing rank's own traceback, not torchrun's summary"""
+    rc, lines, report = _torchrun(["--gpus", "2", "--dry-run", "--rung", "0"], {"CGCN_BENCH_FAIL_RUNGS": "0"})
+    assert rc != 0 and not lines
+    assert "rung 0 told to fail (test hook)" in report and "stderr.log" in report
 
 
 def test_external_launcher_without_probes_runs_the_conservative_form():
@@ -150,18 +207,12 @@ def test_external_launcher_without_probes_runs_the_conservative_form():
 def test_external_launcher_on_the_gpu_box_probes_then_runs():
     """The driver's own form on real hardware: `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`, here
     with two gloo ranks sharing the one GPU a test box has.  Rank 0 must run the probe job(s) as children BEFORE either
-    rank touches the GPU, both ranks must then run the measured job with the chosen switches, and the line must say so."""
-    import socket
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
-                        "--workload", "chr21", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-roofline"],
-                       env=env, capture_output=True, text=True, timeout=1200)
-    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    assert p.returncode == 0, p.stderr[-3000:]
+    rank touches the GPU, both ranks must then run the measured job with the chosen switches, and the line must say so.
+    One rank is held back 2 s before the group's rendezvous (the ranks of a real job are never in lockstep)."""
+    rc, lines, report = _torchrun(["--gpus", "2", "--backend", "gloo", "--share-gpu", "--workload", "chr21", "--steps", "3",
+                                   "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-roofline"],
+                                  {"CGCN_BENCH_TEST_SKEW_RANK": "0", "CGCN_BENCH_TEST_SKEW_S": "2"}, timeout=1200)
+    assert rc == 0, report
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     lad = d["launch_ladder"]

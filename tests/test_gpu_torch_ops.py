@@ -85,6 +85,24 @@ def test_opcheck_head_logits():
     assert torch.allclose(torch.ops.chromegcn.head_logits(*args).reshape(S * n, Cn), want, atol=2e-5, rtol=1e-5)
 
 
+def test_head_logits_with_strided_and_misaligned_parameters():
+    """ADVICE r4: every parameter of chromegcn::head_logits arrives as a view that needs a dense copy (odd storage offset =
+    not 16-byte aligned, or strided); the copies must all stay alive until the launch -- with temporaries dropped one by
+    one the caching allocator hands the same block to consecutive same-size copies (bn_w and bn_b alias)."""
+    S, n, d, Cn = 2, 300, 128, 103
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(S, n, d, device=DEV, generator=gen)
+    pool = torch.randn(4, d + 1, device=DEV, generator=gen)
+    bw, bb, rm = pool[0, 1:], pool[1, 1:], pool[2, 1:]            # odd offsets: data_ptr % 16 != 0
+    rv = (0.5 + torch.rand(d, 2, device=DEV, generator=gen))[:, 1]  # strided
+    Wo = (torch.randn(d, Cn, device=DEV, generator=gen) / d ** 0.5).t()  # [C, d] view of a [d, C] tensor
+    bo = (0.1 * torch.randn(Cn + 1, device=DEV, generator=gen))[1:]
+    assert bw.data_ptr() % 16 and not rv.is_contiguous() and not Wo.is_contiguous()
+    got = torch.ops.chromegcn.head_logits(x, bw, bb, rm, rv, 1e-5, Wo, bo)
+    want = torch.nn.functional.linear(torch.nn.functional.batch_norm(torch.relu(x).reshape(S * n, d), rm, rv, bw, bb, False, 0.0, 1e-5), Wo, bo)
+    assert torch.allclose(got.reshape(S * n, Cn), want, atol=5e-5, rtol=1e-5)
+
+
 def test_opcheck_and_values_of_sgd_step():
     n = 5000
     p = torch.randn(n, device=DEV); g = torch.randn(n, device=DEV); m = torch.randn(n, device=DEV)
