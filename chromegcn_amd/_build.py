@@ -44,6 +44,58 @@ def source_hash(extra=None) -> str:
     return h.hexdigest()
 
 
+# Test-only builds of the SAME sources (tests/test_gpu_ring_stress.py): the ring kernel's row team or matrix team held
+# back by wave- and slot-dependent delays.  They live beside the product library under variants/ (git-ignored like it,
+# shipped to the GPU box like it), are opened explicitly by path (`_lib.open_library`) and never replace it.
+TEST_VARIANTS = {
+    "ring_slow_row": ["-DCGCN_EXPERIMENT_BUILD", "-DRING_TEST_SLOW_ROW=1"],
+    "ring_slow_matrix": ["-DCGCN_EXPERIMENT_BUILD", "-DRING_TEST_SLOW_MATRIX=1"],
+}
+
+
+def variant_path(name: str) -> str:
+    return os.path.join(ROOT, "variants", "libcgcn_test_%s.so" % name)
+
+
+def variant_is_stale(name: str) -> bool:
+    p = variant_path(name)
+    try:
+        with open(p + ".srchash") as f:
+            return not os.path.exists(p) or f.read().strip() != source_hash(TEST_VARIANTS[name])
+    except OSError:
+        return True
+
+
+def build_test_variants(force=False, verbose=False):
+    """Build (side by side) every stale test variant; returns their paths.  Only kernels.hip differs, but a variant is a
+    whole library so that it can be opened beside the product one."""
+    hipcc = hipcc_path()
+    if hipcc is None:
+        raise RuntimeError("chromegcn_amd: hipcc not found; cannot build the test variants")
+    os.makedirs(os.path.join(ROOT, "variants"), exist_ok=True)
+    jobs = []
+    for name, flags in TEST_VARIANTS.items():
+        if not force and not variant_is_stale(name):
+            continue
+        target = variant_path(name)
+        tmp = "%s.tmp.%d" % (target, os.getpid())
+        cmd = [hipcc] + BASE_FLAGS + ["-I" + os.path.join(ROOT, "include")] + flags + SRC + ["-o", tmp]
+        if verbose:
+            print(" ".join(cmd))
+        jobs.append((name, target, tmp, subprocess.Popen(cmd)))
+    for name, target, tmp, p in jobs:
+        try:
+            if p.wait() != 0:
+                raise RuntimeError("chromegcn_amd: building test variant %s failed" % name)
+            os.replace(tmp, target)
+            with open(target + ".srchash", "w") as f:
+                f.write(source_hash(TEST_VARIANTS[name]) + "\n")
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+    return [variant_path(n) for n in TEST_VARIANTS]
+
+
 def is_stale() -> bool:
     """True when the in-tree library is missing or was built from other sources than the ones in the tree."""
     if not os.path.exists(LIB) or not os.path.exists(HASH):
@@ -87,4 +139,7 @@ def build_library(force=False, verbose=False, out=None):
 
 
 if __name__ == "__main__":
+    import sys
     print(build_library(force=True, verbose=True))
+    if "--test-variants" in sys.argv:
+        print(build_test_variants(force=True, verbose=True))

@@ -467,7 +467,7 @@ __device__ unsigned long long kt_stamps[8 * 16];
 extern "C" int cgcn_debug_kt_stamps(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(kt_stamps), sizeof(unsigned long long) * 8 * 16) == hipSuccess ? 0 : -1;
 }
-// stamp WITHOUT a vector-memory wait (loads in flight across the stamp stay in flight): k_bwd_rowlocal_rs, period KT_PERIOD
+// stamp WITHOUT a vector-memory wait (loads in flight across the stamp stay in flight), period KT_PERIOD
 #ifndef KT_PERIOD
 #define KT_PERIOD 2
 #endif
@@ -1193,16 +1193,41 @@ __global__ __launch_bounds__(512) void k_bwd_rowlocal256(int M, int n, const flo
 #ifndef RING_PRIME
 #define RING_PRIME 0     // matrix team: request the next slot's first operands under the current slot's last MFMAs (measured: no gain)
 #endif
+// Every switch below changes WHAT the kernel computes or how its teams meet (decomposition builds of tools/ring_decomp.sh:
+// garbage results by design; the slowed teams of tests/test_gpu_ring_stress.py: same results, other timing).  None of
+// them can be reached by a stray -D: they need -DCGCN_EXPERIMENT_BUILD, which chromegcn_amd/_build.py refuses for the
+// in-tree library.
+#if (defined(RING_NO_WAIT) || defined(RING_SKIP_MFMA) || defined(RING_SKIP_ROWTEAM) || defined(RING_SKIP_LOADS) || \
+     defined(RING_TEST_SLOW_ROW) || defined(RING_TEST_SLOW_MATRIX)) && !defined(CGCN_EXPERIMENT_BUILD)
+#error "RING_NO_WAIT / RING_SKIP_* / RING_TEST_SLOW_* are experiment switches: build a variant with -DCGCN_EXPERIMENT_BUILD (tools/mkvariant.py), never the shipped library"
+#endif
+#if defined(RING_TEST_SLOW_ROW) || defined(RING_TEST_SLOW_MATRIX)
+// test builds only: hold this wave back by a wave- and slot-dependent time (0 ... ~4 us), so that the waves of a team
+// fall out of step with each other and one team runs the other one's flags dry (SLOW_ROW: the matrix team polls FULL
+// on every slot; SLOW_MATRIX: the ring fills up and the row team polls FREE on every slot)
+__device__ __forceinline__ void ring_test_delay(int wave, int it) {
+  unsigned h = (unsigned)wave * 2654435761u ^ (unsigned)it * 40503u ^ (unsigned)blockIdx.x * 97u;
+  h ^= h >> 7;
+  for (unsigned i = 0; i < (h & 15u); ++i) __builtin_amdgcn_s_sleep(10);
+}
+#endif
 __device__ __forceinline__ void ring_wait(const unsigned* flag, unsigned target) {
 #ifdef RING_NO_WAIT   // experiment only (results are garbage): the two teams run free of each other -> their pure interference
   return;
 #endif
-  // Every spin is bounded: a poll is ~200 cycles, a launch lasts ~10^5, so 2^22 polls (~0.4 s) can only mean a broken
-  // protocol -- trap (the launch fails with an error) instead of hanging the device.
-  for (unsigned spins = 0;; ++spins) {
+  // Every spin is bounded by WALL time, not by a poll count (a debugger, thread trace or heavy instrumentation slows the
+  // polls by orders of magnitude): the 100 MHz real-time counter is looked at once per 2^16 polls (a healthy launch never
+  // gets that far: a poll is ~200 cycles, a launch ~10^5), and 10 s without progress can only mean a broken protocol --
+  // trap (the launch fails with an error) instead of hanging the device.
+  unsigned long long t0 = 0;
+  for (unsigned spins = 1;; ++spins) {
     const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
     if ((int)(v - target) >= 0) break;
-    if (spins > (1u << 22)) __builtin_trap();
+    if ((spins & 0xFFFFu) == 0u) {
+      const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+      if (t0 == 0) t0 = now;
+      else if (now - t0 > 1000000000ull) __builtin_trap();   // 10 s at 100 MHz
+    }
     __builtin_amdgcn_s_sleep(1);
   }
   asm volatile("" ::: "memory");   // nothing of the slot is read or written ahead of the poll
@@ -1391,6 +1416,9 @@ __global__ __launch_bounds__(RING_THREADS) void k_bwd_rowlocal_ring(int M, int n
         dcg_acc += gamma;
       }
       const int slot = it % NSL;
+#ifdef RING_TEST_SLOW_ROW
+      ring_test_delay(wave, it);
+#endif
       if (it >= NSL) ring_wait(&FREE[slot], 8u * (unsigned)(it / NSL));   // the matrix team is done with the slot's last use
 #ifndef RING_SKIP_MFMA
 #pragma unroll
@@ -1488,6 +1516,9 @@ __global__ __launch_bounds__(RING_THREADS) void k_bwd_rowlocal_ring(int M, int n
       };
       for (int it = 0; it < ns; ++it) {
         const int slot = it % NSL;
+#ifdef RING_TEST_SLOW_MATRIX
+        ring_test_delay(wave, it);
+#endif
 #ifndef RING_SKIP_MFMA
         const float* __restrict__ Hb = Hs[slot];
         const float* __restrict__ Ub = Us[slot];

@@ -19,6 +19,8 @@ def pytest_configure(config):
         from chromegcn_amd import _build
         if _build.is_stale() and _build.hipcc_path() is not None:
             _build.build_library()
+        if _build.hipcc_path() is not None and any(_build.variant_is_stale(v) for v in _build.TEST_VARIANTS):
+            _build.build_test_variants()      # tests/test_gpu_ring_stress.py (slowed ring teams); never the product library
 
 
 # Order of the -m gpu tier (the driver runs it with -x, so whatever comes first gates everything behind it): the tests

@@ -1,0 +1,148 @@
+"""Stress test of k_bwd_rowlocal_ring's flag-synchronised LDS ring (autograd of models/ChromeModels.py:37-40 +
+models/SubLayers.py:43-50).  The ring has no workgroup barrier between the first row and the last: its
+failure mode is a RARE wrong bit pattern (a slot reused one poll too early, a flag read before the write it announces),
+and whether it shows depends on how the two teams' timing falls on a given box.  So the timing is varied on purpose:
+
+  * product    -- the shipped library;
+  * slow_row   -- a test build (-DCGCN_EXPERIMENT_BUILD -DRING_TEST_SLOW_ROW) whose ROW-team waves sleep a wave- and
+                  slot-dependent time before every slot: the waves of the team fall out of step and the matrix team runs
+                  the FULL flags dry on every slot;
+  * slow_matrix -- ... whose MATRIX-team waves sleep: the ring fills up, the row team polls FREE on every slot.
+
+The delays change no arithmetic, so all three builds must give the SAME BITS, launch after launch -- EVERY launch is
+compared on the device (a mismatch flag accumulated without a host sync; ADVICE r4: the old tool checked one launch in
+ten) -- and match a float64 restatement of the row-local math at 2e-5.  The head form of the kernel
+(<HEAD, DROP>: other register pressure, other prefetch depth) is driven through the whole captured train step.
+Launch counts: CGCN_RING_STRESS_LAUNCHES (default 1000 per size and build)."""
+import os
+
+import pytest
+import torch
+
+import chromegcn_amd as C
+from chromegcn_amd import _build, _lib, graph as G, synth
+from chromegcn_amd.finetune import GCNStage
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+LAUNCHES = int(os.environ.get("CGCN_RING_STRESS_LAUNCHES", "1000"))
+BUILDS = ["product", "ring_slow_row", "ring_slow_matrix"]
+# odd sizes on purpose: last slot not full, fewer slots than workgroups, strand boundary inside a slot, one strand
+SIZES = [(2, 1), (2, 7), (1, 16), (2, 129), (1, 2049), (2, 4099), (2, 5776), (1, 16264), (2, 16264), (2, 29910), (2, 70001)]
+
+
+def _open(build):
+    if build == "product":
+        return _lib.load()
+    path = _build.variant_path(build)
+    if _build.variant_is_stale(build):
+        pytest.fail("test variant %s is missing or stale: python -m chromegcn_amd._build --test-variants" % path)
+    return _lib.open_library(path)
+
+
+def _inputs(S, n, d=128):
+    gen = torch.Generator(device=DEV).manual_seed(n * 3 + S)
+    r = lambda *s: torch.randn(*s, device=DEV, generator=gen)
+    x, z, h, dxn = r(S, n, d), torch.tanh(r(S, n, d)), r(S, n, d), r(S, n, d)
+    gate = torch.rand(S, n, device=DEV, generator=gen)
+    W, wg = r(d, d) / d ** 0.5, r(d) / d ** 0.5
+    rs = torch.rand(n, device=DEV, generator=gen) + 0.1
+    return x, z, h, dxn, gate, W, wg, rs
+
+
+def _float64_truth(S, n, d, x, z, h, dxn, gate, W, wg, rs):
+    X, Z, Hh, Gu = (t.double().reshape(S * n, d) for t in (x, z, h, dxn))
+    gt = gate.double().reshape(S * n)
+    gamma = gt * (1 - gt) * (Gu * (Z - X)).sum(1)
+    dU = (gt[:, None] * Gu + gamma[:, None] * wg.double()[None, :]) * (1 - Z * Z)
+    return {"dHs": (dU * rs.double().repeat(S)[:, None]) @ W.double().T, "dW": Hh.T @ dU, "db": dU.sum(0),
+            "dwg": (gamma[:, None] * Z).sum(0), "dcg": gamma.sum().reshape(1)}
+
+
+_first = {}   # (S, n) -> the product build's outputs: every build must reproduce them bit for bit
+
+
+@pytest.mark.parametrize("S,n", SIZES)
+@pytest.mark.parametrize("build", BUILDS)
+def test_every_launch_bit_identical_and_right(build, S, n):
+    lib = _open(build)
+    d = 128
+    x, z, h, dxn, gate, W, wg, rs = _inputs(S, n)
+    g = G.upload(G.normalize_graph("none", None, n), DEV)
+    P, st = _lib.ptr, _lib.stream_ptr
+    dhs = torch.zeros_like(x)
+    dW, db, dwg, dcg = torch.zeros_like(W), torch.zeros(d, device=DEV), torch.zeros(d, device=DEV), torch.zeros(1, device=DEV)
+    wsb = lib.cgcn_layer_bwd_workspace_bytes(n, S, d)
+    ws = torch.zeros(wsb, dtype=torch.uint8, device=DEV)
+
+    def run(with_dhs=True):   # dX == NULL: the row-local launch + the second-stage sum only (no gather)
+        rc = lib.cgcn_debug_layer_bwd_phases(st(), n, S, d, P(g.rowptr), P(g.col), None, P(rs), P(x), P(z), P(h), P(gate), P(W), P(wg),
+                                             P(dxn), None, None, P(dhs) if with_dhs else None, P(dW), P(db), P(dwg), P(dcg), 0, 0.0, None, 0,
+                                             None, P(ws), wsb, 3, None)
+        assert rc == 0, lib.cgcn_strerror(rc)
+
+    outs = (dhs, dW, db, dwg, dcg)
+    run()
+    first = [t.clone() for t in outs]
+    truth = _float64_truth(S, n, d, x, z, h, dxn, gate, W, wg, rs)
+    for k, a in zip(("dHs", "dW", "db", "dwg", "dcg"), first):
+        err = float((a.double().reshape(truth[k].shape) - truth[k]).abs().max() / truth[k].abs().max().clamp_min(1e-30))
+        assert err < 2e-5, (build, S, n, k, err)
+    if build == "product":
+        _first[(S, n)] = first
+    elif (S, n) in _first:   # a slowed team changes when things happen, never what is computed
+        for k, a, b in zip(("dHs", "dW", "db", "dwg", "dcg"), first, _first[(S, n)]):
+            assert torch.equal(a, b), "%s differs from the product build: S=%d n=%d %s" % (build, S, n, k)
+    # the form without the dHs product (nobody differentiates the layer's input) gives the same sums
+    run(with_dhs=False)
+    assert all(torch.equal(a, b) for a, b in zip(first[1:], outs[1:]))
+    bad = torch.zeros((), dtype=torch.int64, device=DEV)
+    for _ in range(LAUNCHES):
+        dhs.fill_(float("nan"))
+        run()
+        for a, b in zip(first, outs):   # every launch, on the device, no host sync
+            bad += (a != b).sum()
+    assert int(bad) == 0, "%s: %d differing elements over %d launches at S=%d n=%d" % (build, int(bad), LAUNCHES, S, n)
+
+
+def _train(handle, epochs, monkeypatch):
+    """`epochs` replays of a captured 3-chromosome train split (dropout on: the <HEAD, DROP> and plain ring forms, input
+    gradients wanted: the dHs product) with every library call of the engine going to `handle`."""
+    monkeypatch.setattr(_lib, "_lib", handle)
+    torch.manual_seed(0)
+    d, Cn = 128, 103
+    model = C.ChromeGCN(d, d, Cn, 0.2, True, 2).to(DEV)
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if "GC" in k and k.endswith("weight"):
+                p.copy_(torch.randn_like(p) / d ** 0.5)
+    opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-6)
+    stage = GCNStage(model, opt, "hic", DEV, hip_graphs=True, input_grad=True, cache_input_aggregation=False)
+    names = []
+    for i, (n, pairs) in enumerate([(4099, 60000), (16264, 250000), (2047, 30000)]):
+        nm = "c%d" % i
+        stage.add_chromosome(nm, synth.chrom_features(n, d, Cn, 50 + i), synth.contact_graph(n, pairs, 60 + i))
+        names.append(nm)
+    losses = []
+    for _ in range(epochs):
+        preds, _t, total = stage.run_split("train", names, to_cpu=False)
+        losses.append(total if isinstance(total, float) else float(total))
+    torch.cuda.synchronize()
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    return losses, preds.clone(), state
+
+
+def test_head_form_whole_step_same_bits_under_slowed_teams(monkeypatch):
+    """the whole captured step -- head form of the ring with dropout (layer 2), plain form (layer 1), gathers, fused SGD --
+    replayed for many epochs: losses of every epoch, final predictions, parameters and BatchNorm statistics must be
+    bit-identical between the product build and both slowed builds (3 chromosomes x epochs x 2 ring launches each)."""
+    epochs = max(10, LAUNCHES // 10)
+    real = _lib.load()
+    ref = _train(real, epochs, monkeypatch)
+    for build in BUILDS[1:]:
+        got = _train(_open(build), epochs, monkeypatch)
+        assert got[0] == ref[0], "%s: per-epoch losses differ" % build
+        assert torch.equal(got[1], ref[1]), "%s: predictions differ" % build
+        for k in ref[2]:
+            assert torch.equal(got[2][k], ref[2][k]), "%s: %s differs" % (build, k)
+    monkeypatch.setattr(_lib, "_lib", real)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Decomposition of k_bwd_rowlocal_ring (tuning tool): isolated launch times of the plain and the head form with the row team
 # alone (-DRING_SKIP_MFMA), the matrix team alone (-DRING_SKIP_ROWTEAM) and without flag waits (-DRING_NO_WAIT; garbage
-# results, pure co-run interference).  Variants: python tools/mkvariant.py rowonly='-DRING_SKIP_MFMA=1' matonly='-DRING_SKIP_ROWTEAM=1' nowait='-DRING_NO_WAIT=1'
+# results, pure co-run interference).  Variants: python tools/mkvariant.py rowonly='-DCGCN_EXPERIMENT_BUILD -DRING_SKIP_MFMA=1' matonly='-DCGCN_EXPERIMENT_BUILD -DRING_SKIP_ROWTEAM=1' nowait='-DCGCN_EXPERIMENT_BUILD -DRING_NO_WAIT=1'
 for v in base rowonly matonly nowait base; do
   if [ $v = base ]; then unset CHROMEGCN_LIB; else export CHROMEGCN_LIB=$GRAFT_REPO_ROOT/variants/libcgcn_$v.so; fi
   for wl in chr1 genome; do
