@@ -52,6 +52,10 @@ def parse():
     ap.add_argument("--generator", default=None, choices=["uniform", "hic_like", "hub"],
                     help="contact generator (synth.contact_graph): uniform (headline), hic_like = distance decay, hub = top-K-style "
                          "heavy-tailed degrees with hubs of 2-10 k neighbours (data/7create_graph_new.py:93-104)")
+    ap.add_argument("--adj-type", default="hic", choices=["hic", "both", "constant", "none"],
+                    help="the reference's -adj_type (config_args.py:45, utils/util_methods.py:146-174): hic (headline), both = Hi-C + "
+                         "the +-7 band + I with summed values, constant = the band + I alone (the library's sliding-window route), "
+                         "none = I")
     ap.add_argument("--d", type=int, default=128)
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--dropout", type=float, default=0.2)
@@ -101,7 +105,7 @@ LADDER = [
     ("captured fwd+bwd, eager all-reduce, all-gather of predictions", ["--no-group-graph", "--gather", "all"]),
     ("no HIP graphs at all, eager all-reduce, all-gather of predictions", ["--no-group-graph", "--gather", "all", "--no-hip-graph"]),
 ]
-_PASS_THROUGH = ("--backend", "--d", "--layers", "--dropout", "--generator", "--workload", "--e2e-windows")
+_PASS_THROUGH = ("--backend", "--d", "--layers", "--dropout", "--generator", "--workload", "--e2e-windows", "--adj-type")
 _PASS_FLAGS = ("--share-gpu", "--dry-run", "--hic-like", "--p2p-allreduce", "--no-hip-graph", "--no-group-graph")
 
 
@@ -409,6 +413,9 @@ def kernel_costs(n, nnz, S, d, C, P_rl, P_head):
         "k_bwd_rowlocal(head)": (4 * t + 4 * n * d + t + S * 4 * n + par + (4 * d * d + 8 * d + 4), 4.0 * S * n * d * d),   # dym [n,d] in, dL/dXn out
         "k_bwd_sliced": (4 * (n + 1) + 4 * nnz + 3 * t + S * 4 * n, 2.0 * nnz * S * d),      # dHs, dXn in; dX out
         "k_head_fused": (t + 2 * 4 * n * C + 4 * n * d + 2 * 4 * (C * d + C) + 4 * 4 * d, 6.0 * n * d * C),   # X, targets, W_out in; probs, dym, dW_out/db_out/BN sums out
+        # band graphs ('constant'): the window sums stream the table once -- no index list among the algorithmic bytes
+        "k_band_aggregate": (4 * n + 2 * t, 2.0 * nnz * S * d),                               # 1/deg, X in; H out
+        "k_bwd_band": (3 * t + S * 4 * n, 2.0 * nnz * S * d),                                 # dHs, dXn, gate in; dX out
     }
     return {k: (v[0], v[1], gat if k in ("k_aggregate_sliced", "k_layer_fwd", "k_bwd_sliced") else 0.0) for k, v in costs.items()}
 
@@ -442,7 +449,9 @@ def time_kernels(stage, name, reps, dropout_p):
     c16, c16t = aux_ptr(g.col), aux_ptr(g.col_t)   # the engine's own cgcn_graph_aux (16-bit indices, longest row)
     # the route the LIBRARY takes for this graph (table size against the current threshold, hub-heavy graphs): asked,
     # not re-derived here -- a hub graph on a small table runs k_aggregate_sliced + k_layer_dense, not k_layer_fwd
-    split = lib.cgcn_debug_layer_fwd_route(n, S, d, c16) == 1
+    route = lib.cgcn_debug_layer_fwd_route(n, S, d, c16)
+    band = route == 2 and g.val is None      # the sliding-window kernels (k_band_aggregate / k_bwd_band)
+    split = route in (1, 2)
 
     def ev_time(fn):
         for _ in range(3):
@@ -470,7 +479,7 @@ def time_kernels(stage, name, reps, dropout_p):
         t_d1 = ev_time(lambda: fwd(1, h, None, None))
         t_d2 = ev_time(lambda: fwd(L, h, None, colstats))
         # L forward launches per step: L - 1 in the inter-layer-dropout form, the last with the column statistics
-        out_t["k_aggregate_sliced"] = (t_agg, L)
+        out_t["k_band_aggregate" if band else "k_aggregate_sliced"] = (t_agg, L)
         out_t["k_layer_dense"] = (((L - 1) * t_d1 + t_d2) / L, L)
     else:
         t_f1 = ev_time(lambda: fwd(1, None, h, None))
@@ -521,7 +530,7 @@ def time_kernels(stage, name, reps, dropout_p):
     out_t[rl + "(head)"] = (ev_time(lambda: bwd(1, True)), 1)
     out_t[rl] = (ev_time(lambda: bwd(1, False)), max(L - 1, 0))
     _lib.check(bwd(3, False), "bwd")
-    out_t["k_bwd_sliced"] = (ev_time(lambda: bwd(2, False)), L)
+    out_t["k_bwd_band" if band else "k_bwd_sliced"] = (ev_time(lambda: bwd(2, False)), L)
     torch.cuda.synchronize()
     return out_t, (lib.cgcn_layer_bwd_workspace_bytes(n, S, d) // ((d * d + 2 * d + 4) * 4), lib.cgcn_head_bwd_partials(n))
 
@@ -564,6 +573,43 @@ def host_info():
     return cpu_model
 
 
+def band_roofline(stage, names, d):
+    """The band route's aggregation kernel against the HBM roof: k_band_aggregate (through cgcn_spmm on the stage's own
+    'constant' graphs) timed alone with HIP events, 50 launches per chromosome; algorithmic bytes = 1/deg + X in, H out
+    (SURVEY 8d's per-SpMM figure without an index list: a band has none)."""
+    from chromegcn_amd import _lib
+    from chromegcn_amd.graph import aux_ptr, is_band
+    lib = _lib.load()
+    P, st = _lib.ptr, _lib.stream_ptr
+    tot_s = tot_b = 0.0
+    launches = 0
+    for nm in names:
+        c = stage.chroms[nm]
+        g = c.graph
+        if not is_band(g.col):
+            return None
+        S, n, _ = c.x.shape
+        h = torch.empty_like(c.x)
+        fn = lambda: lib.cgcn_spmm(st(), n, n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), c.x.data_ptr(), h.data_ptr(), aux_ptr(g.col))
+        for _ in range(3):
+            _lib.check(fn(), "band launch")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            fn()
+        e1.record()
+        e1.synchronize()
+        tot_s += e0.elapsed_time(e1) / 50 * 1e-3
+        tot_b += 4.0 * n + 2.0 * S * 4 * n * d
+        launches += 1
+    gbps = tot_b / tot_s / 1e9
+    return {"kernel": "k_band_aggregate (adj_type constant: +-7 band + I as a sliding-window stream)", "bound": "hbm", "achieved": gbps,
+            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS, "avg_kernel_us": tot_s / launches * 1e6,
+            "algorithmic_bytes_per_launch": tot_b / launches, "traffic": None,
+            "note": "mean over the %d train chromosomes, each launched alone 50 times (HIP events); input rows hot in the Infinity Cache "
+                    "between launches (the table is 6-31 MB), as they are inside a train step" % launches}
+
+
 def cpu_baseline(args, chroms, budget_s):
     """The oracle (torch-CPU restatement of the reference ops, finetune.py:29-53) timed on this box's host cores on a
     BOUNDED sample of the same workload: train steps on the sample's chromosomes, adjacency cached (the reference
@@ -583,7 +629,7 @@ def cpu_baseline(args, chroms, budget_s):
 
     def one(cached=True):
         t0 = time.perf_counter()
-        O.finetune_epoch(model, data, graphs, opt, "train", "hic", adj_cache=cache if cached else None)
+        O.finetune_epoch(model, data, graphs, opt, "train", args.adj_type, adj_cache=cache if cached else None)
         return time.perf_counter() - t0
 
     # torch's CPU spmm does not scale to every core of a big host (256 threads measured 20x slower than 8-32): pick
@@ -694,7 +740,7 @@ def main():
     # Reference semantics: EVERY step redoes all four sparse aggregations and produces d loss / d features, like the
     # reference.  (The engine's defaults cache A X of the first layer -- loop invariant, the features are fixed -- and
     # skip the unobservable input gradient; measured separately below, never as `value`.)
-    stage = GCNStage(model, opt, "hic", dev, hip_graphs=not args.no_hip_graph, input_grad=True,
+    stage = GCNStage(model, opt, args.adj_type, dev, hip_graphs=not args.no_hip_graph, input_grad=True,
                      group=dist.group.WORLD if multi else None, cache_input_aggregation=False,
                      group_graph=False if args.no_group_graph else None, p2p_allreduce=True if args.p2p_allreduce else None,
                      prediction_gather=args.gather, force_collectives=bool(args.force_collectives),
@@ -803,6 +849,30 @@ def main():
                 extras["%s_generator_ms_per_step" % gen] = g_el / steps * 1e3
                 extras["%s_generator_windows_per_s" % gen] = windows * steps / g_el
                 del s2, m2, o2
+            # the reference's other adjacency modes (-adj_type, config_args.py:45; utils/util_methods.py:146-174) on the same genome:
+            # 'both' = Hi-C + the +-7 band + I with summed values (explicit-value kernels), 'constant' = the band + I alone
+            # (recognised as a band: sliding-window kernels, no index list), 'none' = I
+            for adj in ("both", "constant", "none"):
+                if adj == args.adj_type:
+                    continue
+                torch.manual_seed(0)
+                m2 = C.ChromeGCN(args.d, args.d, synth.N_LABELS, args.dropout, True, args.layers).to(dev)
+                o2 = torch.optim.SGD(m2.parameters(), lr=0.25, momentum=0.9, weight_decay=1e-6)
+                s2 = GCNStage(m2, o2, adj, dev, hip_graphs=not args.no_hip_graph, input_grad=True, cache_input_aggregation=False)
+                for nm in names:
+                    f2, h2 = synth.synthetic_chromosome(nm, d=args.d, hic_like=args.hic_like)
+                    s2.add_chromosome(nm, f2, h2)
+                for _ in range(3):
+                    s2.run_split("train", names, to_cpu=False)
+                g_el, _, _ = timed(lambda: s2.run_split("train", names, to_cpu=False), steps)
+                extras["%s_ms_per_step" % adj] = g_el / steps * 1e3
+                extras["%s_windows_per_s" % adj] = windows * steps / g_el
+                if adj == "constant" and not args.no_roofline:
+                    extras["constant_band_roofline"] = band_roofline(s2, names, args.d)
+                del s2, m2, o2
+            extras["adjacency_note"] = ("same genome and train epoch under the reference's other -adj_type settings (`value` is %s): both = "
+                                        "Hi-C + band + I, values 1 / 2 (nnz about 1.45x hic's); constant = the +-7 band + I (15 entries per "
+                                        "row), aggregated by the sliding-window kernels k_band_aggregate / k_bwd_band; none = I" % args.adj_type)
             extras["generators_note"] = ("same genome shape and train epoch on synth.contact_graph's other generators: hic_like = "
                                          "contact probability ~ 1 / distance, hub = top-K-style heavy-tailed degrees with 8 hubs of "
                                          "2 000 - 10 000 neighbours per chromosome; `value` is the %s generator" % args.generator)
@@ -858,7 +928,8 @@ def main():
                     e["bytes"] += costs[ck][0] * per_step
                     e["flops"] += costs[ck][1] * per_step
                     e["gather"] += costs[ck][2] * per_step
-        wl_key = ("genome" if genome else args.workload) + {"uniform": "", "hic_like": "_hic", "hub": "_hub"}[args.generator] + "_d%d" % args.d
+        wl_key = (("genome" if genome else args.workload) + {"uniform": "", "hic_like": "_hic", "hub": "_hub"}[args.generator] + "_d%d" % args.d
+                  + ("" if args.adj_type == "hic" else "_" + args.adj_type))
 
         def roof_entry(k, e):
             if not e["launches"] or not e["bytes"]:
@@ -919,9 +990,9 @@ def main():
             wl = ("synthetic GM12878-shaped genome (SURVEY 8d config 3): %d train chromosomes, %d windows, 250000 contact "
                   "pairs each (nnz(A+I) %d..%d), d=%d, L=%d, C=%d, dropout=%.2f, SGD lr .25 m .9 wd 1e-6; step = one train "
                   "epoch in reference semantics: per chromosome f+r fwd, BCE, bwd incl. d/dx, optimizer step; all four "
-                  "aggregations every step%s" %
+                  "aggregations every step%s%s" %
                   (len(names), windows, min(s[2] for s in shapes), max(s[2] for s in shapes), args.d, args.layers,
-                   synth.N_LABELS, args.dropout,
+                   synth.N_LABELS, args.dropout, "" if args.adj_type == "hic" else "; adj_type=%s" % args.adj_type,
                    "; chromosomes sharded over %d ranks (LPT), one flat-gradient all-reduce per step group (%s)" % (world, "RCCL" if args.backend == "nccl" else args.backend) if multi else ""))
         else:
             wl = ("%s-like synthetic Hi-C chromosome per rank: n=%d windows, %d contact pairs (nnz(A+I)=%d), d=%d, L=%d, "

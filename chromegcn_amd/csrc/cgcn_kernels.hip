@@ -1932,6 +1932,37 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HAS_VAL ? 6
   }
 }
 
+// Horizontal fusion: the workgroups past the gather tiles of the layer backward's last launch (k_bwd_sliced, k_bwd_band)
+// do the (independent) second-stage sum of the row-local kernel's partials, so that reduction costs no launch of its own
+// and overlaps the gather's tail.  `extra` = index of the workgroup past the gather tiles; 512 threads.
+// EXT: the head slabs stage through the caller's LDS (`scratch`: >= 4 * 32 * 17 doubles) instead of static arrays of their own.
+template <int S, int D, bool EXT = false>
+__device__ __forceinline__ void bwd_riders(int extra, int n, int P, const float* __restrict__ part, float* __restrict__ dW,
+                                           float* __restrict__ db, float* __restrict__ dwg, float* __restrict__ dcg,
+                                           int accumulate, const SgdFuse& sg, int reduce_slabs, const HeadApply& hp,
+                                           int head_slabs, void* scratch = nullptr) {
+  if (extra < reduce_slabs) {
+    reduce_slab<512>(extra, P, D, part, dW, db, dwg, dcg, accumulate, sg);
+    return;
+  }
+  extra -= reduce_slabs;
+  if (extra < head_slabs) {
+    // the head's deferred second stage (dW_out / db_out slabs, BatchNorm column sums): the row-local launch of the last
+    // layer used to carry these 266 workgroups, but every workgroup of that kernel needs the whole LDS of a CU, so they
+    // ran as a second wave behind the 256 resident ones (+5 us); here they share CUs with the gather workgroups
+    const int wslabs = (hp.hf_CP * D + hp.hf_CP) / 64;
+    if (extra < wslabs)
+      head_finalize_slab<512, EXT>(extra, hp.hf_P, D, hp.hf_C, hp.hf_CP, hp.hf_part, hp.hf_dWout, hp.hf_dbout, hp.hf_accumulate, hp.dloss, scratch);
+    else
+      head_stats_finalize<512, EXT, 4>(extra - wslabs, hp.hf_P, n, S, D, hp.hf_CP, hp.hf_part, hp.hf_dbn_w, hp.hf_dbn_b, nullptr,
+                                       hp.hf_accumulate, hp.dloss, scratch);
+    return;
+  }
+  // fused optimizer step (cgcn_sgd_fuse) for every arena element whose gradient an EARLIER launch finished: all but
+  // this layer's own dW / db / dwg / dcg, which the slabs above step as they finish them
+  sgd_other_elements(sg, extra - head_slabs, D, dW, db, dwg, dcg);
+}
+
 // ------------------------------------------------------------------------------------------
 // k_bwd_sliced: dX = mask * ((1-g) dXn + Ahat^T dHs), dHs = diag(rs) dU W^T from k_bwd_rowlocal: the aggregation over
 // the transposed adjacency with an element-wise epilogue, feature-sliced (above).
@@ -1948,30 +1979,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HAS_VAL ? 6
                                                     float* __restrict__ db, float* __restrict__ dwg,
                                                     float* __restrict__ dcg, int accumulate, SgdFuse sg, int reduce_slabs,
                                                     const int* __restrict__ order, HeadApply hp, int head_slabs) {
-  // Horizontal fusion: the workgroups past the gather tiles do the (independent) second-stage sum of the
-  // row-local kernel's partials, so that reduction costs no launch of its own and overlaps the gather's tail.
   if ((int)blockIdx.x >= gather_blocks) {
-    int extra = (int)blockIdx.x - gather_blocks;
-    if (extra < reduce_slabs) {
-      reduce_slab<512>(extra, P, D, part, dW, db, dwg, dcg, accumulate, sg);
-      return;
-    }
-    extra -= reduce_slabs;
-    if (extra < head_slabs) {
-      // the head's deferred second stage (dW_out / db_out slabs, BatchNorm column sums): the row-local launch of the last
-      // layer used to carry these 266 workgroups, but every workgroup of that kernel needs the whole LDS of a CU, so they
-      // ran as a second wave behind the 256 resident ones (+5 us); here they share CUs with the gather workgroups
-      const int wslabs = (hp.hf_CP * D + hp.hf_CP) / 64;
-      if (extra < wslabs)
-        head_finalize_slab<512>(extra, hp.hf_P, D, hp.hf_C, hp.hf_CP, hp.hf_part, hp.hf_dWout, hp.hf_dbout, hp.hf_accumulate, hp.dloss);
-      else
-        head_stats_finalize<512, false, 4>(extra - wslabs, hp.hf_P, n, S, D, hp.hf_CP, hp.hf_part, hp.hf_dbn_w, hp.hf_dbn_b, nullptr,
-                                           hp.hf_accumulate, hp.dloss);
-      return;
-    }
-    // fused optimizer step (cgcn_sgd_fuse) for every arena element whose gradient an EARLIER launch finished: all but
-    // this layer's own dW / db / dwg / dcg, which the slabs above step as they finish them
-    sgd_other_elements(sg, extra - head_slabs, D, dW, db, dwg, dcg);
+    bwd_riders<S, D>((int)blockIdx.x - gather_blocks, n, P, part, dW, db, dwg, dcg, accumulate, sg, reduce_slabs, hp, head_slabs);
     return;
   }
   constexpr int NSL = S * D / 32, QPR = D / 32;
@@ -2002,6 +2011,148 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HAS_VAL ? 6
   }
   if (SLICED_NT & 4) __builtin_nontemporal_store(o, (f32x4*)&dX[g_off]);
   else *(f32x4*)&dX[g_off] = o;
+}
+
+// ------------------------------------------------------------------------------------------
+// Band graphs (adj_type 'constant': utils/util_methods.py:137-150 -- the +-7 diagonals plus I, row-normalised; the band
+// half of 'both' too).  Row i of Ahat is the contiguous window [max(0, i - BW), min(n - 1, i + BW)] with unit values, so
+// the aggregation is a (2 BW + 1)-row sliding-window sum: a STREAM, not a gather.  The CSR route walks the same rows as
+// 15 index-driven line loads per output line (15x the table through the vL1D, index list on top: the random-gather
+// rate); here a workgroup stages the R + 2 BW rows its R-row tile needs ONCE in LDS (zero rows past either end of the
+// strand) and every output is 15 LDS reads: the table moves through the memory system once (+ 2 BW / R halo rows, served
+// by the neighbouring tile's L2 -- tiles are dealt to the XCDs in contiguous ranges), which prices the launch at the
+// algorithmic bytes of SURVEY 8(d): read X, write H.
+//   tile: 512 threads; a thread owns one 16-byte column chunk (CH = D / 4 chunks per row) of RPT = R / (512 / CH)
+//   consecutive rows; loads: all of a thread's tile rows in flight at once, ds_write_b128, ONE barrier, then RPT + 2 BW
+//   ds_read_b128 (conflict-free: a 16-lane read group covers 256 contiguous bytes) and the window sums in ascending row
+//   order starting from zero -- the CSR kernels' list order, so the band route and the CSR route give the same bits.
+// k_band_aggregate: H = diag(rs) Ahat X.   k_bwd_band: dX = mask * ((1-g) dXn + Ahat^T dHs) (Ahat is symmetric; dHs comes
+// pre-scaled), with k_bwd_sliced's riders (second-stage sums, the head's slabs, the fused SGD step) in trailing workgroups.
+// ------------------------------------------------------------------------------------------
+#ifndef BAND_R
+#define BAND_R 32
+#endif
+constexpr int BAND_W = 7;   // the reference's constant_range (utils/util_methods.py:147)
+template <int D, int R>
+struct BandGeo {
+  static constexpr int CH = D / 4, RL = 512 / CH, RPT = R / RL, ROWS = R + 2 * BAND_W, NL = (ROWS * CH + 511) / 512;
+  static constexpr int TROWS = NL * RL;   // rows of the LDS tile: ROWS rounded up to whole staging passes (no predicated store)
+  static_assert(RL * RPT == R && RPT >= 1, "tile height is a multiple of the row lanes");
+};
+// window sums of tile `tile` of one strand's table T [n][D]: acc[p] = sum_{j in window(r0 + rl RPT + p)} T[j][4 c .. 4 c + 3]
+template <int D, int R>
+__device__ __forceinline__ void band_tile_sums(const float* __restrict__ T, int n, int r0, float* __restrict__ tile,
+                                               f32x4 (&acc)[BandGeo<D, R>::RPT]) {
+  using G = BandGeo<D, R>;
+  // branch-free staging: every load has a valid (clamped) address and is issued before the first wait; rows past either
+  // end of the strand become zeros by a select
+  f32x4 v[G::NL];
+  const int c0 = (int)threadIdx.x % G::CH, q0 = (int)threadIdx.x / G::CH;
+#pragma unroll
+  for (int u = 0; u < G::NL; ++u) {
+    const int j = r0 - BAND_W + q0 + (512 / G::CH) * u;
+    v[u] = *(const f32x4*)&T[(size_t)min(max(j, 0), n - 1) * D + 4 * c0];
+  }
+#pragma unroll
+  for (int u = 0; u < G::NL; ++u) {
+    const int row = q0 + (512 / G::CH) * u;
+    const int j = r0 - BAND_W + row;
+    const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+    *(f32x4*)&tile[row * D + 4 * c0] = (j >= 0 && j < n) ? v[u] : z;   // (rows >= ROWS of the padded tile: written, never read)
+  }
+  __syncthreads();
+  const int c = (int)threadIdx.x % G::CH, rl = (int)threadIdx.x / G::CH;
+  // one pass down the thread's RPT + 2 BW tile rows; row k belongs to the windows of outputs p with 0 <= k - p <= 2 BW, and
+  // every output adds its rows in ascending order (few registers live: the kernel runs 8 waves per SIMD)
+#pragma unroll
+  for (int p = 0; p < G::RPT; ++p) acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float* __restrict__ col = &tile[rl * G::RPT * D + 4 * c];
+  constexpr int NK = G::RPT + 2 * BAND_W, KB = 4;   // KB rows per batch of LDS reads (all in flight, then added)
+#pragma unroll
+  for (int k0 = 0; k0 < NK; k0 += KB) {
+    f32x4 w[KB];
+#pragma unroll
+    for (int u = 0; u < KB; ++u)
+      if (k0 + u < NK) w[u] = *(const f32x4*)&col[(k0 + u) * D];
+#pragma unroll
+    for (int u = 0; u < KB; ++u)
+#pragma unroll
+      for (int p = 0; p < G::RPT; ++p)
+        if (k0 + u < NK && k0 + u - p >= 0 && k0 + u - p <= 2 * BAND_W) acc[p] += w[u];
+    // the sums of this batch happen HERE (left alone the compiler sinks them into the callers' store branches and keeps
+    // every row of the column live: 64+ registers, spills at 8 waves)
+#pragma unroll
+    for (int p = 0; p < G::RPT; ++p) asm volatile("" : "+v"(acc[p]));
+  }
+}
+
+template <int S, int D, int R>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8))) void k_band_aggregate(int n, const float* __restrict__ rs, const float* __restrict__ X,
+                                                        float* __restrict__ H) {
+  using G = BandGeo<D, R>;
+  const int tiles = (n + R - 1) / R;
+  const int b = xcd_contiguous((int)blockIdx.x, S * tiles);
+  const int s = b / tiles, r0 = (b - s * tiles) * R;
+  __shared__ __attribute__((aligned(16))) float tile[G::TROWS * D];
+  f32x4 acc[G::RPT];
+  band_tile_sums<D, R>(X + (size_t)s * n * D, n, r0, tile, acc);
+  const int c = (int)threadIdx.x % G::CH, rl = (int)threadIdx.x / G::CH;
+#pragma unroll
+  for (int p = 0; p < G::RPT; ++p) {
+    const int i = r0 + rl * G::RPT + p;
+    if (i < n) {
+      const f32x4 o = acc[p] * (rs ? rs[i] : 1.f);
+      float* dst = &H[((size_t)s * n + i) * D + 4 * c];
+      if (SLICED_NT & 1) __builtin_nontemporal_store(o, (f32x4*)dst);
+      else *(f32x4*)dst = o;
+    }
+  }
+}
+
+template <int S, int D, int R>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8))) void k_bwd_band(int n, const float* __restrict__ dHs, const float* dXn,
+                                                  const float* __restrict__ gate, float* dX, float keep_scale, uint32_t thresh,
+                                                  const unsigned long long* __restrict__ rng_state, uint32_t stream_id,
+                                                  int gather_blocks, int P, const float* __restrict__ part,
+                                                  float* __restrict__ dW, float* __restrict__ db, float* __restrict__ dwg,
+                                                  float* __restrict__ dcg, int accumulate, SgdFuse sg, int reduce_slabs,
+                                                  HeadApply hp, int head_slabs) {
+  using G = BandGeo<D, R>;
+  __shared__ __attribute__((aligned(16))) float tile[G::TROWS * D];
+  static_assert(sizeof(tile) >= 4 * (512 / HEAD_STAT_COLS) * (HEAD_STAT_COLS + 1) * sizeof(double), "rider staging fits the tile");
+  if ((int)blockIdx.x >= gather_blocks) {
+    bwd_riders<S, D, true>((int)blockIdx.x - gather_blocks, n, P, part, dW, db, dwg, dcg, accumulate, sg, reduce_slabs, hp, head_slabs, tile);
+    return;
+  }
+  const int tiles = (n + R - 1) / R;
+  const int b = xcd_contiguous((int)blockIdx.x, gather_blocks);
+  const int s = b / tiles, r0 = (b - s * tiles) * R;
+  const int c = (int)threadIdx.x % G::CH, rl = (int)threadIdx.x / G::CH;
+  // the (1-g) dXn term first: its loads are in flight during the tile's staging (dXn may be dX itself: every thread reads
+  // exactly the elements it writes)
+  f32x4 res[G::RPT];
+#pragma unroll
+  for (int p = 0; p < G::RPT; ++p) {
+    const int i = r0 + rl * G::RPT + p;
+    res[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (i < n) res[p] = ld_stream4(&dXn[((size_t)s * n + i) * D + 4 * c]) * (1.f - gate[(size_t)s * n + i]);
+  }
+  f32x4 acc[G::RPT];
+  band_tile_sums<D, R>(dHs + (size_t)s * n * D, n, r0, tile, acc);
+  const uint32_t key = thresh ? dropout_key(rng_state, stream_id) : 0u;
+#pragma unroll
+  for (int p = 0; p < G::RPT; ++p) {
+    const int i = r0 + rl * G::RPT + p;
+    if (i >= n) continue;
+    const size_t g_off = ((size_t)s * n + i) * D + 4 * c;
+    f32x4 o = res[p] + acc[p];
+    if (thresh) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = dropout_keep(key, (uint32_t)(g_off + e), thresh) ? o[e] * keep_scale : 0.f;
+    }
+    if (SLICED_NT & 4) __builtin_nontemporal_store(o, (f32x4*)&dX[g_off]);
+    else *(f32x4*)&dX[g_off] = o;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2205,6 +2356,15 @@ static inline const uint16_t* use_col16(const cgcn_graph_aux* aux, const float* 
 #endif
 static inline bool hub_graph(const cgcn_graph_aux* aux) { return aux && aux->max_row_len > FWD_HUB_ROW; }
 static inline const int32_t* row_order(const cgcn_graph_aux* aux) { return aux ? aux->row_order : nullptr; }
+// band graphs (cgcn_graph_aux::band_halfwidth; implicit unit values): the sliding-window kernels instead of the CSR walk
+static inline bool band_graph(const cgcn_graph_aux* aux, const float* val) { return aux && aux->band_halfwidth == BAND_W && !val; }
+static void launch_band_aggregate(hipStream_t st, int n, int S, int d, const float* rs, const float* X, float* H) {
+  const int blocks = S * ((n + BAND_R - 1) / BAND_R);
+  if (S == 1 && d == 128) hipLaunchKernelGGL((k_band_aggregate<1, 128, BAND_R>), dim3(blocks), dim3(512), 0, st, n, rs, X, H);
+  else if (S == 2 && d == 128) hipLaunchKernelGGL((k_band_aggregate<2, 128, BAND_R>), dim3(blocks), dim3(512), 0, st, n, rs, X, H);
+  else if (S == 1 && d == 256) hipLaunchKernelGGL((k_band_aggregate<1, 256, BAND_R>), dim3(blocks), dim3(512), 0, st, n, rs, X, H);
+  else hipLaunchKernelGGL((k_band_aggregate<2, 256, BAND_R>), dim3(blocks), dim3(512), 0, st, n, rs, X, H);
+}
 
 int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d, const int32_t* rowptr, const int32_t* col,
               const float* val, const float* row_scale, const float* X, float* Y, const cgcn_graph_aux* aux) {
@@ -2221,6 +2381,10 @@ int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d, const 
     const long long rows = (long long)S * n_rows;
     const int blocks = (int)((rows + 3) / 4 < 8192 ? (rows + 3) / 4 : 8192);
     hipLaunchKernelGGL(k_spmm_any, dim3(blocks), dim3(256), 0, st, n_rows, n_cols, S, d, rowptr, col, val, row_scale, X, Y);
+    return launch_status();
+  }
+  if (n_rows == n_cols && band_graph(aux, val)) {   // a band operator: the sliding-window stream (see k_band_aggregate)
+    launch_band_aggregate(st, n_rows, S, d, row_scale, X, Y);
     return launch_status();
   }
   if (n_rows == n_cols && ((double)n_rows * S * d * 4.0 >= (double)g_fwd_split_bytes.load() || hub_graph(aux))) {
@@ -2284,6 +2448,7 @@ int cgcn_layer_fwd_colstats_tiles(int n, int S, int d, int* rows_per_tile) {
 int cgcn_debug_layer_fwd_route(int n, int S, int d, const cgcn_graph_aux* aux) {
   const int rc = check_shape(n, S, d);
   if (rc) return rc;
+  if (band_graph(aux, nullptr)) return 2;
   return (fwd_split_shape(n, S, d) || hub_graph(aux)) ? 1 : 0;
 }
 
@@ -2305,14 +2470,16 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   hipStream_t st = (hipStream_t)stream;
   // Three routes.  H_in given: the row-local kernel alone.  Training (H is wanted anyway) on a table that does not
   // fit the L2s: feature-sliced aggregation into H, then the row-local kernel on it.  Otherwise the fused kernel.
-  const bool split = !H_in && H && (fwd_split_shape(n, S, d) || hub_graph(aux));
+  const bool band = band_graph(aux, val);
+  const bool split = !H_in && H && (fwd_split_shape(n, S, d) || hub_graph(aux) || band);
   // cgcn_layer_fwd_colstats_tiles() reports MERGED records on split-size tables (k_layer_dense's contiguous tile
   // chunks); the fused kernel would write one record per 16 / S-node tile -- more than the caller allocated.  On such
   // tables the column statistics therefore need the two-launch route, i.e. an H (or H_in) buffer.
   if (colstats && !split && !H_in && dense_stat_chunk(n, S, d) != 1) return CGCN_ERR_BAD_ARG;
   if (split) {
     const int gblocks = (S * d / 32) * ((n + 63) / 64);
-    launch_aggregate_sliced(st, gblocks, n, S, d, rowptr, col, use_col16(aux, val, n), val, row_scale, X, H, row_order(aux));
+    if (band) launch_band_aggregate(st, n, S, d, row_scale, X, H);
+    else launch_aggregate_sliced(st, gblocks, n, S, d, rowptr, col, use_col16(aux, val, n), val, row_scale, X, H, row_order(aux));
     if ((rc = launch_status())) return rc;
     H_in = H;
   }
@@ -2482,7 +2649,18 @@ static int layer_bwd_impl(cgcn_stream_t stream, int n, int S, int d, const int32
   const int blocks = (S * d / 32) * ((n + 63) / 64);   // slices x 64-row tiles (k_bwd_sliced)
   if (head) dXn = dX;  // k_bwd_rowlocal left dL/dXn there; each thread reads its elements before overwriting them
   const int sgd_blocks = sg.param ? (sg.count + 511) / 512 : 0;
-  if (const uint16_t* col16_t = use_col16(aux_t, val_t, n)) {
+  if (band_graph(aux_t, val_t)) {   // band operator (symmetric): the sliding-window stream with the same riders
+    const int bblocks = S * ((n + BAND_R - 1) / BAND_R);
+#define CALLB(S_, D_)                                                                                                 \
+  hipLaunchKernelGGL((k_bwd_band<S_, D_, BAND_R>), dim3(bblocks + (fuse_reduce ? slabs : 0) + head_slabs_g + sgd_blocks), dim3(512), 0, st, \
+                     n, dHs, dXn, gate, dX, ks, th, rng_state, in_stream_id, bblocks, P, part, dW, db, dwg, dcg, accumulate, sg, \
+                     fuse_reduce ? slabs : 0, hp, head_slabs_g)
+    if (S == 1 && d == 128) CALLB(1, 128);
+    else if (S == 2 && d == 128) CALLB(2, 128);
+    else if (S == 1 && d == 256) CALLB(1, 256);
+    else CALLB(2, 256);
+#undef CALLB
+  } else if (const uint16_t* col16_t = use_col16(aux_t, val_t, n)) {
 #define CALL16(S_, D_)                                                                                               \
   hipLaunchKernelGGL((k_bwd_sliced<S_, D_, false, uint16_t>), dim3(blocks + (fuse_reduce ? slabs : 0) + head_slabs_g + sgd_blocks), dim3(512), 0, \
                      st, n, rowptr_t, col16_t, val_t, dHs, dXn, gate, dX, ks, th, rng_state, in_stream_id, blocks, P, \

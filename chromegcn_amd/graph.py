@@ -124,7 +124,36 @@ def host_csr_from_matrix(a: sp.spmatrix) -> HostCSR:
 # use may sit inside HIP-graph capture), found again by the address of the int32 array -- the registered operators
 # carry tensors, not graph objects.
 class GraphAux(ctypes.Structure):
-    _fields_ = [("col16", ctypes.c_void_p), ("row_order", ctypes.c_void_p), ("max_row_len", ctypes.c_int32)]
+    _fields_ = [("col16", ctypes.c_void_p), ("row_order", ctypes.c_void_p), ("max_row_len", ctypes.c_int32),
+                ("band_halfwidth", ctypes.c_int32)]
+
+
+BAND_HALFWIDTH = 7   # utils/util_methods.py:147 (constant_range); the width the library's band kernels are built for
+
+
+def band_halfwidth(rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.Tensor], n_cols: int) -> int:
+    """w if the CSR is EXACTLY the band of half-width w = BAND_HALFWIDTH with implicit unit values -- row i holds the columns
+    max(0, i - w) .. min(n - 1, i + w), each once (process_graph's 'constant' branch) -- else 0.  Decided from the arrays
+    themselves (first column, last column and length of every row; rows are sorted and duplicate-free), so a reference-style
+    COO caller's band graph is recognised like the engine's own."""
+    n = int(rowptr.numel()) - 1
+    w = BAND_HALFWIDTH
+    if val is not None or n != n_cols or n < 1 or col.numel() == 0:
+        return 0
+    i = torch.arange(n, device=rowptr.device, dtype=torch.int64)
+    lo, hi = (i - w).clamp_(min=0), (i + w).clamp_(max=n - 1)
+    rp = rowptr.to(torch.int64)
+    if not torch.equal(rp[1:] - rp[:-1], hi - lo + 1):
+        return 0
+    c = col.to(torch.int64)
+    if not (torch.equal(c[rp[:-1]], lo) and torch.equal(c[rp[1:] - 1], hi)):
+        return 0
+    # sorted + unique inside a row is what every builder of this package guarantees; checked here because the hint is
+    # trusted by the kernels: strictly increasing inside every row <=> differences are 1 except at row starts
+    inc = c[1:] - c[:-1]
+    starts = torch.zeros(c.numel(), dtype=torch.bool, device=c.device)
+    starts[rp[1:-1]] = True
+    return w if bool(((inc == 1) | starts[1:]).all()) else 0
 
 
 def tile_sorted_rows(deg: torch.Tensor) -> torch.Tensor:
@@ -158,7 +187,7 @@ def _wants_row_order(longest: int, n_rows: int, nnz: int) -> bool:
 _AUX: Dict[int, tuple] = {}
 
 
-def _register_aux(rowptr: torch.Tensor, col: torch.Tensor, n_cols: int):
+def _register_aux(rowptr: torch.Tensor, col: torch.Tensor, n_cols: int, val: Optional[torch.Tensor] = None):
     if not (torch.is_tensor(col) and col.is_cuda and col.numel() > 0):
         return
     import weakref
@@ -169,8 +198,9 @@ def _register_aux(rowptr: torch.Tensor, col: torch.Tensor, n_cols: int):
     deg = rowptr[1:] - rowptr[:-1]
     longest = int(deg.max().item()) if n_rows > 0 else 0
     order = tile_sorted_rows(deg) if _wants_row_order(longest, n_rows, int(col.numel())) else None
+    band = band_halfwidth(rowptr, col, val, n_cols) if os.environ.get("CGCN_BAND_ROUTE", "1") != "0" else 0
     _AUX[col.data_ptr()] = (weakref.ref(col), (c16, order), GraphAux(None if c16 is None else c16.data_ptr(),
-                                                                      None if order is None else order.data_ptr(), longest))
+                                                                      None if order is None else order.data_ptr(), longest, band))
 
 
 def _aux_entry(col: Optional[torch.Tensor]):
@@ -206,6 +236,12 @@ def max_row_len(col: Optional[torch.Tensor]) -> int:
     return 0 if ent is None else int(ent[2].max_row_len)
 
 
+def is_band(col: Optional[torch.Tensor]) -> bool:
+    """the graph was recognised as the +-7 band (the library's sliding-window route)"""
+    ent = _aux_entry(col)
+    return ent is not None and int(ent[2].band_halfwidth) > 0
+
+
 @dataclass
 class ChromGraph:
     """Device-resident CSR of one chromosome's adjacency, plus the CSR of Ahat^T for the backward
@@ -224,9 +260,9 @@ class ChromGraph:
     host: Optional[HostCSR] = field(default=None, repr=False)
 
     def __post_init__(self):
-        _register_aux(self.rowptr, self.col, self.n)
+        _register_aux(self.rowptr, self.col, self.n, self.val)
         if self.col_t is not self.col:
-            _register_aux(self.rowptr_t, self.col_t, self.n)
+            _register_aux(self.rowptr_t, self.col_t, self.n, self.val_t)
 
     @property
     def device(self):

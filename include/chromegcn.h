@@ -50,7 +50,7 @@ extern "C" {
 #define CGCN_ERR_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after a launch      */
 #define CGCN_ERR_WORKSPACE (-4)   /* workspace too small (see cgcn_*_workspace_bytes)    */
 
-#define CGCN_ABI_VERSION 20
+#define CGCN_ABI_VERSION 21
 
 typedef void *cgcn_stream_t; /* hipStream_t */
 
@@ -72,12 +72,19 @@ typedef void *cgcn_stream_t; /* hipStream_t */
  *                 neighbouring rows) and the groups heaviest first (tiles with hub rows start the launch).  Results are
  *                 independent of the order up to fp32 re-association of a row's sum (a wave chooses how to walk its rows
  *                 by their lengths).  Not checked: an array that is not a permutation leaves rows unwritten.
- * For the backward (aux_t) all three describe the CSR of Ahat^T.
+ *   band_halfwidth : w > 0 says the CSR is EXACTLY a band: row i holds the columns max(0, i - w) .. min(n - 1, i + w), each
+ *                 once (process_graph's 'constant' branch, utils/util_methods.py:137-150: w = 7; the diagonal is the
+ *                 added identity), with implicit unit values (val == NULL).  0 = not a band / unknown.  For w = 7 the
+ *                 aggregation then runs as a sliding-window stream over the table (k_band_aggregate / k_bwd_band: every
+ *                 row read once, no index list) instead of the CSR walk; same bits (same summation order).  Not checked:
+ *                 a wrong hint gives the band's sums, not the CSR's.  ABI 21.
+ * For the backward (aux_t) all four describe the CSR of Ahat^T.
  */
 typedef struct cgcn_graph_aux {
   const uint16_t *col16;
   const int32_t *row_order;
   int32_t max_row_len;
+  int32_t band_halfwidth;
 } cgcn_graph_aux;
 
 /* ABI version of the loaded library (compare with CGCN_ABI_VERSION). */
@@ -141,7 +148,9 @@ void cgcn_debug_set_fwd_split_bytes(long long bytes);
 /* Which kernels a call WOULD launch, so that a profiler prices the kernel that actually runs (bench.py's roofline);
  * nothing is launched, no GPU is needed.
  *   cgcn_debug_layer_fwd_route: the training forward (H given, no H_in) on this graph, under the current split
- *     threshold: 0 = the fused k_layer_fwd, 1 = k_aggregate_sliced + k_layer_dense (large tables, hub-heavy graphs).
+ *     threshold: 0 = the fused k_layer_fwd, 1 = k_aggregate_sliced + k_layer_dense (large tables, hub-heavy graphs),
+ *     2 = k_band_aggregate + k_layer_dense (band graphs: cgcn_graph_aux::band_halfwidth; their backward's last launch
+ *     is k_bwd_band instead of k_bwd_sliced).
  *   cgcn_debug_layer_bwd_route: the row-local launch of cgcn_layer_bwd: 0 = k_bwd_rowlocal256 (d = 256: 32-row tiles,
  *     dHs by a second launch), 2 = k_bwd_rowlocal_ring (d = 128: row / matrix wave teams over a flag-synchronised LDS
  *     ring).  (1 was the 48-row-tile kernel of ABI <= 18: no longer returned.)

@@ -1,0 +1,118 @@
+"""The band route (adj_type 'constant': utils/util_methods.py:137-150, the +-7 diagonals plus I, row-normalised).
+A band graph is recognised from its CSR arrays (graph.band_halfwidth -> cgcn_graph_aux::band_halfwidth) and its
+aggregations run as a sliding-window stream over the feature table (k_band_aggregate / k_bwd_band) instead of the CSR walk.
+Checked here: the recognition; the band kernels against a float64 scipy product and -- bit for bit, they sum in the CSR's
+list order -- against the CSR kernels of the same library on the same graph (hint withheld); the whole layer backward incl.
+input-dropout mask, head mode riders being covered by the full-size oracle cases (tests/test_gpu_fullsize_oracle.py
+'*_constant') and the golden vectors G1/G2 (tests/test_gpu_parity.py, 'constant' cases), which now take this route."""
+import ctypes
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from chromegcn_amd import _lib, graph as G, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+SIZES = [1, 2, 7, 8, 15, 31, 32, 33, 64, 257, 1000, 5776, 16264]
+
+
+def _band(n):
+    return G.upload(G.normalize_graph("constant", None, n), DEV)
+
+
+def _without_hint(g):
+    """the same graph's cgcn_graph_aux with the band hint withheld (-> the CSR kernels)"""
+    return G.GraphAux(G.col16_ptr(g.col), None if G.row_order(g.col) is None else G.row_order(g.col).data_ptr(), G.max_row_len(g.col), 0)
+
+
+def test_band_graphs_are_recognised_and_nothing_else_is():
+    for n in SIZES:
+        g = _band(n)
+        assert G.is_band(g.col) == (n >= 1), n
+        assert g.val is None
+    hic = synth.contact_graph(3000, 20000, 3)
+    for adj in ("hic", "both", "none"):
+        assert not G.is_band(G.upload(G.normalize_graph(adj, hic, 3000), DEV).col), adj
+    # a band with one entry missing, one entry moved, explicit values: not a band
+    h = G.normalize_graph("constant", None, 500)
+    a = sp.csr_matrix((np.ones(h.col.size, np.float32), h.col, h.rowptr), shape=(500, 500)).tolil()
+    a[100, 103] = 0
+    b = sp.csr_matrix(a)
+    b.eliminate_zeros()
+    g = G.ChromGraph(n=500, nnz=b.nnz, rowptr=torch.from_numpy(b.indptr.astype(np.int32)).to(DEV), col=torch.from_numpy(b.indices.astype(np.int32)).to(DEV),
+                     val=None, row_scale=None, rowptr_t=None, col_t=None, val_t=None, symmetric=True)
+    assert not G.is_band(g.col)
+    a[100, 103] = 1
+    a[100, 93] = 0
+    a[100, 300] = 1      # same length, same first column of the row, other last column
+    b = sp.csr_matrix(a)
+    b.eliminate_zeros()
+    g2 = G.ChromGraph(n=500, nnz=b.nnz, rowptr=torch.from_numpy(b.indptr.astype(np.int32)).to(DEV), col=torch.from_numpy(b.indices.astype(np.int32)).to(DEV),
+                      val=None, row_scale=None, rowptr_t=None, col_t=None, val_t=None, symmetric=True)
+    assert not G.is_band(g2.col)
+    gv = G.upload(h, DEV)
+    gv2 = G.ChromGraph(n=500, nnz=gv.nnz, rowptr=gv.rowptr.clone(), col=gv.col.clone(), val=torch.ones(gv.nnz, device=DEV), row_scale=gv.row_scale,
+                       rowptr_t=None, col_t=None, val_t=None, symmetric=True)
+    assert not G.is_band(gv2.col)
+
+
+@pytest.mark.parametrize("S,d", [(2, 128), (1, 128), (2, 256), (1, 256)])
+def test_band_aggregation_same_bits_as_the_csr_route_and_right(S, d):
+    lib = _lib.load()
+    P = _lib.ptr
+    for n in SIZES:
+        g = _band(n)
+        x = torch.randn(S, n, d, device=DEV, generator=torch.Generator(device=DEV).manual_seed(n + d + S))
+        yb, yc = torch.full_like(x, float("nan")), torch.full_like(x, float("nan"))
+        _lib.check(lib.cgcn_spmm(_lib.stream_ptr(), n, n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(yb), G.aux_ptr(g.col)), "spmm band")
+        plain = _without_hint(g)
+        lib.cgcn_debug_set_fwd_split_bytes(0)   # the feature-sliced CSR route at every size (list-order sums, like the band's)
+        try:
+            _lib.check(lib.cgcn_spmm(_lib.stream_ptr(), n, n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(yc), ctypes.addressof(plain)), "spmm csr")
+        finally:
+            lib.cgcn_debug_set_fwd_split_bytes(-1)
+        assert torch.equal(yb, yc), (S, d, n)
+        a = g.host.ahat().astype(np.float64)
+        want = np.stack([np.asarray(sp.diags(g.host.row_scale.astype(np.float64)) @ (a @ x[s].double().cpu().numpy())) for s in range(S)])
+        np.testing.assert_allclose(yb.cpu().numpy(), want, atol=2e-5, rtol=2e-5)
+
+
+@pytest.mark.parametrize("S,d,p", [(2, 128, 0.0), (2, 128, 0.3), (1, 256, 0.0), (2, 256, 0.25)])
+def test_layer_forward_and_backward_same_bits_with_and_without_the_band_route(S, d, p):
+    """cgcn_layer_fwd (H wanted: k_band_aggregate + k_layer_dense) and cgcn_layer_bwd (k_bwd_band with the second-stage
+    sums riding) against the same calls with the hint withheld (forward: the sliced route forced)."""
+    lib = _lib.load()
+    P = _lib.ptr
+    for n in (9, 64, 1000, 5776, 16264):
+        g = _band(n)
+        gen = torch.Generator(device=DEV).manual_seed(n + d)
+        r = lambda *s: torch.randn(*s, device=DEV, generator=gen)
+        x, W, b, wg, cg = r(S, n, d), r(d, d) / d ** 0.5, 0.1 * r(d), r(d) / d ** 0.5, torch.zeros(1, device=DEV)
+        rng = torch.tensor([99, 5], dtype=torch.int64, device=DEV)
+        plain = _without_hint(g)
+        outs = []
+        for aux in (G.aux_ptr(g.col), ctypes.addressof(plain)):
+            if aux != G.aux_ptr(g.col):
+                lib.cgcn_debug_set_fwd_split_bytes(0)
+            try:
+                xn, z, h, gate = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x), torch.empty(S, n, device=DEV)
+                _lib.check(lib.cgcn_layer_fwd(_lib.stream_ptr(), n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(W), P(b), P(wg), P(cg),
+                                              P(xn), P(z), P(h), P(gate), 0.0, None, 0, None, None, aux), "fwd")
+            finally:
+                lib.cgcn_debug_set_fwd_split_bytes(-1)
+            dxn = torch.randn(S, n, d, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+            dx, dhs = torch.empty_like(x), torch.empty_like(x)
+            dW, db, dwg, dcg = torch.empty(d, d, device=DEV), torch.empty(d, device=DEV), torch.empty(d, device=DEV), torch.empty(1, device=DEV)
+            ws_b = lib.cgcn_layer_bwd_workspace_bytes(n, S, d)
+            ws = torch.empty(ws_b, dtype=torch.uint8, device=DEV)
+            _lib.check(lib.cgcn_layer_bwd(_lib.stream_ptr(), n, S, d, P(g.rowptr_t), P(g.col_t), None, P(g.row_scale), P(x), P(z), P(h), P(gate),
+                                          P(W), P(wg), P(dxn), None, P(dx), P(dhs), P(dW), P(db), P(dwg), P(dcg), 0, p, P(rng) if p else None, 1,
+                                          None, P(ws), ws_b, None, None, aux), "bwd")
+            outs.append((xn, z, h, gate, dx, dhs, dW, db, dwg, dcg))
+        for nm, u, v in zip(("Xn", "Z", "H", "gate", "dX", "dHs", "dW", "db", "dwg", "dcg"), *outs):
+            assert torch.equal(u, v), (nm, S, d, n, p)
+    g5 = _band(5776)
+    assert lib.cgcn_debug_layer_fwd_route(5776, S, d, G.aux_ptr(g5.col)) == 2

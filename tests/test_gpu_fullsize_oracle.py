@@ -63,6 +63,12 @@ CASES = [   # name, n, pairs, hic_like, adj_type, seed, d, layers, labels
     # range without saturating the hub windows): these hold the plain 1e-4 bound against float64, no relaxation
     ("chr21_hub_w8", synth.chrom_nodes("chr21"), 250000, "hub", "hic", 26, 128, 2, NC),
     ("chr1_hub_w8", synth.chrom_nodes("chr1"), 250000, "hub", "hic", 27, 128, 2, NC),
+    # adj_type 'constant' (+-7 band + I, utils/util_methods.py:137-150): the band route -- k_band_aggregate in both layers'
+    # forward, k_bwd_band with the second-stage sums, the head's slabs and the fused SGD step riding -- at chr21 size, at the
+    # genome's mean chromosome size, and at d = 256 / L = 4
+    ("chr21_constant", synth.chrom_nodes("chr21"), 250000, False, "constant", 29, 128, 2, NC),
+    ("chr10_constant", synth.chrom_nodes("chr10"), 250000, False, "constant", 30, 128, 2, NC),
+    ("k562_constant_d256_L4", synth.chrom_nodes("chr21"), 250000, False, "constant", 31, 256, 4, NC),
 ]
 
 

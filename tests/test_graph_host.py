@@ -121,3 +121,31 @@ def test_convert_graph_pickle(tmp_path):
     for c, path in out.items():
         h = G.load_csr_cache(path)
         np.testing.assert_allclose(h.to_scipy().toarray(), O.normalized_adjacency("hic", graphs[c], graphs[c].shape[0]).toarray(), rtol=2e-7)
+
+
+def test_band_recognition_from_the_csr_arrays():
+    """graph.band_halfwidth (-> cgcn_graph_aux::band_halfwidth, the library's sliding-window route): exactly the 'constant'
+    graph of utils/util_methods.py:137-150 qualifies"""
+    import torch
+    for n in (1, 2, 7, 8, 15, 100, 1001):
+        h = G.normalize_graph("constant", None, n)
+        rp, c = torch.from_numpy(h.rowptr), torch.from_numpy(h.col)
+        assert G.band_halfwidth(rp, c, None, n) == 7, n
+        assert G.band_halfwidth(rp, c, torch.ones(c.numel()), n) == 0          # explicit values
+        assert G.band_halfwidth(rp, c, None, n + 1) == 0                        # not square
+    rng = np.random.RandomState(0)
+    a = sp.random(300, 300, 0.02, random_state=rng, format="csr")
+    a = a + a.T
+    a.data[:] = 1
+    for adj in ("hic", "both", "none"):
+        h = G.normalize_graph(adj, a, 300)
+        assert G.band_halfwidth(torch.from_numpy(h.rowptr), torch.from_numpy(h.col), None if h.val is None else torch.from_numpy(h.val), 300) == 0
+    # same row lengths and row ends as the band, one interior column replaced by a duplicate-free other one
+    h = G.normalize_graph("constant", None, 50)
+    c = h.col.copy()
+    k = h.rowptr[20] + 3
+    c[k] = c[k] - 0   # unchanged: still a band
+    assert G.band_halfwidth(torch.from_numpy(h.rowptr), torch.from_numpy(c), None, 50) == 7
+    c2 = h.col.copy()
+    c2[h.rowptr[20] + 3] = c2[h.rowptr[20] + 2]   # a repeated column inside a row
+    assert G.band_halfwidth(torch.from_numpy(h.rowptr), torch.from_numpy(c2), None, 50) == 0
