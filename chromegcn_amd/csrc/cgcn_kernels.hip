@@ -11,7 +11,7 @@
 //   k_layer_dense<S,D>      the row-local half of the layer forward on an H that is in memory (after k_aggregate_sliced)
 //   k_bwd_rowlocal_ring     (d = 128) per-row gate/tanh derivative by a row team, H^T dU and dHs = diag(rs) dU W^T on fp32 MFMA by a
 //                           matrix team, the teams meeting through a flag-synchronised ring of LDS slots (no per-tile barrier)
-//   k_bwd_rowlocal256, k_dh_dense<256>   the same work at d = 256: row pass + H^T dU per tile, dHs in a second launch
+//   k_bwd_rowlocal256s      the same work at d = 256: column-slab workgroups, both products per 32-row tile
 //   k_reduce_partials       deterministic second stage of the column / dW sums
 //   k_bwd_sliced<S,D>       dX = mask ((1-g) dXn + Ahat^T dHs): feature-sliced gather + element-wise epilogue
 //
@@ -875,269 +875,14 @@ __global__ __launch_bounds__(512, DENSE_WAVES_PER_SIMD) void k_layer_dense(int n
 }
 
 // ------------------------------------------------------------------------------------------
-// k_dh_dense: B <- B W^T in place, B = diag(row_scale) dU [M, D]: the dHs product for d = 256, where k_bwd_rowlocal's
-// 128 accumulator registers leave no room for the W^T fragments (d = 128 does this product inside the row-local
-// kernel).  Persistent, one 8-wave workgroup per CU, W^T fragments resident in registers (128 at D = 256), 16-row
-// tiles: rows -> LDS -> MFMA -> back to the same rows straight from the accumulators (a tile is read completely
-// before any of it is written; tiles are disjoint across workgroups).
-// ------------------------------------------------------------------------------------------
-#ifndef DH_MB
-#define DH_MB 1
-#endif
-template <int D>
-__global__ __launch_bounds__(512) void k_dh_dense(int M, float* __restrict__ B, const float* __restrict__ W) {
-  constexpr int MB = DH_MB, ROWS = 16 * MB, CBW = D / 128, NW = 8, LD = D + 4, EPL = D / 64, RPW = ROWS / NW;
-  __shared__ __attribute__((aligned(16))) float T[ROWS * LD];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float bw[CBW][D / 4];
-  load_wfrag<D, CBW, true>(W, wave, lane, bw);
-  const int ntiles = (M + ROWS - 1) / ROWS;
-  float rows[RPW][EPL];
-  auto load_tile = [&](int tile) {
-#pragma unroll
-    for (int t = 0; t < RPW; ++t) {
-      const int m = tile * ROWS + wave + t * NW;
-      if (m < M) ld_row<EPL>(rows[t], &B[(size_t)m * D + lane * EPL]);
-      else zero_row<EPL>(rows[t]);
-    }
-  };
-  if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-#pragma unroll
-    for (int t = 0; t < RPW; ++t) st_row<EPL>(&T[(wave + t * NW) * LD + lane * EPL], rows[t]);
-    if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
-    __syncthreads();
-    f32x4 acc[MB][CBW];
-    tile_mfma<MB, D, CBW, LD, true, true>(T, W, bw, wave, lane, acc);
-    const int r = lane & 15, q = lane >> 4;
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int m = tile * ROWS + mb * 16 + q * 4 + e;
-        if (m < M) {
-#pragma unroll
-          for (int cb = 0; cb < CBW; ++cb) B[(size_t)m * D + wave * (16 * CBW) + cb * 16 + r] = acc[mb][cb][e];
-        }
-      }
-    __syncthreads();  // T is rewritten by the next tile
-  }
-}
-
-// ------------------------------------------------------------------------------------------
 // The row-local launch of the layer backward: everything that is local to a (strand, node) row, plus the two dense
 // products on MFMA:  dW = H^T dU  and  dHs = diag(row_scale) dU W^T  (dL/dH, pre-scaled: the operand of the gather
 // over Ahat^T that follows in k_bwd_sliced).  Rows are the flattened [S*n] axis; every workgroup keeps its share of dW
 // in accumulators and writes one partial:
 //   partial layout per workgroup: [D*D dW][D db][D dwg][1 dcg][3 pad]
-// d = 128: k_bwd_rowlocal_ring (below).  d = 256: k_bwd_rowlocal256 + k_dh_dense<256>.
-//
-// k_bwd_rowlocal256: 8 waves, persistent over 32-row tiles (one workgroup per CU at most), every wave owns 32 rows of dW
-// (128 accumulator registers: no room for W^T fragments), single-buffered tile, row pass and dW product in turn; the
-// rows of diag(row_scale) dU go to memory and k_dh_dense<256> turns them into dHs in place.  (Until round 4 this was
-// the D = 256 instantiation of a template that also served d = 128; that kernel -- 16 waves, role-split by product,
-// one workgroup barrier per tile -- is in the history at the round-3 tag and in profiles/r04_rowlocal_ring_experiment.txt.)
-// LDS row stride of the tiles = D + 16 floats (Ht / Ut are read column-wise: lanes (q, r) read row 4kk+q, column c0+r:
-// conflict-free in a half-wave when the stride is 16 mod 32).
-// ------------------------------------------------------------------------------------------
-template <int TR>
-__global__ __launch_bounds__(512) void k_bwd_rowlocal256(int M, int n, const float* __restrict__ dXn,
-                                                         const float* __restrict__ Z, const float* __restrict__ X,
-                                                         const float* __restrict__ gate, const float* __restrict__ dgate,
-                                                         const float* __restrict__ H, const float* __restrict__ wg,
-                                                         const float* __restrict__ rs, float* __restrict__ dHs,
-                                                         float* __restrict__ part, HeadApply hp,
-                                                         float* __restrict__ dxn_store, int row_blocks, int head_slabs) {
-  constexpr int D = 256, NW = 8;
-  // extra workgroups past the row tiles: the head's deferred dW_out / db_out second stage (independent work,
-  // fused "horizontally" so it costs no launch of its own)
-  if ((int)blockIdx.x >= row_blocks) {
-    const int extra = (int)blockIdx.x - row_blocks;
-    const int wslabs = (hp.hf_CP * D + hp.hf_CP) / 64;   // CP is 128 or 256: slab aligned
-    if (extra < wslabs)
-      head_finalize_slab<NW * 64>(extra, hp.hf_P, D, hp.hf_C, hp.hf_CP, hp.hf_part, hp.hf_dWout, hp.hf_dbout,
-                                  hp.hf_accumulate, hp.dloss);
-    else   // BatchNorm weight / bias gradients: float64 second stage of the column sums
-      head_stats_finalize<NW * 64>(extra - wslabs, hp.hf_P, n, hp.S, D, hp.hf_CP, hp.hf_part, hp.hf_dbn_w, hp.hf_dbn_b,
-                                   nullptr, hp.hf_accumulate, hp.dloss);
-    return;
-  }
-  constexpr int IBW = D / 128;        // 16-row blocks of dW owned by one wave
-  constexpr int LD = D + 16;
-  constexpr int EPL = D / 64;
-  constexpr int JB = D / 16;
-  constexpr int RPW = TR / NW;        // rows per wave per tile
-  constexpr int PSTRIDE = D * D + 2 * D + 4;
-  static_assert(TR % NW == 0 && TR % 16 == 0, "tile rows");
-  __shared__ __attribute__((aligned(16))) float Ht[TR * LD];
-  __shared__ __attribute__((aligned(16))) float Ut[TR * LD];
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int r = lane & 15, q = lane >> 4;
-
-  float wgl[EPL], db_acc[EPL], dwg_acc[EPL];
-  float dcg_acc = 0.f;
-#pragma unroll
-  for (int e = 0; e < EPL; ++e) {
-    wgl[e] = wg[lane * EPL + e];
-    db_acc[e] = 0.f;
-    dwg_acc[e] = 0.f;
-  }
-  f32x4 R[IBW][JB];   // dW accumulators acc[ib][jb]
-#pragma unroll
-  for (int ib = 0; ib < IBW; ++ib)
-#pragma unroll
-    for (int jb = 0; jb < JB; ++jb) R[ib][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const uint32_t hkey = (hp.dym && hp.thresh) ? dropout_key(hp.rng_state, HEAD_STREAM_ID) : 0u;
-  const float hgl = (hp.dym && hp.dloss) ? hp.dloss[0] : 1.f;
-
-  const int ntiles = (M + TR - 1) / TR;
-  // The wave's RPW rows of a tile are loaded into registers in one go (all loads issued before the first use); the
-  // loads of the tile after it are issued right after its row pass, a whole tile time before they are needed.
-  float gup[RPW][EPL], z[RPW][EPL], x[RPW][EPL], h[RPW][EPL], gt[RPW], dgt[RPW];
-  auto load_tile = [&](int tile) {
-#pragma unroll
-    for (int t = 0; t < RPW; ++t) {
-      const int m = tile * TR + wave + t * NW;
-      const bool ok = m < M;
-      const size_t off = (size_t)m * D + lane * EPL;
-      if (ok) {
-        ld_row<EPL>(z[t], &Z[off]);
-        ld_row<EPL>(x[t], &X[off]);
-        ld_row<EPL>(h[t], &H[off]);
-        ld_row<EPL>(gup[t], hp.dym ? &hp.dym[(size_t)(m >= n ? m - n : m) * D + lane * EPL] : &dXn[off]);  // S <= 2: m % n without the division
-      } else {
-        zero_row<EPL>(z[t]);
-        zero_row<EPL>(x[t]);
-        zero_row<EPL>(h[t]);
-        zero_row<EPL>(gup[t]);
-      }
-      gt[t] = ok ? gate[m] : 0.f;
-      dgt[t] = (ok && dgate) ? dgate[m] : 0.f;
-    }
-  };
-  // row math of the loaded tile -> H and dU tiles in LDS
-  auto row_pass = [&](int tile) {
-#pragma unroll
-    for (int t = 0; t < RPW; ++t) {
-      const int trow = wave + t * NW;
-      const int m = tile * TR + trow;
-      float du[EPL];
-      if (m < M) {
-        const size_t off = (size_t)m * D + lane * EPL;
-        const float g = gt[t];
-        if (hp.dym) {
-          // dL/dXn of the last layer from the head's backward state (see HeadApply)
-          const int s = m >= n ? 1 : 0;   // S <= 2
-          const float invS = 1.f / (float)hp.S;
-          float is[EPL], mu[EPL], bw_[EPL], c0[EPL], c1[EPL];
-          ld_row<EPL>(is, &hp.invstd[s * D + lane * EPL]);
-          ld_row<EPL>(mu, &hp.mean[s * D + lane * EPL]);
-          ld_row<EPL>(bw_, &hp.bn_w[lane * EPL]);
-          ld_row<EPL>(c0, &hp.bnc[(s * 2 + 0) * D + lane * EPL]);
-          ld_row<EPL>(c1, &hp.bnc[(s * 2 + 1) * D + lane * EPL]);
-#pragma unroll
-          for (int e = 0; e < EPL; ++e) {
-            const float xn = (1.f - g) * x[t][e] + g * z[t][e];
-            float dy = gup[t][e] * invS * hgl;
-            if (hp.thresh) dy = dropout_keep(hkey, (uint32_t)(off + e), hp.thresh) ? dy * hp.keep_scale : 0.f;
-            const float xh = (fmaxf(xn, 0.f) - mu[e]) * is[e];
-            // bnc is for the same upstream d loss as dym (1 when both came from cgcn_head_train): scale alike
-            const float dr = bw_[e] * is[e] * (dy - hgl * c0[e] - xh * (hgl * c1[e]));
-            gup[t][e] = xn > 0.f ? dr : 0.f;
-          }
-          if (dxn_store) st_row<EPL>(&dxn_store[off], gup[t]);  // k_bwd_sliced reads it back as dL/dXn for the (1-g) dXn term
-        }
-        float dg = 0.f;
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) dg += gup[t][e] * (z[t][e] - x[t][e]);
-        dg = wave_sum(dg) + dgt[t];
-        const float gamma = g * (1.f - g) * dg;
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-          const float dz = g * gup[t][e] + gamma * wgl[e];
-          du[e] = dz * (1.f - z[t][e] * z[t][e]);
-          db_acc[e] += du[e];
-          dwg_acc[e] += gamma * z[t][e];
-        }
-        dcg_acc += gamma;
-        if (dHs) {   // diag(row_scale) dU; k_dh_dense multiplies it by W^T in place
-          const float sc = rs ? rs[m >= n ? m - n : m] : 1.f;
-          float dus[EPL];
-#pragma unroll
-          for (int e = 0; e < EPL; ++e) dus[e] = du[e] * sc;
-          st_row<EPL>(&dHs[off], dus);
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) du[e] = 0.f;
-      }
-#pragma unroll
-      for (int e = 0; e < EPL; ++e) {
-        Ht[trow * LD + lane * EPL + e] = h[t][e];
-        Ut[trow * LD + lane * EPL + e] = du[e];
-      }
-    }
-  };
-  // dW += Ht^T Ut  (K = TR rows)
-  auto mma_dw = [&]() {
-#pragma unroll
-    for (int kk = 0; kk < TR / 4; ++kk) {
-      const int k = 4 * kk + q;
-      float a[IBW];
-#pragma unroll
-      for (int ib = 0; ib < IBW; ++ib) a[ib] = Ht[k * LD + (IBW * wave + ib) * 16 + r];
-#pragma unroll
-      for (int jb = 0; jb < JB; ++jb) {
-        const float b = Ut[k * LD + jb * 16 + r];
-#pragma unroll
-        for (int ib = 0; ib < IBW; ++ib) R[ib][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ib], b, R[ib][jb], 0, 0, 0);
-      }
-    }
-  };
-
-  const int tile0 = blockIdx.x;
-  if (tile0 < ntiles) load_tile(tile0);
-  for (int tile = tile0; tile < ntiles; tile += row_blocks) {
-    row_pass(tile);
-    if (tile + row_blocks < ntiles) load_tile(tile + row_blocks);  // in flight during the barrier + MFMA phase
-    __syncthreads();
-    mma_dw();
-    __syncthreads();
-  }
-
-  // ---- write this workgroup's partial
-  float* P = part + (size_t)blockIdx.x * PSTRIDE;
-#pragma unroll
-  for (int ib = 0; ib < IBW; ++ib)
-#pragma unroll
-    for (int jb = 0; jb < JB; ++jb)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int i = (IBW * wave + ib) * 16 + q * 4 + e;
-        const int j = jb * 16 + r;
-        P[i * D + j] = R[ib][jb][e];
-      }
-  // column sums: combine the NW waves through LDS in a fixed order (the tile buffers are idle after the last barrier)
-  float* red = Ht;  // [NW][2*D + 1]
-  constexpr int RS = 2 * D + 1;
-  static_assert(NW * RS <= TR * LD, "column-sum staging fits the H tile");
-#pragma unroll
-  for (int e = 0; e < EPL; ++e) {
-    red[wave * RS + lane * EPL + e] = db_acc[e];
-    red[wave * RS + D + lane * EPL + e] = dwg_acc[e];
-  }
-  if (lane == 0) red[wave * RS + 2 * D] = dcg_acc;
-  __syncthreads();
-  for (int c = threadIdx.x; c < RS; c += blockDim.x) {
-    float s = 0.f;
-    for (int w = 0; w < NW; ++w) s += red[w * RS + c];
-    P[D * D + c] = s;
-  }
-}
-
+// d = 128: k_bwd_rowlocal_ring (below).  d = 256: k_bwd_rowlocal256s (after it).
+// (Rounds 1-4 ran d = 256 as k_bwd_rowlocal256 -- 8 waves, the whole 256 x 256 dW in 128 accumulator registers per wave,
+// one 263 KB record per workgroup -- plus k_dh_dense<256> for the dHs product: in the history at the round-4 tag.)
 // ------------------------------------------------------------------------------------------
 // k_bwd_rowlocal_ring (D = 128): the work of k_bwd_rowlocal<128, 32> as a PRODUCER / CONSUMER pair of wave teams that
 // meet only through a ring of LDS slots with counted flags -- no workgroup barrier between the first tile and the last.
@@ -1198,7 +943,8 @@ __global__ __launch_bounds__(512) void k_bwd_rowlocal256(int M, int n, const flo
 // them can be reached by a stray -D: they need -DCGCN_EXPERIMENT_BUILD, which chromegcn_amd/_build.py refuses for the
 // in-tree library.
 #if (defined(RING_NO_WAIT) || defined(RING_SKIP_MFMA) || defined(RING_SKIP_ROWTEAM) || defined(RING_SKIP_LOADS) || \
-     defined(RING_TEST_SLOW_ROW) || defined(RING_TEST_SLOW_MATRIX)) && !defined(CGCN_EXPERIMENT_BUILD)
+     defined(RING_TEST_SLOW_ROW) || defined(RING_TEST_SLOW_MATRIX) || defined(RL256_SKIP_MFMA) || defined(RL256_SKIP_LOADS)) && \
+    !defined(CGCN_EXPERIMENT_BUILD)
 #error "RING_NO_WAIT / RING_SKIP_* / RING_TEST_SLOW_* are experiment switches: build a variant with -DCGCN_EXPERIMENT_BUILD (tools/mkvariant.py), never the shipped library"
 #endif
 #if defined(RING_TEST_SLOW_ROW) || defined(RING_TEST_SLOW_MATRIX)
@@ -1589,6 +1335,285 @@ __global__ __launch_bounds__(RING_THREADS) void k_bwd_rowlocal_ring(int M, int n
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         *(f32x4*)&P[(own * 16 + q * 4 + e) * D + 64 * h + 4 * r] = (f32x4){accW[h * 4 + 0][e], accW[h * 4 + 1][e], accW[h * 4 + 2][e], accW[h * 4 + 3][e]};
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_bwd_rowlocal256s (d = 256, round 5): the row-local launch with BOTH dense products, like d = 128's ring kernel, and a
+// quarter of the partial-record traffic.  What was wrong with k_bwd_rowlocal256 + k_dh_dense (profiles/r04_chr21_d256L4_*):
+// a workgroup kept the whole 256 x 256 dW in 128 accumulator registers per wave, so (i) there was no room for the W^T
+// fragments -- diag(1/deg) dU went to memory and came back through a second launch -- and (ii) every workgroup wrote a
+// 263 KB partial record: 256 records = 67 MB out and 67 MB back in through the second stage, MORE than the row tensors
+// themselves at chr21 size (47 MB), where a workgroup owns 45 rows.
+// Here the OUTPUT COLUMNS are cut instead: workgroup (range, cs) owns column slab cs (64 of the 256 columns of dU / of the
+// columns of dW and dHs) of a contiguous range of 32-row tiles.  It streams the range's FULL rows (the gate's row sum needs
+// them; the four slab workgroups of a range sit on one XCD -- b, b + 8, b + 16, b + 24 -- so three of the four reads are L2
+// hits), recomputes the row math (cheap VALU, 4x redundant), and per tile runs
+//     dW[:, slab]  += H^T dU[:, slab]             matrix wave w: H columns [32 w, 32 w + 32) x 64  -> 32 accumulator registers
+//     dHs[:, slab]  = diag(1/deg) dU W^T[:, slab]  matrix wave w: rows 16 (w >> 2).., columns 16 (w & 3)..; W rows resident: 64
+// 64 + 64 MFMAs per wave and tile, interleaved one by one (the single dHs chain never waits for its own result).  The
+// four slabs of a range write disjoint column slabs of ONE record: 64 records (16.8 MB) instead of 256 (67 MB), no dU round
+// trip, no k_dh_dense launch.
+// Two TEAMS, as in k_bwd_rowlocal_ring: a row team (waves 0-3: streams, row math, fills a 32-row slot of H and dU) and a
+// matrix team (waves 4-11: both products from the slot), meeting only through counted FULL / FREE flags of two slots -- the
+// barrier-per-tile form of this kernel ran row pass + products (52 us at chr21 size: 24 + 29), not their maximum
+// (profiles/r05_d256_rowlocal_experiment.txt).  A row wave keeps 4 rows in registers, half a tile ahead of their use (a row's loads
+// are issued the moment the registers of the row 4 before it are free).  Sums are in fixed order:
+// bit-reproducible.
+// ------------------------------------------------------------------------------------------
+#ifndef RL256_ROW_WAVES
+#define RL256_ROW_WAVES 8   // 8: 16 waves, 128 registers; 4: 12 waves, 168 (measured: the row team of 4 is latency-bound, 6.8 us per tile against 4.2 of MFMA)
+#endif
+#define RL256_THREADS ((RL256_ROW_WAVES + 8) * 64)
+#ifndef RL256_PRIO
+#define RL256_PRIO 1       // s_setprio of the matrix team
+#endif
+#ifndef RL256_ROW_PRIO
+#define RL256_ROW_PRIO 0   // ... of the row team
+#endif
+template <int TR>
+__global__ __launch_bounds__(RL256_THREADS) void k_bwd_rowlocal256s(int M, int n, const float* __restrict__ dXn,
+                                                          const float* __restrict__ Z, const float* __restrict__ X,
+                                                          const float* __restrict__ gate, const float* __restrict__ dgate,
+                                                          const float* __restrict__ H, const float* __restrict__ wg,
+                                                          const float* __restrict__ rs, float* __restrict__ dHs,
+                                                          float* __restrict__ part, HeadApply hp,
+                                                          float* __restrict__ dxn_store, int row_blocks, int head_slabs,
+                                                          const float* __restrict__ W) {
+  constexpr int D = 256, NRW = RL256_ROW_WAVES, NT = RL256_THREADS, SW = 64;   // SW: slab width (columns)
+  static_assert(TR == 32, "one 16 x 16 dHs tile per matrix wave needs 32-row tiles");
+  constexpr int LD = D + 16, EPL = D / 64, RPW = TR / NRW, PSTRIDE = D * D + 2 * D + 4, RS = 2 * D + 4;
+  static_assert(EPL == 4, "one 16-byte chunk per lane");
+  __shared__ __attribute__((aligned(16))) float Hs[2][TR * LD];
+  if ((int)blockIdx.x >= row_blocks) {   // extra workgroups: the head's deferred second stage (independent work, fused
+    const int extra = (int)blockIdx.x - row_blocks;      // "horizontally"); they stage through the (here unused) slot memory
+    const int wslabs = (hp.hf_CP * D + hp.hf_CP) / 64;
+    static_assert(sizeof(Hs) >= 4 * (NT / HEAD_STAT_COLS) * (HEAD_STAT_COLS + 1) * sizeof(double), "finalize staging fits the H slots");
+    if (extra < wslabs)
+      head_finalize_slab<NT, true>(extra, hp.hf_P, D, hp.hf_C, hp.hf_CP, hp.hf_part, hp.hf_dWout, hp.hf_dbout,
+                                   hp.hf_accumulate, hp.dloss, &Hs[0][0]);
+    else
+      head_stats_finalize<NT, true>(extra - wslabs, hp.hf_P, n, hp.S, D, hp.hf_CP, hp.hf_part, hp.hf_dbn_w, hp.hf_dbn_b,
+                                    nullptr, hp.hf_accumulate, hp.dloss, &Hs[0][0]);
+    return;
+  }
+  __shared__ __attribute__((aligned(16))) float Us[2][TR * LD];
+  __shared__ __attribute__((aligned(16))) float red[NRW][RS];   // column sums of the row waves
+  __shared__ unsigned flg[5];                                    // FULL[2], FREE[2], DONE
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // workgroup -> (range, slab): the four slabs of a range are 8 workgroup ids apart (one XCD under round-robin dispatch)
+  const int b = (int)blockIdx.x, NR = row_blocks >> 2;
+  const int cs = (b >> 3) & 3, range = (b & 7) + 8 * (b >> 5);
+  const int ntiles = (M + TR - 1) / TR;
+  const int t_begin = __builtin_amdgcn_readfirstlane((int)((long long)range * ntiles / NR));
+  const int nt = __builtin_amdgcn_readfirstlane((int)((long long)(range + 1) * ntiles / NR)) - t_begin;   // tiles of this workgroup
+  float* P = part + (size_t)range * PSTRIDE;
+  if (threadIdx.x < 5) flg[threadIdx.x] = 0u;
+  unsigned* const FULL = flg;
+  unsigned* const FREE = flg + 2;
+  unsigned* const DONE = flg + 4;
+
+  if (wave < NRW) {
+    // =============================================================== row team
+    float wgl[EPL], db_acc[EPL], dwg_acc[EPL];
+    float dcg_acc = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      wgl[e] = wg[lane * EPL + e];
+      db_acc[e] = 0.f;
+      dwg_acc[e] = 0.f;
+    }
+    const uint32_t hkey = (hp.dym && hp.thresh) ? dropout_key(hp.rng_state, HEAD_STREAM_ID) : 0u;
+    const float hgl = (hp.dym && hp.dloss) ? hp.dloss[0] : 1.f;
+    constexpr int RIF = RPW < 4 ? RPW : 4;   // rows a wave holds in registers (in flight)
+    float gup[RIF][EPL], z[RIF][EPL], x[RIF][EPL], h[RIF][EPL], gt[RIF], dgt[RIF];
+    auto load_row = [&](int it, int tt) {   // row (wave + NRW tt) of the workgroup's it-th tile, into register set tt % RIF
+      const int t = tt % RIF;
+      const int m = (t_begin + it) * TR + wave + tt * NRW;
+#ifdef RL256_SKIP_LOADS   // decomposition build (garbage results): no row streams
+      const bool ok = false;
+#else
+      const bool ok = it < nt && m < M;
+#endif
+      const size_t off = (size_t)m * D + lane * EPL;
+      if (ok) {
+        ld_row<EPL>(z[t], &Z[off]);
+        ld_row<EPL>(x[t], &X[off]);
+        ld_row<EPL>(h[t], &H[off]);
+        ld_row<EPL>(gup[t], hp.dym ? &hp.dym[(size_t)(m >= n ? m - n : m) * D + lane * EPL] : &dXn[off]);
+      } else {
+        zero_row<EPL>(z[t]);
+        zero_row<EPL>(x[t]);
+        zero_row<EPL>(h[t]);
+        zero_row<EPL>(gup[t]);
+      }
+      gt[t] = ok ? gate[m] : 0.f;
+      dgt[t] = (ok && dgate) ? dgate[m] : 0.f;
+    };
+#pragma unroll
+    for (int t = 0; t < RIF; ++t) load_row(0, t);
+    __syncthreads();   // flags zeroed: THE barrier of this kernel (matched by the matrix team)
+    if (RL256_ROW_PRIO) __builtin_amdgcn_s_setprio(RL256_ROW_PRIO);
+    KT_STAMP_NW(0, 0, true);
+    for (int it = 0; it < nt; ++it) {
+      const int slot = it & 1;
+      if (it >= 2) ring_wait(&FREE[slot], 8u * (unsigned)(it >> 1));
+      KT_STAMP_NW(1 + 2 * it, 0, it < 3);   // the matrix team is done with the slot's last use
+      float* __restrict__ Ht = Hs[slot];
+      float* __restrict__ Ut = Us[slot];
+#pragma unroll
+      for (int tt = 0; tt < RPW; ++tt) {
+        const int t = tt % RIF;
+        const int trow = wave + tt * NRW;
+        const int m = (t_begin + it) * TR + trow;
+        float du[EPL];
+        if (m < M) {
+          const size_t off = (size_t)m * D + lane * EPL;
+          const float g = gt[t];
+          if (hp.dym) {   // dL/dXn of the last layer from the head's backward state (see HeadApply)
+            const int s = m >= n ? 1 : 0;   // S <= 2
+            const float invS = 1.f / (float)hp.S;
+            float is[EPL], mu[EPL], bw_[EPL], c0[EPL], c1[EPL];
+            ld_row<EPL>(is, &hp.invstd[s * D + lane * EPL]);
+            ld_row<EPL>(mu, &hp.mean[s * D + lane * EPL]);
+            ld_row<EPL>(bw_, &hp.bn_w[lane * EPL]);
+            ld_row<EPL>(c0, &hp.bnc[(s * 2 + 0) * D + lane * EPL]);
+            ld_row<EPL>(c1, &hp.bnc[(s * 2 + 1) * D + lane * EPL]);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+              const float xn = (1.f - g) * x[t][e] + g * z[t][e];
+              float dy = gup[t][e] * invS * hgl;
+              if (hp.thresh) dy = dropout_keep(hkey, (uint32_t)(off + e), hp.thresh) ? dy * hp.keep_scale : 0.f;
+              const float xh = (fmaxf(xn, 0.f) - mu[e]) * is[e];
+              const float dr = bw_[e] * is[e] * (dy - hgl * c0[e] - xh * (hgl * c1[e]));
+              gup[t][e] = xn > 0.f ? dr : 0.f;
+            }
+            if (dxn_store && cs == 0) st_row<EPL>(&dxn_store[off], gup[t]);  // one of the four slab workgroups stores the row
+          }
+          float dg = 0.f;
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) dg += gup[t][e] * (z[t][e] - x[t][e]);
+          dg = wave_sum(dg) + dgt[t];
+          const float gamma = g * (1.f - g) * dg;
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) {
+            const float dz = g * gup[t][e] + gamma * wgl[e];
+            du[e] = dz * (1.f - z[t][e] * z[t][e]);
+            db_acc[e] += du[e];
+            dwg_acc[e] += gamma * z[t][e];
+          }
+          dcg_acc += gamma;
+        } else {
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) du[e] = 0.f;
+        }
+        *(f32x4*)&Ht[trow * LD + lane * EPL] = (f32x4){h[t][0], h[t][1], h[t][2], h[t][3]};
+        *(f32x4*)&Ut[trow * LD + lane * EPL] = (f32x4){du[0], du[1], du[2], du[3]};
+        // this row's registers are free: the row RIF rows ahead (of this tile or the next), half a tile ahead of its use
+        if (tt + RIF < RPW) load_row(it, tt + RIF);
+        else load_row(it + 1, tt + RIF - RPW);
+      }
+      ring_arrive(&FULL[slot], lane);
+      KT_STAMP_NW(2 + 2 * it, 0, it < 3);
+    }
+    KT_STAMP_NW(7, 0, true);
+    // column sums: every slab workgroup holds all 256 columns' sums (it computed the full rows); it writes its slab's
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      red[wave][lane * EPL + e] = db_acc[e];
+      red[wave][D + lane * EPL + e] = dwg_acc[e];
+    }
+    if (lane == 0) red[wave][2 * D] = dcg_acc;
+    ring_arrive(DONE, lane);   // among the row waves only: the matrix team is still on its last slots
+    ring_wait(DONE, (unsigned)NRW);
+    for (int c = threadIdx.x; c < 2 * D + 1; c += NRW * 64) {
+      const int col = c < D ? c : (c < 2 * D ? c - D : -1);
+      const bool mine = col >= 0 ? (col >= SW * cs && col < SW * cs + SW) : (cs == 0);
+      if (!mine) continue;
+      float sacc = 0.f;
+#pragma unroll
+      for (int w = 0; w < NRW; ++w) sacc += red[w][c];
+      P[D * D + c] = sacc;
+    }
+  } else {
+    // =============================================================== matrix team
+    const int own = wave - NRW;
+    const int r = lane & 15, q = lane >> 4;
+    const int rb = own >> 2, cb = own & 3;   // this wave's dHs tile: rows 16 rb.., slab columns 16 cb..
+    f32x4 R[2][4];   // dW accumulators: H columns (2 own + ib) * 16.., slab columns jb * 16..
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb) R[ib][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // W^T fragments of this wave's 16 output columns of dHs: B operand of k-step (t, u) = W[64 cs + 16 cb + r][16 t + 4 q + u]
+    f32x4 WT[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+      WT[t] = dHs ? *(const f32x4*)&W[(size_t)(SW * cs + 16 * cb + r) * D + 16 * t + 4 * q] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();   // flags zeroed
+    if (RL256_PRIO) __builtin_amdgcn_s_setprio(RL256_PRIO);
+    // DH: with the dHs product (a gather over Ahat^T follows) or without (dHs == NULL: nobody differentiates the layer's
+    // input): a compile-time switch, so that the interleaved MFMA stream is straight-line code
+    auto tile_loop = [&](auto DH_) {
+      constexpr bool DH = decltype(DH_)::value;
+      for (int it = 0; it < nt; ++it) {
+        const int slot = it & 1;
+        const float* __restrict__ Ht = Hs[slot];
+        const float* __restrict__ Ut = Us[slot];
+        KT_STAMP_NW(8, NRW * 64, it == 0);
+        ring_wait(&FULL[slot], (unsigned)NRW * (unsigned)((it >> 1) + 1));
+        KT_STAMP_NW(9 + 2 * it, NRW * 64, it < 3);
+        // the two products of the tile, one MFMA of each in turn: dW step kk (4 rows of K) holds 8 MFMAs, dHs k-step blocks
+        // t = 2 kk, 2 kk + 1 hold 4 each
+        f32x4 hacc = {0.f, 0.f, 0.f, 0.f};
+#ifndef RL256_SKIP_MFMA   // (decomposition build, garbage results: no products)
+#pragma unroll
+        for (int kk = 0; kk < TR / 4; ++kk) {
+          const int k = 4 * kk + q;
+          float a[2], bq[4];
+#pragma unroll
+          for (int ib = 0; ib < 2; ++ib) a[ib] = Ht[k * LD + (2 * own + ib) * 16 + r];
+#pragma unroll
+          for (int jb = 0; jb < 4; ++jb) bq[jb] = Ut[k * LD + SW * cs + jb * 16 + r];
+          f32x4 ua[2];
+          if (DH) {
+            ua[0] = *(const f32x4*)&Ut[(16 * rb + r) * LD + 16 * (2 * kk) + 4 * q];
+            ua[1] = *(const f32x4*)&Ut[(16 * rb + r) * LD + 16 * (2 * kk + 1) + 4 * q];
+          }
+#pragma unroll
+          for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) {
+              R[ib][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ib], bq[jb], R[ib][jb], 0, 0, 0);
+              if (DH) {
+                const int i = jb * 2 + ib;   // 0..7 -> (t, u) = (2 kk + i / 4, i % 4)
+                hacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[i >> 2][i & 3], WT[2 * kk + (i >> 2)][i & 3], hacc, 0, 0, 0);
+              }
+            }
+        }
+#endif
+        ring_arrive(&FREE[slot], lane);   // every operand of the slot is in registers (s_waitcnt lgkmcnt(0) inside)
+        KT_STAMP_NW(10 + 2 * it, NRW * 64, it < 3);
+        if (DH) {   // rows 16 rb + 4 q + e, column 64 cs + 16 cb + r: 64-byte row segments straight from the accumulators
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int m = (t_begin + it) * TR + 16 * rb + 4 * q + e;
+            if (m < M) dHs[(size_t)m * D + SW * cs + 16 * cb + r] = hacc[e] * (rs ? rs[m >= n ? m - n : m] : 1.f);
+          }
+        }
+      }
+    };
+    if (dHs) tile_loop(std::true_type{});
+    else tile_loop(std::false_type{});
+    KT_STAMP_NW(15, NRW * 64, true);
+    // ---- this workgroup's column slab of the range's partial record: [D*D dW][D db][D dwg][1 dcg][3 pad]
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) P[((2 * own + ib) * 16 + q * 4 + e) * D + SW * cs + jb * 16 + r] = R[ib][jb][e];
   }
 }
 
@@ -2515,12 +2540,20 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   return launch_status();
 }
 
+#ifndef BWD256_MAX_RANGES
+#define BWD256_MAX_RANGES 64
+#endif
 // Workgroups (= partial records) of the row-local launch: one persistent workgroup per CU at most (BWD_MAX_PARTIALS).
-// d = 128: k_bwd_rowlocal_ring, 16-row slots dealt in contiguous, balanced ranges; d = 256: k_bwd_rowlocal256, 32-row tiles.
+// d = 128: k_bwd_rowlocal_ring, 16-row slots dealt in contiguous, balanced ranges; d = 256: k_bwd_rowlocal256s, 32-row tiles,
+// four column-slab workgroups per record.
 static int bwd_partials(int n, int S, int d) {
   const int M = n * S;
   const int tr = d == 128 ? 16 : 32;
   const int ntiles = (M + tr - 1) / tr;
+  if (d == 256) {   // k_bwd_rowlocal256s: 4 column-slab workgroups per record; ranges in multiples of 8 (XCD pairing), <= 64
+    const int nr = ((ntiles < BWD256_MAX_RANGES ? ntiles : BWD256_MAX_RANGES) + 7) / 8 * 8;
+    return nr < 8 ? 8 : nr;
+  }
   const int P = ntiles < BWD_MAX_PARTIALS ? ntiles : BWD_MAX_PARTIALS;
   return P < 1 ? 1 : P;
 }
@@ -2537,7 +2570,7 @@ size_t cgcn_layer_bwd_workspace_bytes(int n, int S, int d) {
   return (size_t)bwd_partials(n, S, d) * ((size_t)d * d + 2 * d + 4) * sizeof(float);
 }
 
-// phases: bit 0 = the row-local launch (k_bwd_rowlocal, + k_dh_dense at d = 256), bit 1 = the launch that follows it
+// phases: bit 0 = the row-local launch (k_bwd_rowlocal_ring / k_bwd_rowlocal256s), bit 1 = the launch that follows it
 // (k_bwd_sliced with the second-stage sums / the optimizer step in its trailing workgroups, or k_reduce_partials).
 // cgcn_layer_bwd runs both; cgcn_debug_layer_bwd_phases lets a profiler time them one at a time.
 static int layer_bwd_impl(cgcn_stream_t stream, int n, int S, int d, const int32_t* rowptr_t, const int32_t* col_t,
@@ -2611,13 +2644,8 @@ static int layer_bwd_impl(cgcn_stream_t stream, int n, int S, int d, const int32
     else RING(true, false);
 #undef RING
   } else
-    hipLaunchKernelGGL((k_bwd_rowlocal256<32>), dim3(P + head_slabs_rl), dim3(512), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, P, head_slabs_rl);
+    hipLaunchKernelGGL((k_bwd_rowlocal256s<32>), dim3(4 * P + head_slabs_rl), dim3(RL256_THREADS), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, 4 * P, head_slabs_rl, W);
   if ((rc = launch_status())) return rc;
-  if ((phases & 1) && d == 256 && dHs && M > 0) {   // dHs = (diag(row_scale) dU) W^T: d = 128 did it inside the row-local kernel
-    const int dh_tiles = (M + 16 * DH_MB - 1) / (16 * DH_MB);
-    hipLaunchKernelGGL((k_dh_dense<256>), dim3(dh_tiles < 256 ? dh_tiles : 256), dim3(512), 0, st, M, dHs, W);
-    if ((rc = launch_status())) return rc;
-  }
   if (!(phases & 2)) return CGCN_OK;
   // The reduction of the per-tile partials and the gather kernel are independent: with an auxiliary stream
   // they run side by side (fork after k_bwd_rowlocal, join before returning; both edges are events, so the

@@ -151,9 +151,10 @@ void cgcn_debug_set_fwd_split_bytes(long long bytes);
  *     threshold: 0 = the fused k_layer_fwd, 1 = k_aggregate_sliced + k_layer_dense (large tables, hub-heavy graphs),
  *     2 = k_band_aggregate + k_layer_dense (band graphs: cgcn_graph_aux::band_halfwidth; their backward's last launch
  *     is k_bwd_band instead of k_bwd_sliced).
- *   cgcn_debug_layer_bwd_route: the row-local launch of cgcn_layer_bwd: 0 = k_bwd_rowlocal256 (d = 256: 32-row tiles,
- *     dHs by a second launch), 2 = k_bwd_rowlocal_ring (d = 128: row / matrix wave teams over a flag-synchronised LDS
- *     ring).  (1 was the 48-row-tile kernel of ABI <= 18: no longer returned.)
+ *   cgcn_debug_layer_bwd_route: the row-local launch of cgcn_layer_bwd: 0 = k_bwd_rowlocal256s (d = 256: four column-slab
+ *     workgroups per range of 32-row tiles, both dense products in the launch; ABI <= 20: k_bwd_rowlocal256 + a second
+ *     launch for dHs), 2 = k_bwd_rowlocal_ring (d = 128: row / matrix wave teams over a flag-synchronised LDS ring).
+ *     (1 was the 48-row-tile kernel of ABI <= 18: no longer returned.)
  * Negative = error code (unsupported shape). */
 int cgcn_debug_layer_fwd_route(int n, int S, int d, const cgcn_graph_aux *aux);
 int cgcn_debug_layer_bwd_route(int n, int S, int d);
@@ -246,8 +247,8 @@ int cgcn_layer_bwd(cgcn_stream_t stream, int n, int S, int d,
 
 /*
  * Profiling hook: cgcn_layer_bwd one launch group at a time, so that each kernel can be bracketed with events on the
- * caller's stream (bench.py's per-kernel roofline).  phases: bit 0 = the row-local launch (k_bwd_rowlocal; + k_dh_dense
- * at d = 256), bit 1 = the launch after it (k_bwd_sliced with the second-stage sums, or k_reduce_partials when dX ==
+ * caller's stream (bench.py's per-kernel roofline).  phases: bit 0 = the row-local launch (k_bwd_rowlocal_ring / k_bwd_rowlocal256s),
+ * bit 1 = the launch after it (k_bwd_sliced / k_bwd_band with the second-stage sums, or k_reduce_partials when dX ==
  * NULL).  phases == 3 is cgcn_layer_bwd without aux_stream / sgd.  A phase-2-only call works on the partials, dHs and
  * (head mode) dL/dXn an earlier phase-1 call left in workspace / dHs / dX.  Stateless like everything else here.
  */

@@ -55,7 +55,7 @@ def test_route_queries_are_pure_host_logic():
         assert lib.cgcn_debug_layer_fwd_route(64, 1, 128, None) == 1     # the test hook forces the split at every size
     finally:
         lib.cgcn_debug_set_fwd_split_bytes(-1)
-    # backward: the ring kernel at d = 128, the 32-row-tile kernel + k_dh_dense at d = 256
+    # backward: the ring kernel at d = 128, the column-slab kernel (k_bwd_rowlocal256s) at d = 256
     assert lib.cgcn_debug_layer_bwd_route(5776, 2, 128) == 2 and lib.cgcn_debug_layer_bwd_route(29910, 1, 128) == 2
     assert lib.cgcn_debug_layer_bwd_route(5776, 2, 256) == 0
     assert lib.cgcn_debug_layer_bwd_route(5776, 3, 128) == -2 and lib.cgcn_debug_layer_fwd_route(5776, 2, 100, None) == -2

@@ -40,7 +40,7 @@ def _open(build):
     return _lib.open_library(path)
 
 
-def _inputs(S, n, d=128):
+def _inputs(S, n, d=128):  # noqa: E302
     gen = torch.Generator(device=DEV).manual_seed(n * 3 + S)
     r = lambda *s: torch.randn(*s, device=DEV, generator=gen)
     x, z, h, dxn = r(S, n, d), torch.tanh(r(S, n, d)), r(S, n, d), r(S, n, d)
@@ -60,6 +60,45 @@ def _float64_truth(S, n, d, x, z, h, dxn, gate, W, wg, rs):
 
 
 _first = {}   # (S, n) -> the product build's outputs: every build must reproduce them bit for bit
+
+
+@pytest.mark.parametrize("S,n", [(2, 1), (2, 7), (1, 16), (2, 129), (1, 2049), (2, 5776), (2, 16264), (2, 40001)])
+def test_d256_two_team_kernel_every_launch_bit_identical_and_right(S, n):
+    """k_bwd_rowlocal256s (d = 256: four column-slab workgroups per range of 32-row tiles, a row team and a matrix team meeting
+    through FULL / FREE flags of two LDS slots): the same checks -- float64 restatement at 2e-5, every launch compared on
+    the device with the first, the dW-only form (dHs == NULL) giving the same sums."""
+    lib = _lib.load()
+    d = 256
+    x, z, h, dxn, gate, W, wg, rs = _inputs(S, n, d)
+    g = G.upload(G.normalize_graph("none", None, n), DEV)
+    P, st = _lib.ptr, _lib.stream_ptr
+    dhs = torch.zeros_like(x)
+    dW, db, dwg, dcg = torch.zeros_like(W), torch.zeros(d, device=DEV), torch.zeros(d, device=DEV), torch.zeros(1, device=DEV)
+    wsb = lib.cgcn_layer_bwd_workspace_bytes(n, S, d)
+    ws = torch.zeros(wsb, dtype=torch.uint8, device=DEV)
+
+    def run(with_dhs=True):
+        rc = lib.cgcn_debug_layer_bwd_phases(st(), n, S, d, P(g.rowptr), P(g.col), None, P(rs), P(x), P(z), P(h), P(gate), P(W), P(wg),
+                                             P(dxn), None, None, P(dhs) if with_dhs else None, P(dW), P(db), P(dwg), P(dcg), 0, 0.0, None, 0,
+                                             None, P(ws), wsb, 3, None)
+        assert rc == 0, lib.cgcn_strerror(rc)
+
+    outs = (dhs, dW, db, dwg, dcg)
+    run()
+    first = [t.clone() for t in outs]
+    truth = _float64_truth(S, n, d, x, z, h, dxn, gate, W, wg, rs)
+    for k, a in zip(("dHs", "dW", "db", "dwg", "dcg"), first):
+        err = float((a.double().reshape(truth[k].shape) - truth[k]).abs().max() / truth[k].abs().max().clamp_min(1e-30))
+        assert err < 2e-5, (S, n, k, err)
+    run(with_dhs=False)
+    assert all(torch.equal(a, b) for a, b in zip(first[1:], outs[1:]))
+    bad = torch.zeros((), dtype=torch.int64, device=DEV)
+    for _ in range(max(LAUNCHES // 2, 10)):
+        dhs.fill_(float("nan"))
+        run()
+        for a, b in zip(first, outs):
+            bad += (a != b).sum()
+    assert int(bad) == 0, "%d differing elements at S=%d n=%d" % (int(bad), S, n)
 
 
 @pytest.mark.parametrize("S,n", SIZES)
