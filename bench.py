@@ -116,6 +116,35 @@ def _free_port():
         return sk.getsockname()[1]
 
 
+def _alive(pid):
+    try:
+        with open("/proc/%d/stat" % pid) as f:
+            return f.read().rsplit(")", 1)[1].split()[0] != "Z"
+    except OSError:
+        return False
+
+
+def _descendants(root):
+    """pids of every descendant of `root` (exact process tree from /proc: no pattern matching, no third-party module --
+    the timeout path is the one case the ladder exists for and must not depend on an optional import)"""
+    kids = {}
+    for ent in os.listdir("/proc"):
+        if not ent.isdigit():
+            continue
+        try:
+            with open("/proc/%s/stat" % ent) as f:
+                ppid = int(f.read().rsplit(")", 1)[1].split()[1])
+        except (OSError, ValueError, IndexError):
+            continue
+        kids.setdefault(ppid, []).append(int(ent))
+    out, todo = [], [root]
+    while todo:
+        for k in kids.get(todo.pop(), []):
+            out.append(k)
+            todo.append(k)
+    return out
+
+
 def _child_job(gpus, argv, timeout_s, relay_stderr=True):
     """Run `bench.py argv` as a child torch.distributed.run job of `gpus` ranks in a process group of its own; returns
     (rc, rank 0's JSON line or None, seconds, why).  A job that outlives `timeout_s` is killed (the whole process group
@@ -153,25 +182,23 @@ def _child_job(gpus, argv, timeout_s, relay_stderr=True):
         # the exact descendants of the launcher we started (by pid), ask the launcher to stop (SIGTERM: its agent
         # terminates the workers), then kill whatever of them is still alive -- a rank stuck in a collective may
         # ignore SIGTERM, and a rank left behind would keep its GPU
-        import psutil
-        try:
-            kids = psutil.Process(proc.pid).children(recursive=True)
-        except psutil.Error:
-            kids = []
+        kids = _descendants(proc.pid)
         proc.send_signal(signal.SIGTERM)
         try:
             proc.wait(timeout=float(os.environ.get("CGCN_BENCH_TERM_GRACE_S", "10")))
         except subprocess.TimeoutExpired:
             pass
-        for k in kids:
+        for pid in kids:
             try:
-                k.kill()
-            except psutil.Error:
+                os.kill(pid, signal.SIGKILL)
+            except OSError:
                 pass
         if proc.poll() is None:
             proc.kill()
         rc = proc.wait()
-        psutil.wait_procs(kids, timeout=10)
+        t_end = time.time() + 10
+        while time.time() < t_end and any(os.path.exists("/proc/%d" % pid) and _alive(pid) for pid in kids):
+            time.sleep(0.1)
     th.join(5)
     if why is None and rc != 0:
         why = "exit code %d" % rc

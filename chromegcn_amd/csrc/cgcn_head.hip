@@ -1072,6 +1072,9 @@ __global__ __launch_bounds__(512, HF_LOWREG ? 4 : 1) void k_head_fused(int n, in
 #ifndef HEAD_RS
 #define HEAD_RS 1   // 0: the 8-wave k_head_fused at d = 128 as well (A/B builds)
 #endif
+#ifndef HEAD_NT_PROBS
+#define HEAD_NT_PROBS 0   // non-temporal probs stores in k_head_fused_rs (A/B: profiles/r05_head_experiments.txt)
+#endif
 #ifndef HEAD_RS_PRIO
 #define HEAD_RS_PRIO 0   // wave priority inside the matrix sub-phases (measured: 2 is neutral for the head, -2 % for the row-local kernel)
 #endif
@@ -1269,7 +1272,10 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
             const float p = pred >= 0.f ? inv : en * inv;
             const float l = fmaxf(pred, 0.f) - pred * tgv[mb][e] + __logf(1.f + en);
             lacc += ok ? l : 0.f;
-            if (ok) probs[(unsigned)(i * C + c0 + j)] = p;
+            if (ok) {   // written once, read by nobody on the device before the epoch's end (HEAD_NT_PROBS: keep it out of the L2s)
+              if (HEAD_NT_PROBS) __builtin_nontemporal_store(p, &probs[(unsigned)(i * C + c0 + j)]);
+              else probs[(unsigned)(i * C + c0 + j)] = p;
+            }
             const float dp = ok ? (p - tgv[mb][e]) * inv_count : 0.f;
             dbo += dp;
             Pb[row * LDP + j] = dp;
