@@ -1847,6 +1847,7 @@ struct SlicedTile {
   unsigned long long super;   // wave-uniform (and workgroup-uniform): rows of the tile with more than SLICED_SUPER neighbours
   int i;                      // this lane's own row: the (8*wave + lane/8)-th of the tile (n if past the end)
   int k0, k1;                 // its neighbour range
+  int g0;                     // first row of the 64-row group the tile holds (a tile's rows are a permutation of one group)
 };
 // order (may be null): the rows in the order the tiles take them (cgcn_graph_aux::row_order): position p -> tile p / 64,
 // wave (p % 64) / 8.  The engine sorts the rows of every 64-row tile by length, so that the 8 rows a wave walks side by
@@ -1863,6 +1864,7 @@ __device__ __forceinline__ SlicedTile sliced_tile(const int* __restrict__ rowptr
     t.t1 = rowptr[row + 1];
   }
   t.super = __ballot(t.t1 - t.t0 > SLICED_SUPER);
+  t.g0 = __builtin_amdgcn_readfirstlane(row) & ~63;   // (position 64 tile always holds a row)
   const int mine = wave * 8 + (lane >> 3);
   t.i = __shfl(row, mine, WAVE);
   t.k0 = __shfl(t.t0, mine, WAVE);
@@ -1934,24 +1936,66 @@ __device__ __forceinline__ void sliced_block(int b, int tiles, int& slice, int& 
   }
 }
 
+constexpr int BAND_W = 7;   // the reference's constant_range (utils/util_methods.py:147)
+// ------------------------------------------------------------------------------------------
+// BP ("band plus", adj_type 'both': utils/util_methods.py:168-171 -- Hi-C + the +-7 band + I, values 1 or 2, not
+// binarised).  The merged CSR walks 15 band entries per row on top of the Hi-C ones, every one a 128-byte line through the
+// vL1D like any other neighbour, with explicit values (int32 indices, 6 waves per SIMD): 1.45x the line loads of 'hic',
+// 1.5x its time.  But the band half of the sum needs no indices and no L1: with cgcn_graph_aux::bp_* the CSR handed to
+// these kernels holds only the UNIT entries that are not the band's own (Hi-C entries outside the band, and the second
+// unit of the value-2 entries inside it), and the band + I part is added from a (64 + 14)-row x 128-byte window of the
+// table that the workgroup stages in LDS once -- 78 line loads per tile instead of 15 x 64 -- so 'both' costs what 'hic'
+// costs plus the staging.  sum_j w_ij x_j = sum_{unit entries} x_j + sum_{|j - i| <= 7} x_j, exact in real arithmetic;
+// fp32: the unit entries in list order from zero, then the window rows in ascending order from zero, then their sum.
+// ------------------------------------------------------------------------------------------
+constexpr int BANDPLUS_CHUNKS = (64 + 2 * BAND_W) * 8;   // [window row][16-byte chunk of the slice's 128-byte line]
+// stage rows [g0 - BW, g0 + 64 + BW) of this workgroup's slice (lane_el_base: element offset of chunk 0 of row 0); zeros
+// outside the strand.  512 threads; followed by a workgroup barrier in the caller.
+__device__ __forceinline__ void bandplus_stage(f32x4* __restrict__ bt, const float* __restrict__ T, size_t slice_el, int n, int g0, int D) {
+  constexpr int NCH = BANDPLUS_CHUNKS;
+#pragma unroll
+  for (int u = 0; u < (NCH + 511) / 512; ++u) {
+    const int idx = (int)threadIdx.x + 512 * u;
+    const int j = g0 - BAND_W + (idx >> 3);
+    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (idx < NCH && j >= 0 && j < n) v = *(const f32x4*)&T[slice_el + (size_t)j * D + (idx & 7) * 4];
+    if (idx < NCH) bt[idx] = v;
+  }
+}
+__device__ __forceinline__ f32x4 bandplus_sum(const f32x4* __restrict__ bt, int i, int g0, int lane) {
+  const int li = i - g0, c = lane & 7;   // window rows i - BW .. i + BW sit at tile rows li .. li + 2 BW
+  f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k <= 2 * BAND_W; ++k) a += bt[(li + k) * 8 + c];
+  return a;
+}
+
 // H = diag(rs) Ahat X, [S, n, D] -> [S, n, D]  (grid: NSL * ceil(n / 64) workgroups of 512)
-template <int S, int D, bool HAS_VAL, typename IT = int>
+template <int S, int D, bool HAS_VAL, typename IT = int, bool BP = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HAS_VAL ? 6 : 8))) void k_aggregate_sliced(int n, const int* __restrict__ rowptr, const IT* __restrict__ col,
                                                           const float* __restrict__ val, const float* __restrict__ rs,
                                                           const float* __restrict__ X, float* __restrict__ H,
                                                           const int* __restrict__ order) {
+  static_assert(!(BP && HAS_VAL), "the band-plus CSR holds unit entries");
   constexpr int NSL = S * D / 32, QPR = D / 32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int slice, tile;
   sliced_block<NSL>(blockIdx.x, (n + 63) / 64, slice, tile);
-  const size_t lane_el = (size_t)(slice / QPR) * n * D + (slice % QPR) * 32 + (lane & 7) * 4;
+  const size_t slice_el = (size_t)(slice / QPR) * n * D + (slice % QPR) * 32;
+  const size_t lane_el = slice_el + (lane & 7) * 4;
   const SlicedTile t = sliced_tile(rowptr, order, n, tile, wave, lane);
+  __shared__ f32x4 bt[BP ? BANDPLUS_CHUNKS : 1];
+  if (BP) {
+    bandplus_stage(bt, X, slice_el, n, t.g0, D);
+    __syncthreads();
+  }
   const int i = t.i;
   const float sc = (i < n && rs) ? rs[i] : 1.f;
   const unsigned lane_off = (unsigned)(lane_el * 4), rowsh = D == 128 ? 9u : 10u;
-  const f32x4 acc = !t.super ? sliced_row_sum<HAS_VAL, IT>(col, val, t.k0, t.k1, (const char*)X, lane_off, rowsh, lane)
-                             : sliced_super_sum<HAS_VAL, IT>(col, val, t, (const char*)X, lane_off, rowsh, lane, wave);
+  f32x4 acc = !t.super ? sliced_row_sum<HAS_VAL, IT>(col, val, t.k0, t.k1, (const char*)X, lane_off, rowsh, lane)
+                       : sliced_super_sum<HAS_VAL, IT>(col, val, t, (const char*)X, lane_off, rowsh, lane, wave);
   if (i < n) {
+    if (BP) acc += bandplus_sum(bt, i, t.g0, lane);
     if (SLICED_NT & 1) __builtin_nontemporal_store(acc * sc, (f32x4*)&H[lane_el + (size_t)i * D]);
     else *(f32x4*)&H[lane_el + (size_t)i * D] = acc * sc;
   }
@@ -1993,7 +2037,7 @@ __device__ __forceinline__ void bwd_riders(int extra, int n, int P, const float*
 // the transposed adjacency with an element-wise epilogue, feature-sliced (above).
 // mask: the dropout the PREVIOUS layer applied to this layer's input (stream_id of that layer).
 // ------------------------------------------------------------------------------------------
-template <int S, int D, bool HAS_VAL, typename IT = int>
+template <int S, int D, bool HAS_VAL, typename IT = int, bool BP = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HAS_VAL ? 6 : 8))) void k_bwd_sliced(int n, const int* __restrict__ rowptr, const IT* __restrict__ col,
                                                     const float* __restrict__ val, const float* __restrict__ dHs,
                                                     const float* dXn, const float* __restrict__ gate, float* dX,
@@ -2004,17 +2048,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HAS_VAL ? 6
                                                     float* __restrict__ db, float* __restrict__ dwg,
                                                     float* __restrict__ dcg, int accumulate, SgdFuse sg, int reduce_slabs,
                                                     const int* __restrict__ order, HeadApply hp, int head_slabs) {
+  // BP: one LDS pool serves the band window of a gather workgroup and the staging of a rider workgroup (never both)
+  constexpr int RIDER_STAGE = 4 * (512 / HEAD_STAT_COLS) * (HEAD_STAT_COLS + 1) * (int)sizeof(double) / 16;
+  __shared__ f32x4 bt[BP ? (BANDPLUS_CHUNKS > RIDER_STAGE ? BANDPLUS_CHUNKS : RIDER_STAGE) : 1];
   if ((int)blockIdx.x >= gather_blocks) {
-    bwd_riders<S, D>((int)blockIdx.x - gather_blocks, n, P, part, dW, db, dwg, dcg, accumulate, sg, reduce_slabs, hp, head_slabs);
+    bwd_riders<S, D, BP>((int)blockIdx.x - gather_blocks, n, P, part, dW, db, dwg, dcg, accumulate, sg, reduce_slabs, hp, head_slabs, bt);
     return;
   }
+  static_assert(!(BP && HAS_VAL), "the band-plus CSR holds unit entries");
   constexpr int NSL = S * D / 32, QPR = D / 32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int slice, tile;
   sliced_block<NSL>(blockIdx.x, (n + 63) / 64, slice, tile);
   const int s = slice / QPR;
-  const size_t lane_el = (size_t)s * n * D + (slice % QPR) * 32 + (lane & 7) * 4;
+  const size_t slice_el = (size_t)s * n * D + (slice % QPR) * 32;
+  const size_t lane_el = slice_el + (lane & 7) * 4;
   const SlicedTile t = sliced_tile(rowptr, order, n, tile, wave, lane);
+  if (BP) {   // the band + I half of Ahat^T dHs (Ahat is symmetric) from a window of the table staged once per workgroup
+    bandplus_stage(bt, dHs, slice_el, n, t.g0, D);
+    __syncthreads();
+  }
   const int i = t.i;
   const unsigned lane_off = (unsigned)(lane_el * 4), rowsh = D == 128 ? 9u : 10u;
   f32x4 res = (f32x4){0.f, 0.f, 0.f, 0.f}, acc;
@@ -2026,6 +2079,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HAS_VAL ? 6
     acc = sliced_super_sum<HAS_VAL, IT>(col, val, t, (const char*)dHs, lane_off, rowsh, lane, wave);
     if (i < n) res = ld_stream4(&dXn[lane_el + (size_t)i * D]) * (1.f - gate[(size_t)s * n + i]);
   }
+  if (BP && i < n) acc += bandplus_sum(bt, i, t.g0, lane);
   if (i >= n) return;
   const size_t g_off = lane_el + (size_t)i * D;
   f32x4 o = res + acc;
@@ -2057,7 +2111,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HAS_VAL ? 6
 #ifndef BAND_R
 #define BAND_R 32
 #endif
-constexpr int BAND_W = 7;   // the reference's constant_range (utils/util_methods.py:147)
 template <int D, int R>
 struct BandGeo {
   static constexpr int CH = D / 4, RL = 512 / CH, RPT = R / RL, ROWS = R + 2 * BAND_W, NL = (ROWS * CH + 511) / 512;
@@ -2324,13 +2377,26 @@ static int dropout_args(float p, const unsigned long long* rng_state, float* kee
 // H = diag(rs) Ahat X, feature-sliced: int32 column indices, or the 16-bit copy when given (implicit values only)
 static void launch_aggregate_sliced(hipStream_t st, int gblocks, int n, int S, int d, const int32_t* rowptr, const int32_t* col,
                                     const uint16_t* col16, const float* val, const float* rs, const float* X, float* H,
-                                    const int32_t* order) {
+                                    const int32_t* order, bool bp = false) {
+#define SD4(CALLX)                         \
+  do {                                     \
+    if (S == 1 && d == 128) CALLX(1, 128); \
+    else if (S == 2 && d == 128) CALLX(2, 128); \
+    else if (S == 1 && d == 256) CALLX(1, 256); \
+    else CALLX(2, 256);                    \
+  } while (0)
+  if (bp) {   // band-plus: (rowptr, col / col16) is the unit-entry CSR, the band + I half comes from the LDS window
+#define CALLBP16(S_, D_) hipLaunchKernelGGL((k_aggregate_sliced<S_, D_, false, uint16_t, true>), dim3(gblocks), dim3(512), 0, st, n, rowptr, col16, nullptr, rs, X, H, order)
+#define CALLBP32(S_, D_) hipLaunchKernelGGL((k_aggregate_sliced<S_, D_, false, int, true>), dim3(gblocks), dim3(512), 0, st, n, rowptr, col, nullptr, rs, X, H, order)
+    if (col16) SD4(CALLBP16);
+    else SD4(CALLBP32);
+#undef CALLBP16
+#undef CALLBP32
+    return;
+  }
   if (col16) {
 #define CALL16(S_, D_) hipLaunchKernelGGL((k_aggregate_sliced<S_, D_, false, uint16_t>), dim3(gblocks), dim3(512), 0, st, n, rowptr, col16, val, rs, X, H, order)
-    if (S == 1 && d == 128) CALL16(1, 128);
-    else if (S == 2 && d == 128) CALL16(2, 128);
-    else if (S == 1 && d == 256) CALL16(1, 256);
-    else CALL16(2, 256);
+    SD4(CALL16);
 #undef CALL16
     return;
   }
@@ -2338,6 +2404,16 @@ static void launch_aggregate_sliced(hipStream_t st, int gblocks, int n, int S, i
   DISPATCH_SDV(S, d, val != nullptr, CALL);
 #undef CALL
 }
+// the arrays the sliced kernels walk for this graph: the band-plus unit-entry CSR when the graph carries one
+struct SlicedCsr {
+  const int32_t* rowptr;
+  const int32_t* col;
+  const uint16_t* col16;
+  const float* val;
+  const int32_t* order;
+  bool bp;
+};
+static inline SlicedCsr sliced_csr(const cgcn_graph_aux* aux, const int32_t* rowptr, const int32_t* col, const float* val, int n_cols);
 
 extern "C" {
 
@@ -2381,8 +2457,15 @@ static inline const uint16_t* use_col16(const cgcn_graph_aux* aux, const float* 
 #endif
 static inline bool hub_graph(const cgcn_graph_aux* aux) { return aux && aux->max_row_len > FWD_HUB_ROW; }
 static inline const int32_t* row_order(const cgcn_graph_aux* aux) { return aux ? aux->row_order : nullptr; }
+static inline SlicedCsr sliced_csr(const cgcn_graph_aux* aux, const int32_t* rowptr, const int32_t* col, const float* val, int n_cols) {
+  if (aux && aux->bp_rowptr && aux->bp_col && val)
+    return SlicedCsr{aux->bp_rowptr, aux->bp_col, n_cols <= 65536 ? aux->bp_col16 : nullptr, nullptr, aux->bp_row_order, true};
+  return SlicedCsr{rowptr, col, use_col16(aux, val, n_cols), val, row_order(aux), false};
+}
 // band graphs (cgcn_graph_aux::band_halfwidth; implicit unit values): the sliding-window kernels instead of the CSR walk
 static inline bool band_graph(const cgcn_graph_aux* aux, const float* val) { return aux && aux->band_halfwidth == BAND_W && !val; }
+// 'both' graphs with a band-plus decomposition (cgcn_graph_aux::bp_*): the unit-entry CSR + the LDS window (see BP above)
+static inline bool bandplus_graph(const cgcn_graph_aux* aux, const float* val) { return aux && aux->bp_rowptr && aux->bp_col && val; }
 static void launch_band_aggregate(hipStream_t st, int n, int S, int d, const float* rs, const float* X, float* H) {
   const int blocks = S * ((n + BAND_R - 1) / BAND_R);
   if (S == 1 && d == 128) hipLaunchKernelGGL((k_band_aggregate<1, 128, BAND_R>), dim3(blocks), dim3(512), 0, st, n, rs, X, H);
@@ -2412,10 +2495,11 @@ int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d, const 
     launch_band_aggregate(st, n_rows, S, d, row_scale, X, Y);
     return launch_status();
   }
-  if (n_rows == n_cols && ((double)n_rows * S * d * 4.0 >= (double)g_fwd_split_bytes.load() || hub_graph(aux))) {
-    // square operator on a table too large for the L2s: the feature-sliced aggregation (see k_aggregate_sliced)
+  if (n_rows == n_cols && ((double)n_rows * S * d * 4.0 >= (double)g_fwd_split_bytes.load() || hub_graph(aux) || bandplus_graph(aux, val))) {
+    // square operator on a table too large for the L2s (or a band-plus graph): the feature-sliced aggregation (see k_aggregate_sliced)
     const int gblocks = (S * d / 32) * ((n_rows + 63) / 64);
-    launch_aggregate_sliced(st, gblocks, n_rows, S, d, rowptr, col, use_col16(aux, val, n_cols), val, row_scale, X, Y, row_order(aux));
+    const SlicedCsr c = sliced_csr(aux, rowptr, col, val, n_cols);
+    launch_aggregate_sliced(st, gblocks, n_rows, S, d, c.rowptr, c.col, c.col16, c.val, row_scale, X, Y, c.order, c.bp);
     return launch_status();
   }
   const int blocks = (n_rows + 3) / 4 < 4096 ? (n_rows + 3) / 4 : 4096;
@@ -2474,7 +2558,7 @@ int cgcn_debug_layer_fwd_route(int n, int S, int d, const cgcn_graph_aux* aux) {
   const int rc = check_shape(n, S, d);
   if (rc) return rc;
   if (band_graph(aux, nullptr)) return 2;
-  return (fwd_split_shape(n, S, d) || hub_graph(aux)) ? 1 : 0;
+  return (fwd_split_shape(n, S, d) || hub_graph(aux) || (aux && aux->bp_rowptr && aux->bp_col)) ? 1 : 0;
 }
 
 int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* rowptr, const int32_t* col, const float* val,
@@ -2496,7 +2580,7 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   // Three routes.  H_in given: the row-local kernel alone.  Training (H is wanted anyway) on a table that does not
   // fit the L2s: feature-sliced aggregation into H, then the row-local kernel on it.  Otherwise the fused kernel.
   const bool band = band_graph(aux, val);
-  const bool split = !H_in && H && (fwd_split_shape(n, S, d) || hub_graph(aux) || band);
+  const bool split = !H_in && H && (fwd_split_shape(n, S, d) || hub_graph(aux) || band || bandplus_graph(aux, val));
   // cgcn_layer_fwd_colstats_tiles() reports MERGED records on split-size tables (k_layer_dense's contiguous tile
   // chunks); the fused kernel would write one record per 16 / S-node tile -- more than the caller allocated.  On such
   // tables the column statistics therefore need the two-launch route, i.e. an H (or H_in) buffer.
@@ -2504,7 +2588,10 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   if (split) {
     const int gblocks = (S * d / 32) * ((n + 63) / 64);
     if (band) launch_band_aggregate(st, n, S, d, row_scale, X, H);
-    else launch_aggregate_sliced(st, gblocks, n, S, d, rowptr, col, use_col16(aux, val, n), val, row_scale, X, H, row_order(aux));
+    else {
+      const SlicedCsr c = sliced_csr(aux, rowptr, col, val, n);
+      launch_aggregate_sliced(st, gblocks, n, S, d, c.rowptr, c.col, c.col16, c.val, row_scale, X, H, c.order, c.bp);
+    }
     if ((rc = launch_status())) return rc;
     H_in = H;
   }
@@ -2688,6 +2775,19 @@ static int layer_bwd_impl(cgcn_stream_t stream, int n, int S, int d, const int32
     else if (S == 1 && d == 256) CALLB(1, 256);
     else CALLB(2, 256);
 #undef CALLB
+  } else if (bandplus_graph(aux_t, val_t)) {   // 'both': the unit-entry CSR + the band window from LDS (BP)
+    const SlicedCsr c = sliced_csr(aux_t, rowptr_t, col_t, val_t, n);
+#define CALLBP(S_, D_, IT_, COL_)                                                                                    \
+  hipLaunchKernelGGL((k_bwd_sliced<S_, D_, false, IT_, true>), dim3(blocks + (fuse_reduce ? slabs : 0) + head_slabs_g + sgd_blocks), dim3(512), 0, \
+                     st, n, c.rowptr, COL_, nullptr, dHs, dXn, gate, dX, ks, th, rng_state, in_stream_id, blocks, P,  \
+                     part, dW, db, dwg, dcg, accumulate, sg, fuse_reduce ? slabs : 0, c.order, hp, head_slabs_g)
+#define CALLBP16(S_, D_) CALLBP(S_, D_, uint16_t, c.col16)
+#define CALLBP32(S_, D_) CALLBP(S_, D_, int, c.col)
+    if (c.col16) { if (S == 1 && d == 128) CALLBP16(1, 128); else if (S == 2 && d == 128) CALLBP16(2, 128); else if (S == 1 && d == 256) CALLBP16(1, 256); else CALLBP16(2, 256); }
+    else { if (S == 1 && d == 128) CALLBP32(1, 128); else if (S == 2 && d == 128) CALLBP32(2, 128); else if (S == 1 && d == 256) CALLBP32(1, 256); else CALLBP32(2, 256); }
+#undef CALLBP16
+#undef CALLBP32
+#undef CALLBP
   } else if (const uint16_t* col16_t = use_col16(aux_t, val_t, n)) {
 #define CALL16(S_, D_)                                                                                               \
   hipLaunchKernelGGL((k_bwd_sliced<S_, D_, false, uint16_t>), dim3(blocks + (fuse_reduce ? slabs : 0) + head_slabs_g + sgd_blocks), dim3(512), 0, \

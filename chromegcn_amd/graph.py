@@ -125,7 +125,8 @@ def host_csr_from_matrix(a: sp.spmatrix) -> HostCSR:
 # carry tensors, not graph objects.
 class GraphAux(ctypes.Structure):
     _fields_ = [("col16", ctypes.c_void_p), ("row_order", ctypes.c_void_p), ("max_row_len", ctypes.c_int32),
-                ("band_halfwidth", ctypes.c_int32)]
+                ("band_halfwidth", ctypes.c_int32), ("bp_rowptr", ctypes.c_void_p), ("bp_col", ctypes.c_void_p),
+                ("bp_col16", ctypes.c_void_p), ("bp_row_order", ctypes.c_void_p)]
 
 
 BAND_HALFWIDTH = 7   # utils/util_methods.py:147 (constant_range); the width the library's band kernels are built for
@@ -177,6 +178,38 @@ def tile_sorted_rows(deg: torch.Tensor) -> torch.Tensor:
     return order.to(torch.int32).contiguous()
 
 
+def band_plus_part(rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.Tensor], n_cols: int):
+    """The "band plus" decomposition of an explicit-value graph (cgcn_graph_aux::bp_*, include/chromegcn.h): for the graph
+    process_graph's 'both' branch makes of a {0,1} Hi-C matrix (utils/util_methods.py:168-171: Hi-C + the +-7 band + I,
+    values 1 or 2, every 2 inside the band, every band position present)
+        sum_j w_ij x_j = sum_{unit entries that are not the band's own} x_j + sum_{|j - i| <= 7} x_j,
+    so the feature-sliced kernels can walk an implicit-value CSR (16-bit indices, 8 waves per SIMD) and take the band half
+    from an LDS window.  Returns (rowptr_bp, col_bp) int32 tensors on the graph's device, or None when the graph is not of
+    that form (then the explicit-value kernels run on the merged CSR, as before)."""
+    n = int(rowptr.numel()) - 1
+    w = BAND_HALFWIDTH
+    if val is None or n != n_cols or n < 1 or col.numel() == 0:
+        return None
+    rp = rowptr.to(torch.int64)
+    deg = rp[1:] - rp[:-1]
+    rows = torch.repeat_interleave(torch.arange(n, device=col.device, dtype=torch.int64), deg)
+    c = col.to(torch.int64)
+    inband = (c - rows).abs() <= w
+    two = val == 2
+    if not bool((((val == 1) | (two & inband))).all()):
+        return None
+    i = torch.arange(n, device=col.device, dtype=torch.int64)
+    want = (i + w).clamp_(max=n - 1) - (i - w).clamp_(min=0) + 1
+    have = torch.zeros(n, dtype=torch.int64, device=col.device).index_add_(0, rows, inband.to(torch.int64))
+    if not torch.equal(have, want):
+        return None   # a band position is missing (or repeated): not the 'both' graph
+    keep = (two & inband) | ((val == 1) & ~inband)
+    deg_bp = torch.zeros(n, dtype=torch.int64, device=col.device).index_add_(0, rows, keep.to(torch.int64))
+    rp_bp = torch.zeros(n + 1, dtype=torch.int64, device=col.device)
+    rp_bp[1:] = torch.cumsum(deg_bp, 0)
+    return rp_bp.to(torch.int32).contiguous(), col[keep].contiguous()
+
+
 def _wants_row_order(longest: int, n_rows: int, nnz: int) -> bool:
     env = os.environ.get("CGCN_ROW_ORDER", "")
     if env in ("0", "1"):
@@ -199,8 +232,20 @@ def _register_aux(rowptr: torch.Tensor, col: torch.Tensor, n_cols: int, val: Opt
     longest = int(deg.max().item()) if n_rows > 0 else 0
     order = tile_sorted_rows(deg) if _wants_row_order(longest, n_rows, int(col.numel())) else None
     band = band_halfwidth(rowptr, col, val, n_cols) if os.environ.get("CGCN_BAND_ROUTE", "1") != "0" else 0
-    _AUX[col.data_ptr()] = (weakref.ref(col), (c16, order), GraphAux(None if c16 is None else c16.data_ptr(),
-                                                                      None if order is None else order.data_ptr(), longest, band))
+    bp = band_plus_part(rowptr, col, val, n_cols) if os.environ.get("CGCN_BANDPLUS_ROUTE", "1") != "0" else None
+    bp_keep, bp_ptrs = (), (None, None, None, None)
+    if bp is not None:
+        rp_bp, col_bp = bp
+        if col_bp.numel() == 0:   # no Hi-C entry at all: the kernels want a valid (if never read) index array
+            col_bp = torch.zeros(1, dtype=torch.int32, device=col.device)
+        c16_bp = col_bp.to(torch.int16) if n_cols <= 65536 else None
+        deg_bp = rp_bp[1:] - rp_bp[:-1]
+        order_bp = tile_sorted_rows(deg_bp) if _wants_row_order(int(deg_bp.max().item()), n_rows, int(col_bp.numel())) else None
+        bp_keep = (rp_bp, col_bp, c16_bp, order_bp)
+        bp_ptrs = tuple(None if t is None else t.data_ptr() for t in bp_keep)
+    _AUX[col.data_ptr()] = (weakref.ref(col), (c16, order) + bp_keep,
+                            GraphAux(None if c16 is None else c16.data_ptr(), None if order is None else order.data_ptr(), longest, band,
+                                     *bp_ptrs))
 
 
 def _aux_entry(col: Optional[torch.Tensor]):
@@ -234,6 +279,12 @@ def row_order(col: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 def max_row_len(col: Optional[torch.Tensor]) -> int:
     ent = _aux_entry(col)
     return 0 if ent is None else int(ent[2].max_row_len)
+
+
+def has_band_plus(col: Optional[torch.Tensor]) -> bool:
+    """the graph carries a band-plus decomposition ('both' at 'hic' speed: the sliced kernels' BP route)"""
+    ent = _aux_entry(col)
+    return ent is not None and bool(ent[2].bp_rowptr)
 
 
 def is_band(col: Optional[torch.Tensor]) -> bool:

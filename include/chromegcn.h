@@ -78,13 +78,27 @@ typedef void *cgcn_stream_t; /* hipStream_t */
  *                 aggregation then runs as a sliding-window stream over the table (k_band_aggregate / k_bwd_band: every
  *                 row read once, no index list) instead of the CSR walk; same bits (same summation order).  Not checked:
  *                 a wrong hint gives the band's sums, not the CSR's.  ABI 21.
- * For the backward (aux_t) all four describe the CSR of Ahat^T.
+ *   bp_rowptr, bp_col, bp_col16, bp_row_order : the "band plus" decomposition of an explicit-value graph whose values are 1
+ *                 or 2 with every 2 inside the +-7 band and every position of the band + I present (process_graph's 'both'
+ *                 branch on a {0,1} Hi-C matrix, utils/util_methods.py:168-171), or all NULL.  (bp_rowptr, bp_col) is the
+ *                 CSR (int32, device) of the UNIT entries that are not the band's own -- entries outside the band, and one
+ *                 unit of each value-2 entry inside it -- so that  sum_j w_ij x_j = sum_{bp entries} x_j + sum_{|j-i|<=7} x_j.
+ *                 bp_col16 / bp_row_order are what col16 / row_order are for the main CSR.  The feature-sliced kernels then
+ *                 walk the bp CSR with implicit values and 16-bit indices and add the band + I half from a window of the
+ *                 table staged once per workgroup in LDS ('both' at 'hic' speed); graphs that carry it take the
+ *                 feature-sliced route at every table size.  Used only when val != NULL; results equal the merged CSR's
+ *                 up to fp32 re-association of a row's sum.  Not checked.  ABI 21.
+ * For the backward (aux_t) all of them describe the CSR of Ahat^T.
  */
 typedef struct cgcn_graph_aux {
   const uint16_t *col16;
   const int32_t *row_order;
   int32_t max_row_len;
   int32_t band_halfwidth;
+  const int32_t *bp_rowptr;
+  const int32_t *bp_col;
+  const uint16_t *bp_col16;
+  const int32_t *bp_row_order;
 } cgcn_graph_aux;
 
 /* ABI version of the loaded library (compare with CGCN_ABI_VERSION). */

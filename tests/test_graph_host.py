@@ -149,3 +149,34 @@ def test_band_recognition_from_the_csr_arrays():
     c2 = h.col.copy()
     c2[h.rowptr[20] + 3] = c2[h.rowptr[20] + 2]   # a repeated column inside a row
     assert G.band_halfwidth(torch.from_numpy(h.rowptr), torch.from_numpy(c2), None, 50) == 0
+
+
+def test_band_plus_decomposition_of_both_graphs_is_exact():
+    """graph.band_plus_part (-> cgcn_graph_aux::bp_*): for process_graph's 'both' graph of a {0,1} matrix, merged = unit
+    entries + band + I exactly; anything else is refused"""
+    import torch
+    rng = np.random.RandomState(1)
+    for n in (1, 5, 8, 40, 700):
+        a = sp.random(n, n, min(1.0, 6.0 / n), random_state=rng, format="csr")
+        a = a + a.T
+        a.data[:] = 1
+        if n > 3:
+            a = a.tolil(); a[2, 2] = 1; a = sp.csr_matrix(a)      # a self-loop in the input: merged diagonal value 2
+        h = G.normalize_graph("both", a, n)
+        if h.val is None:
+            continue
+        bp = G.band_plus_part(torch.from_numpy(h.rowptr), torch.from_numpy(h.col), torch.from_numpy(h.val), n)
+        assert bp is not None, n
+        merged = sp.csr_matrix((h.val, h.col, h.rowptr), shape=(n, n))
+        unit = sp.csr_matrix((np.ones(bp[1].numel(), np.float32), bp[1].numpy(), bp[0].numpy()), shape=(n, n))
+        b = G.normalize_graph("constant", None, n)
+        band = sp.csr_matrix((np.ones(b.col.size, np.float32), b.col, b.rowptr), shape=(n, n))
+        assert abs(merged - (unit + band)).max() == 0
+    # a value 3 (Hi-C entry of value 2 inside the band) / a value 2 outside the band: not of the form
+    a = sp.random(300, 300, 0.02, random_state=rng, format="csr"); a = a + a.T; a.data[:] = 1
+    a2 = a.copy(); a2.data[::5] = 2
+    h = G.normalize_graph("both", a2, 300)
+    assert G.band_plus_part(torch.from_numpy(h.rowptr), torch.from_numpy(h.col), torch.from_numpy(h.val), 300) is None
+    # implicit-value graphs have nothing to decompose
+    h = G.normalize_graph("hic", a, 300)
+    assert G.band_plus_part(torch.from_numpy(h.rowptr), torch.from_numpy(h.col), None, 300) is None
