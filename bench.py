@@ -1000,8 +1000,8 @@ def main():
                     e["bytes"] += costs[ck][0] * per_step
                     e["flops"] += costs[ck][1] * per_step
                     e["gather"] += costs[ck][2] * per_step
-        wl_key = (("genome" if genome else args.workload) + {"uniform": "", "hic_like": "_hic", "hub": "_hub"}[args.generator] + "_d%d" % args.d
-                  + ("" if args.adj_type == "hic" else "_" + args.adj_type))
+        wl_key = (("genome" if genome else args.workload) + {"uniform": "", "hic_like": "_hic", "hub": "_hub"}[args.generator]
+                  + ("" if args.adj_type == "hic" else "_" + args.adj_type) + "_d%d" % args.d)
 
         def roof_entry(k, e):
             if not e["launches"] or not e["bytes"]:

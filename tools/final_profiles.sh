@@ -7,6 +7,7 @@ if [ -z "${SKIP_TESTS:-}" ]; then python -m pytest tests -m gpu -q > gpurun_out/
 python bench.py --hic-like --no-cpu-baseline > gpurun_out/$T/bench_genome_hic.json 2>/dev/null
 for w in chr21 chr1 config1; do python bench.py --workload $w --no-cpu-baseline > gpurun_out/$T/bench_$w.json 2>/dev/null; python bench.py --workload $w --hic-like --no-cpu-baseline > gpurun_out/$T/bench_${w}_hic.json 2>/dev/null; done
 python bench.py --generator hub --no-cpu-baseline > gpurun_out/$T/bench_genome_hub.json 2>/dev/null
+for a in both constant none; do python bench.py --adj-type $a --no-cpu-baseline --no-extras > gpurun_out/$T/bench_genome_adj_$a.json 2>/dev/null; done
 for w in chr21 chr1; do python bench.py --workload $w --generator hub --no-cpu-baseline > gpurun_out/$T/bench_${w}_hub.json 2>/dev/null; done
 python bench.py --workload chr21 --d 256 --layers 4 --no-cpu-baseline > gpurun_out/$T/bench_chr21_d256L4.json 2>/dev/null
 python bench.py --d 256 --layers 4 --no-cpu-baseline > gpurun_out/$T/bench_genome_d256L4.json 2>/dev/null
@@ -21,6 +22,8 @@ bash tools/profile_round.sh $T chr1 --workload chr1
 bash tools/profile_round.sh $T chr1_hic --workload chr1 --hic-like
 bash tools/profile_round.sh $T chr21_d256L4 --workload chr21 --d 256 --layers 4
 bash tools/profile_round.sh $T genome_hub --generator hub
+bash tools/profile_round.sh $T genome_constant --adj-type constant
+bash tools/profile_round.sh $T genome_both --adj-type both
 for f in gpurun_out/$T/bench_*.json; do python - "$f" <<'PY'
 import json,sys
 try:
