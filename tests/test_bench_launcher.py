@@ -180,6 +180,29 @@ def test_external_launcher_ranks_out_of_lockstep(late_rank):
         assert d["ranks_seen_by_backend"] == 2 and d["launch_ladder"]["rung"] == 0
 
 
+def test_hand_started_ranks_without_a_launcher_agent():
+    """two ranks started by hand (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment, no torch.distributed.run,
+    so no agent-hosted store): rank 0 hosts the job's c10d store itself, the ladder's choice and the process group go over it"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                              "TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_RUN_ID")}
+    procs = []
+    for r in (1, 0):   # rank 1 first: it must wait for rank 0's store to come up
+        env = dict(base, WORLD_SIZE="2", RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   CGCN_BENCH_TEST_SKEW_RANK="0", CGCN_BENCH_TEST_SKEW_S="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[1][-2000:] for o in outs)
+    lines = [l for o in outs for l in o[0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["ranks_seen_by_backend"] == 2 and d["launch_ladder"]["rung"] == 0
+
+
 def test_default_process_group_is_initialised_once_per_process():
     """the invariant behind the fix, checked on the source: bench.py reaches init_process_group through init_group only,
     and never destroys a group before the end of the job"""
