@@ -73,6 +73,23 @@ def test_band_graphs_are_recognised_and_nothing_else_is():
     assert not G.is_band(gv2.col)
 
 
+def test_reference_style_coo_of_the_constant_graph_takes_the_band_route():
+    """a caller that hands ChromeGCN.forward the torch sparse COO tensor the REFERENCE's process_graph('constant') returns
+    (D^-1 (band + I), fp32 values 1 / deg_i): recognised as an implicit-value graph on the device and then as a band"""
+    from oracle import chromegcn_oracle as O
+    n = 3000
+    coo = O.process_graph("constant", None, n, "chrX").to(DEV)
+    g = G.graph_from_torch_sparse(coo, DEV)
+    assert g.val is None and G.is_band(g.col)
+    x = torch.randn(2, n, 128, device=DEV)
+    y = torch.empty_like(x)
+    lib = _lib.load()
+    _lib.check(lib.cgcn_spmm(_lib.stream_ptr(), n, n, 2, 128, _lib.ptr(g.rowptr), _lib.ptr(g.col), None, _lib.ptr(g.row_scale), _lib.ptr(x),
+                             _lib.ptr(y), G.aux_ptr(g.col)), "spmm")
+    want = torch.stack([torch.sparse.mm(coo, x[s]) for s in range(2)])
+    torch.testing.assert_close(y, want, atol=2e-5, rtol=2e-5)
+
+
 @pytest.mark.parametrize("S,d", [(2, 128), (1, 128), (2, 256), (1, 256)])
 def test_band_aggregation_same_bits_as_the_csr_route_and_right(S, d):
     lib = _lib.load()
