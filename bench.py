@@ -898,6 +898,12 @@ def main():
                 extras["dropin_d2h_GBps"] = None
                 extras["dropin_d2h_error"] = str(e)
             extras["dropin_exposed_copy_ms"] = (c_el - elapsed) / steps * 1e3
+            # the design hides every group's copy but the last under the next group's kernels: an exposed time of more than half
+            # the whole matrix's own copy time means this box ran the copy stream's transfers one after the other with the
+            # compute stream's graphs (seen on some leases: same link rate, 2.8 ms exposed instead of 0.3) -- a property of the
+            # box's copy-engine scheduling, not of the link
+            if extras.get("dropin_d2h_ms_whole_matrix"):
+                extras["dropin_copies_overlap_compute"] = bool(extras["dropin_exposed_copy_ms"] < 0.5 * extras["dropin_d2h_ms_whole_matrix"])
             extras["dropin_over_headline"] = c_el / elapsed
             extras["pcie_link"] = pcie_link_info(dev)
             extras["dropin_finetune_note"] = ("chromegcn_amd.finetune.finetune()'s epoch: the same train epoch returning CPU predictions "
