@@ -191,3 +191,43 @@ def test_eval_forward_matches_oracle_at_chr1_size():
     preds, _, tot = O.finetune_epoch(orc, {name: feats}, {name: hic}, None, "valid", adj_type)
     assert abs(loss.item() - tot) <= 1e-4 + 1e-4 * abs(tot)
     np.testing.assert_allclose(probs.cpu().numpy(), preds.numpy(), atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("d,layers,input_grad", [(256, 1, False), (256, 2, False), (128, 1, False)])
+def test_head_second_stage_riding_in_the_row_local_launch(d, layers, input_grad):
+    """When nobody differentiates the features (the engine's default) the LAST launch of the step has no gather, so the head's
+    deferred second stage (dW_out / db_out slabs, BatchNorm column sums) rides in the row-local launch instead -- at d = 256 in
+    k_bwd_rowlocal256s's trailing workgroups (staged through its slot memory, 1 024 threads), at d = 128 in the ring kernel's.
+    One-layer models take that placement for the ONLY layer.  Two train steps against the oracle."""
+    n, pairs, labels, seed = 3000, 40000, NC, 41
+    feats = synth.chrom_features(n, d, labels, 1000 + seed)
+    hic = synth.contact_graph(n, pairs, seed)
+    torch.manual_seed(seed)
+    orc = O.GatedGCNOracle(d, labels, 0.0, layers)
+    with torch.no_grad():
+        for k in range(1, layers + 1):
+            getattr(orc, "GC%d" % k).weight.mul_(20.0 * (128.0 / d) ** 0.5)
+            getattr(orc, "W%d" % k).weight.mul_(3)
+    model = C.ChromeGCN(d, d, labels, 0.0, True, layers)
+    model.load_state_dict(orc.state_dict())
+    model.to(DEV)
+    opt = torch.optim.SGD(model.parameters(), lr=0.25, momentum=0.9, weight_decay=1e-6)
+    stage = GCNStage(model, opt, "hic", DEV, hip_graphs=True, input_grad=input_grad, cache_input_aggregation=False)
+    stage.add_chromosome("c", feats, hic)
+    oopt = O.make_sgd(orc, 0.25)
+    cache = {}
+    threads = torch.get_num_threads()
+    torch.set_num_threads(8)
+    try:
+        for step in range(2):
+            loss, probs, _ = stage.train_step("c")
+            torch.cuda.synchronize()
+            preds, _, tot = O.finetune_epoch(orc, {"c": feats}, {"c": hic}, oopt, "train", "hic", adj_cache=cache)
+            assert abs(loss.item() - tot) <= 1e-4 + 1e-4 * abs(tot)
+            np.testing.assert_allclose(probs.cpu().numpy(), preds.numpy(), atol=1e-4, rtol=1e-4)
+            osd = orc.state_dict()
+            for k, v in model.state_dict().items():
+                tol = 1e-5 if "running" in k else 1e-4
+                np.testing.assert_allclose(v.cpu().numpy(), osd[k].numpy(), atol=tol, rtol=tol, err_msg="%s after step %d" % (k, step))
+    finally:
+        torch.set_num_threads(threads)
