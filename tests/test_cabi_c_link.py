@@ -10,6 +10,7 @@ from chromegcn_amd import _build
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = r'''
+#include <stddef.h>
 #include <stdio.h>
 #include <string.h>
 #include "chromegcn.h"
@@ -30,6 +31,15 @@ int main(void) {
         if (cgcn_spmm((cgcn_stream_t)0, 10, 10, 1, 128, NULL, NULL, NULL, NULL, NULL, NULL, &aux) != CGCN_ERR_BAD_ARG) return 9;
         if (sizeof(aux.col16) != sizeof(void *) || sizeof(aux.max_row_len) != 4) return 10;
     }
+    /* struct layouts, for the ctypes mirrors (chromegcn_amd/graph.py GraphAux, _lib.py HeadGrad / SgdFuse) */
+    printf("layout cgcn_graph_aux %zu", sizeof(cgcn_graph_aux));
+    printf(" %zu %zu %zu %zu %zu %zu %zu %zu\n", offsetof(cgcn_graph_aux, col16), offsetof(cgcn_graph_aux, row_order),
+           offsetof(cgcn_graph_aux, max_row_len), offsetof(cgcn_graph_aux, band_halfwidth), offsetof(cgcn_graph_aux, bp_rowptr),
+           offsetof(cgcn_graph_aux, bp_col), offsetof(cgcn_graph_aux, bp_col16), offsetof(cgcn_graph_aux, bp_row_order));
+    printf("layout cgcn_head_grad %zu %zu %zu %zu %zu\n", sizeof(cgcn_head_grad), offsetof(cgcn_head_grad, dropout_p),
+           offsetof(cgcn_head_grad, n_partials), offsetof(cgcn_head_grad, accumulate), offsetof(cgcn_head_grad, dbn_b));
+    printf("layout cgcn_sgd_fuse %zu %zu %zu %zu\n", sizeof(cgcn_sgd_fuse), offsetof(cgcn_sgd_fuse, count), offsetof(cgcn_sgd_fuse, lr),
+           offsetof(cgcn_sgd_fuse, rng_state));
     printf("c-abi ok v%d\n", cgcn_abi_version());
     return 0;
 }
@@ -51,3 +61,16 @@ def test_header_is_plain_c_and_a_c_program_links(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, env=env, timeout=120)
     assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
     assert "c-abi ok v" in out.stdout
+    # the ctypes mirrors of the host structs have the C compiler's layout (a field added to one side only would shift every
+    # pointer behind it: the library would read garbage addresses)
+    import ctypes
+    from chromegcn_amd import _lib, graph as G
+    lay = {l.split()[1]: [int(v) for v in l.split()[2:]] for l in out.stdout.splitlines() if l.startswith("layout ")}
+    A = G.GraphAux
+    assert lay["cgcn_graph_aux"] == [ctypes.sizeof(A)] + [getattr(A, f).offset for f in
+                                                          ("col16", "row_order", "max_row_len", "band_halfwidth", "bp_rowptr", "bp_col", "bp_col16", "bp_row_order")]
+    assert [f for f, _ in A._fields_] == ["col16", "row_order", "max_row_len", "band_halfwidth", "bp_rowptr", "bp_col", "bp_col16", "bp_row_order"]
+    H = _lib.HeadGrad
+    assert lay["cgcn_head_grad"] == [ctypes.sizeof(H), H.dropout_p.offset, H.n_partials.offset, H.accumulate.offset, H.dbn_b.offset]
+    F = _lib.SgdFuse
+    assert lay["cgcn_sgd_fuse"] == [ctypes.sizeof(F), F.count.offset, F.lr.offset, F.rng_state.offset]
