@@ -669,9 +669,13 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512, FWD_WAVES_PE
 #ifndef DENSE_WAVES_PER_SIMD
 #define DENSE_WAVES_PER_SIMD 4
 #endif
+#ifndef DENSE256_PRE
+#define DENSE256_PRE 1   // d = 256: W fragments resident too (128 registers per wave, one 8-wave workgroup per CU, W read once per
+#endif                   // workgroup instead of once per tile from L2 inside the K loop: profiles/r05_d256_dense_experiment.txt)
+#define DENSE_WPS(D_) (((D_) == 256 && DENSE256_PRE) ? 2 : DENSE_WAVES_PER_SIMD)
 
 template <int S, int D, int MB>
-__global__ __launch_bounds__(512, DENSE_WAVES_PER_SIMD) void k_layer_dense(int n, int ntiles, const float* __restrict__ Hin,
+__global__ __launch_bounds__(512, DENSE_WPS(D)) void k_layer_dense(int n, int ntiles, const float* __restrict__ Hin,
                                                     const float* __restrict__ X, const float* __restrict__ W,
                                                     const float* __restrict__ bias, const float* __restrict__ wg,
                                                     const float* __restrict__ cg, float* __restrict__ Xn,
@@ -686,7 +690,7 @@ __global__ __launch_bounds__(512, DENSE_WAVES_PER_SIMD) void k_layer_dense(int n
   constexpr int LD = D + 4;          // LDS row stride (floats); keeps 16-byte alignment
   constexpr int EPL = D / 64;        // floats per lane in the row-wise passes
   constexpr int RPW = ROWS / NW;     // rows per wave
-  constexpr bool PRE = (D == 128);
+  constexpr bool PRE = (D == 128) || DENSE256_PRE;
   static_assert(D / (16 * CBW) == NW && ROWS % NW == 0, "geometry");
   __shared__ __attribute__((aligned(16))) float T[ROWS * LD];
 
@@ -2437,6 +2441,7 @@ const char* cgcn_strerror(int code) {
 #ifndef DENSE_MAX_BLOCKS
 #define DENSE_MAX_BLOCKS (256 * (DENSE_WAVES_PER_SIMD / 2))   // exactly the workgroups resident at once: one round
 #endif
+static inline int dense_max_blocks(int d) { return (d == 256 && DENSE256_PRE) ? 256 : DENSE_MAX_BLOCKS; }   // d = 256: one workgroup per CU
 #ifndef DENSE_MB
 #define DENSE_MB 1
 #endif
@@ -2544,7 +2549,7 @@ static int dense_stat_chunk(int n, int S, int d) {
   if (!fwd_split_shape(n, S, d)) return 1;
   const int tn = 16 * DENSE_MB / S;
   const int ntiles = (n + tn - 1) / tn;
-  return (ntiles + DENSE_MAX_BLOCKS - 1) / DENSE_MAX_BLOCKS;
+  return (ntiles + dense_max_blocks(d) - 1) / dense_max_blocks(d);
 }
 
 int cgcn_layer_fwd_colstats_tiles(int n, int S, int d, int* rows_per_tile) {
@@ -2600,7 +2605,7 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
     const int tn = 16 * MB / S;
     const int ntiles = (n + tn - 1) / tn;
     const int chunk = dense_stat_chunk(n, S, d);   // with column statistics: contiguous tiles per workgroup = per record
-    const int grid = colstats ? (ntiles + chunk - 1) / chunk : (ntiles < DENSE_MAX_BLOCKS ? ntiles : DENSE_MAX_BLOCKS);
+    const int grid = colstats ? (ntiles + chunk - 1) / chunk : (ntiles < dense_max_blocks(d) ? ntiles : dense_max_blocks(d));
 #define CALL(S_, D_, V_) \
     hipLaunchKernelGGL((k_layer_dense<S_, D_, MB>), dim3(grid), dim3(512), 0, st, n, ntiles, H_in, X, W, b, wg, cg, Xn, Z, gate, \
                        ks, th, rng_state, stream_id, colstats, chunk)
