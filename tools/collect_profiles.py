@@ -15,7 +15,9 @@ def main():
     prof = os.path.join(ROOT, "profiles")
     if old:
         for f in glob.glob(os.path.join(prof, old + "_*")):
-            if "_experiment" not in f and "parity_errors" not in f:
+            # only what the new round's run regenerates goes: per-round kernel-stat / counter summaries and bench lines; every
+            # hand-written record (*.txt: experiments, probes, launch-floor notes ...) stays -- DESIGN.md cites them
+            if f.endswith(".csv") or (f.endswith(".json") and "_bench_line_" in f):
                 os.remove(f)
     traffic = {}
     for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", tag + "_*", "summary"))):
