@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <utility>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
 template <int LDS_FLOATS>
@@ -31,6 +32,21 @@ __global__ void k_nt(float* p, size_t n4) {   // non-temporal stores
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   f32x4* q = (f32x4*)p;
   for (size_t k = i; k < n4; k += stride) __builtin_nontemporal_store((f32x4){1.f, 2.f, 3.f, 4.f}, &q[k]);
+}
+
+// write-through stores (sc1: the line leaves the XCD's L2 with the store instead of staying dirty in it) -- round 5
+template <int MODE>   // 1: sc1, 2: sc0 sc1, 3: sc1 nt
+__global__ void k_wt(float* p, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4* q = (f32x4*)p;
+  const f32x4 v = {1.f, 2.f, 3.f, 4.f};
+  for (size_t k = i; k < n4; k += stride) {
+    if (MODE == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(&q[k]), "v"(v) : "memory");
+    else if (MODE == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(&q[k]), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(&q[k]), "v"(v) : "memory");
+  }
 }
 
 __global__ void k_read(const float* p, size_t n4, float* out) {   // workgroups >= 16 stream n4 float4 and keep a sum
@@ -116,6 +132,23 @@ int main() {
       hipLaunchKernelGGL(k_empty<0>, dim3(16), dim3(1024), 0, st, buf, 0);
     }, nodes / 2, reps) * 2.f;
     printf("  writer of %2zu MB: %6.2f us per launch back to back; writer + empty 16 x 1024 kernel: %6.2f us per pair (the empty one adds %5.2f)\n", mb, w, p, p - w);
+  }
+  // round 5: the same pairs with WRITE-THROUGH stores in the writer (nothing stays dirty in the L2s at its end)
+  for (size_t mb : {16u, 32u}) {
+    const size_t n4 = (mb << 20) / 16;
+    auto E = [&](hipStream_t st) { hipLaunchKernelGGL(k_empty<0>, dim3(16), dim3(1024), 0, st, buf, 0); };
+    auto pair = [&](auto W) {
+      const float w = graph_us_per_node([&](hipStream_t st) { W(st); }, nodes, reps);
+      const float p = graph_us_per_node([&](hipStream_t st) { W(st); E(st); }, nodes / 2, reps) * 2.f;
+      return std::make_pair(w, p);
+    };
+    auto r0 = pair([&](hipStream_t st) { hipLaunchKernelGGL(k_dirty, dim3(1024), dim3(256), 0, st, buf, n4); });
+    auto rn = pair([&](hipStream_t st) { hipLaunchKernelGGL(k_nt, dim3(1024), dim3(256), 0, st, buf, n4); });
+    auto r1 = pair([&](hipStream_t st) { hipLaunchKernelGGL(k_wt<1>, dim3(1024), dim3(256), 0, st, buf, n4); });
+    auto r2 = pair([&](hipStream_t st) { hipLaunchKernelGGL(k_wt<2>, dim3(1024), dim3(256), 0, st, buf, n4); });
+    auto r3 = pair([&](hipStream_t st) { hipLaunchKernelGGL(k_wt<3>, dim3(1024), dim3(256), 0, st, buf, n4); });
+    printf("  %2zu MB writer alone / writer + empty 16 x 1024 (us):  plain %5.2f / %5.2f   nt %5.2f / %5.2f   sc1 %5.2f / %5.2f   sc0 sc1 %5.2f / %5.2f   sc1 nt %5.2f / %5.2f\n",
+           mb, r0.first, r0.second, rn.first, rn.second, r1.first, r1.second, r2.first, r2.second, r3.first, r3.second);
   }
   {   // does the ORDER matter?  W = 32 MB of plain stores (k_layer_dense-like), N = 16 MB of non-temporal stores (k_aggregate_sliced-
       // like), E = empty 16 x 1024 (k_head_bn_finalize-like).  Per triple: W E N (today's order) against W N E.
