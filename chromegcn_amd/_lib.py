@@ -45,9 +45,10 @@ _SIGNATURES = {
     "cgcn_graph_fill": (_c_int, [_c_vp, _c_int, _c_int] + [_c_vp] * 8),
     "cgcn_metrics_workspace_bytes": (_c_sz, [ctypes.c_longlong, _c_int]),
     "cgcn_multilabel_metrics": (_c_int, [_c_vp, ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_float, _c_vp, _c_vp, _c_sz]),
+    "cgcn_multilabel_metrics_nonneg": (_c_int, [_c_vp, ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_float, _c_vp, _c_vp, _c_vp, _c_sz]),
     "cgcn_sgd_step": (_c_int, [_c_vp, ctypes.c_longlong, _c_vp, _c_vp, _c_vp, _c_float, _c_float, _c_float, _c_int, _c_float, _c_vp]),
 }
-ABI_VERSION = 21
+ABI_VERSION = 22
 _lib = None
 
 

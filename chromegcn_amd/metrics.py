@@ -12,9 +12,9 @@ import torch
 from . import _lib
 
 
-def multilabel_metrics(probs: torch.Tensor, targets: torch.Tensor, fdr_cutoff: float = 0.5) -> Dict[str, torch.Tensor]:
-    """probs, targets: [n, C] float32 CUDA tensors.  Returns per-label tensors [C] (NaN where undefined):
-    'auroc', 'aupr', 'recall_at_fdr', 'average_precision'."""
+def _metrics_raw(probs: torch.Tensor, targets: torch.Tensor, fdr_cutoff: float, nonneg: bool) -> torch.Tensor:
+    """one launch sequence; returns a flat device tensor: [4 * C] results, then (nonneg path) the `bad` word as element 4 C
+    (bit pattern of an int32: nonzero = a score was negative or NaN and the results are to be discarded)"""
     if not probs.is_cuda or not targets.is_cuda:
         raise RuntimeError("chromegcn_amd.metrics: tensors must be on the GPU (there is no CPU fallback; "
                            "the reference's sklearn path is utils/metrics.py)")
@@ -28,10 +28,33 @@ def multilabel_metrics(probs: torch.Tensor, targets: torch.Tensor, fdr_cutoff: f
     if ws_bytes == 0:
         raise RuntimeError("chromegcn_amd.metrics: unsupported size n=%d C=%d" % (n, C))
     ws = torch.empty(ws_bytes, device=probs.device, dtype=torch.uint8)
-    out = torch.empty((4, C), device=probs.device, dtype=torch.float32)
-    _lib.check(lib.cgcn_multilabel_metrics(_lib.stream_ptr(), n, C, probs.data_ptr(), targets.data_ptr(), float(fdr_cutoff),
-                                           out.data_ptr(), ws.data_ptr(), ws_bytes), "cgcn_multilabel_metrics")
+    out = torch.empty(4 * C + 1, device=probs.device, dtype=torch.float32)
+    if nonneg:
+        _lib.check(lib.cgcn_multilabel_metrics_nonneg(_lib.stream_ptr(), n, C, probs.data_ptr(), targets.data_ptr(), float(fdr_cutoff),
+                                                      out.data_ptr(), out.data_ptr() + 16 * C, ws.data_ptr(), ws_bytes),
+                   "cgcn_multilabel_metrics_nonneg")
+    else:
+        _lib.check(lib.cgcn_multilabel_metrics(_lib.stream_ptr(), n, C, probs.data_ptr(), targets.data_ptr(), float(fdr_cutoff),
+                                               out.data_ptr(), ws.data_ptr(), ws_bytes), "cgcn_multilabel_metrics")
+    return out
+
+
+def _split(flat: torch.Tensor, C: int) -> Dict[str, torch.Tensor]:
+    out = flat[:4 * C].view(4, C)
     return {"auroc": out[0], "aupr": out[1], "recall_at_fdr": out[2], "average_precision": out[3]}
+
+
+def multilabel_metrics(probs: torch.Tensor, targets: torch.Tensor, fdr_cutoff: float = 0.5) -> Dict[str, torch.Tensor]:
+    """probs, targets: [n, C] float32 CUDA tensors.  Returns per-label tensors [C] (NaN where undefined):
+    'auroc', 'aupr', 'recall_at_fdr', 'average_precision'.
+    Scores are taken for probabilities first (non-negative: 32-bit keys and the library's own segmented radix sort,
+    cgcn_multilabel_metrics_nonneg); if the device reports a negative score or a NaN the general path (any float scores,
+    64-bit keys) runs instead -- same results either way where both apply."""
+    C = probs.shape[1]
+    flat = _metrics_raw(probs, targets, fdr_cutoff, nonneg=True)
+    if int(flat[4 * C:].view(torch.int32).item()) != 0:
+        flat = _metrics_raw(probs, targets, fdr_cutoff, nonneg=False)
+    return _split(flat, C)
 
 
 def compute_metrics(all_predictions, all_targets, loss, args=None, elapsed=0.0, data_dict=None, cell_type=None,
@@ -42,7 +65,11 @@ def compute_metrics(all_predictions, all_targets, loss, args=None, elapsed=0.0, 
     this does NOT threshold all_predictions in place (utils/evals.py:99-100)."""
     p = torch.as_tensor(all_predictions).to(device=device, dtype=torch.float32)
     t = torch.as_tensor(all_targets).to(device=device, dtype=torch.float32)
-    m = {k: v.double().cpu().numpy() for k, v in multilabel_metrics(p, t, 0.5).items()}
+    C = p.shape[1]
+    host = _metrics_raw(p, t, 0.5, nonneg=True).cpu()          # ONE device-to-host copy: results + the `bad` word
+    if int(host[4 * C:].view(torch.int32).item()) != 0:        # scores that are not probabilities: the general path
+        host = _metrics_raw(p, t, 0.5, nonneg=False).cpu()
+    m = {k: v.double().numpy() for k, v in _split(host, C).items()}
     auc = m["auroc"][~np.isnan(m["auroc"])]
     aupr = m["aupr"][~np.isnan(m["aupr"])]
     fdr = m["recall_at_fdr"][~np.isnan(m["recall_at_fdr"])]

@@ -50,7 +50,7 @@ extern "C" {
 #define CGCN_ERR_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after a launch      */
 #define CGCN_ERR_WORKSPACE (-4)   /* workspace too small (see cgcn_*_workspace_bytes)    */
 
-#define CGCN_ABI_VERSION 21
+#define CGCN_ABI_VERSION 22
 
 typedef void *cgcn_stream_t; /* hipStream_t */
 
@@ -408,6 +408,18 @@ size_t cgcn_metrics_workspace_bytes(long long n, int C);
  */
 int cgcn_multilabel_metrics(cgcn_stream_t stream, long long n, int C, const float *probs, const float *targets,
                             float fdr_cutoff, float *out, void *workspace, size_t workspace_bytes);
+
+/*
+ * The same metrics for NON-NEGATIVE scores -- probabilities, which is what the reference's compute_metrics is given
+ * (finetune.py:52 stores F.sigmoid(pred); utils/evals.py:26): with the sign known a (score, target) pair is a 32-bit
+ * key and the library sorts every label's list with its own segmented radix sort (4 passes of 8 bits over all labels
+ * at once) instead of one device-wide sort of 64-bit keys; same `out`, same workspace size
+ * (cgcn_metrics_workspace_bytes), same tie rule, bit-identical results.
+ * bad: device int32[1]; set to 1 when a score was negative or NaN -- `out` is then unspecified and the caller repeats
+ * the call with cgcn_multilabel_metrics (chromegcn_amd.metrics does; it reads `bad` with the results, no extra sync).
+ */
+int cgcn_multilabel_metrics_nonneg(cgcn_stream_t stream, long long n, int C, const float *probs, const float *targets,
+                                   float fdr_cutoff, float *out, int32_t *bad, void *workspace, size_t workspace_bytes);
 
 /*
  * torch.optim.SGD step on one flat fp32 buffer (utils/util_methods.py:14-19 builds

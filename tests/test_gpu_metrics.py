@@ -66,3 +66,49 @@ def test_compute_metrics_keys_and_aggregation(golden):
     assert out["loss"] == 1.25 and out["time"] == 0.5
     with pytest.raises(RuntimeError):
         M.multilabel_metrics(torch.zeros(4, 2), torch.zeros(4, 2))
+
+
+@pytest.mark.parametrize("n,C", [(1, 1), (2, 3), (63, 2), (4096, 3), (4097, 5), (70000, 9), (12289, 103), (37, 2600)])
+def test_probability_path_equals_general_path_bit_for_bit(n, C):
+    """cgcn_multilabel_metrics_nonneg (32-bit keys, the library's own segmented radix sort: partial last tiles, one-tile and
+    many-tile labels, the flat pack and -- thousands of labels -- the tile pack) against cgcn_multilabel_metrics (64-bit keys,
+    one device-wide sort) on probabilities: same curve kernels behind both, so the results must be the same bits."""
+    g = torch.Generator().manual_seed(n * 131 + C)
+    tg = (torch.rand(n, C, generator=g) < 0.2).float()
+    pr = torch.sigmoid(torch.randn(n, C, generator=g) * 2 + tg)
+    pr[:, 0] = (pr[:, 0] * 50).round() / 50          # heavy ties
+    if C > 1:
+        pr[:, 1] = 0.5 + pr[:, 1] * 1e-4             # every key in a handful of top digits (skew)
+    if C > 2:
+        pr[::3, 2] = 0.0                             # exact zeros, and -0.0 folded onto them
+        pr[1::3, 2] = -0.0
+    pr, tg = pr.to(DEV), tg.to(DEV)
+    fast = M._metrics_raw(pr, tg, 0.5, nonneg=True).cpu()
+    slow = M._metrics_raw(pr, tg, 0.5, nonneg=False).cpu()
+    assert int(fast[4 * C:].view(torch.int32).item()) == 0
+    a, b = fast[:4 * C].numpy(), slow[:4 * C].numpy()
+    assert np.array_equal(a, b, equal_nan=True), np.abs(np.nan_to_num(a) - np.nan_to_num(b)).max()
+
+
+def test_probability_path_on_views_that_are_not_16_byte_aligned():
+    g = torch.Generator().manual_seed(3)
+    n, C = 5000, 7
+    buf_p = torch.rand(n * C + 3, generator=g).to(DEV)
+    buf_t = (torch.rand(n * C + 3, generator=g) < 0.3).float().to(DEV)
+    pr, tg = buf_p[1:1 + n * C].view(n, C), buf_t[3:3 + n * C].view(n, C)   # storage offsets 4 and 12 bytes
+    assert pr.data_ptr() % 16 != 0 and pr.is_contiguous()
+    fast = M._metrics_raw(pr, tg, 0.5, nonneg=True).cpu()[:4 * C].numpy()
+    want = O.multilabel_metrics_np(tg.cpu().numpy().astype(np.float64), pr.cpu().numpy())
+    for j, k in enumerate(("auroc", "aupr", "recall_at_fdr", "average_precision")):
+        np.testing.assert_allclose(fast[j * C:(j + 1) * C], want[k], rtol=3e-6, atol=3e-7, equal_nan=True, err_msg=k)
+
+
+def test_probability_path_reports_scores_that_are_not_probabilities():
+    pr = torch.rand(300, 4)
+    pr[17, 2] = -0.25
+    tg = (torch.rand(300, 4) < 0.5).float()
+    flat = M._metrics_raw(pr.to(DEV), tg.to(DEV), 0.5, nonneg=True)
+    assert int(flat[16:].view(torch.int32).item()) != 0
+    pr[17, 2] = float("nan")
+    flat = M._metrics_raw(pr.to(DEV), tg.to(DEV), 0.5, nonneg=True)
+    assert int(flat[16:].view(torch.int32).item()) != 0
