@@ -965,6 +965,22 @@ def main():
             ev()
         ev_el, _, _ = timed(ev, max(steps // 2, 3))
         extras["inference_windows_per_s"] = windows * max(steps // 2, 3) / ev_el
+        if genome and not multi:
+            # the reference's compute_metrics on this split's predictions (runner.py:41 -> utils/evals.py:26),
+            # on the device; ms per call incl. the one device-to-host copy of the per-label results
+            from chromegcn_amd import metrics as _M
+            pm, tm, _ = stage.run_split("train", names, to_cpu=False)
+            for _ in range(2):
+                _M.compute_metrics(pm, tm, 0.0, None, 0.0)
+            torch.cuda.synchronize()
+            t0m = time.perf_counter()
+            for _ in range(5):
+                _M.compute_metrics(pm, tm, 0.0, None, 0.0)
+            torch.cuda.synchronize()
+            extras["metrics_train_split_ms"] = (time.perf_counter() - t0m) / 5 * 1e3
+            extras["metrics_note"] = ("chromegcn_amd.metrics.compute_metrics (AUROC / AUPR / recall@FDR50 / mAP per label) on the "
+                                      "train split's %d x %d predictions, on the device: 32-bit keys, the library's segmented radix "
+                                      "sort; not part of `value`" % (pm.shape[0], pm.shape[1]))
         # the engine's default configuration: first-layer aggregation cached, no gradient w.r.t. the input features
         # (finetune.py:33-34 asks for it but nothing can observe it)
         stage.cache_input_aggregation = True

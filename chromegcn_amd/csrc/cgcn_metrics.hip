@@ -340,7 +340,7 @@ __global__ __launch_bounds__(64) void k_metrics_final(long long n, int C, int nc
 // pack kernel already writes label c's keys to the contiguous segment [c n, (c + 1) n)), and the sort is written here: a
 // SEGMENTED least-significant-digit radix sort, 8-bit digits over key bits 1 .. 31 (4 passes; the target bit does not
 // take part -- ties are one curve point whatever their order), every pass three launches over all labels at once:
-//   k_rs_pass<false>  per 4096-key tile: digit counts                                   -> hist[label][tile][256]
+//   k_rs_pass<false>  per 4096-key tile: digit counts (LDS atomics, a lane's runs of equal digits merged) -> hist[label][tile][256]
 //   k_rs_scan         per label: exclusive prefix of a digit's counts over the tiles (in place) and over the digits
 //   k_rs_pass<true>   per tile: stable local ranks, keys staged in LDS in digit order, runs written out coalesced
 // 12 B per key and pass (two reads, one write) instead of 16 B x 2 for five device-wide passes over 64-bit keys, and no
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void k_metrics_pack32_flat(long long n, int C,
   }
 }
 
-template <bool SCATTER, bool MATCH = true>
+template <bool SCATTER>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_pass(long long n, int T, int shift, const unsigned* __restrict__ in,
                                                          unsigned* __restrict__ out, unsigned* __restrict__ hist,
                                                          const unsigned* __restrict__ base) {
@@ -458,11 +458,26 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_pass(long long n, int T, int 
     key[r] = i < n ? src[i] : 0xFFFFFFFFu;
   }
   unsigned* mycnt = cnt[w];
-  if (!SCATTER && !MATCH) {
-    // counts only, digits of mantissa bits (about uniform): one LDS atomic per key, nothing waits for it
+  if (!SCATTER) {
+    // counts only: a lane adds a RUN of equal digits among its own 16 keys with one LDS atomic (no return value, nothing
+    // waits for it).  Mantissa digits (about uniform): a run is one key and the 64 lanes of an atomic rarely meet in a word;
+    // the top digit (exponent bits: a handful of values hold every key): a lane's 16 keys are one or two runs, so the
+    // same-address serialisation that 16 atomics per lane would pay is paid once.
+    unsigned cd = (key[0] >> shift) & 255u;
+    unsigned cc = w0 + lane < n ? 1u : 0u;
 #pragma unroll
-    for (int r = 0; r < RS_ROUNDS; ++r)
-      if (w0 + r * WAVE + lane < n) atomicAdd(&mycnt[(key[r] >> shift) & 255u], 1u);
+    for (int r = 1; r < RS_ROUNDS; ++r) {
+      const unsigned d = (key[r] >> shift) & 255u;
+      if (w0 + r * WAVE + lane < n) {
+        if (d == cd) ++cc;
+        else {
+          if (cc) atomicAdd(&mycnt[cd], cc);
+          cd = d;
+          cc = 1u;
+        }
+      }
+    }
+    if (cc) atomicAdd(&mycnt[cd], cc);
   } else {
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; ++r) {
@@ -481,16 +496,12 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_pass(long long n, int T, int 
       }
       const unsigned below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));   // peers in lower lanes
       const unsigned peers = (unsigned)__builtin_popcount(mlo) + (unsigned)__builtin_popcount(mhi);
-      if (!SCATTER) {   // counts only, top digit (exponent bits: a few values hold every key): one atomic per group of peers
-        if (valid && below == 0) atomicAdd(&mycnt[d], peers);
-      } else {
-        // the wave's running count of the digit: read by every peer, rewritten by the first one.  LDS operations of one
-        // wave complete in issue order, so the next round's read sees this write; relaxed atomics keep the compiler from
-        // holding the word in a register across rounds.
-        const unsigned prior = __hip_atomic_load(&mycnt[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        rank[r] = (unsigned short)(prior + below);
-        if (valid && below == 0) __hip_atomic_store(&mycnt[d], prior + peers, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-      }
+      // the wave's running count of the digit: read by every peer, rewritten by the first one.  LDS operations of one
+      // wave complete in issue order, so the next round's read sees this write; relaxed atomics keep the compiler from
+      // holding the word in a register across rounds.
+      const unsigned prior = __hip_atomic_load(&mycnt[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      rank[r] = (unsigned short)(prior + below);
+      if (valid && below == 0) __hip_atomic_store(&mycnt[d], prior + peers, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
   }
   __syncthreads();
@@ -653,10 +664,9 @@ int cgcn_multilabel_metrics_nonneg(cgcn_stream_t stream, long long n, int C, con
     unsigned* a = k_a;
     unsigned* b = k_b;
     for (int shift = 1; shift < 32; shift += 8) {   // key bits 1 .. 31: four passes, the sorted keys end up in k_a again
-      if (shift + 8 >= 32) hipLaunchKernelGGL((k_rs_pass<false, true>), dim3(T, C), dim3(RS_THREADS), 0, st, n, T, shift, (const unsigned*)a, b, hist, (const unsigned*)base);
-      else hipLaunchKernelGGL((k_rs_pass<false, false>), dim3(T, C), dim3(RS_THREADS), 0, st, n, T, shift, (const unsigned*)a, b, hist, (const unsigned*)base);
+      hipLaunchKernelGGL(k_rs_pass<false>, dim3(T, C), dim3(RS_THREADS), 0, st, n, T, shift, (const unsigned*)a, b, hist, (const unsigned*)base);
       hipLaunchKernelGGL(k_rs_scan, dim3(C), dim3(256), 0, st, T, hist, base);
-      hipLaunchKernelGGL((k_rs_pass<true, true>), dim3(T, C), dim3(RS_THREADS), 0, st, n, T, shift, (const unsigned*)a, b, hist, (const unsigned*)base);
+      hipLaunchKernelGGL(k_rs_pass<true>, dim3(T, C), dim3(RS_THREADS), 0, st, n, T, shift, (const unsigned*)a, b, hist, (const unsigned*)base);
       unsigned* tsw = a; a = b; b = tsw;
     }
   }
