@@ -112,3 +112,12 @@ def test_probability_path_reports_scores_that_are_not_probabilities():
     pr[17, 2] = float("nan")
     flat = M._metrics_raw(pr.to(DEV), tg.to(DEV), 0.5, nonneg=True)
     assert int(flat[16:].view(torch.int32).item()) != 0
+
+
+def test_metrics_of_an_empty_split_are_nan_on_both_paths():
+    pr, tg = torch.zeros(0, 5, device=DEV), torch.zeros(0, 5, device=DEV)
+    for nonneg in (True, False):
+        flat = M._metrics_raw(pr, tg, 0.5, nonneg=nonneg).cpu()
+        assert torch.isnan(flat[:20]).all()
+        if nonneg:
+            assert int(flat[20:].view(torch.int32).item()) == 0
