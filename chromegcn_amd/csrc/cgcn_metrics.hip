@@ -4,12 +4,16 @@
 // the CPU with one scikit-learn call per label per metric after every split (runner.py:41,45,51 ->
 // utils/evals.py:89-92 -> utils/metrics.py:148-183,238-253): AUROC, area under the precision-recall curve
 // (trapezoid over sklearn's precision_recall_curve points), recall at the first point with FDR <= cutoff,
-// and average precision (mAP).  Here: ONE device-wide radix sort (rocprim::radix_sort_keys, called directly) of 64-bit keys
-// (label | descending score | target) -- every label's list comes out contiguous and sorted and the whole chip
-// works on it (a segmented sort with one long segment per label used a fraction of the chip) -- and a chunked scan
-// of the sorted lists (one wave per 4096-element chunk),
-// treating tied scores as one curve point exactly like sklearn's distinct-threshold curves.  All curve
-// arithmetic is fp64 and summed in a fixed order.
+// and average precision (mAP).  Here, two paths that share everything but the sort:
+//   * scores that are probabilities (non-negative: what the reference passes, finetune.py:52): 32-bit keys
+//     [descending score image | target], label c's keys in the contiguous segment [c n, (c + 1) n), sorted by the segmented
+//     radix sort written in this file (cgcn_multilabel_metrics_nonneg; see "Non-negative scores" below);
+//   * any float scores: ONE device-wide radix sort (rocprim::radix_sort_keys, called directly) of 64-bit keys
+//     (label | descending score | target) -- every label's list comes out contiguous and sorted and the whole chip works on
+//     it (a rocprim segmented sort with one long segment per label used a fraction of the chip) -- cgcn_multilabel_metrics;
+// then a chunked scan of the sorted lists (one wave per 4096-element chunk), treating tied scores as one curve point exactly
+// like sklearn's distinct-threshold curves.  All curve arithmetic is fp64 and summed in a fixed order; counts are integers
+// (ballot + popcount).
 #include <cstring>  // rocprim 4.x headers use memset without including it
 #include <rocprim/rocprim.hpp>
 
@@ -279,7 +283,12 @@ __global__ __launch_bounds__(64) void k_metrics_chunks(long long n, int nch, con
         s_aupr += (rec_ - pr) * (prec + pp) * 0.5;
         s_ap += (rec_ - pr) * prec;
       }
-      const unsigned long long qb = __ballot(end && (1.0 - prec) <= fdr_cutoff);
+      // recall at FDR <= cutoff: utils/metrics.py:153-154 compares 1 - tps / (tps + fps) (an IEEE quotient) with the cutoff,
+      // and precision is EXACTLY 1/2 whenever tp = fp at a run end -- 7 * (1/14 refined) is not.  Where the fast quotient
+      // lands within 1e-9 of the cutoff the predicate is taken from the true division (a handful of lanes per label).
+      double fdr = 1.0 - prec;
+      if (end && __builtin_fabs(fdr - fdr_cutoff) < 1e-9) fdr = 1.0 - tp / tot;
+      const unsigned long long qb = __ballot(end && fdr <= fdr_cutoff);
       const int last = eb ? 63 - __builtin_clzll(eb) : 0;
       const int lq = qb ? 63 - __builtin_clzll(qb) : 0;
       // (wave-uniform source lanes: v_readlane, not a cross-lane permute)

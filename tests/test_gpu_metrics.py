@@ -121,3 +121,22 @@ def test_metrics_of_an_empty_split_are_nan_on_both_paths():
         assert torch.isnan(flat[:20]).all()
         if nonneg:
             assert int(flat[20:].view(torch.int32).item()) == 0
+
+
+def test_recall_at_fdr_when_precision_is_exactly_the_cutoff():
+    """Positives and negatives alternating down the ranking: precision is EXACTLY 1/2 at every even depth (tp = fp), so
+    1 - precision <= 0.5 holds there with equality in the reference's float64 quotient (utils/metrics.py:153-154) -- at
+    depths such as 14, 22, 26, 28 a product with a reciprocal lands one ulp below 1/2 and would miss the deepest such
+    point.  Every label stops alternating at another depth; scores are distinct."""
+    C, n = 40, 400
+    tg = np.zeros((n, C), dtype=np.float32)
+    for c in range(C):
+        k = 1 + c                                   # c-th label alternates P N for 2 (c + 1) elements, then only negatives
+        tg[0:2 * k:2, c] = 1.0
+    pr = np.repeat(np.linspace(0.99, 0.01, n, dtype=np.float32)[:, None], C, axis=1)
+    want = O.multilabel_metrics_np(tg.astype(np.float64), pr)
+    got = M.multilabel_metrics(torch.from_numpy(pr).to(DEV), torch.from_numpy(tg).to(DEV))
+    np.testing.assert_allclose(got["recall_at_fdr"].cpu().numpy(), want["recall_at_fdr"], rtol=1e-6, atol=0, err_msg="recall_at_fdr")
+    assert (want["recall_at_fdr"] == 1.0).all()     # the deepest point with tp = fp holds every positive
+    for k in ("auroc", "aupr", "average_precision"):
+        np.testing.assert_allclose(got[k].cpu().numpy(), want[k], rtol=3e-6, atol=3e-7, equal_nan=True, err_msg=k)
