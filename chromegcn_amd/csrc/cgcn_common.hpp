@@ -114,6 +114,54 @@ static inline uint32_t dropout_threshold(float p) {
   return (uint32_t)t;
 }
 
+// ------------------------------------------------------------------------------------------
+// Accumulate mode of the head's BatchNorm batch statistics (round 5, d = 128, split-size tables): instead of one
+// (mean, M2) record per k_layer_dense workgroup that k_head_bn_finalize merges in a launch of its own -- a launch that
+// costs 6-7 us of the epoch per chromosome although it computes for 3 (profiles/r05_tiny_kernels_bound.txt) -- every
+// workgroup ADDS its sum x and sum x^2 per (strand, column) to STAT_ACC_SLOTS copies of the totals as 64-bit FIXED-POINT
+// integer atomics: integer addition is associative, so the totals are the same bits whatever order the workgroups arrive
+// in (float atomics would not be), and the head kernel derives mean / invstd from them in its prologue.
+//   word ((slot S + s) D + c) 2 + q,  q = 0: sum relu(x), q = 1: sum relu(x)^2, value * 2^STAT_ACC_FBITS
+//   word STAT_ACC_SLOTS S D 2: nonzero when a workgroup's partial did not fit: the statistics then read NaN (loudly wrong
+//   instead of silently wrapped)
+// One word per value, 32 fraction bits: resolution 1.2e-10 per add (<= 6e-8 on a total: 4e-6 of sum x^2 even for |x| ~ 1e-3
+// at n = 15 000); a workgroup's partial must stay below 2^22 so that the total of <= 512 workgroups stays below 2^31, i.e.
+// sum relu(x)^2 < 2.1e9 per column -- rms |x| < 265 at n = 30 000.  (Two words would lift the range but cost 3-6 us per
+// launch instead of 1: tools/micro/atomic_tail.hip; the engine falls back to records when a chromosome's features are
+// outside the range, finetune.GCNStage.add_chromosome.)
+// Slots: 512 adders on one word serialise (+10 us per word, same file); 8 copies cost +1 us.
+// ------------------------------------------------------------------------------------------
+constexpr int STAT_ACC_SLOTS = 8;
+constexpr int STAT_ACC_FBITS = 32;
+static inline size_t stat_acc_words(int S, int d) { return (size_t)STAT_ACC_SLOTS * S * d * 2 + 2; }
+__device__ __forceinline__ void stat_acc_add(unsigned long long* acc, int S, int D, int slot, int s, int c, double sum1, double sum2) {
+  const double sc = (double)(1ll << STAT_ACC_FBITS), lim = 4194304.0;   // 2^22
+  unsigned long long* w = acc + ((size_t)(slot * S + s) * D + c) * 2;
+  if (!(__builtin_fabs(sum1) < lim) || !(sum2 < lim)) {
+    atomicOr(acc + (size_t)STAT_ACC_SLOTS * S * D * 2, 1ull);
+    return;
+  }
+  atomicAdd(&w[0], (unsigned long long)(long long)__builtin_rint(sum1 * sc));
+  atomicAdd(&w[1], (unsigned long long)(long long)__builtin_rint(sum2 * sc));
+}
+// mean, biased variance sum M2 = sum (x - mean)^2 of (strand s, column c) over n rows from the totals
+__device__ __forceinline__ void stat_acc_get(const unsigned long long* __restrict__ acc, int S, int D, int s, int c, int n,
+                                             double& mean, double& m2) {
+  long long t1 = 0, t2 = 0;
+#pragma unroll
+  for (int slot = 0; slot < STAT_ACC_SLOTS; ++slot) {
+    const unsigned long long* w = acc + ((size_t)(slot * S + s) * D + c) * 2;
+    t1 += (long long)w[0];
+    t2 += (long long)w[1];
+  }
+  const double isc = 1.0 / (double)(1ll << STAT_ACC_FBITS);
+  const double s1 = (double)t1 * isc, s2 = (double)t2 * isc;
+  mean = s1 / (double)n;
+  m2 = s2 - mean * s1;
+  if (m2 < 0.0) m2 = 0.0;
+  if (acc[(size_t)STAT_ACC_SLOTS * S * D * 2] != 0ull) mean = m2 = __builtin_nan("");
+}
+
 #define HEAD_STREAM_ID 0x4845u  // dropout stream of the classifier head ("HE")
 
 // Optional prologue of k_bwd_rowlocal for the LAST gated layer: instead of reading dL/dXn it is

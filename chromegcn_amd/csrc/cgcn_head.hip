@@ -1069,6 +1069,32 @@ __global__ __launch_bounds__(512, HF_LOWREG ? 4 : 1) void k_head_fused(int n, in
 // accumulators -- lives in the SAME 40 registers).  LDS: W_out 72 KB + two Yt + two Pt tiles 73 KB.
 // Same partial records, label passes and results as k_head_fused.
 // ------------------------------------------------------------------------------------------
+// Accumulate mode (cgcn_common.hpp, STAT_ACC_*; sa.acc != nullptr): the batch statistics come from the integer totals
+// cgcn_layer_fwd left, every lane decodes the columns it needs in its prologue (`mean` / `invstd` are then not read), and the
+// first workgroup of the first label pass does what k_head_bn_finalize did besides: save_mean / save_invstd for the backward,
+// the running statistics (forward strand, then reverse: the reference calls the model once per strand) and the call count.
+struct HeadStatAcc {
+  const unsigned long long* acc;
+  float eps, momentum;
+  float* run_mean;
+  float* run_var;
+  long long* nbt;
+  float* save_mean;
+  float* save_invstd;
+};
+__device__ __forceinline__ void head_stat(const HeadStatAcc& sa, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                          int n, int S, int D, int s, int c, float& mu, float& is) {
+  if (sa.acc) {
+    double m, m2;
+    stat_acc_get(sa.acc, S, D, s, c, n, m, m2);
+    mu = (float)m;
+    is = (float)(1.0 / sqrt(m2 / (double)n + (double)sa.eps));
+  } else {
+    mu = mean[s * D + c];
+    is = invstd[s * D + c];
+  }
+}
+
 #ifndef HEAD_RS
 #define HEAD_RS 1   // 0: the 8-wave k_head_fused at d = 128 as well (A/B builds)
 #endif
@@ -1109,7 +1135,7 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
                                                         const unsigned long long* __restrict__ rng_state, float inv_count,
                                                         float* __restrict__ probs, float* __restrict__ loss_part,
                                                         float* __restrict__ dym, float* __restrict__ part,
-                                                        int c0, int Cp, int CPT, int first_, int last_) {
+                                                        int c0, int Cp, int CPT, int first_, int last_, HeadStatAcc sa) {
   constexpr int D = 128, TR = 16 * NRB, EPL = 2, RPW = TR / 8, KQ = D / 4;   // NRB: 16-row MFMA blocks per tile (2 = HEADB_TILE)
   constexpr int CP = 128, CBMAX = 8;
   constexpr int LDP = CP + 18, LDY = D + 16, LDW = D + 16;
@@ -1158,10 +1184,7 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
       gw[e] = bn_w[c];
       gb[e] = bn_b[c];
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        mu[s][e] = mean[(s < S ? s : 0) * D + c];
-        is[s][e] = invstd[(s < S ? s : 0) * D + c];
-      }
+      for (int s = 0; s < 2; ++s) head_stat(sa, mean, invstd, n, S, D, s < S ? s : 0, c, mu[s][e], is[s][e]);
     }
     // this wave's X rows of a tile are requested one tile ahead (at the top of phase B of the tile before: in flight
     // during its pred product and epilogue); the targets of this lane's logits at the end of that phase B
@@ -1305,9 +1328,25 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
     for (int i = 0; i < NB; ++i) accW[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float sdy[2] = {0.f, 0.f}, sdyx[2] = {0.f, 0.f}, mu[2], is[2];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      mu[s] = mean[(s < S ? s : 0) * D + own * 16 + (lane & 15)];
-      is[s] = invstd[(s < S ? s : 0) * D + own * 16 + (lane & 15)];
+    for (int s = 0; s < 2; ++s) head_stat(sa, mean, invstd, n, S, D, s < S ? s : 0, own * 16 + (lane & 15), mu[s], is[s]);
+    if (sa.acc && blockIdx.x == 0 && first && wave == 8) {
+      // (one wave of the first workgroup: two columns per lane, both strands; see HeadStatAcc)
+      if (lane == 0 && sa.nbt) sa.nbt[0] += S;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int c = lane * 2 + u;
+        float rm = sa.run_mean[c], rv = sa.run_var[c];
+        for (int st = 0; st < S; ++st) {
+          double m, m2;
+          stat_acc_get(sa.acc, S, D, st, c, n, m, m2);
+          sa.save_mean[st * D + c] = (float)m;
+          sa.save_invstd[st * D + c] = (float)(1.0 / sqrt(m2 / (double)n + (double)sa.eps));
+          rm = (1.f - sa.momentum) * rm + sa.momentum * (float)m;
+          rv = (1.f - sa.momentum) * rv + sa.momentum * (float)(m2 / (double)(n - 1));
+        }
+        sa.run_mean[c] = rm;
+        sa.run_var[c] = rv;
+      }
     }
     __syncthreads();   // Wl complete
     // X of this lane's (row, column) elements of a tile, for the BatchNorm sums of its epilogue: requested a whole matrix
@@ -1690,7 +1729,12 @@ static int head_train_impl(cgcn_stream_t stream, int n, int S, int d, int C, con
   if (!X || !bn_w || !bn_b || !Wout || !bout || !target || !probs || !loss || !workspace || !run_mean || !run_var ||
       !save_mean || !save_invstd || n < 2)
     return CGCN_ERR_BAD_ARG;
-  if (col_stats && (col_stats_rows < 1 || col_stats_tiles != (n + col_stats_rows - 1) / col_stats_rows)) return CGCN_ERR_BAD_ARG;
+  // accumulate mode (cgcn_layer_fwd_colstats_tiles reported rows = -1): the buffer holds integer totals, not records
+  const size_t acc_tile_bytes = (size_t)S * d * 2 * sizeof(float);
+  const bool stat_acc = col_stats && col_stats_rows == -1;
+  if (stat_acc && (d != 128 || !HEAD_RS || (size_t)col_stats_tiles * acc_tile_bytes < stat_acc_words(S, d) * 8 || ((uintptr_t)col_stats & 7)))
+    return CGCN_ERR_BAD_ARG;
+  if (col_stats && !stat_acc && (col_stats_rows < 1 || col_stats_tiles != (n + col_stats_rows - 1) / col_stats_rows)) return CGCN_ERR_BAD_ARG;
   const bool drop = dropout_p > 0.f;
   if (drop && (!rng_state || dropout_p >= 1.f)) return CGCN_ERR_BAD_ARG;
   if (workspace_bytes < cgcn_head_workspace_bytes(n, S, d, C)) return CGCN_ERR_WORKSPACE;
@@ -1714,10 +1758,15 @@ static int head_train_impl(cgcn_stream_t stream, int n, int S, int d, int C, con
     else hipLaunchKernelGGL((k_head_colstats<256>), dim3(nblk), dim3(256), 0, st, n, S, rpb, X, w_stats);
     if ((rc = launch_status())) return rc;
   }
-  if (phases & 1) {
+  if ((phases & 1) && !stat_acc) {
     launch_bn_finalize(st, n, S, d, nblk, rpb, stats, momentum, eps, run_mean, run_var, num_batches_tracked, save_mean, save_invstd);
     if ((rc = launch_status())) return rc;
   }
+  // accumulate mode: no finalize launch; the main kernel reads the totals (and its first workgroup finishes the bookkeeping --
+  // only when the whole call runs: a profiling call of phase 2 alone must not touch the running statistics again)
+  const HeadStatAcc sa = {stat_acc ? (const unsigned long long*)col_stats : nullptr, eps, momentum,
+                          run_mean, run_var, (phases & 1) ? num_batches_tracked : nullptr, save_mean, save_invstd};
+  const HeadStatAcc sa_prof = {sa.acc, eps, 0.f, run_mean, run_var, nullptr, save_mean, save_invstd};
   const int P = head_bwd_partials(n);
   const int CP = head_cp(C);
   const float keep_scale = drop ? 1.f / (1.f - dropout_p) : 1.f;
@@ -1744,7 +1793,7 @@ static int head_train_impl(cgcn_stream_t stream, int n, int S, int d, int C, con
 #define HRS2(M_, NB_, DR_, NRB_)                                                                                       \
         hipLaunchKernelGGL((k_head_fused_rs<M_, NB_, DR_, NRB_>), dim3(P), dim3(1024), 0, st, n, S, C, X, bn_w, bn_b, save_mean, save_invstd, \
                          Wout, bout, target, keep_scale, thresh, rng_state, inv_count, probs, w_loss, w_dym, w_part, c0, Cp, \
-                         CP, first, last)
+                         CP, first, last, (phases & 1) ? sa : sa_prof)
 #define HRS(M_, NB_)                                                                                                   \
       do {                                                                                                             \
         if (thresh) { if (tr16) HRS2(M_, NB_, true, 1); else HRS2(M_, NB_, true, 2); }                                  \

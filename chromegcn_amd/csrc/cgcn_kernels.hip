@@ -682,7 +682,8 @@ __global__ __launch_bounds__(512, DENSE_WPS(D)) void k_layer_dense(int n, int nt
                                                     float* __restrict__ Zout, float* __restrict__ gate,
                                                     float keep_scale, uint32_t thresh,
                                                     const unsigned long long* __restrict__ rng_state,
-                                                    uint32_t stream_id, float* __restrict__ colstats, int stat_chunk) {
+                                                    uint32_t stream_id, float* __restrict__ colstats, int stat_chunk,
+                                                    int stat_acc) {
   constexpr int ROWS = 16 * MB;      // MFMA rows in the tile
   constexpr int R = ROWS / S;        // nodes in the tile
   constexpr int CBW = (D == 128) ? 1 : 2;  // 16-wide output column blocks per wave
@@ -872,9 +873,15 @@ __global__ __launch_bounds__(512, DENSE_WPS(D)) void k_layer_dense(int n, int nt
     __syncthreads();  // T is rewritten by the next tile
   }
   if (colstats && threadIdx.x < S * D && tfirst < tend) {
-    float* out = colstats + ((size_t)blockIdx.x * S * D + threadIdx.x) * 2;
-    out[0] = st_mean;
-    out[1] = st_m2;
+    if (stat_acc) {   // accumulate mode (cgcn_common.hpp, STAT_ACC_*): this workgroup's sum x and sum x^2, formed in double
+      const double nb = (double)st_cnt, mb = (double)st_mean;
+      stat_acc_add((unsigned long long*)colstats, S, D, (int)blockIdx.x & (STAT_ACC_SLOTS - 1), (int)threadIdx.x / D,
+                   (int)threadIdx.x % D, nb * mb, (double)st_m2 + nb * mb * mb);
+    } else {
+      float* out = colstats + ((size_t)blockIdx.x * S * D + threadIdx.x) * 2;
+      out[0] = st_mean;
+      out[1] = st_m2;
+    }
   }
 }
 
@@ -1979,10 +1986,16 @@ template <int S, int D, bool HAS_VAL, typename IT = int, bool BP = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HAS_VAL ? 6 : 8))) void k_aggregate_sliced(int n, const int* __restrict__ rowptr, const IT* __restrict__ col,
                                                           const float* __restrict__ val, const float* __restrict__ rs,
                                                           const float* __restrict__ X, float* __restrict__ H,
-                                                          const int* __restrict__ order) {
+                                                          const int* __restrict__ order,
+                                                          unsigned long long* __restrict__ zero_words, int zero_count) {
   static_assert(!(BP && HAS_VAL), "the band-plus CSR holds unit entries");
   constexpr int NSL = S * D / 32, QPR = D / 32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the accumulators of the statistics the row-local launch behind this one adds to (STAT_ACC_*): zeroed here, by the launch
+  // that precedes it in the same call, so that no launch of its own is needed
+  const int zblocks = (int)gridDim.x < 8 ? (int)gridDim.x : 8;
+  if (zero_words && (int)blockIdx.x < zblocks)
+    for (int i = (int)blockIdx.x * 512 + (int)threadIdx.x; i < zero_count; i += zblocks * 512) zero_words[i] = 0ull;
   int slice, tile;
   sliced_block<NSL>(blockIdx.x, (n + 63) / 64, slice, tile);
   const size_t slice_el = (size_t)(slice / QPR) * n * D + (slice % QPR) * 32;
@@ -2381,7 +2394,8 @@ static int dropout_args(float p, const unsigned long long* rng_state, float* kee
 // H = diag(rs) Ahat X, feature-sliced: int32 column indices, or the 16-bit copy when given (implicit values only)
 static void launch_aggregate_sliced(hipStream_t st, int gblocks, int n, int S, int d, const int32_t* rowptr, const int32_t* col,
                                     const uint16_t* col16, const float* val, const float* rs, const float* X, float* H,
-                                    const int32_t* order, bool bp = false) {
+                                    const int32_t* order, bool bp = false, unsigned long long* zero_words = nullptr,
+                                    int zero_count = 0) {
 #define SD4(CALLX)                         \
   do {                                     \
     if (S == 1 && d == 128) CALLX(1, 128); \
@@ -2390,8 +2404,8 @@ static void launch_aggregate_sliced(hipStream_t st, int gblocks, int n, int S, i
     else CALLX(2, 256);                    \
   } while (0)
   if (bp) {   // band-plus: (rowptr, col / col16) is the unit-entry CSR, the band + I half comes from the LDS window
-#define CALLBP16(S_, D_) hipLaunchKernelGGL((k_aggregate_sliced<S_, D_, false, uint16_t, true>), dim3(gblocks), dim3(512), 0, st, n, rowptr, col16, nullptr, rs, X, H, order)
-#define CALLBP32(S_, D_) hipLaunchKernelGGL((k_aggregate_sliced<S_, D_, false, int, true>), dim3(gblocks), dim3(512), 0, st, n, rowptr, col, nullptr, rs, X, H, order)
+#define CALLBP16(S_, D_) hipLaunchKernelGGL((k_aggregate_sliced<S_, D_, false, uint16_t, true>), dim3(gblocks), dim3(512), 0, st, n, rowptr, col16, nullptr, rs, X, H, order, zero_words, zero_count)
+#define CALLBP32(S_, D_) hipLaunchKernelGGL((k_aggregate_sliced<S_, D_, false, int, true>), dim3(gblocks), dim3(512), 0, st, n, rowptr, col, nullptr, rs, X, H, order, zero_words, zero_count)
     if (col16) SD4(CALLBP16);
     else SD4(CALLBP32);
 #undef CALLBP16
@@ -2399,12 +2413,12 @@ static void launch_aggregate_sliced(hipStream_t st, int gblocks, int n, int S, i
     return;
   }
   if (col16) {
-#define CALL16(S_, D_) hipLaunchKernelGGL((k_aggregate_sliced<S_, D_, false, uint16_t>), dim3(gblocks), dim3(512), 0, st, n, rowptr, col16, val, rs, X, H, order)
+#define CALL16(S_, D_) hipLaunchKernelGGL((k_aggregate_sliced<S_, D_, false, uint16_t>), dim3(gblocks), dim3(512), 0, st, n, rowptr, col16, val, rs, X, H, order, zero_words, zero_count)
     SD4(CALL16);
 #undef CALL16
     return;
   }
-#define CALL(S_, D_, V_) hipLaunchKernelGGL((k_aggregate_sliced<S_, D_, V_, int>), dim3(gblocks), dim3(512), 0, st, n, rowptr, col, val, rs, X, H, order)
+#define CALL(S_, D_, V_) hipLaunchKernelGGL((k_aggregate_sliced<S_, D_, V_, int>), dim3(gblocks), dim3(512), 0, st, n, rowptr, col, val, rs, X, H, order, zero_words, zero_count)
   DISPATCH_SDV(S, d, val != nullptr, CALL);
 #undef CALL
 }
@@ -2552,8 +2566,23 @@ static int dense_stat_chunk(int n, int S, int d) {
   return (ntiles + dense_max_blocks(d) - 1) / dense_max_blocks(d);
 }
 
+// Accumulate mode of the column statistics (cgcn_common.hpp, STAT_ACC_*): split-size tables at d = 128, where the head that
+// consumes them is k_head_fused_rs.  CGCN_STAT_ACC=0 in the environment / cgcn_debug_set_stat_acc(0): records for all shapes.
+static int stat_acc_default() {
+  const char* e = getenv("CGCN_STAT_ACC");
+  return (e && *e) ? atoi(e) : 1;
+}
+static std::atomic<int> g_stat_acc{stat_acc_default()};
+void cgcn_debug_set_stat_acc(int on) { g_stat_acc.store(on < 0 ? stat_acc_default() : on); }
+static bool stat_acc_shape(int n, int S, int d) { return g_stat_acc.load() != 0 && d == 128 && n >= 2 && fwd_split_shape(n, S, d); }
+
 int cgcn_layer_fwd_colstats_tiles(int n, int S, int d, int* rows_per_tile) {
   if (check_shape(n, S, d) != CGCN_OK || n == 0) return 0;
+  if (stat_acc_shape(n, S, d)) {   // the buffer holds the integer accumulators; rows_per_tile = -1 tells cgcn_head_train
+    if (rows_per_tile) *rows_per_tile = -1;
+    const size_t tile_bytes = (size_t)S * d * 2 * sizeof(float);
+    return (int)((stat_acc_words(S, d) * 8 + tile_bytes - 1) / tile_bytes);
+  }
   const int tn = (16 * pick_mb(n, S) / S) * dense_stat_chunk(n, S, d);
   if (rows_per_tile) *rows_per_tile = tn;
   return (n + tn - 1) / tn;
@@ -2586,6 +2615,8 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   // fit the L2s: feature-sliced aggregation into H, then the row-local kernel on it.  Otherwise the fused kernel.
   const bool band = band_graph(aux, val);
   const bool split = !H_in && H && (fwd_split_shape(n, S, d) || hub_graph(aux) || band || bandplus_graph(aux, val));
+  const bool acc = colstats && stat_acc_shape(n, S, d);   // (a split-size table: the row-local kernel below runs either way)
+  bool acc_zeroed = false;
   // cgcn_layer_fwd_colstats_tiles() reports MERGED records on split-size tables (k_layer_dense's contiguous tile
   // chunks); the fused kernel would write one record per 16 / S-node tile -- more than the caller allocated.  On such
   // tables the column statistics therefore need the two-launch route, i.e. an H (or H_in) buffer.
@@ -2595,12 +2626,16 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
     if (band) launch_band_aggregate(st, n, S, d, row_scale, X, H);
     else {
       const SlicedCsr c = sliced_csr(aux, rowptr, col, val, n);
-      launch_aggregate_sliced(st, gblocks, n, S, d, c.rowptr, c.col, c.col16, c.val, row_scale, X, H, c.order, c.bp);
+      launch_aggregate_sliced(st, gblocks, n, S, d, c.rowptr, c.col, c.col16, c.val, row_scale, X, H, c.order, c.bp,
+                              acc ? (unsigned long long*)colstats : nullptr, acc ? (int)stat_acc_words(S, d) : 0);
+      acc_zeroed = acc;
     }
     if ((rc = launch_status())) return rc;
     H_in = H;
   }
   if (H_in) {
+    // (accumulate mode without a sliced aggregation launch in this call -- a caller's H_in, a band graph: a memset node)
+    if (acc && !acc_zeroed && hipMemsetAsync(colstats, 0, stat_acc_words(S, d) * 8, st) != hipSuccess) return CGCN_ERR_LAUNCH;
     constexpr int MB = DENSE_MB;
     const int tn = 16 * MB / S;
     const int ntiles = (n + tn - 1) / tn;
@@ -2608,7 +2643,7 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
     const int grid = colstats ? (ntiles + chunk - 1) / chunk : (ntiles < dense_max_blocks(d) ? ntiles : dense_max_blocks(d));
 #define CALL(S_, D_, V_) \
     hipLaunchKernelGGL((k_layer_dense<S_, D_, MB>), dim3(grid), dim3(512), 0, st, n, ntiles, H_in, X, W, b, wg, cg, Xn, Z, gate, \
-                       ks, th, rng_state, stream_id, colstats, chunk)
+                       ks, th, rng_state, stream_id, colstats, chunk, acc ? 1 : 0)
     DISPATCH_SDV(S, d, false, CALL);
 #undef CALL
     return launch_status();

@@ -30,6 +30,7 @@ from typing import Dict, Iterable, List, Optional, Sequence
 import torch
 import torch.nn.functional as F
 
+from . import _lib as _lib_mod
 from . import graph as G
 from .dist import ShardPlan, plan_shards
 
@@ -253,6 +254,7 @@ class GCNStage:
         g = G.upload(h, self.device)
         x = torch.stack([feats["forward"], feats["backward"]]).to(self.device, torch.float32).contiguous()
         t = feats["target"].to(self.device, torch.float32).contiguous()
+        self._check_stat_range(n, x)
         known = self._meta.get(name)
         self.chroms[name] = _Chrom(name, n, g, x, t, cost, _SourceKey(feats, hic))
         if known is None or known[:2] != (n, t.shape[1]):
@@ -270,6 +272,23 @@ class GCNStage:
             if not materialising:
                 self._targets_cpu.clear()
                 self._targets_dev.clear()
+
+    def _check_stat_range(self, n: int, x: torch.Tensor):
+        """The library accumulates the head's BatchNorm batch sums as 64-bit fixed point with 32 fraction bits (accumulate mode,
+        include/chromegcn.h: cgcn_layer_fwd_colstats_tiles): sum relu(Xn)^2 must stay below 2^31 per column.  A gated layer keeps
+        |Xn| <= max(1, max |X|) (tanh and a convex mix; inter-layer dropout scales by 1 / (1 - p)), so the features bound the
+        sums: outside the range (|x| in the hundreds) the stage asks the library for per-workgroup records instead."""
+        if x.numel() == 0 or x.device.type != "cuda":
+            return
+        keep = 1.0 / max(1e-6, 1.0 - float(getattr(self.model, "dropout", 0.0) or 0.0))
+        bound = max(1.0, float(x.abs().max())) * keep ** max(int(getattr(self.model, "n_layers", 1)) - 1, 0)
+        if n * bound * bound >= 2.0 ** 30 and not getattr(GCNStage, "_stat_acc_off", False):
+            import warnings
+            warnings.warn("chromegcn_amd: feature magnitudes up to %.3g on %d windows are outside the range of the fixed-point "
+                          "BatchNorm sums; using per-workgroup records (cgcn_debug_set_stat_acc(0)) for this process" % (bound, n))
+            _lib_mod.load().cgcn_debug_set_stat_acc(0)
+            GCNStage._stat_acc_off = True
+            self._drop_graphs()
 
     def _cost_estimate(self, hic, n: int, d: int) -> float:
         """LPT cost of a chromosome (dist.plan_shards): gather work ~ nnz(A + I) d, dense work ~ 3 n d^2 / 16, with

@@ -50,7 +50,7 @@ extern "C" {
 #define CGCN_ERR_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after a launch      */
 #define CGCN_ERR_WORKSPACE (-4)   /* workspace too small (see cgcn_*_workspace_bytes)    */
 
-#define CGCN_ABI_VERSION 22
+#define CGCN_ABI_VERSION 23
 
 typedef void *cgcn_stream_t; /* hipStream_t */
 
@@ -152,8 +152,18 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d,
                    const float *H_in, float *colstats, const cgcn_graph_aux *aux);
 
 /* Number of node tiles cgcn_layer_fwd(n, S, d) writes column statistics for (0 = unsupported shape);
- * *rows_per_tile = nodes per tile (the last tile may be shorter). */
+ * *rows_per_tile = nodes per tile (the last tile may be shorter).
+ * *rows_per_tile = -1 (ABI v23; d = 128 on tables that take the two-launch route): ACCUMULATE mode -- the buffer of `tiles`
+ * records is used as 64-bit integer fixed-point totals of sum relu(Xn) and sum relu(Xn)^2 per (strand, column), zeroed and
+ * added to inside cgcn_layer_fwd (order-independent, so bit-reproducible); cgcn_head_train, handed the same (buffer, tiles,
+ * -1), derives the BatchNorm statistics from the totals inside its main kernel and launches no finalize kernel.
+ * Range of the fixed point (32 fraction bits): sum relu(Xn)^2 < 2.1e9 per column (rms |Xn| < 265 at n = 30 000); beyond it
+ * the statistics come out NaN -- call cgcn_debug_set_stat_acc(0) for such inputs (chromegcn_amd's engine does). */
 int cgcn_layer_fwd_colstats_tiles(int n, int S, int d, int *rows_per_tile);
+
+/* Test / tuning hook: 0 = cgcn_layer_fwd_colstats_tiles never reports accumulate mode (records for every shape), 1 = as
+ * described above, negative = restore the default (1, or CGCN_STAT_ACC in the environment).  Process-wide. */
+void cgcn_debug_set_stat_acc(int on);
 
 /* Test / tuning hook: feature-table size in bytes from which cgcn_layer_fwd takes the two-launch route when H is
  * given (0 = always, negative = restore the built-in default).  Process-wide. */

@@ -96,15 +96,26 @@ def test_sgd_and_spmm_argument_checks(env):
     assert lib.cgcn_spmm(_lib.stream_ptr(), env["n"], env["n"], env["S"], 98, P(g.rowptr), P(g.col), None, P(g.row_scale), P(env["x"]), P(y), None) == UNSUPPORTED
 
 
-def test_colstats_on_a_split_size_table_needs_an_aggregation_buffer(env):
-    """cgcn_layer_fwd_colstats_tiles reports merged records on tables that take the two-launch route; the
-    fused kernel (no H, no H_in) would write one record per 16/S-node tile -- past the caller's buffer.  Rejected."""
+@pytest.fixture(params=["accumulate", "records"])
+def mode(request, env):
+    env["lib"].cgcn_debug_set_stat_acc(1 if request.param == "accumulate" else 0)
+    yield request.param
+    env["lib"].cgcn_debug_set_stat_acc(-1)
+
+
+def test_colstats_on_a_split_size_table_needs_an_aggregation_buffer(env, mode):
+    """cgcn_layer_fwd_colstats_tiles reports merged records (or, ABI v23, integer totals) on tables that take the
+    two-launch route; the fused kernel (no H, no H_in) would write one record per 16/S-node tile -- past the caller's buffer.
+    Rejected in both modes; nothing is written past what was reported."""
     lib = env["lib"]
     P = _lib.ptr
     n, S, d = 8192, 2, 128                      # 8 MiB table: split-size
     rows = ctypes.c_int(0)
     tiles = lib.cgcn_layer_fwd_colstats_tiles(n, S, d, ctypes.byref(rows))
-    assert rows.value > 16 // S and tiles == (n + rows.value - 1) // rows.value
+    if mode == "records":
+        assert rows.value > 16 // S and tiles == (n + rows.value - 1) // rows.value
+    else:                                       # accumulate mode (ABI v23): the buffer holds the integer totals
+        assert rows.value == -1 and tiles * S * d * 2 * 4 >= (8 * S * d * 2 + 1) * 8
     g = G.upload(G.normalize_graph("hic", synth.contact_graph(n, 20000, 5), n), DEV)
     x, y, z, h = (torch.randn(S, n, d, device=DEV) for _ in range(4))
     gate = torch.empty(S, n, device=DEV)
