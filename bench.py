@@ -538,7 +538,8 @@ def time_kernels(stage, name, reps, dropout_p):
     dbn_w, dbn_b = torch.empty(d, device=dev), torch.empty(d, device=dev)
     hg = _lib.HeadGrad(hws.data_ptr() + o_dym.value, hws.data_ptr() + o_bnc.value, sm.data_ptr(), si.data_ptr(), bn.weight.data_ptr(),
                        float(dropout_p) if drop else 0.0, P(rng) if drop else None, hws.data_ptr() + o_part.value,
-                       lib.cgcn_head_bwd_partials(n), C, dW_out.data_ptr(), db_out.data_ptr(), 0, one.data_ptr(), dbn_w.data_ptr(), dbn_b.data_ptr())
+                       lib.cgcn_head_bwd_partials(n), C, dW_out.data_ptr(), db_out.data_ptr(), 0, one.data_ptr(), dbn_w.data_ptr(), dbn_b.data_ptr(),
+                       colstats.data_ptr() if rows.value == -1 else None)   # accumulate mode (ABI v23): the backward sums live in the statistics buffer
     ws_b = lib.cgcn_layer_bwd_workspace_bytes(n, S, d)
     ws = torch.empty(ws_b, dtype=torch.uint8, device=dev)
     dW, db, dwg, dcg = torch.empty(d, d, device=dev), torch.empty(d, device=dev), torch.empty(d, device=dev), torch.empty(1, device=dev)

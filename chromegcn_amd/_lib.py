@@ -111,7 +111,7 @@ class HeadGrad(ctypes.Structure):
     _fields_ = [("dym", _c_vp), ("bnc", _c_vp), ("save_mean", _c_vp), ("save_invstd", _c_vp), ("bn_w", _c_vp),
                 ("dropout_p", _c_float), ("rng_state", _c_vp), ("part", _c_vp), ("n_partials", _c_int), ("C", _c_int),
                 ("dW_out", _c_vp), ("db_out", _c_vp), ("accumulate", _c_int), ("dloss", _c_vp), ("dbn_w", _c_vp),
-                ("dbn_b", _c_vp)]
+                ("dbn_b", _c_vp), ("stat_acc", _c_vp)]
 
 
 class SgdFuse(ctypes.Structure):

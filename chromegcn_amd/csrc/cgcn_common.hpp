@@ -133,7 +133,50 @@ static inline uint32_t dropout_threshold(float p) {
 // ------------------------------------------------------------------------------------------
 constexpr int STAT_ACC_SLOTS = 8;
 constexpr int STAT_ACC_FBITS = 32;
-static inline size_t stat_acc_words(int S, int d) { return (size_t)STAT_ACC_SLOTS * S * d * 2 + 2; }
+// Backward block behind it (same buffer, zeroed by the same launch): the head's BatchNorm-backward column sums
+// sum dy / sum dy xhat per (strand, column) as ONE word each into the same 8 copies, so that k_head_train_finish is not
+// launched either, then four header words: overflow flag, the two binary points, the loss total, a ticket.
+//   Their rounding error is coherent over the rows and amplified ~1 000x downstream (head_part_stride below): they need
+//   ~1e-10 relative precision AND have no fixed magnitude, so the binary point comes from bounds every workgroup reproduces:
+//   sum |dy| <= keep_scale max|W_out| (|d loss / d pred| <= 1 / (n C) per element) and |xhat| <= sqrt(n).
+__host__ __device__ __forceinline__ constexpr size_t stat_acc_fwd_words(int S, int d) { return (size_t)STAT_ACC_SLOTS * S * d * 2 + 2; }
+__host__ __device__ __forceinline__ constexpr size_t stat_acc_bwd_words(int S, int d) { return (size_t)STAT_ACC_SLOTS * S * d * 2 + 4; }
+static inline size_t stat_acc_words(int S, int d) { return stat_acc_fwd_words(S, d) + stat_acc_bwd_words(S, d); }
+enum { BACC_FLAG = 0, BACC_EXP = 1, BACC_LOSS = 2, BACC_SPARE = 3 };   // header words behind the backward sums
+constexpr int BACC_LOSS_FBITS = 16;   // the loss total: per-element BCE terms (>= 0, <= ~30 each, n C < 2^31 of them) above bit 12 of its word,
+                                      // the arrival count below (<= 4 095 workgroups): share and ticket are ONE atomic
+__device__ __forceinline__ unsigned long long* bacc_base(const unsigned long long* acc, int S, int D) {
+  return (unsigned long long*)acc + stat_acc_fwd_words(S, D);
+}
+// fraction bits for a sum bounded by `bound` (> 0): the bound sits below 2^61
+__device__ __forceinline__ int bacc_fbits(double bound) { return 60 - (ilogb(bound < 1e-300 ? 1e-300 : bound) + 1); }
+__device__ __forceinline__ void bacc_add(unsigned long long* b, int S, int D, int slot, int s, int c, double sdy, double sdyx,
+                                         int fa, int fb) {
+  unsigned long long* w = b + ((size_t)(slot * S + s) * D + c) * 2;
+  const double va = ldexp(sdy, fa), vb = ldexp(sdyx, fb);
+  if (!(__builtin_fabs(va) < 1.15e18) || !(__builtin_fabs(vb) < 1.15e18)) {   // 2^60: outside the bounds (or NaN): loud
+    atomicOr(b + (size_t)STAT_ACC_SLOTS * S * D * 2 + BACC_FLAG, 1ull);
+    return;
+  }
+  atomicAdd(&w[0], (unsigned long long)(long long)__builtin_rint(va));
+  atomicAdd(&w[1], (unsigned long long)(long long)__builtin_rint(vb));
+}
+// bnc of (strand s, column c): mean dy, mean dy xhat (for d loss = 1), from the totals
+__device__ __forceinline__ void bacc_get(const unsigned long long* __restrict__ b, int S, int D, int s, int c, int n, float& c0, float& c1) {
+  long long ta = 0, tb = 0;
+#pragma unroll
+  for (int slot = 0; slot < STAT_ACC_SLOTS; ++slot) {
+    const unsigned long long* w = b + ((size_t)(slot * S + s) * D + c) * 2;
+    ta += (long long)w[0];
+    tb += (long long)w[1];
+  }
+  const unsigned long long* h = b + (size_t)STAT_ACC_SLOTS * S * D * 2;
+  const int fa = (int)(unsigned)(h[BACC_EXP] & 0xFFFFFFFFull) - 1024, fb = (int)(unsigned)(h[BACC_EXP] >> 32) - 1024;
+  const double invn = 1.0 / (double)n;
+  c0 = (float)(ldexp((double)ta, -fa) * invn);
+  c1 = (float)(ldexp((double)tb, -fb) * invn);
+  if (h[BACC_FLAG] != 0ull) c0 = c1 = __builtin_nanf("");
+}
 __device__ __forceinline__ void stat_acc_add(unsigned long long* acc, int S, int D, int slot, int s, int c, double sum1, double sum2) {
   const double sc = (double)(1ll << STAT_ACC_FBITS), lim = 4194304.0;   // 2^22
   unsigned long long* w = acc + ((size_t)(slot * S + s) * D + c) * 2;
@@ -170,6 +213,7 @@ __device__ __forceinline__ void stat_acc_get(const unsigned long long* __restric
 struct HeadApply {
   const float* dym;      // [n][d]   d loss / d (mean over strands of the dropped BatchNorm output)
   const float* bnc;      // [S][2][d] per-strand mean(dy), mean(dy * xhat)
+  const unsigned long long* bacc;   // accumulate mode (STAT_ACC_*): the buffer whose backward block replaces bnc; else nullptr
   const float* mean;     // [S][d]   batch mean of relu(Xn)
   const float* invstd;   // [S][d]
   const float* bn_w;     // [d]

@@ -1081,6 +1081,7 @@ struct HeadStatAcc {
   long long* nbt;
   float* save_mean;
   float* save_invstd;
+  float* loss_out;   // the caller's loss word: written by the last workgroup to arrive (k_head_train_finish is not launched)
 };
 __device__ __forceinline__ void head_stat(const HeadStatAcc& sa, const float* __restrict__ mean, const float* __restrict__ invstd,
                                           int n, int S, int D, int s, int c, float& mu, float& is) {
@@ -1143,6 +1144,7 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
   __shared__ __attribute__((aligned(16))) float Pt[2][TR * LDP];
   __shared__ __attribute__((aligned(16))) float Yt[2][TR * LDY];
   __shared__ float lsum[8];
+  __shared__ float wmax[16];   // accumulate mode: per-wave max |W_out| (the binary points of the backward sums)
   const bool first = MULTI ? first_ != 0 : true, last = MULTI ? last_ != 0 : true;
 
   const int lane = threadIdx.x & 63;
@@ -1163,6 +1165,16 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
     f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (j < Cp) v = *(const f32x4*)&Wout[(size_t)(c0 + j) * D + c4 * 4];
     *(f32x4*)&Wl[j * LDW + c4 * 4] = v;
+  }
+  if (sa.acc && last) {   // max |W_out| over ALL labels (the earlier label passes' share of dym is in the sums too)
+    float mw = 0.f;
+    for (int idx = threadIdx.x; idx < C * (D / 4); idx += 1024) {
+      const f32x4 v = *(const f32x4*)&Wout[(size_t)idx * 4];
+      mw = fmaxf(fmaxf(mw, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mw = fmaxf(mw, __shfl_xor(mw, o, WAVE));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mw;
   }
   // The two roles run SEPARATE loops (the register allocator then sees each role's state on its own path) that execute
   // the same number of workgroup barriers: one before and one after the loop, three per period.
@@ -1319,7 +1331,25 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) t += lsum[w];
-      loss_part[blockIdx.x] = first ? t : loss_part[blockIdx.x] + t;   // the label passes' shares add up
+      const float tl = first ? t : loss_part[blockIdx.x] + t;   // the label passes' shares add up
+      loss_part[blockIdx.x] = tl;
+      if (sa.acc && last) {
+        // accumulate mode: this workgroup's share joins the loss total as a fixed-point integer, and the SAME atomic draws its
+        // ticket (the share sits above bit 12, the arrival count below: BCE terms are >= 0, so nothing borrows): whoever
+        // finds gridDim.x - 1 earlier arrivals in the returned word holds the complete total -- every other share was added
+        // by an atomic that precedes this one at the memory side -- and writes the caller's loss.  One round trip at the
+        // workgroup's tail instead of three.
+        unsigned long long* h = bacc_base(sa.acc, S, D) + (size_t)STAT_ACC_SLOTS * S * D * 2;
+        const bool bad = !(tl >= 0.f && tl < 1e9f);   // NaN (statistics outside the fixed-point range upstream) or absurd: the
+                                                      // total of <= 4 095 shares below 1e9 stays below 2^36 (x 2^16 x 2^12 = 2^64)
+        if (bad) atomicOr(&h[BACC_FLAG], 2ull);
+        const unsigned long long mine = ((bad ? 0ull : (unsigned long long)__builtin_rint(ldexp((double)tl, BACC_LOSS_FBITS))) << 12) | 1ull;
+        const unsigned long long old = atomicAdd(&h[BACC_LOSS], mine);
+        if ((old & 0xFFFull) == (unsigned long long)gridDim.x - 1ull) {
+          const unsigned long long flag = atomicOr(&h[BACC_FLAG], 0ull);
+          sa.loss_out[0] = flag ? __builtin_nanf("") : (float)(ldexp((double)((old + mine) >> 12), -BACC_LOSS_FBITS) * (double)inv_count);
+        }
+      }
     }
   } else {
     // =============================================================== Q: grad team, one tile behind
@@ -1500,6 +1530,17 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
         if (q == 0) {
           out[s * D + own * 16 + r] = a;
           out[(2 + s) * D + own * 16 + r] = b;
+          if (sa.acc && s < S) {   // accumulate mode: the same sums as integer totals for the row-local backward's prologue
+            float mw = 0.f;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) mw = fmaxf(mw, wmax[w]);
+            const double bound = fmax((double)keep_scale * (double)mw, 1e-30) * 1.001;
+            const int fa = bacc_fbits(bound), fb = bacc_fbits(bound * sqrt((double)n) * 1.001);
+            unsigned long long* bb = bacc_base(sa.acc, S, D);
+            bacc_add(bb, S, D, (int)blockIdx.x & (STAT_ACC_SLOTS - 1), s, own * 16 + r, a, b, fa, fb);
+            if (blockIdx.x == 0 && s == 0 && own == 0 && r == 0)
+              bb[(size_t)STAT_ACC_SLOTS * S * D * 2 + BACC_EXP] = ((unsigned long long)(unsigned)(fb + 1024) << 32) | (unsigned long long)(unsigned)(fa + 1024);
+          }
         }
       }
     }
@@ -1765,8 +1806,8 @@ static int head_train_impl(cgcn_stream_t stream, int n, int S, int d, int C, con
   // accumulate mode: no finalize launch; the main kernel reads the totals (and its first workgroup finishes the bookkeeping --
   // only when the whole call runs: a profiling call of phase 2 alone must not touch the running statistics again)
   const HeadStatAcc sa = {stat_acc ? (const unsigned long long*)col_stats : nullptr, eps, momentum,
-                          run_mean, run_var, (phases & 1) ? num_batches_tracked : nullptr, save_mean, save_invstd};
-  const HeadStatAcc sa_prof = {sa.acc, eps, 0.f, run_mean, run_var, nullptr, save_mean, save_invstd};
+                          run_mean, run_var, (phases & 1) ? num_batches_tracked : nullptr, save_mean, save_invstd, loss};
+  const HeadStatAcc sa_prof = {sa.acc, eps, 0.f, run_mean, run_var, nullptr, save_mean, save_invstd, loss};
   const int P = head_bwd_partials(n);
   const int CP = head_cp(C);
   const float keep_scale = drop ? 1.f / (1.f - dropout_p) : 1.f;
@@ -1809,7 +1850,8 @@ static int head_train_impl(cgcn_stream_t stream, int n, int S, int d, int C, con
 #undef HFU
     if ((rc = launch_status())) return rc;
   }
-  if (!(phases & 4)) return CGCN_OK;
+  if (!(phases & 4) || stat_acc) return CGCN_OK;   // accumulate mode: the main kernel left the backward sums as integer
+                                                    // totals (cgcn_head_grad::stat_acc) and wrote the loss itself
   hipLaunchKernelGGL(k_head_train_finish, dim3(1 + d / HEAD_STAT_COLS), dim3(512), 0, st, P, n, S, d, CP, w_part, w_bnc,
                      w_loss, inv_count, loss);
   return launch_status();

@@ -1056,8 +1056,15 @@ __global__ __launch_bounds__(RING_THREADS) void k_bwd_rowlocal_ring(int M, int n
         const int s = i / D, c = i % D, ss = s < hp.S ? s : 0;
         Hc[(s * 4 + 0) * D + c] = hp.invstd[ss * D + c];
         Hc[(s * 4 + 1) * D + c] = hp.mean[ss * D + c];
-        Hc[(s * 4 + 2) * D + c] = hp.bnc[(ss * 2 + 0) * D + c];
-        Hc[(s * 4 + 3) * D + c] = hp.bnc[(ss * 2 + 1) * D + c];
+        if (hp.bacc) {   // accumulate mode: the column means from the integer totals the head kernel left (cgcn_common.hpp)
+          float c0, c1;
+          bacc_get(bacc_base(hp.bacc, hp.S, D), hp.S, D, ss, c, n, c0, c1);
+          Hc[(s * 4 + 2) * D + c] = c0;
+          Hc[(s * 4 + 3) * D + c] = c1;
+        } else {
+          Hc[(s * 4 + 2) * D + c] = hp.bnc[(ss * 2 + 0) * D + c];
+          Hc[(s * 4 + 3) * D + c] = hp.bnc[(ss * 2 + 1) * D + c];
+        }
         if (s == 0) Hc[8 * D + c] = hp.bn_w[c];
       }
     }
@@ -2730,7 +2737,7 @@ static int layer_bwd_impl(cgcn_stream_t stream, int n, int S, int d, const int32
   if (sgd && dX && in_dropout_p > 0.f) return CGCN_ERR_BAD_ARG;
   if ((dX && dX == dXn) || (dHs && (misaligned16(dHs) || dHs == dX)) || (dX && misaligned16(dX)) || misaligned16(W)) return CGCN_ERR_BAD_ARG;
   if (misaligned16(X) || misaligned16(Z) || misaligned16(H) || (dXn && misaligned16(dXn))) return CGCN_ERR_BAD_ARG;  // vector row accesses
-  HeadApply hp = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1.f, 0u, S, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr, nullptr, nullptr};
+  HeadApply hp = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1.f, 0u, S, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr, nullptr, nullptr};
   int head_slabs = 0;
   if (head) {
     if (!head->dym || !head->bnc || !head->save_mean || !head->save_invstd || !head->bn_w) return CGCN_ERR_BAD_ARG;
@@ -2739,7 +2746,10 @@ static int layer_bwd_impl(cgcn_stream_t stream, int n, int S, int d, const int32
     uint32_t hth;
     if ((rc = dropout_args(head->dropout_p, head->rng_state, &hks, &hth))) return rc;
     const int CP = head->C <= 128 ? 128 : 256;
-    hp = HeadApply{head->dym, head->bnc, head->save_mean, head->save_invstd, head->bn_w, head->rng_state, hks, hth, S,
+    // accumulate mode (ABI v23): the BatchNorm-backward column means are decoded from integer totals (d = 128 only: the
+    // head kernel that fills them is k_head_fused_rs)
+    if (head->stat_acc && (d != 128 || ((uintptr_t)head->stat_acc & 7))) return CGCN_ERR_BAD_ARG;
+    hp = HeadApply{head->dym, head->bnc, (const unsigned long long*)head->stat_acc, head->save_mean, head->save_invstd, head->bn_w, head->rng_state, hks, hth, S,
                    head->part, head->dW_out, head->db_out, head->n_partials, head->C, CP, head->accumulate, head->dloss,
                    head->dbn_w, head->dbn_b};
     if ((head->dbn_w == nullptr) != (head->dbn_b == nullptr)) return CGCN_ERR_BAD_ARG;

@@ -390,7 +390,10 @@ class LastLayerHeadLossFn(torch.autograd.Function):
                                          ws.data_ptr(), ws_bytes), "cgcn_head_fwd")
         if need_bwd:
             ctx.save_for_backward(x, z, h, gate, weight, wg, xn, bn_w, bn_b, w_out, ws, save_mean, save_invstd,
-                                  rng_state if (drop or dropout_in > 0) else None)
+                                  rng_state if (drop or dropout_in > 0) else None,
+                                  # accumulate mode (ABI v23, rows = -1): the backward reads the BatchNorm-backward column sums
+                                  # from the statistics buffer (cgcn_head_grad.stat_acc), not from the workspace's bnc
+                                  colstats if cs_rows == -1 else None)
             ctx.graph = graph
             ctx.dropout_p = float(dropout_p) if drop else 0.0
             ctx.dropout_in = float(dropout_in)
@@ -406,7 +409,7 @@ class LastLayerHeadLossFn(torch.autograd.Function):
     def backward(ctx, dloss, _dprobs, _dgate):
         if ctx.eval_grad:
             raise RuntimeError(_EVAL_BWD_MSG)
-        (x, z, h, gate, weight, wg, xn, bn_w, bn_b, w_out, hws, save_mean, save_invstd, rng_state) = ctx.saved_tensors
+        (x, z, h, gate, weight, wg, xn, bn_w, bn_b, w_out, hws, save_mean, save_invstd, rng_state, stat_acc) = ctx.saved_tensors
         g = ctx.graph
         S, n, d = x.shape
         C = w_out.shape[0]
@@ -434,7 +437,7 @@ class LastLayerHeadLossFn(torch.autograd.Function):
         hg = _lib.HeadGrad(hws.data_ptr() + o_dym.value, hws.data_ptr() + o_bnc.value, save_mean.data_ptr(),
                            save_invstd.data_ptr(), bn_w.data_ptr(), ctx.dropout_p, _lib.ptr(rng_state),
                            hws.data_ptr() + o_part.value, lib.cgcn_head_bwd_partials(n), C, dw_out.data_ptr(),
-                           db_out.data_ptr(), 0, dloss.data_ptr(), dbn_w.data_ptr(), dbn_b.data_ptr())
+                           db_out.data_ptr(), 0, dloss.data_ptr(), dbn_w.data_ptr(), dbn_b.data_ptr(), _lib.ptr(stat_acc))
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dhs = torch.empty_like(x) if dx is not None else None
         ws_bytes = lib.cgcn_layer_bwd_workspace_bytes(n, S, d)

@@ -156,7 +156,9 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d,
  * *rows_per_tile = -1 (ABI v23; d = 128 on tables that take the two-launch route): ACCUMULATE mode -- the buffer of `tiles`
  * records is used as 64-bit integer fixed-point totals of sum relu(Xn) and sum relu(Xn)^2 per (strand, column), zeroed and
  * added to inside cgcn_layer_fwd (order-independent, so bit-reproducible); cgcn_head_train, handed the same (buffer, tiles,
- * -1), derives the BatchNorm statistics from the totals inside its main kernel and launches no finalize kernel.
+ * -1), derives the BatchNorm statistics from the totals inside its main kernel and launches no finalize kernel; it also
+ * leaves the BatchNorm-BACKWARD column sums as integer totals in the same buffer (and writes the loss from a ticketed total)
+ * instead of launching a finish kernel: the cgcn_head_grad handed to cgcn_layer_bwd must then carry stat_acc = that buffer.
  * Range of the fixed point (32 fraction bits): sum relu(Xn)^2 < 2.1e9 per column (rms |Xn| < 265 at n = 30 000); beyond it
  * the statistics come out NaN -- call cgcn_debug_set_stat_acc(0) for such inputs (chromegcn_amd's engine does). */
 int cgcn_layer_fwd_colstats_tiles(int n, int S, int d, int *rows_per_tile);
@@ -209,6 +211,9 @@ typedef struct cgcn_head_grad {
                                d loss = 1); NULL when it came from cgcn_head_bwd with dpred (already scaled) */
   float *dbn_w;             /* [d] both set when the workspace came from cgcn_head_train: d(bn weight) / d(bn bias) */
   float *dbn_b;             /* [d] are then finished here as well (same accumulate flag); NULL after cgcn_head_bwd  */
+  const void *stat_acc;     /* ABI v23: NULL, or -- when cgcn_head_train ran in accumulate mode (col_stats_rows = -1) -- the
+                               SAME col_stats buffer: its backward block holds the BatchNorm-backward column sums as integer
+                               totals and `bnc` is not read (cgcn_head_train launched no finish kernel to fill it) */
 } cgcn_head_grad;
 
 /*

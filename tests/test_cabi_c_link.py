@@ -36,8 +36,9 @@ int main(void) {
     printf(" %zu %zu %zu %zu %zu %zu %zu %zu\n", offsetof(cgcn_graph_aux, col16), offsetof(cgcn_graph_aux, row_order),
            offsetof(cgcn_graph_aux, max_row_len), offsetof(cgcn_graph_aux, band_halfwidth), offsetof(cgcn_graph_aux, bp_rowptr),
            offsetof(cgcn_graph_aux, bp_col), offsetof(cgcn_graph_aux, bp_col16), offsetof(cgcn_graph_aux, bp_row_order));
-    printf("layout cgcn_head_grad %zu %zu %zu %zu %zu\n", sizeof(cgcn_head_grad), offsetof(cgcn_head_grad, dropout_p),
-           offsetof(cgcn_head_grad, n_partials), offsetof(cgcn_head_grad, accumulate), offsetof(cgcn_head_grad, dbn_b));
+    printf("layout cgcn_head_grad %zu %zu %zu %zu %zu %zu\n", sizeof(cgcn_head_grad), offsetof(cgcn_head_grad, dropout_p),
+           offsetof(cgcn_head_grad, n_partials), offsetof(cgcn_head_grad, accumulate), offsetof(cgcn_head_grad, dbn_b),
+           offsetof(cgcn_head_grad, stat_acc));
     printf("layout cgcn_sgd_fuse %zu %zu %zu %zu\n", sizeof(cgcn_sgd_fuse), offsetof(cgcn_sgd_fuse, count), offsetof(cgcn_sgd_fuse, lr),
            offsetof(cgcn_sgd_fuse, rng_state));
     printf("c-abi ok v%d\n", cgcn_abi_version());
@@ -71,6 +72,7 @@ def test_header_is_plain_c_and_a_c_program_links(tmp_path):
                                                           ("col16", "row_order", "max_row_len", "band_halfwidth", "bp_rowptr", "bp_col", "bp_col16", "bp_row_order")]
     assert [f for f, _ in A._fields_] == ["col16", "row_order", "max_row_len", "band_halfwidth", "bp_rowptr", "bp_col", "bp_col16", "bp_row_order"]
     H = _lib.HeadGrad
-    assert lay["cgcn_head_grad"] == [ctypes.sizeof(H), H.dropout_p.offset, H.n_partials.offset, H.accumulate.offset, H.dbn_b.offset]
+    assert lay["cgcn_head_grad"] == [ctypes.sizeof(H), H.dropout_p.offset, H.n_partials.offset, H.accumulate.offset, H.dbn_b.offset,
+                                     H.stat_acc.offset]
     F = _lib.SgdFuse
     assert lay["cgcn_sgd_fuse"] == [ctypes.sizeof(F), F.count.offset, F.lr.offset, F.rng_state.offset]

@@ -25,13 +25,13 @@ def _restore_mode():
     GCNStage._stat_acc_off = False
 
 
-def _train(acc, steps=3, dropout=0.2, hip_graphs=True, scale=1.0, seed=0):
+def _train(acc, steps=3, dropout=0.2, hip_graphs=True, scale=1.0, seed=0, labels=LABELS):
     _lib.load().cgcn_debug_set_stat_acc(1 if acc else 0)
     torch.manual_seed(seed)
-    model = C.ChromeGCN(128, 128, LABELS, dropout, True, 2).to(DEV)
+    model = C.ChromeGCN(128, 128, labels, dropout, True, 2).to(DEV)
     opt = torch.optim.SGD(model.parameters(), lr=0.25, momentum=0.9, weight_decay=1e-6)
     stage = GCNStage(model, opt, "hic", DEV, hip_graphs=hip_graphs, input_grad=True, cache_input_aggregation=False)
-    feats = synth.chrom_features(N, 128, LABELS, 3)
+    feats = synth.chrom_features(N, 128, labels, 3)
     feats = {k: (v * scale if k != "target" else v) for k, v in feats.items()}
     stage.add_chromosome("c", feats, synth.contact_graph(N, PAIRS, 3))
     losses = []
@@ -124,3 +124,14 @@ def test_small_and_single_strand_tables_in_accumulate_mode(S, n):
     assert a[5] == r[5] == S
     for u, v, what in ((a[1], r[1], "probs"), (a[2], r[2], "dx"), (a[3], r[3], "running_var"), (a[4], r[4], "dW_out")):
         np.testing.assert_allclose(u.cpu().numpy(), v.cpu().numpy(), rtol=2e-5, atol=1e-7 + 2e-5 * float(v.abs().max()), err_msg=what)
+
+
+def test_more_than_128_labels_two_label_passes_in_accumulate_mode():
+    """C = 150: the head kernel runs twice (label passes of 128): the loss shares add up over the passes, the backward sums and
+    their binary points are taken in the last pass from ALL of W_out, the bookkeeping happens in the first"""
+    la, sa, pa = _train(True, steps=2, labels=150)
+    lr, sr, pr = _train(False, steps=2, labels=150)
+    np.testing.assert_allclose(la, lr, rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(pa.cpu().numpy(), pr.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    for k in sr:
+        np.testing.assert_allclose(sa[k].float().cpu().numpy(), sr[k].float().cpu().numpy(), rtol=2e-5, atol=2e-6, err_msg=k)

@@ -25,6 +25,7 @@ def main():
     R = 20
     dev = torch.device("cuda")
     lib = _lib.load()
+    lib.cgcn_debug_set_stat_acc(0)   # this probe builds its cgcn_head_grad by hand: records mode
     P, st = _lib.ptr, _lib.stream_ptr
     S, d, Cn = 2, 128, synth.N_LABELS
     torch.manual_seed(0)
