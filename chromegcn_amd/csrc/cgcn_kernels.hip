@@ -2190,8 +2190,13 @@ __device__ __forceinline__ void band_tile_sums(const float* __restrict__ T, int 
 
 template <int S, int D, int R>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8))) void k_band_aggregate(int n, const float* __restrict__ rs, const float* __restrict__ X,
-                                                        float* __restrict__ H) {
+                                                        float* __restrict__ H, unsigned long long* __restrict__ zero_words,
+                                                        int zero_count) {
   using G = BandGeo<D, R>;
+  // (the statistics accumulators of the row-local launch behind this one: zeroed here, like k_aggregate_sliced does)
+  const int zblocks = (int)gridDim.x < 8 ? (int)gridDim.x : 8;
+  if (zero_words && (int)blockIdx.x < zblocks)
+    for (int i = (int)blockIdx.x * 512 + (int)threadIdx.x; i < zero_count; i += zblocks * 512) zero_words[i] = 0ull;
   const int tiles = (n + R - 1) / R;
   const int b = xcd_contiguous((int)blockIdx.x, S * tiles);
   const int s = b / tiles, r0 = (b - s * tiles) * R;
@@ -2492,12 +2497,13 @@ static inline SlicedCsr sliced_csr(const cgcn_graph_aux* aux, const int32_t* row
 static inline bool band_graph(const cgcn_graph_aux* aux, const float* val) { return aux && aux->band_halfwidth == BAND_W && !val; }
 // 'both' graphs with a band-plus decomposition (cgcn_graph_aux::bp_*): the unit-entry CSR + the LDS window (see BP above)
 static inline bool bandplus_graph(const cgcn_graph_aux* aux, const float* val) { return aux && aux->bp_rowptr && aux->bp_col && val; }
-static void launch_band_aggregate(hipStream_t st, int n, int S, int d, const float* rs, const float* X, float* H) {
+static void launch_band_aggregate(hipStream_t st, int n, int S, int d, const float* rs, const float* X, float* H,
+                                  unsigned long long* zw = nullptr, int zc = 0) {
   const int blocks = S * ((n + BAND_R - 1) / BAND_R);
-  if (S == 1 && d == 128) hipLaunchKernelGGL((k_band_aggregate<1, 128, BAND_R>), dim3(blocks), dim3(512), 0, st, n, rs, X, H);
-  else if (S == 2 && d == 128) hipLaunchKernelGGL((k_band_aggregate<2, 128, BAND_R>), dim3(blocks), dim3(512), 0, st, n, rs, X, H);
-  else if (S == 1 && d == 256) hipLaunchKernelGGL((k_band_aggregate<1, 256, BAND_R>), dim3(blocks), dim3(512), 0, st, n, rs, X, H);
-  else hipLaunchKernelGGL((k_band_aggregate<2, 256, BAND_R>), dim3(blocks), dim3(512), 0, st, n, rs, X, H);
+  if (S == 1 && d == 128) hipLaunchKernelGGL((k_band_aggregate<1, 128, BAND_R>), dim3(blocks), dim3(512), 0, st, n, rs, X, H, zw, zc);
+  else if (S == 2 && d == 128) hipLaunchKernelGGL((k_band_aggregate<2, 128, BAND_R>), dim3(blocks), dim3(512), 0, st, n, rs, X, H, zw, zc);
+  else if (S == 1 && d == 256) hipLaunchKernelGGL((k_band_aggregate<1, 256, BAND_R>), dim3(blocks), dim3(512), 0, st, n, rs, X, H, zw, zc);
+  else hipLaunchKernelGGL((k_band_aggregate<2, 256, BAND_R>), dim3(blocks), dim3(512), 0, st, n, rs, X, H, zw, zc);
 }
 
 int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d, const int32_t* rowptr, const int32_t* col,
@@ -2630,8 +2636,10 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   if (colstats && !split && !H_in && dense_stat_chunk(n, S, d) != 1) return CGCN_ERR_BAD_ARG;
   if (split) {
     const int gblocks = (S * d / 32) * ((n + 63) / 64);
-    if (band) launch_band_aggregate(st, n, S, d, row_scale, X, H);
-    else {
+    if (band) {
+      launch_band_aggregate(st, n, S, d, row_scale, X, H, acc ? (unsigned long long*)colstats : nullptr, acc ? (int)stat_acc_words(S, d) : 0);
+      acc_zeroed = acc;
+    } else {
       const SlicedCsr c = sliced_csr(aux, rowptr, col, val, n);
       launch_aggregate_sliced(st, gblocks, n, S, d, c.rowptr, c.col, c.col16, c.val, row_scale, X, H, c.order, c.bp,
                               acc ? (unsigned long long*)colstats : nullptr, acc ? (int)stat_acc_words(S, d) : 0);
