@@ -467,8 +467,11 @@ def time_kernels(stage, name, reps, dropout_p):
     gate = torch.empty(S, n, device=dev)
     rng = m._rng_state
     rows = ctypes.c_int(0)
-    tiles = lib.cgcn_layer_fwd_colstats_tiles(n, S, d, ctypes.byref(rows))
-    colstats = torch.empty((tiles, S, d, 2), device=dev)
+    # the statistics mode the ENGINE uses for this chromosome (accumulate where its features are in range: GCNStage._stat_acc_for)
+    acc = bool(getattr(c, "stat_acc", False))
+    tiles = lib.cgcn_layer_fwd_colstats_plan(n, S, d, _lib.COLSTATS_ACCUMULATE if acc else _lib.COLSTATS_RECORDS, ctypes.byref(rows))
+    acc = rows.value == -1
+    colstats = torch.zeros((tiles, S, d, 2), device=dev)
     L = m.n_layers
     gc1, w1, gcL, wL, bn, out = m.GC1, m.W1, getattr(m, "GC%d" % L), getattr(m, "W%d" % L), m.batch_norm, m.out
     drop = dropout_p > 0
@@ -476,9 +479,10 @@ def time_kernels(stage, name, reps, dropout_p):
     c16, c16t = aux_ptr(g.col), aux_ptr(g.col_t)   # the engine's own cgcn_graph_aux (16-bit indices, longest row)
     # the route the LIBRARY takes for this graph (table size against the current threshold, hub-heavy graphs): asked,
     # not re-derived here -- a hub graph on a small table runs k_aggregate_sliced + k_layer_dense, not k_layer_fwd
-    route = lib.cgcn_debug_layer_fwd_route(n, S, d, c16)
+    route = lib.cgcn_debug_layer_fwd_route(n, S, d, c16, 0)           # the layers without column statistics
+    route_last = lib.cgcn_debug_layer_fwd_route(n, S, d, c16, rows.value)   # the last layer (accumulate mode: always two launches)
     band = route == 2 and g.val is None      # the sliding-window kernels (k_band_aggregate / k_bwd_band)
-    split = route in (1, 2)
+    split, split_last = route in (1, 2), route_last in (1, 2)
 
     def ev_time(fn):
         for _ in range(3):
@@ -498,20 +502,33 @@ def time_kernels(stage, name, reps, dropout_p):
                                   gc.weight.data_ptr(), gc.bias.data_ptr(), wk.weight.data_ptr(), wk.bias.data_ptr(),
                                   xn.data_ptr(), z.data_ptr(), P(hbuf), gate.data_ptr(), 0.0 if (last or not drop) else float(dropout_p),
                                   None if (last or not drop) else P(rng), layer, P(h_in), cs.data_ptr() if (last and cs is not None) else None,
-                                  c16)
+                                  rows.value if (last and cs is not None) else 0, c16)
 
     out_t = {}
-    if split:
-        t_agg = ev_time(lambda: lib.cgcn_spmm(st(), n, n, S, d, P(g.rowptr), P(g.col), P(g.val), P(g.row_scale), c.x.data_ptr(), h.data_ptr(), c16))
-        t_d1 = ev_time(lambda: fwd(1, h, None, None))
-        t_d2 = ev_time(lambda: fwd(L, h, None, colstats))
-        # L forward launches per step: L - 1 in the inter-layer-dropout form, the last with the column statistics
-        out_t["k_band_aggregate" if band else "k_aggregate_sliced"] = (t_agg, L)
-        out_t["k_layer_dense"] = (((L - 1) * t_d1 + t_d2) / L, L)
+    agg = lambda: lib.cgcn_spmm(st(), n, n, S, d, P(g.rowptr), P(g.col), P(g.val), P(g.row_scale), c.x.data_ptr(), h.data_ptr(), c16)
+    # L forward launches per step: L - 1 in the inter-layer-dropout form, the last with the column statistics (whose
+    # accumulate mode takes the two-launch route at every table size: the aggregation launch zeroes the totals)
+    t_d2 = None
+    n_agg, n_dense, t_dense = 0, 0, 0.0
+    if split and L > 1:
+        t_dense += (L - 1) * ev_time(lambda: fwd(1, h, None, None))
+        n_agg += L - 1
+        n_dense += L - 1
+    elif L > 1:
+        out_t["k_layer_fwd"] = (ev_time(lambda: fwd(1, None, h, None)), L - 1)
+    if split_last:
+        _lib.check(agg(), "aggregate")
+        t_d2 = ev_time(lambda: fwd(L, h, None, colstats))   # (accumulate mode, H_in form: + the memset node that zeroes the totals)
+        t_dense += t_d2
+        n_agg += 1
+        n_dense += 1
     else:
-        t_f1 = ev_time(lambda: fwd(1, None, h, None))
         t_f2 = ev_time(lambda: fwd(L, None, h, colstats))
-        out_t["k_layer_fwd"] = (((L - 1) * t_f1 + t_f2) / L, L)
+        prev = out_t.get("k_layer_fwd", (0.0, 0))
+        out_t["k_layer_fwd"] = ((prev[0] * prev[1] + t_f2) / (prev[1] + 1), prev[1] + 1)
+    if n_agg:
+        out_t["k_band_aggregate" if band else "k_aggregate_sliced"] = (ev_time(agg), n_agg)
+        out_t["k_layer_dense"] = (t_dense / n_dense, n_dense)
     # ---- head: cgcn_head_train once in full (valid state for the phases and for the backward's head mode), then k_head_fused alone
     hws_b = lib.cgcn_head_workspace_bytes(n, S, d, C)
     hws = torch.empty(hws_b, dtype=torch.uint8, device=dev)
@@ -525,11 +542,24 @@ def time_kernels(stage, name, reps, dropout_p):
                                                 c.target.data_ptr(), float(dropout_p) if drop else 0.0, P(rng) if drop else None,
                                                 probs.data_ptr(), loss.data_ptr(), sm.data_ptr(), si.data_ptr(), colstats.data_ptr(), tiles,
                                                 rows.value, hws.data_ptr(), hws_b, ph)
-    _lib.check(fwd(L, h if split else None, None if split else h, colstats), "fwd")
+    def refill():   # the last layer's forward on the aggregation already in h: fresh column statistics (accumulate mode: zeroed totals)
+        return fwd(L, h if split_last else None, None if split_last else h, colstats)
+    _lib.check(refill(), "fwd")
     _lib.check(head(7), "head")
-    out_t["k_head_fused"] = (ev_time(lambda: head(2)), 1)
-    out_t["k_head_bn_finalize"] = (ev_time(lambda: head(1)), 1)
-    out_t["k_head_train_finish"] = (ev_time(lambda: head(4)), 1)
+    if acc:
+        # accumulate mode: the main kernel ADDS its backward sums and draws a ticket from the buffer -- every timed launch
+        # needs freshly zeroed and refilled totals in front of it: the pair is timed and the refill (timed above) subtracted.
+        # k_head_bn_finalize / k_head_train_finish are not launched in this mode and not listed.
+        def pair():
+            rc = refill()
+            return rc if rc else head(2)
+        out_t["k_head_fused"] = (max(ev_time(pair) - t_d2, 0.0), 1)
+        _lib.check(refill(), "fwd")
+        _lib.check(head(7), "head")   # valid state for the backward's head mode
+    else:
+        out_t["k_head_fused"] = (ev_time(lambda: head(2)), 1)
+        out_t["k_head_bn_finalize"] = (ev_time(lambda: head(1)), 1)
+        out_t["k_head_train_finish"] = (ev_time(lambda: head(4)), 1)
     # ---- backward: row-local launch (head mode = last layer, plain = first layer), then the sliced gather launch
     o_dym, o_bnc, o_part = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
     _lib.check(lib.cgcn_head_workspace_layout(n, S, d, C, ctypes.byref(o_dym), ctypes.byref(o_bnc), ctypes.byref(o_part)), "layout")
@@ -539,7 +569,7 @@ def time_kernels(stage, name, reps, dropout_p):
     hg = _lib.HeadGrad(hws.data_ptr() + o_dym.value, hws.data_ptr() + o_bnc.value, sm.data_ptr(), si.data_ptr(), bn.weight.data_ptr(),
                        float(dropout_p) if drop else 0.0, P(rng) if drop else None, hws.data_ptr() + o_part.value,
                        lib.cgcn_head_bwd_partials(n), C, dW_out.data_ptr(), db_out.data_ptr(), 0, one.data_ptr(), dbn_w.data_ptr(), dbn_b.data_ptr(),
-                       colstats.data_ptr() if rows.value == -1 else None)   # accumulate mode (ABI v23): the backward sums live in the statistics buffer
+                       colstats.data_ptr() if acc else None)   # accumulate mode: the backward sums live in the statistics buffer
     ws_b = lib.cgcn_layer_bwd_workspace_bytes(n, S, d)
     ws = torch.empty(ws_b, dtype=torch.uint8, device=dev)
     dW, db, dwg, dcg = torch.empty(d, d, device=dev), torch.empty(d, device=dev), torch.empty(d, device=dev), torch.empty(1, device=dev)

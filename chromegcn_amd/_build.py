@@ -20,7 +20,10 @@ SRC = [os.path.join(PKG, "csrc", "cgcn_kernels.hip"), os.path.join(PKG, "csrc", 
 HDR = [os.path.join(ROOT, "include", "chromegcn.h"), os.path.join(PKG, "csrc", "cgcn_common.hpp")]
 LIB = os.path.join(PKG, "libchromegcn_hip.so")
 HASH = LIB + ".srchash"
-BASE_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared"]
+# what the compiler reports for every kernel of the build (registers, spills, scratch, LDS, occupancy), written next to the
+# library by build_library: tests/test_kernel_resources.py fails on any spilled register or scratch byte
+RESOURCES = LIB + ".resources.json"
+BASE_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Rpass-analysis=kernel-resource-usage"]
 
 
 def hipcc_path():
@@ -82,7 +85,7 @@ def build_test_variants(force=False, verbose=False):
         cmd = [hipcc] + BASE_FLAGS + ["-I" + os.path.join(ROOT, "include")] + flags + SRC + ["-o", tmp]
         if verbose:
             print(" ".join(cmd))
-        jobs.append((name, target, tmp, subprocess.Popen(cmd)))
+        jobs.append((name, target, tmp, subprocess.Popen(cmd, stderr=subprocess.DEVNULL)))
     for name, target, tmp, p in jobs:
         try:
             if p.wait() != 0:
@@ -94,6 +97,28 @@ def build_test_variants(force=False, verbose=False):
             if os.path.exists(tmp):
                 os.remove(tmp)
     return [variant_path(n) for n in TEST_VARIANTS]
+
+
+def parse_resource_remarks(text: str):
+    """-Rpass-analysis=kernel-resource-usage remarks -> [{name, vgprs, agprs, spill, sgpr_spill, scratch, lds, occupancy}] (one per kernel)"""
+    import re
+    rows, cur = [], None
+    keys = {"VGPRs": "vgprs", "AGPRs": "agprs", "VGPRs Spill": "spill", "SGPRs Spill": "sgpr_spill",
+            "ScratchSize [bytes/lane]": "scratch", "LDS Size [bytes/block]": "lds", "Occupancy [waves/SIMD]": "occupancy"}
+    for ln in text.splitlines():
+        m = re.search(r"remark:\s+(Function Name|[A-Za-z ]+(?: \[[^\]]+\])?): (\S+)", ln)
+        if not m:
+            continue
+        k, v = m.group(1).strip(), m.group(2)
+        if k == "Function Name":
+            cur = {"name": v}
+            rows.append(cur)
+        elif cur is not None and k in keys:
+            try:
+                cur[keys[k]] = int(v)
+            except ValueError:
+                cur[keys[k]] = v
+    return rows
 
 
 def is_stale() -> bool:
@@ -126,16 +151,37 @@ def build_library(force=False, verbose=False, out=None):
     if verbose:
         print(" ".join(cmd))
     try:
-        subprocess.run(cmd, check=True)
+        res = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+        remarks = [ln for ln in res.stderr.splitlines() if "remark:" in ln]
+        other = [ln for ln in res.stderr.splitlines() if "remark:" not in ln]
+        if other and (verbose or res.returncode != 0):
+            print("\n".join(other))
+        if res.returncode != 0:
+            raise subprocess.CalledProcessError(res.returncode, cmd)
         os.replace(tmp, target)
     finally:
         if os.path.exists(tmp):
             os.remove(tmp)
     if out is None:
+        import json
+        with open(RESOURCES + ".tmp.%d" % os.getpid(), "w") as f:
+            json.dump({"source_hash": source_hash([]), "kernels": parse_resource_remarks("\n".join(remarks))}, f, indent=0)
+        os.replace(RESOURCES + ".tmp.%d" % os.getpid(), RESOURCES)
         with open(HASH + ".tmp.%d" % os.getpid(), "w") as f:
             f.write(source_hash([]) + "\n")
         os.replace(HASH + ".tmp.%d" % os.getpid(), HASH)
     return target
+
+
+def kernel_resources():
+    """The compiler's resource report of the in-tree library's kernels, or None when there is none for the current sources."""
+    import json
+    try:
+        with open(RESOURCES) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None
+    return d["kernels"] if d.get("source_hash") == source_hash([]) else None
 
 
 if __name__ == "__main__":

@@ -143,6 +143,7 @@ __host__ __device__ __forceinline__ constexpr size_t stat_acc_fwd_words(int S, i
 __host__ __device__ __forceinline__ constexpr size_t stat_acc_bwd_words(int S, int d) { return (size_t)STAT_ACC_SLOTS * S * d * 2 + 4; }
 static inline size_t stat_acc_words(int S, int d) { return stat_acc_fwd_words(S, d) + stat_acc_bwd_words(S, d); }
 enum { BACC_FLAG = 0, BACC_EXP = 1, BACC_LOSS = 2, BACC_SPARE = 3 };   // header words behind the backward sums
+constexpr unsigned long long BACC_LOSS_BAD = 1ull << 63;   // ORed into the loss word: a share or a backward sum was out of range
 constexpr int BACC_LOSS_FBITS = 16;   // the loss total: per-element BCE terms (>= 0, <= ~30 each, n C < 2^31 of them) above bit 12 of its word,
                                       // the arrival count below (<= 4 095 workgroups): share and ticket are ONE atomic
 __device__ __forceinline__ unsigned long long* bacc_base(const unsigned long long* acc, int S, int D) {
@@ -155,7 +156,8 @@ __device__ __forceinline__ void bacc_add(unsigned long long* b, int S, int D, in
   unsigned long long* w = b + ((size_t)(slot * S + s) * D + c) * 2;
   const double va = ldexp(sdy, fa), vb = ldexp(sdyx, fb);
   if (!(__builtin_fabs(va) < 1.15e18) || !(__builtin_fabs(vb) < 1.15e18)) {   // 2^60: outside the bounds (or NaN): loud
-    atomicOr(b + (size_t)STAT_ACC_SLOTS * S * D * 2 + BACC_FLAG, 1ull);
+    atomicOr(b + (size_t)STAT_ACC_SLOTS * S * D * 2 + BACC_FLAG, 1ull);          // the row-local backward's prologue reads NaN
+    atomicOr(b + (size_t)STAT_ACC_SLOTS * S * D * 2 + BACC_LOSS, BACC_LOSS_BAD); // ... and so does the loss (head_loss_ticket)
     return;
   }
   atomicAdd(&w[0], (unsigned long long)(long long)__builtin_rint(va));

@@ -417,17 +417,131 @@ __global__ __launch_bounds__(256) void k_sum_scale(int m, const float* __restric
   if (threadIdx.x == 0) out[0] = sm[0] * scale;
 }
 
+// Accumulate mode of the training head kernels (k_head_fused, k_head_fused_rs; cgcn_common.hpp, STAT_ACC_*; sa.acc != nullptr):
+// the batch statistics come from the integer totals
+// cgcn_layer_fwd left, every lane decodes the columns it needs in its prologue (`mean` / `invstd` are then not read), and the
+// first workgroup of the first label pass does what k_head_bn_finalize did besides: save_mean / save_invstd for the backward,
+// the running statistics (forward strand, then reverse: the reference calls the model once per strand) and the call count.
+struct HeadStatAcc {
+  const unsigned long long* acc;
+  float eps, momentum;
+  float* run_mean;
+  float* run_var;
+  long long* nbt;
+  float* save_mean;
+  float* save_invstd;
+  float* loss_out;   // the caller's loss word: written by the last workgroup to arrive (k_head_train_finish is not launched)
+};
+// Accumulate mode: the workgroup decodes the totals ONCE, cooperatively -- thread t the (strand, column) pair t: 16 eight-byte
+// loads, an int64 sum, a float64 division and 1 / sqrt -- into an LDS stash [mean S D][invstd S D]; every thread then picks
+// the few columns it needs (head_stat, after a workgroup barrier).  (Round 5 / the first round-6 version had every thread
+// decode its own columns: 4 pairs per thread of the d = 128 kernel, 8 at d = 256 -- 13 us of a 52 us launch there,
+// profiles/r06_stat_acc_experiment.txt.)
+template <int D>
+__device__ __forceinline__ void head_stat_stage(const HeadStatAcc& sa, int n, int S, float* __restrict__ stash, int nthreads) {
+  for (int idx = threadIdx.x; idx < S * D; idx += nthreads) {
+    double m, m2;
+    stat_acc_get(sa.acc, S, D, idx / D, idx % D, n, m, m2);
+    stash[idx] = (float)m;
+    stash[2 * D + idx] = (float)(1.0 / sqrt(m2 / (double)n + (double)sa.eps));
+  }
+}
+template <int D>
+__device__ __forceinline__ void head_stat(const HeadStatAcc& sa, const float* __restrict__ stash, const float* __restrict__ mean,
+                                          const float* __restrict__ invstd, int s, int c, float& mu, float& is) {
+  if (sa.acc) {
+    mu = stash[s * D + c];
+    is = stash[2 * D + s * D + c];
+  } else {
+    mu = mean[s * D + c];
+    is = invstd[s * D + c];
+  }
+}
+
+// The bookkeeping k_head_bn_finalize did besides (one wave of the first workgroup of the first label pass; lane l: columns
+// l EPL .. l EPL + EPL - 1, both strands): save_mean / save_invstd for the backward, the running statistics (forward strand,
+// then reverse: the reference calls the model once per strand), the call count.
+template <int D>
+__device__ __forceinline__ void head_stat_bookkeeping(const HeadStatAcc& sa, int n, int S, int lane) {
+  constexpr int EPL = D / 64;
+  if (lane == 0 && sa.nbt) sa.nbt[0] += S;
+#pragma unroll
+  for (int u = 0; u < EPL; ++u) {
+    const int c = lane * EPL + u;
+    float rm = sa.run_mean[c], rv = sa.run_var[c];
+    for (int st = 0; st < S; ++st) {
+      double m, m2;
+      stat_acc_get(sa.acc, S, D, st, c, n, m, m2);
+      sa.save_mean[st * D + c] = (float)m;
+      sa.save_invstd[st * D + c] = (float)(1.0 / sqrt(m2 / (double)n + (double)sa.eps));
+      rm = (1.f - sa.momentum) * rm + sa.momentum * (float)m;
+      rv = (1.f - sa.momentum) * rv + sa.momentum * (float)(m2 / (double)(n - 1));
+    }
+    sa.run_mean[c] = rm;
+    sa.run_var[c] = rv;
+  }
+}
+// This workgroup's share of the loss joins the total as a fixed-point integer, and the SAME atomic draws its ticket (the share
+// sits above bit 12, the arrival count below: BCE terms are >= 0, so nothing borrows): whoever finds gridDim.x - 1 earlier
+// arrivals in the returned word holds the complete total -- every other share was added by an atomic that precedes this one at
+// the memory side -- and writes the caller's loss.  One round trip at the workgroup's tail instead of three.
+// "Something went wrong" travels in the SAME word, as bit 63 (BACC_LOSS_BAD; the sum stays far below it): a share that is
+// NaN / absurd (statistics outside the fixed-point range upstream) ORs it in before its add, and so does bacc_add for a
+// backward sum that does not fit (the thread that does is ordered before this workgroup's ticket by the workgroup barrier in
+// between).  Operations on ONE word are totally ordered, so the last arriver sees every such OR -- no fence: an agent-scope
+// fence writes the L2 back on this chip (private L2 per XCD) and cost 40 us per launch when every thread issued one
+// (profiles/r06_stat_acc_experiment.txt); round 5 kept the flag in a word of its own, whose update could pass the ticket's.
+// ONE thread of the workgroup calls this, behind a workgroup barrier.
+__device__ __forceinline__ void head_loss_ticket(const HeadStatAcc& sa, int S, int D, float tl, float inv_count) {
+  unsigned long long* h = bacc_base(sa.acc, S, D) + (size_t)STAT_ACC_SLOTS * S * D * 2;
+  const bool bad = !(tl >= 0.f && tl < 1e9f);   // the total of <= 4 095 realistic shares stays far below 2^36 (x 2^16 x 2^12 = 2^64)
+  if (bad) {
+    atomicOr(&h[BACC_FLAG], 2ull);              // (for the consumers behind the kernel boundary)
+    atomicOr(&h[BACC_LOSS], BACC_LOSS_BAD);
+  }
+  const unsigned long long mine = ((bad ? 0ull : (unsigned long long)__builtin_rint(ldexp((double)tl, BACC_LOSS_FBITS))) << 12) | 1ull;
+  const unsigned long long old = atomicAdd(&h[BACC_LOSS], mine);
+  if ((old & 0xFFFull) == (unsigned long long)gridDim.x - 1ull) {
+    const unsigned long long tot = old + mine;
+    sa.loss_out[0] = (tot & BACC_LOSS_BAD) ? __builtin_nanf("")
+                                           : (float)(ldexp((double)((tot & ~BACC_LOSS_BAD) >> 12), -BACC_LOSS_FBITS) * (double)inv_count);
+  }
+}
+// The binary points of the backward sums (cgcn_common.hpp): from max |W_out| over ALL labels (per-wave maxima in wmax[nw]).
+__device__ __forceinline__ void head_bacc_points(const float* wmax, int nw, float keep_scale, int n, int& fa, int& fb) {
+  float mw = 0.f;
+  for (int w = 0; w < nw; ++w) mw = fmaxf(mw, wmax[w]);
+  const double bound = fmax((double)keep_scale * (double)mw, 1e-30) * 1.001;
+  fa = bacc_fbits(bound);
+  fb = bacc_fbits(bound * sqrt((double)n) * 1.001);
+}
+__device__ __forceinline__ float head_wout_absmax(const float* __restrict__ Wout, int count4, int nthreads) {
+  float mw = 0.f;
+  for (int idx = threadIdx.x; idx < count4; idx += nthreads) {
+    const f32x4 v = *(const f32x4*)&Wout[(size_t)idx * 4];
+    mw = fmaxf(fmaxf(mw, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mw = fmaxf(mw, __shfl_xor(mw, o, WAVE));
+  return mw;
+}
+
 // Cross-wave merge of the per-thread BatchNorm-backward column sums into the workgroup's partial record, in float64
 // from here on (a thread's own sum covers 4 rows per tile -- a few dozen fp32 terms whose rounding is random across
 // threads; it is the LARGE partial sums of the later stages whose rounding is coherent over a column, cgcn_common.hpp):
 // two rounds (sum dy, then sum dy*xhat) through an LDS scratch of NW * 2 * D doubles, waves added in a fixed order.
+// Accumulate mode (bacc != nullptr): the same totals also join the integer totals of the statistics buffer (bacc_add; binary
+// points fa / fb), for the row-local backward's prologue.
 template <int D, int NW, int SCRATCH_FLOATS>
 __device__ __forceinline__ void head_stats_partial(float* __restrict__ scratch, double* __restrict__ out,
                                                    const float (&sdy)[2][D / 64], const float (&sdyx)[2][D / 64],
-                                                   int wave, int lane) {
+                                                   int wave, int lane, unsigned long long* bacc = nullptr, int S = 0,
+                                                   int fa = 0, int fb = 0) {
   constexpr int EPL = D / 64, RS = 2 * D;
   static_assert(NW * RS * 2 <= SCRATCH_FLOATS, "reduction scratch must fit in the tile buffer");
+  static_assert(RS == NW * 64 || RS == 2 * NW * 64 || RS * 2 == NW * 64, "a thread's columns are the same in both rounds");
   double* red = (double*)scratch;
+  double keep[2] = {0.0, 0.0};   // round 0's total of this thread's first two (strand, column) pairs (RS <= 2 NW 64)
   for (int round = 0; round < 2; ++round) {
     __syncthreads();
 #pragma unroll
@@ -435,10 +549,15 @@ __device__ __forceinline__ void head_stats_partial(float* __restrict__ scratch, 
 #pragma unroll
       for (int e = 0; e < EPL; ++e) red[wave * RS + s * D + lane * EPL + e] = (double)(round ? sdyx[s][e] : sdy[s][e]);
     __syncthreads();
-    for (int c = threadIdx.x; c < RS; c += NW * 64) {
+    int k = 0;
+    for (int c = threadIdx.x; c < RS; c += NW * 64, ++k) {
       double t = 0.0;
       for (int w = 0; w < NW; ++w) t += red[w * RS + c];
       out[round * RS + c] = t;
+      if (bacc) {
+        if (round == 0) keep[k & 1] = t;
+        else if (c / D < S) bacc_add(bacc, S, D, (int)blockIdx.x & (STAT_ACC_SLOTS - 1), c / D, c % D, keep[k & 1], t, fa, fb);
+      }
     }
   }
 }
@@ -717,7 +836,7 @@ __global__ __launch_bounds__(512, HF_LOWREG ? 4 : 1) void k_head_fused(int n, in
                                                     const unsigned long long* __restrict__ rng_state, float inv_count,
                                                     float* __restrict__ probs, float* __restrict__ loss_part,
                                                     float* __restrict__ dym, float* __restrict__ part,
-                                                    int c0, int Cp, int CPT, int first, int last) {
+                                                    int c0, int Cp, int CPT, int first, int last, HeadStatAcc sa) {
   constexpr int TR = HEADB_TILE, NW = 8, EPL = D / 64, RPW = TR / NW, KQ = D / 4;
   constexpr int CP = CBMAX * 16, NCBW = CBMAX / 8;
   constexpr int LDP = CP + ((CP & 16) ? 2 : 18);
@@ -727,6 +846,7 @@ __global__ __launch_bounds__(512, HF_LOWREG ? 4 : 1) void k_head_fused(int n, in
   __shared__ __attribute__((aligned(16))) float Pt[TR * LDP];
   __shared__ __attribute__((aligned(16))) float Yt[TR * LDY];
   __shared__ float lsum[NW];
+  __shared__ float wmax[NW];   // accumulate mode: per-wave max |W_out| (the binary points of the backward sums)
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -735,6 +855,12 @@ __global__ __launch_bounds__(512, HF_LOWREG ? 4 : 1) void k_head_fused(int n, in
   const int CB = (Cp + 15) / 16;
   const float invS = 1.f / (float)S;
   const int PS = head_part_stride(CPT, D);
+  if (sa.acc && last) {   // max |W_out| over ALL labels (the earlier label passes' share of dym is in the sums too)
+    const float mw = head_wout_absmax(Wout, C * (D / 4), NW * 64);
+    if (lane == 0) wmax[wave] = mw;
+  }
+  // accumulate mode: one wave of the first workgroup of the first label pass does k_head_bn_finalize's bookkeeping
+  if (sa.acc && blockIdx.x == 0 && first && wave == NW - 1) head_stat_bookkeeping<D>(sa, n, S, lane);
 
   HF_STAMP(0);
   HF_STAMP(1);
@@ -770,6 +896,11 @@ __global__ __launch_bounds__(512, HF_LOWREG ? 4 : 1) void k_head_fused(int n, in
   float dbo = 0.f, lacc = 0.f;
   float sdy[2][EPL], sdyx[2][EPL];   // per thread: <= a few dozen rows in fp32; float64 from the cross-wave merge on
   float mu[2][EPL], is[2][EPL], gw[EPL], gb[EPL];
+  if (sa.acc) {   // accumulate mode: batch mean / invstd decoded from the integer totals, once per workgroup (head_stat_stage)
+    static_assert(TR * LDY >= 4 * D, "the stash fits the Y tile");
+    head_stat_stage<D>(sa, n, S, Yt, NW * 64);
+    __syncthreads();
+  }
 #pragma unroll
   for (int e = 0; e < EPL; ++e) {
     const int c = lane * EPL + e;
@@ -778,10 +909,10 @@ __global__ __launch_bounds__(512, HF_LOWREG ? 4 : 1) void k_head_fused(int n, in
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       sdy[s][e] = sdyx[s][e] = 0.f;
-      mu[s][e] = mean[(s < S ? s : 0) * D + c];
-      is[s][e] = invstd[(s < S ? s : 0) * D + c];
+      head_stat<D>(sa, Yt, mean, invstd, s < S ? s : 0, c, mu[s][e], is[s][e]);   // (accumulate mode: from the stash in Yt)
     }
   }
+  if (sa.acc) __syncthreads();   // the stash has been read: Yt becomes the tile
 
   const int ntiles = (n + TR - 1) / TR;
   // All global loads of a tile -- this wave's X rows, the targets / bias of this lane's logits -- are issued together.
@@ -1035,13 +1166,24 @@ __global__ __launch_bounds__(512, HF_LOWREG ? 4 : 1) void k_head_fused(int n, in
   HF_STAMP(11);
   lacc = wave_sum(lacc);
   if (lane == 0) lsum[wave] = lacc;
-  if (last) head_stats_partial<D, NW, TR * LDY>(Yt, (double*)(P + CPT * D + CPT), sdy, sdyx, wave, lane);
+  if (last) {
+    unsigned long long* bb = sa.acc ? bacc_base(sa.acc, S, D) : nullptr;
+    int fa = 0, fb = 0;
+    if (sa.acc) {   // (wmax: written in the prologue, every workgroup barrier of the tile loop in between)
+      head_bacc_points(wmax, NW, keep_scale, n, fa, fb);
+      if (blockIdx.x == 0 && threadIdx.x == 0)
+        bb[(size_t)STAT_ACC_SLOTS * S * D * 2 + BACC_EXP] = ((unsigned long long)(unsigned)(fb + 1024) << 32) | (unsigned long long)(unsigned)(fa + 1024);
+    }
+    head_stats_partial<D, NW, TR * LDY>(Yt, (double*)(P + CPT * D + CPT), sdy, sdyx, wave, lane, bb, S, fa, fb);
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) t += lsum[w];
-    loss_part[blockIdx.x] = first ? t : loss_part[blockIdx.x] + t;   // the label passes' shares add up
+    const float tl = first ? t : loss_part[blockIdx.x] + t;   // the label passes' shares add up
+    loss_part[blockIdx.x] = tl;
+    if (sa.acc && last) head_loss_ticket(sa, S, D, tl, inv_count);   // k_head_train_finish is not launched
   }
   HF_STAMP(12);
 }
@@ -1069,33 +1211,6 @@ __global__ __launch_bounds__(512, HF_LOWREG ? 4 : 1) void k_head_fused(int n, in
 // accumulators -- lives in the SAME 40 registers).  LDS: W_out 72 KB + two Yt + two Pt tiles 73 KB.
 // Same partial records, label passes and results as k_head_fused.
 // ------------------------------------------------------------------------------------------
-// Accumulate mode (cgcn_common.hpp, STAT_ACC_*; sa.acc != nullptr): the batch statistics come from the integer totals
-// cgcn_layer_fwd left, every lane decodes the columns it needs in its prologue (`mean` / `invstd` are then not read), and the
-// first workgroup of the first label pass does what k_head_bn_finalize did besides: save_mean / save_invstd for the backward,
-// the running statistics (forward strand, then reverse: the reference calls the model once per strand) and the call count.
-struct HeadStatAcc {
-  const unsigned long long* acc;
-  float eps, momentum;
-  float* run_mean;
-  float* run_var;
-  long long* nbt;
-  float* save_mean;
-  float* save_invstd;
-  float* loss_out;   // the caller's loss word: written by the last workgroup to arrive (k_head_train_finish is not launched)
-};
-__device__ __forceinline__ void head_stat(const HeadStatAcc& sa, const float* __restrict__ mean, const float* __restrict__ invstd,
-                                          int n, int S, int D, int s, int c, float& mu, float& is) {
-  if (sa.acc) {
-    double m, m2;
-    stat_acc_get(sa.acc, S, D, s, c, n, m, m2);
-    mu = (float)m;
-    is = (float)(1.0 / sqrt(m2 / (double)n + (double)sa.eps));
-  } else {
-    mu = mean[s * D + c];
-    is = invstd[s * D + c];
-  }
-}
-
 #ifndef HEAD_RS
 #define HEAD_RS 1   // 0: the 8-wave k_head_fused at d = 128 as well (A/B builds)
 #endif
@@ -1167,15 +1282,14 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
     *(f32x4*)&Wl[j * LDW + c4 * 4] = v;
   }
   if (sa.acc && last) {   // max |W_out| over ALL labels (the earlier label passes' share of dym is in the sums too)
-    float mw = 0.f;
-    for (int idx = threadIdx.x; idx < C * (D / 4); idx += 1024) {
-      const f32x4 v = *(const f32x4*)&Wout[(size_t)idx * 4];
-      mw = fmaxf(fmaxf(mw, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mw = fmaxf(mw, __shfl_xor(mw, o, WAVE));
+    const float mw = head_wout_absmax(Wout, C * (D / 4), 1024);
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mw;
   }
+  // accumulate mode: batch mean / invstd decoded from the integer totals once per workgroup into Pt[1] (first written in S3 of
+  // period 1, read by both roles right behind the "Wl complete" barrier)
+  float* const stash = Pt[1];
+  static_assert(TR * LDP >= 4 * D, "the stash fits a P tile");
+  if (sa.acc) head_stat_stage<D>(sa, n, S, stash, 1024);
   // The two roles run SEPARATE loops (the register allocator then sees each role's state on its own path) that execute
   // the same number of workgroup barriers: one before and one after the loop, three per period.
   // In every role phase the lane-derived indices are re-derived from an opaque copy of the lane id: addresses kept live
@@ -1195,8 +1309,6 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
       const int c = lane * EPL + e;
       gw[e] = bn_w[c];
       gb[e] = bn_b[c];
-#pragma unroll
-      for (int s = 0; s < 2; ++s) head_stat(sa, mean, invstd, n, S, D, s < S ? s : 0, c, mu[s][e], is[s][e]);
     }
     // this wave's X rows of a tile are requested one tile ahead (at the top of phase B of the tile before: in flight
     // during its pred product and epilogue); the targets of this lane's logits at the end of that phase B
@@ -1227,7 +1339,11 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
       load_rows(blockIdx.x);
       load_targets(blockIdx.x);
     }
-    __syncthreads();   // Wl complete
+    __syncthreads();   // Wl complete (and the statistics stash)
+#pragma unroll
+    for (int e = 0; e < EPL; ++e)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) head_stat<D>(sa, stash, mean, invstd, s < S ? s : 0, lane * EPL + e, mu[s][e], is[s][e]);
     for (int k = 0; k <= mt; ++k) {
       const int tile = (int)blockIdx.x + k * G;
       const int node0 = tile * TR;
@@ -1333,23 +1449,7 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
       for (int w = 0; w < 8; ++w) t += lsum[w];
       const float tl = first ? t : loss_part[blockIdx.x] + t;   // the label passes' shares add up
       loss_part[blockIdx.x] = tl;
-      if (sa.acc && last) {
-        // accumulate mode: this workgroup's share joins the loss total as a fixed-point integer, and the SAME atomic draws its
-        // ticket (the share sits above bit 12, the arrival count below: BCE terms are >= 0, so nothing borrows): whoever
-        // finds gridDim.x - 1 earlier arrivals in the returned word holds the complete total -- every other share was added
-        // by an atomic that precedes this one at the memory side -- and writes the caller's loss.  One round trip at the
-        // workgroup's tail instead of three.
-        unsigned long long* h = bacc_base(sa.acc, S, D) + (size_t)STAT_ACC_SLOTS * S * D * 2;
-        const bool bad = !(tl >= 0.f && tl < 1e9f);   // NaN (statistics outside the fixed-point range upstream) or absurd: the
-                                                      // total of <= 4 095 shares below 1e9 stays below 2^36 (x 2^16 x 2^12 = 2^64)
-        if (bad) atomicOr(&h[BACC_FLAG], 2ull);
-        const unsigned long long mine = ((bad ? 0ull : (unsigned long long)__builtin_rint(ldexp((double)tl, BACC_LOSS_FBITS))) << 12) | 1ull;
-        const unsigned long long old = atomicAdd(&h[BACC_LOSS], mine);
-        if ((old & 0xFFFull) == (unsigned long long)gridDim.x - 1ull) {
-          const unsigned long long flag = atomicOr(&h[BACC_FLAG], 0ull);
-          sa.loss_out[0] = flag ? __builtin_nanf("") : (float)(ldexp((double)((old + mine) >> 12), -BACC_LOSS_FBITS) * (double)inv_count);
-        }
-      }
+      if (sa.acc && last) head_loss_ticket(sa, S, D, tl, inv_count);   // (the Q team's integer adds: before the barrier above)
     }
   } else {
     // =============================================================== Q: grad team, one tile behind
@@ -1357,28 +1457,10 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
 #pragma unroll
     for (int i = 0; i < NB; ++i) accW[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float sdy[2] = {0.f, 0.f}, sdyx[2] = {0.f, 0.f}, mu[2], is[2];
+    if (sa.acc && blockIdx.x == 0 && first && wave == 8) head_stat_bookkeeping<D>(sa, n, S, lane);   // (see HeadStatAcc)
+    __syncthreads();   // Wl complete (and the statistics stash)
 #pragma unroll
-    for (int s = 0; s < 2; ++s) head_stat(sa, mean, invstd, n, S, D, s < S ? s : 0, own * 16 + (lane & 15), mu[s], is[s]);
-    if (sa.acc && blockIdx.x == 0 && first && wave == 8) {
-      // (one wave of the first workgroup: two columns per lane, both strands; see HeadStatAcc)
-      if (lane == 0 && sa.nbt) sa.nbt[0] += S;
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int c = lane * 2 + u;
-        float rm = sa.run_mean[c], rv = sa.run_var[c];
-        for (int st = 0; st < S; ++st) {
-          double m, m2;
-          stat_acc_get(sa.acc, S, D, st, c, n, m, m2);
-          sa.save_mean[st * D + c] = (float)m;
-          sa.save_invstd[st * D + c] = (float)(1.0 / sqrt(m2 / (double)n + (double)sa.eps));
-          rm = (1.f - sa.momentum) * rm + sa.momentum * (float)m;
-          rv = (1.f - sa.momentum) * rv + sa.momentum * (float)(m2 / (double)(n - 1));
-        }
-        sa.run_mean[c] = rm;
-        sa.run_var[c] = rv;
-      }
-    }
-    __syncthreads();   // Wl complete
+    for (int s = 0; s < 2; ++s) head_stat<D>(sa, stash, mean, invstd, s < S ? s : 0, own * 16 + (lane & 15), mu[s], is[s]);
     // X of this lane's (row, column) elements of a tile, for the BatchNorm sums of its epilogue: requested a whole matrix
     // product before they are used -- the rows have left the L2 since P read them (a 30 MB table), and their latency was
     // all of the epilogue's time when they were requested there
@@ -1531,11 +1613,8 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
           out[s * D + own * 16 + r] = a;
           out[(2 + s) * D + own * 16 + r] = b;
           if (sa.acc && s < S) {   // accumulate mode: the same sums as integer totals for the row-local backward's prologue
-            float mw = 0.f;
-#pragma unroll
-            for (int w = 0; w < 16; ++w) mw = fmaxf(mw, wmax[w]);
-            const double bound = fmax((double)keep_scale * (double)mw, 1e-30) * 1.001;
-            const int fa = bacc_fbits(bound), fb = bacc_fbits(bound * sqrt((double)n) * 1.001);
+            int fa, fb;
+            head_bacc_points(wmax, 16, keep_scale, n, fa, fb);
             unsigned long long* bb = bacc_base(sa.acc, S, D);
             bacc_add(bb, S, D, (int)blockIdx.x & (STAT_ACC_SLOTS - 1), s, own * 16 + r, a, b, fa, fb);
             if (blockIdx.x == 0 && s == 0 && own == 0 && r == 0)
@@ -1773,7 +1852,7 @@ static int head_train_impl(cgcn_stream_t stream, int n, int S, int d, int C, con
   // accumulate mode (cgcn_layer_fwd_colstats_tiles reported rows = -1): the buffer holds integer totals, not records
   const size_t acc_tile_bytes = (size_t)S * d * 2 * sizeof(float);
   const bool stat_acc = col_stats && col_stats_rows == -1;
-  if (stat_acc && (d != 128 || !HEAD_RS || (size_t)col_stats_tiles * acc_tile_bytes < stat_acc_words(S, d) * 8 || ((uintptr_t)col_stats & 7)))
+  if (stat_acc && ((size_t)col_stats_tiles * acc_tile_bytes < stat_acc_words(S, d) * 8 || ((uintptr_t)col_stats & 7)))
     return CGCN_ERR_BAD_ARG;
   if (col_stats && !stat_acc && (col_stats_rows < 1 || col_stats_tiles != (n + col_stats_rows - 1) / col_stats_rows)) return CGCN_ERR_BAD_ARG;
   const bool drop = dropout_p > 0.f;
@@ -1820,7 +1899,7 @@ static int head_train_impl(cgcn_stream_t stream, int n, int S, int d, int C, con
 #define HFU(D_)                                                                                                        \
     hipLaunchKernelGGL((k_head_fused<D_, 8>), dim3(P), dim3(512), 0, st, n, S, C, X, bn_w, bn_b, save_mean, save_invstd, \
                        Wout, bout, target, keep_scale, thresh, rng_state, inv_count, probs, w_loss, w_dym, w_part, c0, Cp, \
-                       CP, first, last)
+                       CP, first, last, (phases & 1) ? sa : sa_prof)
     if (d == 128 && HEAD_RS) {
       const bool nb7 = Cp > 96 && Cp <= 112;
       // Tile height.  A launch lasts (tiles per workgroup + 1) periods -- the Q team runs one tile behind the P team --,

@@ -669,13 +669,8 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512, FWD_WAVES_PE
 #ifndef DENSE_WAVES_PER_SIMD
 #define DENSE_WAVES_PER_SIMD 4
 #endif
-#ifndef DENSE256_PRE
-#define DENSE256_PRE 1   // d = 256: W fragments resident too (128 registers per wave, one 8-wave workgroup per CU, W read once per
-#endif                   // workgroup instead of once per tile from L2 inside the K loop: profiles/r05_d256_dense_experiment.txt)
-#define DENSE_WPS(D_) (((D_) == 256 && DENSE256_PRE) ? 2 : DENSE_WAVES_PER_SIMD)
-
 template <int S, int D, int MB>
-__global__ __launch_bounds__(512, DENSE_WPS(D)) void k_layer_dense(int n, int ntiles, const float* __restrict__ Hin,
+__global__ __launch_bounds__(512, DENSE_WAVES_PER_SIMD) void k_layer_dense(int n, int ntiles, const float* __restrict__ Hin,
                                                     const float* __restrict__ X, const float* __restrict__ W,
                                                     const float* __restrict__ bias, const float* __restrict__ wg,
                                                     const float* __restrict__ cg, float* __restrict__ Xn,
@@ -686,12 +681,13 @@ __global__ __launch_bounds__(512, DENSE_WPS(D)) void k_layer_dense(int n, int nt
                                                     int stat_acc) {
   constexpr int ROWS = 16 * MB;      // MFMA rows in the tile
   constexpr int R = ROWS / S;        // nodes in the tile
-  constexpr int CBW = (D == 128) ? 1 : 2;  // 16-wide output column blocks per wave
+  static_assert(D == 128, "d = 256 has its own kernel (k_layer_dense256)");
+  constexpr int CBW = 1;             // 16-wide output column blocks per wave
   constexpr int NW = 8;
   constexpr int LD = D + 4;          // LDS row stride (floats); keeps 16-byte alignment
   constexpr int EPL = D / 64;        // floats per lane in the row-wise passes
   constexpr int RPW = ROWS / NW;     // rows per wave
-  constexpr bool PRE = (D == 128) || DENSE256_PRE;
+  constexpr bool PRE = true;         // W fragments resident in registers
   static_assert(D / (16 * CBW) == NW && ROWS % NW == 0, "geometry");
   __shared__ __attribute__((aligned(16))) float T[ROWS * LD];
 
@@ -871,6 +867,176 @@ __global__ __launch_bounds__(512, DENSE_WPS(D)) void k_layer_dense(int n, int nt
       }
     }
     __syncthreads();  // T is rewritten by the next tile
+  }
+  if (colstats && threadIdx.x < S * D && tfirst < tend) {
+    if (stat_acc) {   // accumulate mode (cgcn_common.hpp, STAT_ACC_*): this workgroup's sum x and sum x^2, formed in double
+      const double nb = (double)st_cnt, mb = (double)st_mean;
+      stat_acc_add((unsigned long long*)colstats, S, D, (int)blockIdx.x & (STAT_ACC_SLOTS - 1), (int)threadIdx.x / D,
+                   (int)threadIdx.x % D, nb * mb, (double)st_m2 + nb * mb * mb);
+    } else {
+      float* out = colstats + ((size_t)blockIdx.x * S * D + threadIdx.x) * 2;
+      out[0] = st_mean;
+      out[1] = st_m2;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_layer_dense256 (round 6): k_layer_dense for D = 256 as ONE 16-wave workgroup per CU.
+// W is 256 KB -- half of a CU's register file -- so it has to be spread over all 16 waves that fit a CU at 128 registers:
+// wave w owns the 16 output columns [16 w, 16 w + 16) and keeps their 64 B-operand registers resident (k_layer_dense<S,256>
+// held 128 per wave in 8 waves, spilled 20 registers and could not co-reside with a second workgroup).  The fragments arrive
+// COALESCED: every wave reads whole 1 KiB rows of W (16 float4 per lane, all requested before the first wait) and the
+// workgroup transposes them through LDS in four 64-row rounds -- the 8-wave kernel's prologue issued 128 four-byte loads
+// per lane against a matrix that all 2 048 waves of the launch wanted at the same moment (12 us of a 33 us kernel,
+// profiles/r05_d256_dense_experiment.txt; here 5 us).
+// Per 16-row tile (R = 16 / S nodes x S strands): wave w puts row w of H into the LDS tile and holds row w of X for the
+// residual mix (both one tile ahead), 64 fp32 MFMAs per wave (one 16 x 16 accumulator, K = 256 in the permuted order of
+// tile_mfma), tanh(U + b) -> LDS, then wave w finishes row w: gate (DPP wave sum), mix, dropout, 16-byte stores.
+// Column statistics (the last layer): one (strand, column) per thread over the tile's nodes, Chan-merged over the
+// workgroup's contiguous tile chunk, emitted as one record or as fixed-point integer totals -- exactly k_layer_dense's.
+// What bounds it (profiles/r06_dense256_experiment.txt): the ALUs.  A tile costs a SIMD 256 MFMAs x 32 cycles plus ~4 800
+// cycles of vector work (tanh 27 instructions x 16 wave-elements, the row pass), and the two ADD UP: on this chip the fp32
+// MFMA rate equals the fp32 vector rate (MI355X_MICROARCH.md) and a version of this kernel that issued every wave's tanh and
+// row pass BETWEEN the MFMAs of the next tile (three-stage pipeline, one barrier per tile, straight-line block with buffer-
+// descriptor stores and LDS-DMA loads) ran at the same 5.7-6.1 us per tile as this phase-by-phase one -- removed.
+// ------------------------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(1024) void k_layer_dense256(int n, int ntiles, const float* __restrict__ Hin,
+                                                          const float* __restrict__ X, const float* __restrict__ W,
+                                                          const float* __restrict__ bias, const float* __restrict__ wg,
+                                                          const float* __restrict__ cg, float* __restrict__ Xn,
+                                                          float* __restrict__ Zout, float* __restrict__ gate,
+                                                          float keep_scale, uint32_t thresh,
+                                                          const unsigned long long* __restrict__ rng_state,
+                                                          uint32_t stream_id, float* __restrict__ colstats, int stat_chunk,
+                                                          int stat_acc) {
+  constexpr int D = 256, ROWS = 16, R = ROWS / S, LD = D + 4, KCH = 64, TILE = ROWS * LD;
+  // one W staging round (64 rows); afterwards the A tile T, the tanh tile Zt and the relu(Xn) tile St of the statistics
+  __shared__ __attribute__((aligned(16))) float smem[KCH * LD];
+  static_assert(KCH * LD >= 3 * TILE, "the tiles fit the staging buffer");
+  float* const T = smem;
+  float* const Zt = smem + TILE;
+  float* const St = smem + 2 * TILE;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int j = wave * 16 + r;                // this lane's output column
+  const int l4 = lane * 4;
+  const int ms = wave / R, mr = wave % R;     // this wave's row of a tile: strand, node inside the tile
+  // Tile walk as k_layer_dense: without column statistics tiles b, b + G, ...; with them a CONTIGUOUS chunk per workgroup
+  const int tfirst = colstats ? (int)blockIdx.x * stat_chunk : (int)blockIdx.x;
+  const int tstep = colstats ? 1 : (int)gridDim.x;
+  const int tend = colstats ? min(ntiles, tfirst + stat_chunk) : ntiles;
+  auto load_row = [&](f32x4& dst, const float* __restrict__ src, int tile) {
+    const int i = tile * R + mr;
+    dst = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (i < n) dst = *(const f32x4*)&src[((size_t)ms * n + i) * D + l4];
+  };
+  KT_STAMP(8);
+  // ---- W -> registers through LDS (round c: rows 64 c .. 64 c + 63)
+  float bw[64];
+  {
+    f32x4 wv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) wv[u] = *(const f32x4*)&W[(size_t)(wave + 16 * u) * D + l4];   // row wave + 16 u, whole
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c) __syncthreads();   // the round before has been read
+#pragma unroll
+      for (int uu = 0; uu < 4; ++uu) *(f32x4*)&smem[(wave + 16 * uu) * LD + l4] = wv[4 * c + uu];
+      __syncthreads();
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bw[16 * c + 4 * tt + u] = smem[(16 * tt + 4 * q + u) * LD + j];   // k = 64 c + 16 tt + 4 q + u
+    }
+  }
+  f32x4 hrow = {0.f, 0.f, 0.f, 0.f}, xnext = hrow, xres = hrow;
+  if (tfirst < tend) {
+    load_row(hrow, Hin, tfirst);
+    load_row(xnext, X, tfirst);
+  }
+  const float bj = bias[j];
+  const f32x4 wg4 = *(const f32x4*)&wg[l4];
+  const float c0 = cg[0];
+  const uint32_t key = thresh ? dropout_key(rng_state, stream_id) : 0u;
+  float st_cnt = 0.f, st_mean = 0.f, st_m2 = 0.f;   // running statistics of this thread's (strand, column)
+  __syncthreads();   // the last round has been read: the buffer becomes the tiles
+  KT_STAMP(9);
+  for (int tile = tfirst; tile < tend; tile += tstep) {
+    const int node0 = tile * R;
+    KT_STAMP(10);
+    *(f32x4*)&T[wave * LD + l4] = hrow;
+    xres = xnext;
+    if (tile + tstep < tend) {   // both input streams one tile ahead
+      load_row(hrow, Hin, tile + tstep);
+      load_row(xnext, X, tile + tstep);
+    }
+    __syncthreads();
+    KT_STAMP(11);
+    // ---- U = H W (this wave's 16 columns)
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    {
+      const float* __restrict__ Ta = T + r * LD + 4 * q;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const f32x4 a = *(const f32x4*)&Ta[16 * t];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], bw[4 * t + u], acc, 0, 0, 0);
+      }
+    }
+    KT_STAMP(12);
+    // ---- Z = tanh(U + b) -> the tanh tile (its last readers, the row pass of the tile before, are behind the barrier above)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) Zt[(q * 4 + e) * LD + j] = tanhf(acc[e] + bj);
+    __syncthreads();   // (also: every wave is done reading T)
+    KT_STAMP(13);
+    // ---- row `wave`: gate, residual mix, dropout, coalesced stores
+    {
+      const int i = node0 + mr;
+      const f32x4 z4 = *(const f32x4*)&Zt[wave * LD + l4];
+      float dot = z4[0] * wg4[0] + z4[1] * wg4[1] + z4[2] * wg4[2] + z4[3] * wg4[3];
+      dot = wave_sum(dot);
+      const float g = sigmoidf_(dot + c0);
+      f32x4 xo = {0.f, 0.f, 0.f, 0.f};
+      if (i < n) {
+        const size_t g_off = ((size_t)ms * n + i) * D + l4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xo[e] = (1.f - g) * xres[e] + g * z4[e];
+          if (thresh) xo[e] = dropout_keep(key, (uint32_t)(g_off + e), thresh) ? xo[e] * keep_scale : 0.f;
+        }
+        *(f32x4*)&Xn[g_off] = xo;
+        if (Zout) *(f32x4*)&Zout[g_off] = z4;
+        if (lane == 0) gate[(size_t)ms * n + i] = g;
+      }
+      if (colstats) *(f32x4*)&St[wave * LD + l4] = (f32x4){fmaxf(xo[0], 0.f), fmaxf(xo[1], 0.f), fmaxf(xo[2], 0.f), fmaxf(xo[3], 0.f)};
+    }
+    KT_STAMP(14);
+    // ---- optional: first stage of the classifier head's BatchNorm statistics while the tile is on chip: per (strand,
+    // column) the exact two-pass (mean, M2) of relu(Xn) over this tile's nodes, Chan-merged into the chunk's
+    if (colstats) {
+      __syncthreads();
+      const int idx = threadIdx.x;
+      if (idx < S * D) {
+        const int s = idx / D, c = idx % D;
+        const int cnt = min(R, n - node0);
+        const float inv = 1.f / (float)cnt;
+        float v[R];
+        float sum = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+          v[rr] = St[(s * R + rr) * LD + c];
+          sum += rr < cnt ? v[rr] : 0.f;
+        }
+        const float mean = sum * inv;
+        float m2 = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) m2 += rr < cnt ? (v[rr] - mean) * (v[rr] - mean) : 0.f;
+        chan_combine(st_cnt, st_mean, st_m2, (float)cnt, mean, m2);
+      }
+    }
   }
   if (colstats && threadIdx.x < S * D && tfirst < tend) {
     if (stat_acc) {   // accumulate mode (cgcn_common.hpp, STAT_ACC_*): this workgroup's sum x and sum x^2, formed in double
@@ -1418,8 +1584,18 @@ __global__ __launch_bounds__(RL256_THREADS) void k_bwd_rowlocal256s(int M, int n
   __shared__ __attribute__((aligned(16))) float Us[2][TR * LD];
   __shared__ __attribute__((aligned(16))) float red[NRW][RS];   // column sums of the row waves
   __shared__ unsigned flg[5];                                    // FULL[2], FREE[2], DONE
+  __shared__ float Hc[2 * 2 * D];                                // accumulate mode: bnc decoded from the integer totals, [S][2][D]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (hp.dym && hp.bacc) {   // (complete at THE barrier below; cgcn_common.hpp, bacc_get)
+    for (int idx = threadIdx.x; idx < hp.S * D; idx += NT) {
+      const int s = idx / D, c = idx % D;
+      float c0, c1;
+      bacc_get(bacc_base(hp.bacc, hp.S, D), hp.S, D, s, c, n, c0, c1);
+      Hc[(s * 2 + 0) * D + c] = c0;
+      Hc[(s * 2 + 1) * D + c] = c1;
+    }
+  }
   // workgroup -> (range, slab): the four slabs of a range are 8 workgroup ids apart (one XCD under round-robin dispatch)
   const int b = (int)blockIdx.x, NR = row_blocks >> 2;
   const int cs = (b >> 3) & 3, range = (b & 7) + 8 * (b >> 5);
@@ -1496,8 +1672,13 @@ __global__ __launch_bounds__(RL256_THREADS) void k_bwd_rowlocal256s(int M, int n
             ld_row<EPL>(is, &hp.invstd[s * D + lane * EPL]);
             ld_row<EPL>(mu, &hp.mean[s * D + lane * EPL]);
             ld_row<EPL>(bw_, &hp.bn_w[lane * EPL]);
-            ld_row<EPL>(c0, &hp.bnc[(s * 2 + 0) * D + lane * EPL]);
-            ld_row<EPL>(c1, &hp.bnc[(s * 2 + 1) * D + lane * EPL]);
+            if (hp.bacc) {
+              ld_row<EPL>(c0, &Hc[(s * 2 + 0) * D + lane * EPL]);
+              ld_row<EPL>(c1, &Hc[(s * 2 + 1) * D + lane * EPL]);
+            } else {
+              ld_row<EPL>(c0, &hp.bnc[(s * 2 + 0) * D + lane * EPL]);
+              ld_row<EPL>(c1, &hp.bnc[(s * 2 + 1) * D + lane * EPL]);
+            }
 #pragma unroll
             for (int e = 0; e < EPL; ++e) {
               const float xn = (1.f - g) * x[t][e] + g * z[t][e];
@@ -2467,7 +2648,7 @@ const char* cgcn_strerror(int code) {
 #ifndef DENSE_MAX_BLOCKS
 #define DENSE_MAX_BLOCKS (256 * (DENSE_WAVES_PER_SIMD / 2))   // exactly the workgroups resident at once: one round
 #endif
-static inline int dense_max_blocks(int d) { return (d == 256 && DENSE256_PRE) ? 256 : DENSE_MAX_BLOCKS; }   // d = 256: one workgroup per CU
+static inline int dense_max_blocks(int d) { return d == 256 ? 256 : DENSE_MAX_BLOCKS; }   // d = 256 (k_layer_dense256): one workgroup per CU
 #ifndef DENSE_MB
 #define DENSE_MB 1
 #endif
@@ -2549,28 +2730,17 @@ int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d, const 
 // Nodes per column-statistics record of cgcn_layer_fwd(n, S, d).  The fused kernel emits one record per 16 / S-node
 // tile.  Tables that take the split route (and the same tables when an H_in is streamed) go through k_layer_dense,
 // which merges the tiles of one workgroup into one record: chunk tiles, so that at most DENSE_MAX_BLOCKS records exist.
-// payloads of 2 KiB per node (d = 256, both strands): the split route only between these table sizes (default: never)
-#ifndef FWD_SPLIT_WIDE_LO
-#define FWD_SPLIT_WIDE_LO (1ull << 40)
-#endif
-#ifndef FWD_SPLIT_WIDE_HI
-#define FWD_SPLIT_WIDE_HI 0ull
-#endif
 static bool fwd_split_shape(int n, int S, int d) {
   const long long split_bytes = g_fwd_split_bytes.load();
   const double table = (double)n * S * d * 4.0;
   if (split_bytes == 0) return true;   // the debug hook's 0 forces the split at every shape
-  if (table < (double)split_bytes) return false;
-  if (S * d <= 256) return true;
-  // d = 256, both strands (16 column slices, strand = pass): k_aggregate_sliced + k_layer_dense against the fused
-  // k_layer_fwd<2,256>, us per launch (tools/strand_split_probe.py, profiles/r03_d256_strand_split_experiment.txt):
-  //   uniform  n 5 776: 79 vs 73   7 000: 90 vs 99   10 000: 101 vs 120   16 264: 132 vs 164   29 910: 218 vs 226
-  //   hic-like n 5 776: 73 vs 72   8 500: 93 vs 100  12 000: 107 vs 108   16 264: 129 vs 127   29 910: 207 vs 183
-  // One launch per strand loses everywhere (2 x S = 1 fused: 116 / 173 / 246 us).  A 13.5 ... 40 MiB band for the split
-  // makes the d = 256, 4-layer genome epoch 4.2 % faster on uniform graphs (23.52 -> 22.53 ms) and 2.5 % slower on
-  // distance-decay graphs (20.81 -> 21.34 ms): whole 2 KiB rows of near-diagonal neighbours hit L2 in the fused kernel at
-  // any table size.  Hi-C contacts decay with distance, so the fused kernel stays the route at this payload.
-  return table >= (double)FWD_SPLIT_WIDE_LO && table <= (double)FWD_SPLIT_WIDE_HI;
+  // Payloads of 2 KiB per node (d = 256, both strands: 16 column slices, two per XCD) take the same threshold since round 6.
+  // Rounds 3-5 kept the fused k_layer_fwd<2,256> at every size (tools/strand_split_probe.py, profiles/
+  // r03_d256_strand_split_experiment.txt: the two launches won on uniform graphs above 7 000 nodes and lost on distance-decay
+  // graphs, 207 vs 183 us at n = 29 910) because the row-local launch was k_layer_dense<2,256>: 33 us at n = 5 776, ~130 at
+  // 29 910.  k_layer_dense256 takes 27 / 93 us: config 4's chr21-size step 0.727 -> 0.673 ms on uniform graphs, 0.742 -> 0.692
+  // on distance-decay graphs (profiles/r06_dense256_experiment.txt).
+  return table >= (double)split_bytes;
 }
 static int dense_stat_chunk(int n, int S, int d) {
   if (!fwd_split_shape(n, S, d)) return 1;
@@ -2579,19 +2749,20 @@ static int dense_stat_chunk(int n, int S, int d) {
   return (ntiles + dense_max_blocks(d) - 1) / dense_max_blocks(d);
 }
 
-// Accumulate mode of the column statistics (cgcn_common.hpp, STAT_ACC_*): split-size tables at d = 128, where the head that
-// consumes them is k_head_fused_rs.  CGCN_STAT_ACC=0 in the environment / cgcn_debug_set_stat_acc(0): records for all shapes.
-static int stat_acc_default() {
-  const char* e = getenv("CGCN_STAT_ACC");
-  return (e && *e) ? atoi(e) : 1;
+// Column statistics: RECORDS (one (mean, M2) record per node tile -- per contiguous chunk of tiles on the two-launch route)
+// or ACCUMULATE (cgcn_common.hpp, STAT_ACC_*: fixed-point integer totals; the two-launch route only, whose aggregation
+// launch zeroes them).  The mode is the CALLER's, per call (ABI v24): the plan below says what to allocate for it,
+// cgcn_layer_fwd is told what the plan said (colstats_rows) and never consults process state about it.
+static int acc_chunk(int n, int S, int d) {   // contiguous tiles per k_layer_dense workgroup: one round of workgroups
+  const int tn = 16 * DENSE_MB / S;
+  const int ntiles = (n + tn - 1) / tn;
+  return (ntiles + dense_max_blocks(d) - 1) / dense_max_blocks(d);
 }
-static std::atomic<int> g_stat_acc{stat_acc_default()};
-void cgcn_debug_set_stat_acc(int on) { g_stat_acc.store(on < 0 ? stat_acc_default() : on); }
-static bool stat_acc_shape(int n, int S, int d) { return g_stat_acc.load() != 0 && d == 128 && n >= 2 && fwd_split_shape(n, S, d); }
 
-int cgcn_layer_fwd_colstats_tiles(int n, int S, int d, int* rows_per_tile) {
+int cgcn_layer_fwd_colstats_plan(int n, int S, int d, int mode, int* rows_per_tile) {
   if (check_shape(n, S, d) != CGCN_OK || n == 0) return 0;
-  if (stat_acc_shape(n, S, d)) {   // the buffer holds the integer accumulators; rows_per_tile = -1 tells cgcn_head_train
+  if (mode != CGCN_COLSTATS_RECORDS && mode != CGCN_COLSTATS_ACCUMULATE) return 0;
+  if (mode == CGCN_COLSTATS_ACCUMULATE && n >= 2) {   // the buffer holds the integer accumulators; rows_per_tile = -1 says so
     if (rows_per_tile) *rows_per_tile = -1;
     const size_t tile_bytes = (size_t)S * d * 2 * sizeof(float);
     return (int)((stat_acc_words(S, d) * 8 + tile_bytes - 1) / tile_bytes);
@@ -2601,18 +2772,19 @@ int cgcn_layer_fwd_colstats_tiles(int n, int S, int d, int* rows_per_tile) {
   return (n + tn - 1) / tn;
 }
 
-int cgcn_debug_layer_fwd_route(int n, int S, int d, const cgcn_graph_aux* aux) {
+int cgcn_debug_layer_fwd_route(int n, int S, int d, const cgcn_graph_aux* aux, int colstats_rows) {
   const int rc = check_shape(n, S, d);
   if (rc) return rc;
   if (band_graph(aux, nullptr)) return 2;
-  return (fwd_split_shape(n, S, d) || hub_graph(aux) || (aux && aux->bp_rowptr && aux->bp_col)) ? 1 : 0;
+  const bool need_dense = colstats_rows == -1 || colstats_rows > 16 * DENSE_MB / S;   // see cgcn_layer_fwd
+  return (fwd_split_shape(n, S, d) || hub_graph(aux) || (aux && aux->bp_rowptr && aux->bp_col) || need_dense) ? 1 : 0;
 }
 
 int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* rowptr, const int32_t* col, const float* val,
                    const float* row_scale, const float* X, const float* W, const float* b, const float* wg,
                    const float* cg, float* Xn, float* Z, float* H, float* gate, float dropout_p,
                    const unsigned long long* rng_state, unsigned int stream_id, const float* H_in, float* colstats,
-                   const cgcn_graph_aux* aux) {
+                   int colstats_rows, const cgcn_graph_aux* aux) {
   int rc = check_shape(n, S, d);
   if (rc) return rc;
   if (n == 0) return CGCN_OK;
@@ -2627,13 +2799,25 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   // Three routes.  H_in given: the row-local kernel alone.  Training (H is wanted anyway) on a table that does not
   // fit the L2s: feature-sliced aggregation into H, then the row-local kernel on it.  Otherwise the fused kernel.
   const bool band = band_graph(aux, val);
-  const bool split = !H_in && H && (fwd_split_shape(n, S, d) || hub_graph(aux) || band || bandplus_graph(aux, val));
-  const bool acc = colstats && stat_acc_shape(n, S, d);   // (a split-size table: the row-local kernel below runs either way)
+  // Column statistics as the caller planned them (cgcn_layer_fwd_colstats_plan): -1 = accumulate mode, else the nodes per
+  // record.  One record per 16 / S-node tile is what the fused kernel writes; merged records (k_layer_dense's contiguous
+  // tile chunks) and the integer totals come from the row-local kernel, i.e. need the two-launch route: H or H_in.
+  const int tn0 = 16 * DENSE_MB / S;
+  const bool acc = colstats && colstats_rows == -1;
+  int chunk = 1;
+  if (colstats) {
+    if (acc) {
+      if (n < 2 || ((uintptr_t)colstats & 7)) return CGCN_ERR_BAD_ARG;
+      chunk = acc_chunk(n, S, d);
+    } else {
+      if (colstats_rows < tn0 || colstats_rows % tn0) return CGCN_ERR_BAD_ARG;
+      chunk = colstats_rows / tn0;
+    }
+  }
+  const bool need_dense = colstats && (acc || chunk != 1);
+  const bool split = !H_in && H && (fwd_split_shape(n, S, d) || hub_graph(aux) || band || bandplus_graph(aux, val) || need_dense);
   bool acc_zeroed = false;
-  // cgcn_layer_fwd_colstats_tiles() reports MERGED records on split-size tables (k_layer_dense's contiguous tile
-  // chunks); the fused kernel would write one record per 16 / S-node tile -- more than the caller allocated.  On such
-  // tables the column statistics therefore need the two-launch route, i.e. an H (or H_in) buffer.
-  if (colstats && !split && !H_in && dense_stat_chunk(n, S, d) != 1) return CGCN_ERR_BAD_ARG;
+  if (need_dense && !split && !H_in) return CGCN_ERR_BAD_ARG;
   if (split) {
     const int gblocks = (S * d / 32) * ((n + 63) / 64);
     if (band) {
@@ -2654,12 +2838,18 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
     constexpr int MB = DENSE_MB;
     const int tn = 16 * MB / S;
     const int ntiles = (n + tn - 1) / tn;
-    const int chunk = dense_stat_chunk(n, S, d);   // with column statistics: contiguous tiles per workgroup = per record
     const int grid = colstats ? (ntiles + chunk - 1) / chunk : (ntiles < dense_max_blocks(d) ? ntiles : dense_max_blocks(d));
-#define CALL(S_, D_, V_) \
-    hipLaunchKernelGGL((k_layer_dense<S_, D_, MB>), dim3(grid), dim3(512), 0, st, n, ntiles, H_in, X, W, b, wg, cg, Xn, Z, gate, \
+    if (d == 256) {   // one 16-wave workgroup per CU (k_layer_dense256)
+      if (S == 1) hipLaunchKernelGGL((k_layer_dense256<1>), dim3(grid), dim3(1024), 0, st, n, ntiles, H_in, X, W, b, wg, cg, Xn, Z, gate,
+                                     ks, th, rng_state, stream_id, colstats, chunk, acc ? 1 : 0);
+      else hipLaunchKernelGGL((k_layer_dense256<2>), dim3(grid), dim3(1024), 0, st, n, ntiles, H_in, X, W, b, wg, cg, Xn, Z, gate,
+                              ks, th, rng_state, stream_id, colstats, chunk, acc ? 1 : 0);
+      return launch_status();
+    }
+#define CALL(S_) \
+    hipLaunchKernelGGL((k_layer_dense<S_, 128, MB>), dim3(grid), dim3(512), 0, st, n, ntiles, H_in, X, W, b, wg, cg, Xn, Z, gate, \
                        ks, th, rng_state, stream_id, colstats, chunk, acc ? 1 : 0)
-    DISPATCH_SDV(S, d, false, CALL);
+    if (S == 1) CALL(1); else CALL(2);
 #undef CALL
     return launch_status();
   }
@@ -2754,9 +2944,9 @@ static int layer_bwd_impl(cgcn_stream_t stream, int n, int S, int d, const int32
     uint32_t hth;
     if ((rc = dropout_args(head->dropout_p, head->rng_state, &hks, &hth))) return rc;
     const int CP = head->C <= 128 ? 128 : 256;
-    // accumulate mode (ABI v23): the BatchNorm-backward column means are decoded from integer totals (d = 128 only: the
-    // head kernel that fills them is k_head_fused_rs)
-    if (head->stat_acc && (d != 128 || ((uintptr_t)head->stat_acc & 7))) return CGCN_ERR_BAD_ARG;
+    // accumulate mode (ABI v23; d = 256 since v24): the BatchNorm-backward column means are decoded from the integer totals
+    // the head kernel left (k_bwd_rowlocal_ring / k_bwd_rowlocal256s prologue)
+    if (head->stat_acc && ((uintptr_t)head->stat_acc & 7)) return CGCN_ERR_BAD_ARG;
     hp = HeadApply{head->dym, head->bnc, (const unsigned long long*)head->stat_acc, head->save_mean, head->save_invstd, head->bn_w, head->rng_state, hks, hth, S,
                    head->part, head->dW_out, head->db_out, head->n_partials, head->C, CP, head->accumulate, head->dloss,
                    head->dbn_w, head->dbn_b};

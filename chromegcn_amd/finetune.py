@@ -36,10 +36,11 @@ from .dist import ShardPlan, plan_shards
 
 
 class _Chrom:
-    __slots__ = ("name", "n", "graph", "x", "target", "cost", "h1", "src_key")
+    __slots__ = ("name", "n", "graph", "x", "target", "cost", "h1", "src_key", "stat_acc")
 
-    def __init__(self, name, n, graph, x, target, cost, src_key=None):
+    def __init__(self, name, n, graph, x, target, cost, src_key=None, stat_acc=False):
         self.name, self.n, self.graph, self.x, self.target, self.cost = name, n, graph, x, target, cost
+        self.stat_acc = bool(stat_acc)   # this chromosome's head takes its BatchNorm sums as fixed-point totals (GCNStage._stat_acc_for)
         self.h1 = {"h": None}  # cached A X of the first layer (features and graph are fixed per chromosome)
         self.src_key = src_key  # identity + version of the caller's tensors / graph object this was built from
 
@@ -150,6 +151,11 @@ class GCNStage:
                  resulting x.grad is unobservable there (the tensors are loop-local and finetune returns only
                  predictions, targets and the loss), so the default skips that last gather; train_step returns
                  dx = None then
+    stat_acc   : the head's BatchNorm sums as fixed-point integer totals (accumulate mode, include/chromegcn.h:
+                 cgcn_layer_fwd_colstats_plan; two launches fewer per step).  None = decided PER CHROMOSOME from a bound on
+                 its own features (_stat_acc_for) -- a function of the chromosome's data alone, so every rank of a job and
+                 every stage of a process takes the same decision for it; CGCN_STAT_ACC=0 in the environment = never;
+                 False = never (per-workgroup records); True = always (NaN loss when a chromosome is out of range)
     group      : torch.distributed process group (None = single process)
     force_collectives : take the multi-rank path (shard plan, all-reduce, prediction gathers) even when the group has
                  one rank -- the only way to drive the engine's RCCL calls on a single-GPU box"""
@@ -157,8 +163,10 @@ class GCNStage:
     def __init__(self, model, optimizer=None, adj_type: str = "hic", device="cuda", hip_graphs: bool = True,
                  input_grad: bool = False, group=None, fused_head: bool = True, cache_input_aggregation: bool = True,
                  force_collectives: bool = False, group_graph: Optional[bool] = None, p2p_allreduce: Optional[bool] = None,
-                 prediction_gather: str = "all", aux_group=None, epoch_graph: Optional[bool] = None):
+                 prediction_gather: str = "all", aux_group=None, epoch_graph: Optional[bool] = None,
+                 stat_acc: Optional[bool] = None):
         self.model = model
+        self.stat_acc = stat_acc if stat_acc is not None else (None if os.environ.get("CGCN_STAT_ACC", "1") != "0" else False)
         # one HIP graph for a whole single-rank split (every chromosome's step, back to back) instead of one graph launch
         # per chromosome, when the predictions stay on the device; CGCN_EPOCH_GRAPH=0 / epoch_graph=False = one graph per
         # chromosome (profiles/r04_epoch_graph_experiment.txt)
@@ -254,9 +262,8 @@ class GCNStage:
         g = G.upload(h, self.device)
         x = torch.stack([feats["forward"], feats["backward"]]).to(self.device, torch.float32).contiguous()
         t = feats["target"].to(self.device, torch.float32).contiguous()
-        self._check_stat_range(n, x)
         known = self._meta.get(name)
-        self.chroms[name] = _Chrom(name, n, g, x, t, cost, _SourceKey(feats, hic))
+        self.chroms[name] = _Chrom(name, n, g, x, t, cost, _SourceKey(feats, hic), self._stat_acc_for(name, n, x))
         if known is None or known[:2] != (n, t.shape[1]):
             self._meta[name] = (n, t.shape[1], cost)
             self._invalidate_layout(name)
@@ -273,22 +280,24 @@ class GCNStage:
                 self._targets_cpu.clear()
                 self._targets_dev.clear()
 
-    def _check_stat_range(self, n: int, x: torch.Tensor):
-        """The library accumulates the head's BatchNorm batch sums as 64-bit fixed point with 32 fraction bits (accumulate mode,
-        include/chromegcn.h: cgcn_layer_fwd_colstats_tiles): sum relu(Xn)^2 must stay below 2^31 per column.  A gated layer keeps
-        |Xn| <= max(1, max |X|) (tanh and a convex mix; inter-layer dropout scales by 1 / (1 - p)), so the features bound the
-        sums: outside the range (|x| in the hundreds) the stage asks the library for per-workgroup records instead."""
-        if x.numel() == 0 or x.device.type != "cuda":
-            return
+    def _stat_acc_for(self, name: str, n: int, x: torch.Tensor) -> bool:
+        """Whether this chromosome's steps take the head's BatchNorm batch sums as 64-bit fixed point with 32 fraction bits
+        (accumulate mode): sum relu(Xn)^2 must stay below 2^31 per column.  A gated layer keeps |Xn| <= max(1, max |X|) (tanh
+        and a convex mix; inter-layer dropout scales by 1 / (1 - p)), so the chromosome's own features bound the sums; outside
+        the range (|x| in the hundreds) THIS chromosome uses per-workgroup records -- nothing process-wide changes, the
+        other chromosomes of the stage, other stages and other ranks are not affected (round 5 flipped a library switch)."""
+        if self.stat_acc is not None:
+            return bool(self.stat_acc)
+        if n < 2 or x.numel() == 0 or x.device.type != "cuda":
+            return False
         keep = 1.0 / max(1e-6, 1.0 - float(getattr(self.model, "dropout", 0.0) or 0.0))
         bound = max(1.0, float(x.abs().max())) * keep ** max(int(getattr(self.model, "n_layers", 1)) - 1, 0)
-        if n * bound * bound >= 2.0 ** 30 and not getattr(GCNStage, "_stat_acc_off", False):
+        ok = n * bound * bound < 2.0 ** 29    # a factor 4 below the totals' range (the per-workgroup partials: 2^22 each)
+        if not ok:
             import warnings
-            warnings.warn("chromegcn_amd: feature magnitudes up to %.3g on %d windows are outside the range of the fixed-point "
-                          "BatchNorm sums; using per-workgroup records (cgcn_debug_set_stat_acc(0)) for this process" % (bound, n))
-            _lib_mod.load().cgcn_debug_set_stat_acc(0)
-            GCNStage._stat_acc_off = True
-            self._drop_graphs()
+            warnings.warn("chromegcn_amd: feature magnitudes up to %.3g on the %d windows of %s are outside the range of the "
+                          "fixed-point BatchNorm sums; this chromosome uses per-workgroup records" % (bound, n, name))
+        return ok
 
     def _cost_estimate(self, hic, n: int, d: int) -> float:
         """LPT cost of a chromosome (dist.plan_shards): gather work ~ nnz(A + I) d, dense work ~ 3 n d^2 / 16, with
@@ -470,7 +479,7 @@ class GCNStage:
         if self.fused_head and hasattr(self.model, "forward_loss"):
             loss, probs, _ = self.model.forward_loss(x, c.graph, c.target,   # fused head + loss kernels
                                                      h1_cache=c.h1 if self.cache_input_aggregation else None,
-                                                     out_slots=slot)
+                                                     out_slots=slot, stat_acc=c.stat_acc)
             return loss, probs
         logits, _ = self.model.forward_strands(x, c.graph)
         pred = (logits[0] + logits[1]) / 2                                # finetune.py:43

@@ -172,7 +172,7 @@ class ChromeGCN(nn.Module):
         x, gates = self._gated_stack(x_fr, graph, self._step_rng())
         return self._head(x), gates
 
-    def forward_loss(self, x_fr, adj, target, h1_cache=None, out_slots=None):
+    def forward_loss(self, x_fr, adj, target, h1_cache=None, out_slots=None, stat_acc=False):
         """The whole per-chromosome forward of the GCN stage (finetune.py:41-45,52) in fused kernels:
         gated stack on both strands, then ReLU/BatchNorm/dropout/Linear/strand-mean/BCE.  The last gated
         layer and the head form one autograd node (ops.LastLayerHeadLossFn).
@@ -180,6 +180,7 @@ class ChromeGCN(nn.Module):
         features only, not on any weight, so a caller whose features are fixed (GCNStage: they never change
         across epochs) computes it on the first call and streams it afterwards instead of repeating the gather.
         out_slots: optional {'probs': [n,C], 'loss': [1]} views the head writes its results into (ops._out_slots).
+        stat_acc: the caller has bounded the features (ops.last_layer_head_loss): BatchNorm sums as fixed-point totals.
         Returns (loss [], probs [n,C] = sigmoid(pred), gates)."""
         ops._require_cuda(x_fr, "x_fr")
         graph = as_graph(adj, x_fr.device, n=x_fr.shape[1])
@@ -192,5 +193,5 @@ class ChromeGCN(nn.Module):
             x, gc, wk, bn, out, graph, target, self.training, p, p if L > 1 else 0.0, rng, L,
             layer_sink=self._sink(gc.weight, gc.bias, wk.weight, wk.bias),
             head_sink=self._sink(bn.weight, bn.bias, out.weight, out.bias), h_cache=h1_cache if L == 1 else None,
-            out_slots=out_slots)
+            out_slots=out_slots, stat_acc=stat_acc)
         return loss, probs, gates + [g]

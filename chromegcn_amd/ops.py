@@ -169,7 +169,7 @@ class GatedLayerFn(torch.autograd.Function):
                                       _lib.ptr(graph.val), _lib.ptr(graph.row_scale), x.data_ptr(), weight.data_ptr(),
                                       bias.data_ptr(), wg.data_ptr(), cg.data_ptr(), xn.data_ptr(), _lib.ptr(z),
                                       _lib.ptr(h), gate.data_ptr(), float(dropout_out),
-                                      _lib.ptr(rng_state) if dropout_out > 0 else None, int(layer_id), _lib.ptr(h_in), None,
+                                      _lib.ptr(rng_state) if dropout_out > 0 else None, int(layer_id), _lib.ptr(h_in), None, 0,
                                       G.aux_ptr(graph.col)),
                    "cgcn_layer_fwd")
         h = _store_h_cache(h_cache, h_in, h)
@@ -326,7 +326,7 @@ class LastLayerHeadLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, gate_w, gate_b, bn_w, bn_b, w_out, b_out, graph, target, run_mean, run_var, nbt,
                 momentum, eps, training, dropout_p, dropout_in, rng_state, layer_id, layer_sink, head_sink, h_cache,
-                out_slots=None):
+                out_slots=None, stat_acc=False):
         _check_feat(x, graph)
         for t, nm in ((weight, "weight"), (bias, "bias"), (gate_w, "gate weight"), (gate_b, "gate bias"),
                       (bn_w, "bn weight"), (bn_b, "bn bias"), (w_out, "out.weight"), (b_out, "out.bias"), (target, "target")):
@@ -352,15 +352,19 @@ class LastLayerHeadLossFn(torch.autograd.Function):
         colstats, cs_tiles, cs_rows = None, 0, 0
         if need_bwd:
             # the layer kernel also emits the first stage of the head's BatchNorm statistics (tile still on chip)
+            # stat_acc: the caller vouches for the range of the fixed-point totals (include/chromegcn.h,
+            # cgcn_layer_fwd_colstats_plan; GCNStage does, per chromosome) -> accumulate mode: no finalize / finish launches;
+            # otherwise per-workgroup records.  Accumulate mode needs the two-launch route, i.e. an H buffer of this call.
             rows = ctypes.c_int(0)
-            cs_tiles = lib.cgcn_layer_fwd_colstats_tiles(n, S, d, ctypes.byref(rows))
+            mode = _lib.COLSTATS_ACCUMULATE if (stat_acc and (h is not None or h_in is not None)) else _lib.COLSTATS_RECORDS
+            cs_tiles = lib.cgcn_layer_fwd_colstats_plan(n, S, d, mode, ctypes.byref(rows))
             cs_rows = rows.value
             colstats = torch.empty((cs_tiles, S, d, 2), device=x.device, dtype=torch.float32)
         _lib.check(lib.cgcn_layer_fwd(_lib.stream_ptr(), n, S, d, _lib.ptr(graph.rowptr), _lib.ptr(graph.col),
                                       _lib.ptr(graph.val), _lib.ptr(graph.row_scale), x.data_ptr(), weight.data_ptr(),
                                       bias.data_ptr(), wg.data_ptr(), cg.data_ptr(), xn.data_ptr(), _lib.ptr(z),
                                       _lib.ptr(h), gate.data_ptr(), 0.0, None, int(layer_id), _lib.ptr(h_in), _lib.ptr(colstats),
-                                      G.aux_ptr(graph.col)), "cgcn_layer_fwd")
+                                      cs_rows, G.aux_ptr(graph.col)), "cgcn_layer_fwd")
         h = _store_h_cache(h_cache, h_in, h)
         ws_bytes = lib.cgcn_head_workspace_bytes(n, S, d, C)
         if ws_bytes == 0:
@@ -427,7 +431,7 @@ class LastLayerHeadLossFn(torch.autograd.Function):
             dw, db, dwg, dcg = torch.empty_like(weight), torch.empty(d, **f32), torch.empty(d, **f32), torch.empty(1, **f32)
         hws_bytes = hws.numel()
         if dloss is None:
-            return (None,) * 25
+            return (None,) * 26
         dloss = dloss.contiguous().view(1)
         # dym, bnc and the partials are already in the workspace cgcn_head_train filled (for d loss = 1); every head
         # gradient is finished inside cgcn_layer_bwd (cgcn_head_grad.dloss / dbn_w / dbn_b), so no head launch here
@@ -455,15 +459,18 @@ class LastLayerHeadLossFn(torch.autograd.Function):
             _sgd_fuse["done"] = True
         gl = (None,) * 4 if ctx.layer_sink is not None else (dw, db, dwg.view(ctx.shapes[0]), dcg.view(ctx.shapes[1]))
         gh = (None,) * 4 if ctx.head_sink is not None else (dbn_w, dbn_b, dw_out, db_out)
-        return (dx,) + gl + gh + (None,) * 16
+        return (dx,) + gl + gh + (None,) * 17
 
 
 def last_layer_head_loss(x, gc, wk, bn, out, graph, target, training, dropout_p, dropout_in, rng_state, layer_id,
-                         layer_sink=None, head_sink=None, h_cache=None, out_slots=None):
+                         layer_sink=None, head_sink=None, h_cache=None, out_slots=None, stat_acc=False):
+    """stat_acc: accumulate mode of the head's BatchNorm sums (fixed-point integer totals, two launches fewer per step).  Its
+    range is finite (sum relu(x)^2 < 2.1e9 per column) and outside it the loss is NaN, so it is the caller's statement about
+    its inputs: False (records, any magnitude) unless the caller has bounded them -- finetune.GCNStage does per chromosome."""
     return LastLayerHeadLossFn.apply(x, gc.weight, gc.bias, wk.weight, wk.bias, bn.weight, bn.bias, out.weight, out.bias,
                                      graph, target, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum,
                                      bn.eps, bool(training), float(dropout_p), float(dropout_in), rng_state, int(layer_id),
-                                     layer_sink, head_sink, h_cache, out_slots)
+                                     layer_sink, head_sink, h_cache, out_slots, bool(stat_acc))
 
 
 def head_loss(x, bn: torch.nn.BatchNorm1d, out: torch.nn.Linear, target, training, dropout_p, rng_state, grad_sink=None,

@@ -112,7 +112,7 @@ def gated_layer(x: Tensor, weight: Tensor, bias: Tensor, gate_w: Tensor, gate_b:
     _lib.check(lib.cgcn_layer_fwd(_lib.stream_ptr(), n, S, d, _P(rowptr), _P(col), _P(val), _P(row_scale), x.data_ptr(),
                                   weight.data_ptr(), bias.data_ptr(), wg.data_ptr(), cg.data_ptr(), xn.data_ptr(),
                                   z.data_ptr(), h.data_ptr(), gate.data_ptr(), float(dropout_out),
-                                  _P(rng_state) if dropout_out > 0 else None, int(layer_id), None, None, aux_ptr(col)), "cgcn_layer_fwd")
+                                  _P(rng_state) if dropout_out > 0 else None, int(layer_id), None, None, 0, aux_ptr(col)), "cgcn_layer_fwd")
     return xn, gate, z, h
 
 

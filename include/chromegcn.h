@@ -50,7 +50,7 @@ extern "C" {
 #define CGCN_ERR_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after a launch      */
 #define CGCN_ERR_WORKSPACE (-4)   /* workspace too small (see cgcn_*_workspace_bytes)    */
 
-#define CGCN_ABI_VERSION 23
+#define CGCN_ABI_VERSION 24
 
 typedef void *cgcn_stream_t; /* hipStream_t */
 
@@ -136,36 +136,43 @@ int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d,
  * H_in (may be NULL): a previously computed H = diag(row_scale) Ahat X for this X and graph (H does not
  * depend on the layer's weights).  When given, the gather is skipped and H_in is streamed instead; H is
  * then not written (pass H = NULL, the saved tensor for the backward is H_in itself).
- * colstats (may be NULL): [tiles][S][d][2] output, tiles / rows per tile from cgcn_layer_fwd_colstats_tiles.
- * Per node tile and (strand, column): mean and sum of squared deviations of relu(Xn) -- the first stage of
- * the classifier head's BatchNorm batch statistics (models/ChromeModels.py:58-59, nn.BatchNorm1d in training
- * mode), taken while the tile is on chip; hand it to cgcn_head_train as col_stats.
- * On tables for which cgcn_layer_fwd_colstats_tiles reports merged records (rows_per_tile > 16 / S: the feature table
- * is too large for the L2s) colstats needs H or H_in as well -- the merged records are produced by the two-launch
- * route only; colstats with H == NULL and H_in == NULL is CGCN_ERR_BAD_ARG there.
+ * colstats (may be NULL) / colstats_rows: the first stage of the classifier head's BatchNorm batch statistics
+ * (models/ChromeModels.py:58-59, nn.BatchNorm1d in training mode) of relu(Xn), taken while the tile is on chip, in the form
+ * cgcn_layer_fwd_colstats_plan planned: colstats_rows = the plan's *rows_per_tile, colstats = a buffer of the plan's tile
+ * count x [S][d][2] floats.  Hand (colstats, tiles, colstats_rows) to cgcn_head_train as col_stats.
+ *   colstats_rows > 0 (RECORDS): per tile of colstats_rows nodes and (strand, column) the mean and the sum of squared
+ *     deviations.  colstats_rows must be a multiple of 16 / S; more than 16 / S nodes per record (merged records) are
+ *     produced by the two-launch route only and need H or H_in (CGCN_ERR_BAD_ARG otherwise).
+ *   colstats_rows = -1 (ACCUMULATE): the buffer holds 64-bit fixed-point integer totals (see the plan); two-launch route
+ *     only (its aggregation launch zeroes them): needs H or H_in, n >= 2, an 8-byte aligned buffer.
+ * The mode is an argument of the call (ABI v24): nothing about it is read from process state.
  */
 int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d,
                    const int32_t *rowptr, const int32_t *col, const float *val, const float *row_scale,
                    const float *X, const float *W, const float *b, const float *wg, const float *cg,
                    float *Xn, float *Z, float *H, float *gate,
                    float dropout_p, const unsigned long long *rng_state, unsigned int stream_id,
-                   const float *H_in, float *colstats, const cgcn_graph_aux *aux);
+                   const float *H_in, float *colstats, int colstats_rows, const cgcn_graph_aux *aux);
 
-/* Number of node tiles cgcn_layer_fwd(n, S, d) writes column statistics for (0 = unsupported shape);
- * *rows_per_tile = nodes per tile (the last tile may be shorter).
- * *rows_per_tile = -1 (ABI v23; d = 128 on tables that take the two-launch route): ACCUMULATE mode -- the buffer of `tiles`
- * records is used as 64-bit integer fixed-point totals of sum relu(Xn) and sum relu(Xn)^2 per (strand, column), zeroed and
- * added to inside cgcn_layer_fwd (order-independent, so bit-reproducible); cgcn_head_train, handed the same (buffer, tiles,
- * -1), derives the BatchNorm statistics from the totals inside its main kernel and launches no finalize kernel; it also
- * leaves the BatchNorm-BACKWARD column sums as integer totals in the same buffer (and writes the loss from a ticketed total)
- * instead of launching a finish kernel: the cgcn_head_grad handed to cgcn_layer_bwd must then carry stat_acc = that buffer.
- * Range of the fixed point (32 fraction bits): sum relu(Xn)^2 < 2.1e9 per column (rms |Xn| < 265 at n = 30 000); beyond it
- * the statistics come out NaN -- call cgcn_debug_set_stat_acc(0) for such inputs (chromegcn_amd's engine does). */
-int cgcn_layer_fwd_colstats_tiles(int n, int S, int d, int *rows_per_tile);
+/* Column-statistics modes of cgcn_layer_fwd / cgcn_head_train. */
+#define CGCN_COLSTATS_RECORDS 0
+#define CGCN_COLSTATS_ACCUMULATE 1
 
-/* Test / tuning hook: 0 = cgcn_layer_fwd_colstats_tiles never reports accumulate mode (records for every shape), 1 = as
- * described above, negative = restore the default (1, or CGCN_STAT_ACC in the environment).  Process-wide. */
-void cgcn_debug_set_stat_acc(int on);
+/* What to allocate for the column statistics of cgcn_layer_fwd(n, S, d) in `mode`: returns the number of tiles ([S][d][2]
+ * floats each; 0 = unsupported shape or mode), *rows_per_tile = the value to pass as colstats_rows / col_stats_rows.
+ * CGCN_COLSTATS_RECORDS: *rows_per_tile = nodes per record (the last one may be shorter): 16 / S on tables that take the
+ *   fused route, a multiple of it (one record per row-local workgroup) on tables that take the two-launch route.
+ * CGCN_COLSTATS_ACCUMULATE (n >= 2; falls back to records for n < 2): *rows_per_tile = -1 -- the buffer is used as 64-bit
+ *   integer fixed-point totals of sum relu(Xn) and sum relu(Xn)^2 per (strand, column), zeroed and added to inside
+ *   cgcn_layer_fwd (order-independent, so bit-reproducible); cgcn_head_train, handed the same (buffer, tiles, -1), derives
+ *   the BatchNorm statistics from the totals inside its main kernel and launches no finalize kernel; it also leaves the
+ *   BatchNorm-BACKWARD column sums as integer totals in the same buffer (and writes the loss from a ticketed total) instead
+ *   of launching a finish kernel: the cgcn_head_grad handed to cgcn_layer_bwd must then carry stat_acc = that buffer.
+ *   Range of the fixed point (32 fraction bits): sum relu(Xn)^2 < 2.1e9 per column (rms |Xn| < 265 at n = 30 000); beyond
+ *   it the statistics -- and the loss -- come out NaN (loudly wrong, never silently wrapped).  The caller decides per call
+ *   from what it knows about its inputs: chromegcn_amd's engine bounds |Xn| by the input features per chromosome
+ *   (finetune.GCNStage), its module-level entry points default to records. */
+int cgcn_layer_fwd_colstats_plan(int n, int S, int d, int mode, int *rows_per_tile);
 
 /* Test / tuning hook: feature-table size in bytes from which cgcn_layer_fwd takes the two-launch route when H is
  * given (0 = always, negative = restore the built-in default).  Process-wide. */
@@ -173,16 +180,17 @@ void cgcn_debug_set_fwd_split_bytes(long long bytes);
 
 /* Which kernels a call WOULD launch, so that a profiler prices the kernel that actually runs (bench.py's roofline);
  * nothing is launched, no GPU is needed.
- *   cgcn_debug_layer_fwd_route: the training forward (H given, no H_in) on this graph, under the current split
- *     threshold: 0 = the fused k_layer_fwd, 1 = k_aggregate_sliced + k_layer_dense (large tables, hub-heavy graphs),
- *     2 = k_band_aggregate + k_layer_dense (band graphs: cgcn_graph_aux::band_halfwidth; their backward's last launch
- *     is k_bwd_band instead of k_bwd_sliced).
+ *   cgcn_debug_layer_fwd_route: the training forward (H given, no H_in) on this graph with column statistics as planned
+ *     (colstats_rows as for cgcn_layer_fwd; 0 = none), under the current split threshold: 0 = the fused k_layer_fwd,
+ *     1 = k_aggregate_sliced + k_layer_dense / k_layer_dense256 (large tables, hub-heavy graphs, accumulate mode),
+ *     2 = k_band_aggregate + the row-local kernel (band graphs: cgcn_graph_aux::band_halfwidth; their backward's last
+ *     launch is k_bwd_band instead of k_bwd_sliced).
  *   cgcn_debug_layer_bwd_route: the row-local launch of cgcn_layer_bwd: 0 = k_bwd_rowlocal256s (d = 256: four column-slab
  *     workgroups per range of 32-row tiles, both dense products in the launch; ABI <= 20: k_bwd_rowlocal256 + a second
  *     launch for dHs), 2 = k_bwd_rowlocal_ring (d = 128: row / matrix wave teams over a flag-synchronised LDS ring).
  *     (1 was the 48-row-tile kernel of ABI <= 18: no longer returned.)
  * Negative = error code (unsupported shape). */
-int cgcn_debug_layer_fwd_route(int n, int S, int d, const cgcn_graph_aux *aux);
+int cgcn_debug_layer_fwd_route(int n, int S, int d, const cgcn_graph_aux *aux, int colstats_rows);
 int cgcn_debug_layer_bwd_route(int n, int S, int d);
 
 /*

@@ -41,24 +41,26 @@ def test_route_queries_are_pure_host_logic():
     import ctypes
     lib = _lib.load()
     # forward: fused below the split threshold (8 MiB of feature table), two launches above, or for a hub-heavy graph
-    assert lib.cgcn_debug_layer_fwd_route(5776, 2, 128, None) == 0       # 5.9 MB
-    assert lib.cgcn_debug_layer_fwd_route(29910, 2, 128, None) == 1      # 30.6 MB
-    assert lib.cgcn_debug_layer_fwd_route(5776, 2, 256, None) == 0       # d = 256, both strands: the fused kernel at every size
-    assert lib.cgcn_debug_layer_fwd_route(29910, 2, 256, None) == 0
+    assert lib.cgcn_debug_layer_fwd_route(5776, 2, 128, None, 0) == 0       # 5.9 MB
+    assert lib.cgcn_debug_layer_fwd_route(29910, 2, 128, None, 0) == 1      # 30.6 MB
+    assert lib.cgcn_debug_layer_fwd_route(5776, 2, 256, None, 0) == 1       # d = 256, both strands (11.8 MB): the same threshold since round 6
+    assert lib.cgcn_debug_layer_fwd_route(3000, 2, 256, None, 0) == 0 and lib.cgcn_debug_layer_fwd_route(29910, 2, 256, None, 0) == 1
+    assert lib.cgcn_debug_layer_fwd_route(5776, 2, 128, None, 8) == 0 and lib.cgcn_debug_layer_fwd_route(5776, 2, 128, None, 24) == 1   # merged records
+    assert lib.cgcn_debug_layer_fwd_route(5776, 2, 128, None, -1) == 1      # accumulate mode: the two-launch route at every size
 
     class Aux(ctypes.Structure):
         _fields_ = [("col16", ctypes.c_void_p), ("row_order", ctypes.c_void_p), ("max_row_len", ctypes.c_int32)]
     hub = Aux(None, None, 9000)
-    assert lib.cgcn_debug_layer_fwd_route(5776, 2, 128, ctypes.byref(hub)) == 1
+    assert lib.cgcn_debug_layer_fwd_route(5776, 2, 128, ctypes.byref(hub), 0) == 1
     lib.cgcn_debug_set_fwd_split_bytes(0)
     try:
-        assert lib.cgcn_debug_layer_fwd_route(64, 1, 128, None) == 1     # the test hook forces the split at every size
+        assert lib.cgcn_debug_layer_fwd_route(64, 1, 128, None, 0) == 1     # the test hook forces the split at every size
     finally:
         lib.cgcn_debug_set_fwd_split_bytes(-1)
     # backward: the ring kernel at d = 128, the column-slab kernel (k_bwd_rowlocal256s) at d = 256
     assert lib.cgcn_debug_layer_bwd_route(5776, 2, 128) == 2 and lib.cgcn_debug_layer_bwd_route(29910, 1, 128) == 2
     assert lib.cgcn_debug_layer_bwd_route(5776, 2, 256) == 0
-    assert lib.cgcn_debug_layer_bwd_route(5776, 3, 128) == -2 and lib.cgcn_debug_layer_fwd_route(5776, 2, 100, None) == -2
+    assert lib.cgcn_debug_layer_bwd_route(5776, 3, 128) == -2 and lib.cgcn_debug_layer_fwd_route(5776, 2, 100, None, 0) == -2
     # one partial record per workgroup of the row-local launch: at most one per CU, 16-row slots at d = 128
     rec = (128 * 128 + 2 * 128 + 4) * 4
     assert lib.cgcn_layer_bwd_workspace_bytes(5776, 2, 128) == 256 * rec

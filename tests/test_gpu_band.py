@@ -131,7 +131,7 @@ def test_layer_forward_and_backward_same_bits_with_and_without_the_band_route(S,
             try:
                 xn, z, h, gate = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x), torch.empty(S, n, device=DEV)
                 _lib.check(lib.cgcn_layer_fwd(_lib.stream_ptr(), n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(W), P(b), P(wg), P(cg),
-                                              P(xn), P(z), P(h), P(gate), 0.0, None, 0, None, None, aux), "fwd")
+                                              P(xn), P(z), P(h), P(gate), 0.0, None, 0, None, None, 0, aux), "fwd")
             finally:
                 lib.cgcn_debug_set_fwd_split_bytes(-1)
             dxn = torch.randn(S, n, d, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
@@ -146,7 +146,7 @@ def test_layer_forward_and_backward_same_bits_with_and_without_the_band_route(S,
         for nm, u, v in zip(("Xn", "Z", "H", "gate", "dX", "dHs", "dW", "db", "dwg", "dcg"), *outs):
             assert torch.equal(u, v), (nm, S, d, n, p)
     g5 = _band(5776)
-    assert lib.cgcn_debug_layer_fwd_route(5776, S, d, G.aux_ptr(g5.col)) == 2
+    assert lib.cgcn_debug_layer_fwd_route(5776, S, d, G.aux_ptr(g5.col), 0) == 2
 
 
 # ---- 'both' (Hi-C + band + I, values 1 / 2): the band-plus route of the feature-sliced kernels (cgcn_graph_aux::bp_*) -------
@@ -212,7 +212,7 @@ def test_layer_forward_and_backward_on_the_band_plus_route(S, d, p):
             try:
                 xn, z, h, gate = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x), torch.empty(S, n, device=DEV)
                 _lib.check(lib.cgcn_layer_fwd(_lib.stream_ptr(), n, S, d, P(g.rowptr), P(g.col), P(g.val), P(g.row_scale), P(x), P(W), P(b), P(wg), P(cg),
-                                              P(xn), P(z), P(h), P(gate), 0.0, None, 0, None, None, aux), "fwd")
+                                              P(xn), P(z), P(h), P(gate), 0.0, None, 0, None, None, 0, aux), "fwd")
             finally:
                 lib.cgcn_debug_set_fwd_split_bytes(-1)
             dxn = torch.randn(S, n, d, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))

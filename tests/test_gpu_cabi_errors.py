@@ -27,7 +27,7 @@ def fwd(e, **over):
     P, g = _lib.ptr, a["g"]
     return a["lib"].cgcn_layer_fwd(_lib.stream_ptr(), a["n"], a["S"], a["d"], P(g.rowptr), P(g.col), None, P(g.row_scale),
                                    a.get("xptr", P(a["x"])), P(a["W"]), P(a["b"]), P(a["wg"]), P(a["cg"]), a.get("yptr", P(a["y"])),
-                                   P(a["z"]), P(a["h"]), P(a["gate"]), a.get("p", 0.0), None, 0, None, None, None)
+                                   P(a["z"]), P(a["h"]), P(a["gate"]), a.get("p", 0.0), None, 0, None, None, 0, None)
 
 
 def test_strerror_names_every_code(env):
@@ -74,8 +74,12 @@ def test_workspaces_are_checked(env):
     assert lib.cgcn_head_workspace_bytes(n, S, d, 0) == 0 and lib.cgcn_head_workspace_bytes(n, S, d, 257) == 0
     assert lib.cgcn_metrics_workspace_bytes(10, 0) == 0 and lib.cgcn_metrics_workspace_bytes(10, 3) > 0
     rows = ctypes.c_int(0)
-    assert lib.cgcn_layer_fwd_colstats_tiles(n, S, d, ctypes.byref(rows)) == (n + rows.value - 1) // rows.value
-    assert lib.cgcn_layer_fwd_colstats_tiles(n, S, 64, ctypes.byref(rows)) == 0
+    assert lib.cgcn_layer_fwd_colstats_plan(n, S, d, _lib.COLSTATS_RECORDS, ctypes.byref(rows)) == (n + rows.value - 1) // rows.value
+    assert lib.cgcn_layer_fwd_colstats_plan(n, S, 64, _lib.COLSTATS_RECORDS, ctypes.byref(rows)) == 0
+    assert lib.cgcn_layer_fwd_colstats_plan(n, S, d, 7, ctypes.byref(rows)) == 0                       # no such mode
+    tiles = lib.cgcn_layer_fwd_colstats_plan(n, S, d, _lib.COLSTATS_ACCUMULATE, ctypes.byref(rows))    # any table size, d = 128 / 256
+    assert rows.value == -1 and tiles * S * d * 2 * 4 >= (8 * S * d * 2 + 1) * 8
+    assert lib.cgcn_layer_fwd_colstats_plan(1, S, d, _lib.COLSTATS_ACCUMULATE, ctypes.byref(rows)) == 1 and rows.value > 0   # n < 2: records
 
 
 def test_sgd_and_spmm_argument_checks(env):
@@ -97,36 +101,45 @@ def test_sgd_and_spmm_argument_checks(env):
 
 
 @pytest.fixture(params=["accumulate", "records"])
-def mode(request, env):
-    env["lib"].cgcn_debug_set_stat_acc(1 if request.param == "accumulate" else 0)
-    yield request.param
-    env["lib"].cgcn_debug_set_stat_acc(-1)
+def mode(request):
+    return request.param
 
 
 def test_colstats_on_a_split_size_table_needs_an_aggregation_buffer(env, mode):
-    """cgcn_layer_fwd_colstats_tiles reports merged records (or, ABI v23, integer totals) on tables that take the
-    two-launch route; the fused kernel (no H, no H_in) would write one record per 16/S-node tile -- past the caller's buffer.
-    Rejected in both modes; nothing is written past what was reported."""
+    """the plan reports merged records (or integer totals) for tables that take the two-launch route; the fused
+    kernel (no H, no H_in) would write one record per 16/S-node tile -- past the caller's buffer.  Rejected in both modes, and
+    -- the mode being an ARGUMENT since ABI v24 -- whatever the process-wide route threshold says at the time of the call;
+    nothing is written past what was planned."""
     lib = env["lib"]
     P = _lib.ptr
     n, S, d = 8192, 2, 128                      # 8 MiB table: split-size
     rows = ctypes.c_int(0)
-    tiles = lib.cgcn_layer_fwd_colstats_tiles(n, S, d, ctypes.byref(rows))
+    tiles = lib.cgcn_layer_fwd_colstats_plan(n, S, d, _lib.COLSTATS_ACCUMULATE if mode == "accumulate" else _lib.COLSTATS_RECORDS, ctypes.byref(rows))
     if mode == "records":
         assert rows.value > 16 // S and tiles == (n + rows.value - 1) // rows.value
-    else:                                       # accumulate mode (ABI v23): the buffer holds the integer totals
+    else:                                       # accumulate mode: the buffer holds the integer totals
         assert rows.value == -1 and tiles * S * d * 2 * 4 >= (8 * S * d * 2 + 1) * 8
     g = G.upload(G.normalize_graph("hic", synth.contact_graph(n, 20000, 5), n), DEV)
     x, y, z, h = (torch.randn(S, n, d, device=DEV) for _ in range(4))
     gate = torch.empty(S, n, device=DEV)
     cs = torch.full((tiles * S * d * 2 + 4096,), 7.0, device=DEV)   # guard zone behind the records
-    def call(hptr):
+    def call(hptr, r=None):
         return lib.cgcn_layer_fwd(_lib.stream_ptr(), n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(env["W"]),
-                                  P(env["b"]), P(env["wg"]), P(env["cg"]), P(y), P(z), hptr, P(gate), 0.0, None, 0, None, P(cs), None)
+                                  P(env["b"]), P(env["wg"]), P(env["cg"]), P(y), P(z), hptr, P(gate), 0.0, None, 0, None, P(cs),
+                                  rows.value if r is None else r, None)
     assert call(None) == BAD_ARG
-    assert call(P(h)) == OK
-    torch.cuda.synchronize()
-    assert bool((cs[tiles * S * d * 2:] == 7.0).all())             # nothing written past the reported records
+    assert call(P(h), 0) == BAD_ARG and call(P(h), 3) == BAD_ARG and call(P(h), -2) == BAD_ARG   # not a plan's value
+    for split_bytes in (-1, 0, 1 << 40):        # ADVICE r5: the threshold moved between plan and call: same records, no overrun
+        lib.cgcn_debug_set_fwd_split_bytes(split_bytes)
+        try:
+            assert call(None) == BAD_ARG
+            cs.fill_(7.0)
+            assert call(P(h)) == OK
+            torch.cuda.synchronize()
+            assert bool((cs[tiles * S * d * 2:] == 7.0).all())             # nothing written past the planned records
+            assert not bool((cs[:S * d * 2] == 7.0).all())                 # ... and something inside them
+        finally:
+            lib.cgcn_debug_set_fwd_split_bytes(-1)
 
 
 def test_fused_sgd_rejects_input_dropout_with_an_input_gradient(env):

@@ -154,13 +154,13 @@ def test_layer_fwd_colstats_are_the_tile_statistics_of_relu_output(S, n, d):
     wg = (torch.randn(d, generator=gen) / d ** 0.5).to(DEV); cg = torch.zeros(1, device=DEV)
     xn = torch.empty_like(x); gate = torch.empty(S, n, device=DEV)
     rows = ctypes.c_int(0)
-    tiles = lib.cgcn_layer_fwd_colstats_tiles(n, S, d, ctypes.byref(rows))
+    tiles = lib.cgcn_layer_fwd_colstats_plan(n, S, d, _lib.COLSTATS_RECORDS, ctypes.byref(rows))
     R = rows.value
     assert tiles == (n + R - 1) // R and R >= 1
     cs = torch.full((tiles, S, d, 2), float("nan"), device=DEV)
     P = _lib.ptr
     _lib.check(lib.cgcn_layer_fwd(_lib.stream_ptr(), n, S, d, P(g.rowptr), P(g.col), P(g.val), P(g.row_scale), P(x), P(W), P(b),
-                                  P(wg), P(cg), P(xn), None, None, P(gate), 0.0, None, 0, None, P(cs), None), "cgcn_layer_fwd")
+                                  P(wg), P(cg), P(xn), None, None, P(gate), 0.0, None, 0, None, P(cs), R, None), "cgcn_layer_fwd")
     y = torch.relu(xn).double().cpu().numpy()
     cs = cs.cpu().numpy()
     for t in range(tiles):

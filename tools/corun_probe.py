@@ -25,7 +25,6 @@ def main():
     R = 20
     dev = torch.device("cuda")
     lib = _lib.load()
-    lib.cgcn_debug_set_stat_acc(0)   # this probe builds its cgcn_head_grad by hand: records mode
     P, st = _lib.ptr, _lib.stream_ptr
     S, d, Cn = 2, 128, synth.N_LABELS
     torch.manual_seed(0)
@@ -39,7 +38,7 @@ def main():
     gate = torch.empty(S, n, device=dev)
     rng = m._rng_state
     rows = ctypes.c_int(0)
-    tiles = lib.cgcn_layer_fwd_colstats_tiles(n, S, d, ctypes.byref(rows))
+    tiles = lib.cgcn_layer_fwd_colstats_plan(n, S, d, _lib.COLSTATS_RECORDS, ctypes.byref(rows))   # this probe builds its cgcn_head_grad by hand: records mode
     colstats = torch.empty((tiles, S, d, 2), device=dev)
     gc1, w1, gc2, w2, bn, out = m.GC1, m.W1, m.GC2, m.W2, m.batch_norm, m.out
     aux, aux2 = G.aux_ptr(g.col), G.aux_ptr(g2.col)
@@ -54,7 +53,7 @@ def main():
         gc, wk = (gc2, w2) if last else (gc1, w1)
         return lib.cgcn_layer_fwd(st(), n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), x.data_ptr(), gc.weight.data_ptr(), gc.bias.data_ptr(),
                                   wk.weight.data_ptr(), wk.bias.data_ptr(), xn.data_ptr(), z.data_ptr(), None, gate.data_ptr(),
-                                  0.0 if last else 0.2, None if last else P(rng), 2 if last else 1, P(h), colstats.data_ptr() if last else None, aux)
+                                  0.0 if last else 0.2, None if last else P(rng), 2 if last else 1, P(h), colstats.data_ptr() if last else None, rows.value if last else 0, aux)
     hws_b = lib.cgcn_head_workspace_bytes(n, S, d, Cn)
     hws = torch.empty(hws_b, dtype=torch.uint8, device=dev)
     probs, loss = torch.empty(n, Cn, device=dev), torch.empty(1, device=dev)

@@ -48,8 +48,8 @@ def main():
                     st = _lib.stream_ptr
                     P = _lib.ptr
                     t_spmm = timeit(lambda: lib.cgcn_spmm(st(), n, n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(y), None))
-                    t_fwd = timeit(lambda: lib.cgcn_layer_fwd(st(), n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(W), P(b), P(wg), P(cg), P(xn), P(z), P(hh), P(gate), 0.0, None, 0, None, None, None))
-                    t_inf = timeit(lambda: lib.cgcn_layer_fwd(st(), n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(W), P(b), P(wg), P(cg), P(xn), None, None, P(gate), 0.0, None, 0, None, None, None))
+                    t_fwd = timeit(lambda: lib.cgcn_layer_fwd(st(), n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(W), P(b), P(wg), P(cg), P(xn), P(z), P(hh), P(gate), 0.0, None, 0, None, None, 0, None))
+                    t_inf = timeit(lambda: lib.cgcn_layer_fwd(st(), n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(W), P(b), P(wg), P(cg), P(xn), None, None, P(gate), 0.0, None, 0, None, None, 0, None))
                     t_bwd = timeit(lambda: lib.cgcn_layer_bwd(st(), n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(z), P(hh), P(gate), P(W), P(wg), P(dxn), None, P(dx), P(dhs), P(dW), P(db), P(dwg), P(dcg), 0, 0.0, None, 0, None, P(ws), wsb, None, None, None))
                     gb = 4.0 * h.nnz * S * d
                     print(json.dumps({"shape": name, "hic_like": hic_like, "n": n, "nnz": h.nnz, "S": S, "d": d,

@@ -15,12 +15,15 @@ from tools.kbench import timeit
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     ns = [16264, 29910]
+    d = 128
     for a in sys.argv[1:]:
         if a.startswith("--n="):
             ns = [int(v) for v in a[4:].split(",")]
+        if a.startswith("--d="):
+            d = int(a[4:])
     libs = [(a.split("=")[0], _lib.open_library(os.path.join(ROOT, a.split("=")[1]))) for a in args]
     dev = torch.device("cuda")
-    d, S = 128, 2
+    S = 2
     P = _lib.ptr; st = _lib.stream_ptr
     for n in ns:
         torch.manual_seed(n)
@@ -38,13 +41,13 @@ def main():
             gate = torch.empty(S, n, device=dev)
             rows = ctypes.c_int(0)
             lib.cgcn_debug_set_fwd_split_bytes(0)   # H_in route at every size
-            tiles = lib.cgcn_layer_fwd_colstats_tiles(n, S, d, ctypes.byref(rows))
+            tiles = lib.cgcn_layer_fwd_colstats_plan(n, S, d, _lib.COLSTATS_RECORDS, ctypes.byref(rows))   # records (this tool decodes them)
             cs = torch.zeros(tiles, S, d, 2, device=dev)
             # rowptr / col are not touched on the H_in route, but the entry point checks them for NULL
             dummy = torch.zeros(4, dtype=torch.int32, device=dev)
             def run(stats, drop):
                 return lambda: lib.cgcn_layer_fwd(st(), n, S, d, P(dummy), P(dummy), None, None, P(x), P(W), P(b), P(wg), P(cg), P(xn), P(z), None, P(gate),
-                                                  0.2 if drop else 0.0, P(rng) if drop else None, 1, P(h), P(cs) if stats else None, None)
+                                                  0.2 if drop else 0.0, P(rng) if drop else None, 1, P(h), P(cs) if stats else None, rows.value if stats else 0, None)
             rc = run(True, False)()
             assert rc == 0, rc
             torch.cuda.synchronize()

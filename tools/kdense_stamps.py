@@ -13,7 +13,7 @@ for n in [int(a) for a in sys.argv[2:]]:
     dummy = torch.zeros(4, dtype=torch.int32, device=dev)
     P = _lib.ptr; st = _lib.stream_ptr
     lib.cgcn_debug_set_fwd_split_bytes(0)
-    run = lambda: lib.cgcn_layer_fwd(st(), n, S, d, P(dummy), P(dummy), None, None, P(x), P(W), P(b), P(wg), P(cg), P(xn), P(z), None, P(gate), 0.0, None, 1, P(h), None, None)
+    run = lambda: lib.cgcn_layer_fwd(st(), n, S, d, P(dummy), P(dummy), None, None, P(x), P(W), P(b), P(wg), P(cg), P(xn), P(z), None, P(gate), 0.0, None, 1, P(h), None, 0, None)
     assert run() == 0; torch.cuda.synchronize()
     if os.environ.get("KT"):
         buf = np.zeros(8 * 16, dtype=np.uint64)

@@ -31,8 +31,8 @@ def main():
         rpt = torch.from_numpy(rowptr).to(dev); ct = torch.from_numpy(col).to(dev)
         rs = torch.ones(n, device=dev)
         t_sp = timeit(lambda: lib.cgcn_spmm(st(), n, n, S, d, P(rpt), P(ct), None, P(rs), P(x), P(y), None))
-        t_f = timeit(lambda: lib.cgcn_layer_fwd(st(), n, S, d, P(rpt), P(ct), None, P(rs), P(x), P(W), P(b), P(wg), P(cg), P(xn), P(z), P(hh), P(gate), 0.0, None, 0, None, None, None))
-        t_i = timeit(lambda: lib.cgcn_layer_fwd(st(), n, S, d, P(rpt), P(ct), None, P(rs), P(x), P(W), P(b), P(wg), P(cg), P(xn), None, None, P(gate), 0.0, None, 0, None, None, None))
+        t_f = timeit(lambda: lib.cgcn_layer_fwd(st(), n, S, d, P(rpt), P(ct), None, P(rs), P(x), P(W), P(b), P(wg), P(cg), P(xn), P(z), P(hh), P(gate), 0.0, None, 0, None, None, 0, None))
+        t_i = timeit(lambda: lib.cgcn_layer_fwd(st(), n, S, d, P(rpt), P(ct), None, P(rs), P(x), P(W), P(b), P(wg), P(cg), P(xn), None, None, P(gate), 0.0, None, 0, None, None, 0, None))
         print(json.dumps({"graph": name, "nnz": int(col.shape[0]), "spmm_us": round(t_sp, 1), "fwd_train_us": round(t_f, 1), "fwd_infer_us": round(t_i, 1)}))
 
 if __name__ == "__main__":

@@ -34,7 +34,7 @@ def main():
         print("wg", b_ * 32, "start+%.2fus" % ((t[b_, 0] - t0) / 100.0), " ".join("%.2f" % ((t[b_, i + 1] - t[b_, i]) / 100.0) for i in range(7)), " total %.2f" % ((t[b_, 7] - t[b_, 0]) / 100.0))
     print("layer_bwd_us", round(timeit(bwd), 1))
     b = torch.zeros(d, device=dev); cg = torch.zeros(1, device=dev); xn = torch.empty_like(x)
-    fwd = lambda: lib.cgcn_layer_fwd(st(), n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(W), P(b), P(wg), P(cg), P(xn), P(z), P(hh), P(gate), 0.0, None, 0, None, None, None)
+    fwd = lambda: lib.cgcn_layer_fwd(st(), n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(W), P(b), P(wg), P(cg), P(xn), P(z), P(hh), P(gate), 0.0, None, 0, None, None, 0, None)
     for _ in range(5): assert fwd() == 0
     torch.cuda.synchronize()
     assert raw.cgcn_debug_kt_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0

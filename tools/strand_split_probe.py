@@ -32,7 +32,7 @@ def main():
         def both(o):
             xn, z, h, gate = o
             return lambda: lib.cgcn_layer_fwd(st(), n, 2, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(W), P(b), P(wg), P(cg),
-                                              P(xn), P(z), P(h), P(gate), 0.0, None, 0, None, None, c16)
+                                              P(xn), P(z), P(h), P(gate), 0.0, None, 0, None, None, 0, c16)
 
         def per_strand(o):
             xn, z, h, gate = o
@@ -40,7 +40,7 @@ def main():
                 rc = 0
                 for s in range(2):
                     rc |= lib.cgcn_layer_fwd(st(), n, 1, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x[s]), P(W), P(b), P(wg), P(cg),
-                                             P(xn[s]), P(z[s]), P(h[s]), P(gate[s]), 0.0, None, 0, None, None, c16)
+                                             P(xn[s]), P(z[s]), P(h[s]), P(gate[s]), 0.0, None, 0, None, None, 0, c16)
                 return rc
             return f
 
