@@ -28,7 +28,7 @@ def pytest_configure(config):
 # next, and every test that starts other processes (launchers, rendezvous, sockets: infrastructure, not arithmetic) LAST,
 # so that a hiccup there can never again cost the parity evidence (GPUTEST_r04: 1 launcher test failed, 201 parity tests
 # never ran).
-_GPU_ORDER = ["test_gpu_parity", "test_gpu_fullsize_oracle", "test_gpu_modules", "test_gpu_loop", "test_gpu_head", "test_gpu_graph",
+_GPU_ORDER = ["test_gpu_parity", "test_gpu_fullsize_oracle", "test_gpu_epoch_oracle", "test_gpu_modules", "test_gpu_loop", "test_gpu_head", "test_gpu_graph",
               "test_gpu_stat_acc", "test_gpu_runner", "test_gpu_sgd_fuse", "test_gpu_dropout_sgd", "test_gpu_sliced_routes", "test_gpu_band",
               "test_gpu_ring_stress", "test_gpu_torch_ops", "test_gpu_metrics", "test_gpu_handoff", "test_gpu_saliency",
               "test_gpu_cabi_errors", "test_gpu_fullsize"]

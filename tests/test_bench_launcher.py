@@ -61,6 +61,15 @@ def test_self_launch_two_ranks_dry_run_prints_one_line():
     assert d["n_gpus"] == 2 and d["ranks_seen_by_backend"] == 2 and d["dry_run"] is True
 
 
+def test_self_launch_eight_ranks_dry_run_prints_one_line():
+    """the driver's widest run: 8 ranks over the 16 train chromosomes (two step groups), one line from rank 0"""
+    rc, lines, err = _run(["--gpus", "8", "--backend", "gloo", "--dry-run"], timeout=900)
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["ranks_seen_by_backend"] == 8 and d["dry_run"] is True
+
+
 def test_single_rank_dry_run_needs_no_launcher():
     rc, lines, err = _run(["--dry-run"])
     assert rc == 0, err[-2000:]
@@ -113,6 +122,19 @@ def test_n_gt_1_code_path_over_rccl_with_one_forced_rank(gather):
     rc1, lines1, err1 = _run(common, timeout=900)
     assert rc1 == 0, err1[-3000:]
     assert abs(json.loads(lines1[0])["final_loss"] - d["final_loss"]) < 2e-3 * abs(d["final_loss"])
+
+
+@pytest.mark.gpu
+def test_self_launch_eight_ranks_share_one_gpu_genome_epoch():
+    """bench.py's own N = 8 branch on the real engine -- 8 processes on the one device (gloo), the 16 train
+    chromosomes as two step groups of 8, rows of seven ranks gathered on rank 0 -- one JSON line, strong scaling"""
+    rc, lines, err = _run(["--gpus", "8", "--backend", "gloo", "--share-gpu", "--steps", "2", "--warmup", "1",
+                           "--no-cpu-baseline", "--no-extras", "--no-roofline"], timeout=1500)
+    assert rc == 0, err[-3000:]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["ranks_seen_by_backend"] == 8 and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["config"]["prediction_gather"].startswith("rank0")
 
 
 # ---- the launch ladder (VERDICT r3 #3): a rung that fails or hangs must cost a probe, not the run ---------------------

@@ -1,5 +1,7 @@
-"""N > 1 path on CPU: world_size-2 gloo run of the GCN stage (sharding + one flat-gradient all-reduce
-per step group) against a single-process emulation that averages the same chromosomes' gradients.
+"""N > 1 path on CPU: world_size 2 / 4 / 8 gloo runs of the GCN stage (sharding + one flat-gradient all-reduce
+per step group) against a single-process emulation that averages the same chromosomes' gradients.  World 8 over
+5 train chromosomes / a 3-chromosome evaluation split has what an 8-GPU run of the real genome has and a 2-rank run
+does not: ranks that hold no chromosome in a round, seven senders into rank 0, a last step group that is not full.
 The compute engine here is the oracle model behind the stage's model interface (tests may use it;
 the product never does) -- what is under test is the host logic in chromegcn_amd.finetune / .dist."""
 import os
@@ -23,6 +25,7 @@ from oracle import chromegcn_oracle as O  # noqa: E402
 
 D, C = 128, 7
 SIZES = {"chr2": 90, "chr4": 61, "chr5": 120, "chr6": 75, "chr7": 33}
+VALID = ["chr6", "chr2", "chr7"]   # a 3-chromosome evaluation split (data/create_data.py:44-45 has three valid / test chromosomes)
 
 
 class OracleStrands(O.GatedGCNOracle):
@@ -77,7 +80,8 @@ def emulate(world, epochs):
             opt.step()
         tot.append(t)
     preds, targets, ev = stage.run_split("valid")
-    return {k: v.clone() for k, v in m.state_dict().items()}, tot, preds, ev
+    preds3, _, ev3 = stage.run_split("valid", VALID)
+    return {k: v.clone() for k, v in m.state_dict().items()}, tot, preds, ev, preds3, ev3
 
 
 def worker(rank, world, port, epochs, q, gather="all"):
@@ -108,7 +112,13 @@ def worker(rank, world, port, epochs, q, gather="all"):
         assert abs(ev_all - ev) < 1e-6
         if whole:
             assert torch.equal(preds_all, preds)
-    q.put((rank, {k: v.numpy() for k, v in m.state_dict().items()}, tot, preds.numpy() if whole else None, ev))
+        stage.prediction_gather = gather
+    preds3, targets3, ev3 = stage.run_split("valid", VALID)   # fewer chromosomes than ranks at world 4 / 8
+    assert (preds3 is not None) == whole
+    if whole:
+        assert preds3.shape[0] == sum(SIZES[c] for c in VALID) and targets3.shape == preds3.shape
+    q.put((rank, {k: v.numpy() for k, v in m.state_dict().items()}, tot, preds.numpy() if whole else None, ev,
+           preds3.numpy() if whole else None, ev3))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -131,33 +141,58 @@ def test_plan_shards_properties():
     assert plan_shards({}, 4).rounds == []
 
 
-@pytest.mark.timeout(300)
-@pytest.mark.parametrize("gather", ["all", "rank0", "none"])
-def test_two_rank_gloo_matches_single_process_emulation(gather):
-    """gather: where the split's predictions are assembled -- on every rank (all-gather per round), on rank 0 only (every
-    owner sends its rows straight to rank 0, like nn.DataParallel's output gather, main.py:92-94), or nowhere"""
-    world, epochs = 2, 2
+def _run_world(world, epochs, gather):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
     procs = [ctx.Process(target=worker, args=(r, world, port, epochs, q, gather)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=240) for _ in range(world)]
+    results = [q.get(timeout=400) for _ in range(world)]
     for p in procs:
-        p.join(60)
+        p.join(90)
         assert p.exitcode == 0
-    ref_sd, ref_tot, ref_preds, ref_ev = emulate(world, epochs)
     results.sort(key=lambda r: r[0])
-    for rank, sd, tot, preds, ev in results:
+    return results
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,gather", [(2, "all"), (2, "rank0"), (2, "none"), (4, "rank0"), (4, "all"), (8, "rank0"), (8, "all")])
+def test_gloo_ranks_match_single_process_emulation(world, gather):
+    """gather: where the split's predictions are assembled -- on every rank (all-gather per round), on rank 0 only (every
+    owner sends its rows straight to rank 0, like nn.DataParallel's output gather, main.py:92-94), or nowhere.
+    world 4: two step groups, the second with one chromosome and three idle ranks; world 8: one step group of 5 + 3 idle
+    ranks, seven ranks sending to rank 0, and the 3-chromosome evaluation split leaves 5 ranks without work."""
+    epochs = 2
+    results = _run_world(world, epochs, gather)
+    ref_sd, ref_tot, ref_preds, ref_ev, ref_preds3, ref_ev3 = emulate(world, epochs)
+    for rank, sd, tot, preds, ev, preds3, ev3 in results:
         np.testing.assert_allclose(tot, ref_tot, rtol=1e-5, atol=1e-6)
         for k in ref_sd:
             if "running" in k or "num_batches" in k:
                 continue  # per-rank BN statistics are averaged across ranks (documented deviation)
             np.testing.assert_allclose(sd[k], ref_sd[k].numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
-    # both ranks hold identical models (incl. the averaged BN buffers) and identical full predictions
-    for k in results[0][1]:
-        np.testing.assert_array_equal(results[0][1][k], results[1][1][k])
-    if gather == "all":
-        np.testing.assert_array_equal(results[0][3], results[1][3])
-    assert abs(results[0][4] - results[1][4]) < 1e-6
+        assert abs(ev3 - results[0][6]) < 1e-6
+        if preds3 is not None:
+            assert preds3.shape == tuple(ref_preds3.shape)
+    # every rank holds the identical model (incl. the averaged BN buffers) and, where assembled, identical predictions
+    for r in results[1:]:
+        for k in results[0][1]:
+            np.testing.assert_array_equal(results[0][1][k], r[1][k])
+        assert abs(results[0][4] - r[4]) < 1e-6
+        if gather == "all":
+            np.testing.assert_array_equal(results[0][3], r[3])
+            np.testing.assert_array_equal(results[0][5], r[5])
+
+
+def test_plan_for_eight_ranks_over_the_real_genome_sizes():
+    """the shapes of the driver's 8-GPU run: 16 train chromosomes -> exactly two full step groups (the 8 largest first); 3
+    valid / 3 test chromosomes -> one round with five idle ranks"""
+    sizes = {c: synth.chrom_nodes(c) for c in synth.HG19_LEN}
+    train = {c: float(n) for c, n in sizes.items() if synth.split_of(c) == "train"}
+    assert len(train) == 16
+    p = plan_shards(train, 8)
+    assert len(p.rounds) == 2 and all(g is not None for r in p.rounds for g in r)
+    assert min(train[c] for c in p.rounds[0]) >= max(train[c] for c in p.rounds[1])
+    pv = plan_shards({c: float(sizes[c]) for c in ("chr3", "chr12", "chr17")}, 8)
+    assert len(pv.rounds) == 1 and sum(g is None for g in pv.rounds[0]) == 5

@@ -119,13 +119,16 @@ def free_port():
     return p
 
 
-@pytest.mark.timeout(1200)
-@pytest.mark.parametrize("genome", [False, True], ids=["five_small_chromosomes", "full_size_train_genome_configs2"])
-def test_two_ranks_on_one_gpu_match_the_gradient_averaging_emulation(genome):
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("world,genome", [(2, False), (2, True), (8, False), (8, True)],
+                         ids=["2_ranks_five_small_chromosomes", "2_ranks_full_size_train_genome_configs2",
+                              "8_ranks_five_small_chromosomes_idle_ranks", "8_ranks_full_size_train_genome_two_step_groups"])
+def test_ranks_on_one_gpu_match_the_gradient_averaging_emulation(world, genome):
     """genome=True is BASELINE.json configs[2]'s code path at full size -- the 16 train chromosomes (242 908 windows,
-    250 000 contact pairs each) sharded by plan_shards -- on the two ranks one GPU can host (8 ranks need the node)."""
+    250 000 contact pairs each) sharded by plan_shards -- on ranks that share the one GPU a test box has (gloo: RCCL refuses
+    two ranks per device).  world 8 is the driver's 8-GPU shape: two chromosomes per rank = exactly two step groups, seven
+    ranks' rows gathered; with five small chromosomes three ranks hold nothing at all (VERDICT r5 #2)."""
     import torch.multiprocessing as mp
-    world = 2
     epochs = 1 if genome else EPOCHS
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -139,9 +142,11 @@ def test_two_ranks_on_one_gpu_match_the_gradient_averaging_emulation(genome):
         assert p.exitcode == 0
     ref_sd, ref_tot, ref_preds, ref_ev, plan = emulate(world, genome, epochs)
     if genome:
-        assert len(plan.rounds) == 8 and all(g is not None for r in plan.rounds for g in r)
-    else:
+        assert len(plan.rounds) == 16 // world and all(g is not None for r in plan.rounds for g in r)
+    elif world == 2:
         assert len(plan.rounds) == 3 and all(any(g is None for g in r) is (i == 2) for i, r in enumerate(plan.rounds))
+    else:
+        assert len(plan.rounds) == 1 and sum(g is None for g in plan.rounds[0]) == world - 5
     results.sort(key=lambda r: r[0])
     for rank, sd, tot, preds, preds_dev, ev, rng in results:
         # dropout RNG state: the seed is untouched by the statistics sync, the step counter advanced once per step group
@@ -154,9 +159,10 @@ def test_two_ranks_on_one_gpu_match_the_gradient_averaging_emulation(genome):
         np.testing.assert_array_equal(preds_dev.shape, ref_preds.shape)
         # (evaluation predictions are not compared with the emulation: they depend on the BatchNorm running statistics,
         #  which the multi-rank run averages across ranks -- the documented deviation; rank 0 == rank 1 is checked below)
-    # both ranks hold identical models (incl. the averaged BatchNorm buffers) and identical full predictions
-    for k in results[0][1]:
-        np.testing.assert_array_equal(results[0][1][k], results[1][1][k], err_msg=k)
-    np.testing.assert_array_equal(results[0][3], results[1][3])
-    np.testing.assert_array_equal(results[0][4], results[1][4])
-    assert abs(results[0][5] - results[1][5]) < 1e-6
+    # every rank holds the identical model (incl. the averaged BatchNorm buffers) and identical full predictions
+    for other in results[1:]:
+        for k in results[0][1]:
+            np.testing.assert_array_equal(results[0][1][k], other[1][k], err_msg=k)
+        np.testing.assert_array_equal(results[0][3], other[3])
+        np.testing.assert_array_equal(results[0][4], other[4])
+        assert abs(results[0][5] - other[5]) < 1e-6
