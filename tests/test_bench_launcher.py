@@ -134,7 +134,7 @@ def test_self_launch_eight_ranks_share_one_gpu_genome_epoch():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 8 and d["ranks_seen_by_backend"] == 8 and d["value"] > 0 and d["scaling"] == "strong"
-    assert d["config"]["prediction_gather"].startswith("rank0")
+    assert "rank0" in d["config"]["prediction_gather"]   # (gloo cannot send device tensors point to point: "all [asked for rank0: ...]")
 
 
 # ---- the launch ladder: a rung that fails or hangs must cost a probe, not the run ---------------------
