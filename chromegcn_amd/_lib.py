@@ -40,7 +40,8 @@ _SIGNATURES = {
     "cgcn_debug_head_train_phases": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp] * 6 + [_c_float, _c_float] + [_c_vp] * 3 + [_c_float]
                                      + [_c_vp] * 6 + [_c_int, _c_int, _c_vp, _c_sz, _c_int]),
     "cgcn_head_bwd": (_c_int, [_c_vp] + [_c_int] * 4 + [_c_vp] * 8 + [_c_float] + [_c_vp] * 6 + [_c_int, _c_vp, _c_sz]),
-    "cgcn_sddmm": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 5),
+    "cgcn_sddmm": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 5 + [_c_int]),
+    "cgcn_saliency_normalize": (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp]),
     "cgcn_graph_count": (_c_int, [_c_vp, _c_int, _c_int] + [_c_vp] * 5),
     "cgcn_graph_fill": (_c_int, [_c_vp, _c_int, _c_int] + [_c_vp] * 8),
     "cgcn_metrics_workspace_bytes": (_c_sz, [ctypes.c_longlong, _c_int]),

@@ -2452,7 +2452,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8))) void k
 template <int S, int D>
 __global__ __launch_bounds__(256) void k_sddmm(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
                                                const float* __restrict__ A, const float* __restrict__ B,
-                                               float* __restrict__ out) {
+                                               float* __restrict__ out, int accumulate) {
   using G = Geo<S, D>;
   constexpr int NV = G::NV;
   constexpr unsigned ROWB = D * 4;
@@ -2496,7 +2496,43 @@ __global__ __launch_bounds__(256) void k_sddmm(int n, const int* __restrict__ ro
           if (lane == j + u) mine = d;
         }
       }
-      if (lane < cnt) out[kb + lane] = mine;
+      if (lane < cnt) out[kb + lane] = accumulate ? out[kb + lane] + mine : mine;   // (the saliency sums one product per layer)
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_saliency_rows: the row normalisation of the adjacency saliency (scripts/visualize.py:49-55) on the CSR pattern, in the
+// reference's order of operations: v = |val * raw| per stored entry, divided by the row's sum (1 where the sum is 0), then by
+// the row's maximum of those quotients (1 where it is 0).  Entries outside the pattern are zeros of the dense matrix the
+// reference builds: they add nothing to a sum and never raise a maximum of non-negative numbers.  One wave per row, 64
+// entries per step, two passes over the row (the second one hits the L1).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_saliency_rows(int n, const int* __restrict__ rowptr, const float* __restrict__ val,
+                                                       const float* __restrict__ raw, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int i = wave; i < n; i += nwaves) {
+    const int k0 = rowptr[i], k1 = rowptr[i + 1];
+    float s = 0.f;
+    for (int kb = k0; kb < k1; kb += WAVE) {
+      const int k = kb + lane;
+      s += k < k1 ? fabsf((val ? val[k] : 1.f) * raw[k]) : 0.f;
+    }
+    s = wave_sum(s);
+    if (s == 0.f) s = 1.f;
+    float m = 0.f;
+    for (int kb = k0; kb < k1; kb += WAVE) {
+      const int k = kb + lane;
+      m = fmaxf(m, k < k1 ? fabsf((val ? val[k] : 1.f) * raw[k]) / s : 0.f);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, WAVE));
+    if (m == 0.f) m = 1.f;
+    for (int kb = k0; kb < k1; kb += WAVE) {
+      const int k = kb + lane;
+      if (k < k1) out[k] = fabsf((val ? val[k] : 1.f) * raw[k]) / s / m;
     }
   }
 }
@@ -3085,17 +3121,26 @@ int cgcn_debug_layer_bwd_phases(cgcn_stream_t stream, int n, int S, int d, const
 }
 
 int cgcn_sddmm(cgcn_stream_t stream, int n, int S, int d, const int32_t* rowptr, const int32_t* col, const float* A,
-               const float* B, float* out) {
+               const float* B, float* out, int accumulate) {
   int rc = check_shape(n, S, d);
   if (rc) return rc;
   if (n == 0) return CGCN_OK;
   if (!rowptr || !col || !A || !B || !out || misaligned16(A) || misaligned16(B)) return CGCN_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int blocks = (n + 3) / 4 < 4096 ? (n + 3) / 4 : 4096;
-  if (S == 1 && d == 128) hipLaunchKernelGGL((k_sddmm<1, 128>), dim3(blocks), dim3(256), 0, st, n, rowptr, col, A, B, out);
-  else if (S == 2 && d == 128) hipLaunchKernelGGL((k_sddmm<2, 128>), dim3(blocks), dim3(256), 0, st, n, rowptr, col, A, B, out);
-  else if (S == 1 && d == 256) hipLaunchKernelGGL((k_sddmm<1, 256>), dim3(blocks), dim3(256), 0, st, n, rowptr, col, A, B, out);
-  else hipLaunchKernelGGL((k_sddmm<2, 256>), dim3(blocks), dim3(256), 0, st, n, rowptr, col, A, B, out);
+  if (S == 1 && d == 128) hipLaunchKernelGGL((k_sddmm<1, 128>), dim3(blocks), dim3(256), 0, st, n, rowptr, col, A, B, out, accumulate);
+  else if (S == 2 && d == 128) hipLaunchKernelGGL((k_sddmm<2, 128>), dim3(blocks), dim3(256), 0, st, n, rowptr, col, A, B, out, accumulate);
+  else if (S == 1 && d == 256) hipLaunchKernelGGL((k_sddmm<1, 256>), dim3(blocks), dim3(256), 0, st, n, rowptr, col, A, B, out, accumulate);
+  else hipLaunchKernelGGL((k_sddmm<2, 256>), dim3(blocks), dim3(256), 0, st, n, rowptr, col, A, B, out, accumulate);
+  return launch_status();
+}
+
+int cgcn_saliency_normalize(cgcn_stream_t stream, int n, const int32_t* rowptr, const float* val, const float* raw, float* out) {
+  if (n < 0) return CGCN_ERR_BAD_ARG;
+  if (n == 0) return CGCN_OK;
+  if (!rowptr || !raw || !out) return CGCN_ERR_BAD_ARG;
+  const int blocks = (n + 3) / 4 < 4096 ? (n + 3) / 4 : 4096;
+  hipLaunchKernelGGL(k_saliency_rows, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, rowptr, val, raw, out);
   return launch_status();
 }
 

@@ -48,17 +48,35 @@ def spmm(x, graph):
                                     graph.val_t)
 
 
-def sddmm(a, b, graph: ChromGraph, transposed=False):
-    """out[k] = sum_s <a[s,i,:], b[s,col[k],:]> on the graph's pattern (cgcn_sddmm).  No autograd."""
+def sddmm(a, b, graph: ChromGraph, transposed=False, out=None):
+    """out[k] = sum_s <a[s,i,:], b[s,col[k],:]> on the graph's pattern (cgcn_sddmm).  No autograd.
+    out given: the product is ADDED to it (the saliency sums one product per layer)."""
     _check_feat(a, graph, "a")
     _check_feat(b, graph, "b")
     a, b = _dense(a), _dense(b)
     S, n, d = a.shape
     rowptr, col = (graph.rowptr_t, graph.col_t) if transposed else (graph.rowptr, graph.col)
-    out = torch.empty(col.shape[0], device=a.device, dtype=torch.float32)
+    acc = out is not None
+    if acc:
+        if out.shape != (col.shape[0],) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != a.device:
+            raise RuntimeError("chromegcn_amd: sddmm accumulates into a contiguous fp32 [nnz] tensor on the features' device")
+    else:
+        out = torch.empty(col.shape[0], device=a.device, dtype=torch.float32)
     lib = _lib.load()
     _lib.check(lib.cgcn_sddmm(_lib.stream_ptr(), n, S, d, rowptr.data_ptr(), col.data_ptr(), a.data_ptr(), b.data_ptr(),
-                              out.data_ptr()), "cgcn_sddmm")
+                              out.data_ptr(), 1 if acc else 0), "cgcn_sddmm")
+    return out
+
+
+def saliency_normalize(raw, graph: ChromGraph):
+    """|val * raw| divided by its row sum, then by the row maximum of the quotients (scripts/visualize.py:49-55) on the
+    graph's pattern, one launch (cgcn_saliency_normalize)."""
+    _require_cuda(raw, "raw")
+    raw = raw.contiguous()
+    out = torch.empty_like(raw)
+    lib = _lib.load()
+    _lib.check(lib.cgcn_saliency_normalize(_lib.stream_ptr(), graph.n, graph.rowptr.data_ptr(), _lib.ptr(graph.val), raw.data_ptr(),
+                                           out.data_ptr()), "cgcn_saliency_normalize")
     return out
 
 

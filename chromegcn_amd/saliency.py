@@ -30,18 +30,13 @@ def adjacency_saliency(model, x_f: torch.Tensor, x_r: torch.Tensor, adj, targets
         ops._saliency_tap = None
     # dL/dA_ij (A = diag(rs) Ahat) = <dU_i, (XW)_j>;  a_ij * dL/dA_ij = ahat_ij * <rs_i dU_i W^T, X_j> = ahat_ij * <dHs_i, X_j>
     # with dHs = diag(rs) dL/dU W^T, which the layer backward leaves behind (cgcn_layer_bwd)
-    total = torch.zeros(graph.col.shape[0], device=x.device)
+    total = None
     for (xin, dhs, g) in tap:
-        total += ops.sddmm(dhs, xin, graph)
+        total = ops.sddmm(dhs, xin, graph, out=total)                # one product per layer, summed in place
+    if total is None:
+        total = torch.zeros(graph.col.shape[0], device=x.device)
+    if normalize:                                                     # visualize.py:49-55, one launch on the pattern
+        return graph, ops.saliency_normalize(total, graph)
     if graph.val is not None:
         total = total * graph.val
-    sal = total.abs()                                             # visualize.py:49  |adj * adj.grad|
-    if normalize:
-        rows = torch.repeat_interleave(torch.arange(graph.n, device=x.device), (graph.rowptr[1:] - graph.rowptr[:-1]).long())
-        s = torch.zeros(graph.n, device=x.device).index_add_(0, rows, sal)
-        s[s == 0] = 1                                             # :50-52
-        sal = sal / s[rows]
-        m = torch.zeros(graph.n, device=x.device).index_reduce_(0, rows, sal, "amax", include_self=True)
-        m[m == 0] = 1                                             # :53-55
-        sal = sal / m[rows]
-    return graph, sal
+    return graph, total.abs()                                         # visualize.py:49  |adj * adj.grad|

@@ -388,9 +388,17 @@ int cgcn_head_bwd(cgcn_stream_t stream, int n, int S, int d, int C, const float 
  *     out[k] = sum_s < A[s,i,:], B[s,col[k],:] >     for every stored entry k of row i.
  * With A = dL/dU and B = X W of one layer this is dL/dA_ij on the pattern, i.e. the adjacency saliency
  * of scripts/visualize.py:29-49 (which materialises a dense n x n gradient on the CPU).  A, B: [S,n,d].
+ * accumulate != 0: out[k] += the product (the saliency sums one product per layer).
  */
 int cgcn_sddmm(cgcn_stream_t stream, int n, int S, int d, const int32_t *rowptr, const int32_t *col,
-               const float *A, const float *B, float *out);
+               const float *A, const float *B, float *out, int accumulate);
+
+/*
+ * The row normalisation of that saliency, scripts/visualize.py:49-55, on the pattern and in the reference's order of
+ * operations: v[k] = |val[k] * raw[k]| (val == NULL: ones), out[k] = (v[k] / s_i) / m_i with s_i = the sum of row i's v (1 where
+ * it is 0) and m_i = the maximum of row i's quotients (1 where it is 0).  raw, out: [nnz]; out may alias raw.
+ */
+int cgcn_saliency_normalize(cgcn_stream_t stream, int n, const int32_t *rowptr, const float *val, const float *raw, float *out);
 
 /* adj_type codes of the device-side normaliser: the branches of process_graph, utils/util_methods.py:148-174 */
 #define CGCN_ADJ_HIC 0
