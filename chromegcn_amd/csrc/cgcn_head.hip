@@ -433,7 +433,7 @@ struct HeadStatAcc {
   float* loss_out;   // the caller's loss word: written by the last workgroup to arrive (k_head_train_finish is not launched)
 };
 // Accumulate mode: the workgroup decodes the totals ONCE, cooperatively -- thread t the (strand, column) pair t: 16 eight-byte
-// loads, an int64 sum, a float64 division and 1 / sqrt -- into an LDS stash [mean S D][invstd S D]; every thread then picks
+// loads, an int64 sum, a float64 division and 1 / sqrt -- into an LDS stash [mean 2 D][invstd 2 D][unbiased variance 2 D]; every thread then picks
 // the few columns it needs (head_stat, after a workgroup barrier).  (Round 5 / the first round-6 version had every thread
 // decode its own columns: 4 pairs per thread of the d = 128 kernel, 8 at d = 256 -- 13 us of a 52 us launch there,
 // profiles/r06_stat_acc_experiment.txt.)
@@ -444,6 +444,7 @@ __device__ __forceinline__ void head_stat_stage(const HeadStatAcc& sa, int n, in
     stat_acc_get(sa.acc, S, D, idx / D, idx % D, n, m, m2);
     stash[idx] = (float)m;
     stash[2 * D + idx] = (float)(1.0 / sqrt(m2 / (double)n + (double)sa.eps));
+    stash[4 * D + idx] = (float)(m2 / (double)(n - 1));   // the unbiased variance of the running statistics (head_stat_bookkeeping)
   }
 }
 template <int D>
@@ -460,9 +461,10 @@ __device__ __forceinline__ void head_stat(const HeadStatAcc& sa, const float* __
 
 // The bookkeeping k_head_bn_finalize did besides (one wave of the first workgroup of the first label pass; lane l: columns
 // l EPL .. l EPL + EPL - 1, both strands): save_mean / save_invstd for the backward, the running statistics (forward strand,
-// then reverse: the reference calls the model once per strand), the call count.
+// then reverse: the reference calls the model once per strand), the call count -- from the workgroup's stash (head_stat_stage),
+// behind its barrier: decoding the totals a second time held the first workgroup back by 2-3 us, the launch's serial tail.
 template <int D>
-__device__ __forceinline__ void head_stat_bookkeeping(const HeadStatAcc& sa, int n, int S, int lane) {
+__device__ __forceinline__ void head_stat_bookkeeping(const HeadStatAcc& sa, const float* __restrict__ stash, int S, int lane) {
   constexpr int EPL = D / 64;
   if (lane == 0 && sa.nbt) sa.nbt[0] += S;
 #pragma unroll
@@ -470,12 +472,11 @@ __device__ __forceinline__ void head_stat_bookkeeping(const HeadStatAcc& sa, int
     const int c = lane * EPL + u;
     float rm = sa.run_mean[c], rv = sa.run_var[c];
     for (int st = 0; st < S; ++st) {
-      double m, m2;
-      stat_acc_get(sa.acc, S, D, st, c, n, m, m2);
-      sa.save_mean[st * D + c] = (float)m;
-      sa.save_invstd[st * D + c] = (float)(1.0 / sqrt(m2 / (double)n + (double)sa.eps));
-      rm = (1.f - sa.momentum) * rm + sa.momentum * (float)m;
-      rv = (1.f - sa.momentum) * rv + sa.momentum * (float)(m2 / (double)(n - 1));
+      const float m = stash[st * D + c];
+      sa.save_mean[st * D + c] = m;
+      sa.save_invstd[st * D + c] = stash[2 * D + st * D + c];
+      rm = (1.f - sa.momentum) * rm + sa.momentum * m;
+      rv = (1.f - sa.momentum) * rv + sa.momentum * stash[4 * D + st * D + c];
     }
     sa.run_mean[c] = rm;
     sa.run_var[c] = rv;
@@ -859,8 +860,6 @@ __global__ __launch_bounds__(512, HF_LOWREG ? 4 : 1) void k_head_fused(int n, in
     const float mw = head_wout_absmax(Wout, C * (D / 4), NW * 64);
     if (lane == 0) wmax[wave] = mw;
   }
-  // accumulate mode: one wave of the first workgroup of the first label pass does k_head_bn_finalize's bookkeeping
-  if (sa.acc && blockIdx.x == 0 && first && wave == NW - 1) head_stat_bookkeeping<D>(sa, n, S, lane);
 
   HF_STAMP(0);
   HF_STAMP(1);
@@ -897,9 +896,11 @@ __global__ __launch_bounds__(512, HF_LOWREG ? 4 : 1) void k_head_fused(int n, in
   float sdy[2][EPL], sdyx[2][EPL];   // per thread: <= a few dozen rows in fp32; float64 from the cross-wave merge on
   float mu[2][EPL], is[2][EPL], gw[EPL], gb[EPL];
   if (sa.acc) {   // accumulate mode: batch mean / invstd decoded from the integer totals, once per workgroup (head_stat_stage)
-    static_assert(TR * LDY >= 4 * D, "the stash fits the Y tile");
+    static_assert(TR * LDY >= 6 * D, "the stash fits the Y tile");
     head_stat_stage<D>(sa, n, S, Yt, NW * 64);
     __syncthreads();
+    // one wave of the first workgroup of the first label pass does k_head_bn_finalize's bookkeeping
+    if (blockIdx.x == 0 && first && wave == NW - 1) head_stat_bookkeeping<D>(sa, Yt, S, lane);
   }
 #pragma unroll
   for (int e = 0; e < EPL; ++e) {
@@ -1275,20 +1276,28 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
   float* P = part + (size_t)blockIdx.x * PS;
 
   // ---- W_out -> LDS (all 16 waves, 16-byte pieces)
+  float mwl = 0.f;   // max |W_out| over the rows this thread stages
   for (int idx = threadIdx.x; idx < NB * 16 * (D / 4); idx += 1024) {
     const int j = idx / (D / 4), c4 = idx % (D / 4);
     f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (j < Cp) v = *(const f32x4*)&Wout[(size_t)(c0 + j) * D + c4 * 4];
     *(f32x4*)&Wl[j * LDW + c4 * 4] = v;
+    mwl = fmaxf(fmaxf(mwl, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
   }
-  if (sa.acc && last) {   // max |W_out| over ALL labels (the earlier label passes' share of dym is in the sums too)
-    const float mw = head_wout_absmax(Wout, C * (D / 4), 1024);
+  if (sa.acc && last) {   // max |W_out| over ALL labels (the earlier label passes' share of dym is in the sums too): one pass
+    float mw;             // (C <= 128) has just staged all of them; several passes read the whole matrix once more
+    if (MULTI) mw = head_wout_absmax(Wout, C * (D / 4), 1024);
+    else {
+      mw = mwl;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mw = fmaxf(mw, __shfl_xor(mw, o, WAVE));
+    }
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mw;
   }
   // accumulate mode: batch mean / invstd decoded from the integer totals once per workgroup into Pt[1] (first written in S3 of
   // period 1, read by both roles right behind the "Wl complete" barrier)
   float* const stash = Pt[1];
-  static_assert(TR * LDP >= 4 * D, "the stash fits a P tile");
+  static_assert(TR * LDP >= 6 * D, "the stash fits a P tile");
   if (sa.acc) head_stat_stage<D>(sa, n, S, stash, 1024);
   // The two roles run SEPARATE loops (the register allocator then sees each role's state on its own path) that execute
   // the same number of workgroup barriers: one before and one after the loop, three per period.
@@ -1457,8 +1466,8 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
 #pragma unroll
     for (int i = 0; i < NB; ++i) accW[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float sdy[2] = {0.f, 0.f}, sdyx[2] = {0.f, 0.f}, mu[2], is[2];
-    if (sa.acc && blockIdx.x == 0 && first && wave == 8) head_stat_bookkeeping<D>(sa, n, S, lane);   // (see HeadStatAcc)
     __syncthreads();   // Wl complete (and the statistics stash)
+    if (sa.acc && blockIdx.x == 0 && first && wave == 8) head_stat_bookkeeping<D>(sa, stash, S, lane);   // (see HeadStatAcc)
 #pragma unroll
     for (int s = 0; s < 2; ++s) head_stat<D>(sa, stash, mean, invstd, s < S ? s : 0, own * 16 + (lane & 15), mu[s], is[s]);
     // X of this lane's (row, column) elements of a tile, for the BatchNorm sums of its epilogue: requested a whole matrix
