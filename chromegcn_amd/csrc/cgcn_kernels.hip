@@ -1120,7 +1120,8 @@ __global__ __launch_bounds__(1024) void k_layer_dense256(int n, int ntiles, cons
 // them can be reached by a stray -D: they need -DCGCN_EXPERIMENT_BUILD, which chromegcn_amd/_build.py refuses for the
 // in-tree library.
 #if (defined(RING_NO_WAIT) || defined(RING_SKIP_MFMA) || defined(RING_SKIP_ROWTEAM) || defined(RING_SKIP_LOADS) || \
-     defined(RING_TEST_SLOW_ROW) || defined(RING_TEST_SLOW_MATRIX) || defined(RL256_SKIP_MFMA) || defined(RL256_SKIP_LOADS)) && \
+     defined(RING_TEST_SLOW_ROW) || defined(RING_TEST_SLOW_MATRIX) || defined(RL256_SKIP_MFMA) || defined(RL256_SKIP_LOADS) || \
+     defined(BSX_NORIDERS) || defined(BSX_NODXN) || defined(BSX_NOSTORE)) && \
     !defined(CGCN_EXPERIMENT_BUILD)
 #error "RING_NO_WAIT / RING_SKIP_* / RING_TEST_SLOW_* are experiment switches: build a variant with -DCGCN_EXPERIMENT_BUILD (tools/mkvariant.py), never the shipped library"
 #endif
@@ -2257,7 +2258,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HAS_VAL ? 6
   constexpr int RIDER_STAGE = 4 * (512 / HEAD_STAT_COLS) * (HEAD_STAT_COLS + 1) * (int)sizeof(double) / 16;
   __shared__ f32x4 bt[BP ? (BANDPLUS_CHUNKS > RIDER_STAGE ? BANDPLUS_CHUNKS : RIDER_STAGE) : 1];
   if ((int)blockIdx.x >= gather_blocks) {
+#ifndef BSX_NORIDERS   // (decomposition build, profiles/r06_bwd_sliced_gap.txt: the riders return at once -- gradients are garbage)
     bwd_riders<S, D, BP>((int)blockIdx.x - gather_blocks, n, P, part, dW, db, dwg, dcg, accumulate, sg, reduce_slabs, hp, head_slabs, bt);
+#endif
     return;
   }
   static_assert(!(BP && HAS_VAL), "the band-plus CSR holds unit entries");
@@ -2278,7 +2281,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HAS_VAL ? 6
   f32x4 res = (f32x4){0.f, 0.f, 0.f, 0.f}, acc;
   if (!t.super) {
     // the (1-g) dXn term first: its loads are in flight during the walk
+#ifndef BSX_NODXN      // (decomposition build: no (1-g) dXn operand)
     if (i < n) res = ld_stream4(&dXn[lane_el + (size_t)i * D]) * (1.f - gate[(size_t)s * n + i]);
+#endif
     acc = sliced_row_sum<HAS_VAL, IT>(col, val, t.k0, t.k1, (const char*)dHs, lane_off, rowsh, lane);
   } else {
     acc = sliced_super_sum<HAS_VAL, IT>(col, val, t, (const char*)dHs, lane_off, rowsh, lane, wave);
@@ -2293,6 +2298,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HAS_VAL ? 6
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = dropout_keep(key, (uint32_t)(g_off + e), thresh) ? o[e] * keep_scale : 0.f;
   }
+#ifdef BSX_NOSTORE     // (decomposition build: the result leaves only if it is a number no input produces)
+  if (o[0] != 1.2345e33f) return;
+#endif
   if (SLICED_NT & 4) __builtin_nontemporal_store(o, (f32x4*)&dX[g_off]);
   else *(f32x4*)&dX[g_off] = o;
 }
