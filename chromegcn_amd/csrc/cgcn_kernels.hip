@@ -2782,7 +2782,7 @@ static bool fwd_split_shape(int n, int S, int d) {
   // Rounds 3-5 kept the fused k_layer_fwd<2,256> at every size (tools/strand_split_probe.py, profiles/
   // r03_d256_strand_split_experiment.txt: the two launches won on uniform graphs above 7 000 nodes and lost on distance-decay
   // graphs, 207 vs 183 us at n = 29 910) because the row-local launch was k_layer_dense<2,256>: 33 us at n = 5 776, ~130 at
-  // 29 910.  k_layer_dense256 takes 27 / 93 us: config 4's chr21-size step 0.727 -> 0.673 ms on uniform graphs, 0.742 -> 0.692
+  // 29 910.  k_layer_dense256 takes 27 / 93 us: config 4's chr21-size step 0.742 -> 0.727 ms on uniform graphs, 0.692 -> 0.673
   // on distance-decay graphs (profiles/r06_dense256_experiment.txt).
   return table >= (double)split_bytes;
 }

@@ -35,6 +35,8 @@ def _open(build):
     if build == "product":
         return _lib.load()
     path = _build.variant_path(build)
+    if _build.variant_is_stale(build) and _build.hipcc_path() is not None:
+        _build.build_test_variants()     # lazily, by the tests that need them (a child process: hipcc never touches the GPU)
     if _build.variant_is_stale(build):
         pytest.fail("test variant %s is missing or stale: python -m chromegcn_amd._build --test-variants" % path)
     return _lib.open_library(path)
