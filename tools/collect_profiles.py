@@ -32,6 +32,10 @@ def main():
         if lines:
             wl = os.path.basename(f)[len("bench_"):-len(".json")]
             open(os.path.join(prof, "%s_bench_line_%s.json" % (tag, wl)), "w").write(lines[-1] + "\n")
+    for extra in ("saliency_kernel_stats.csv", "pytest.log"):
+        src = os.path.join(ROOT, "gpurun_out", tag, extra)
+        if os.path.exists(src):
+            shutil.copy(src, os.path.join(prof, "%s_%s" % (tag, "pytest_gpu.log" if extra == "pytest.log" else extra)))
     if "chr21_d256L4_d256" in traffic:   # bench.py keys its lookup by workload (+ generator) + width
         traffic["chr21_d256"] = traffic.pop("chr21_d256L4_d256")
     note = traffic.pop("_note", None)

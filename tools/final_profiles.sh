@@ -14,6 +14,7 @@ python bench.py --d 256 --layers 4 --no-cpu-baseline > gpurun_out/$T/bench_genom
 python bench.py --gpus 2 --backend gloo --share-gpu --no-cpu-baseline --no-extras > gpurun_out/$T/bench_genome_2ranks_one_gpu_gloo.json 2>/dev/null
 python bench.py --workload e2e > gpurun_out/$T/bench_e2e.json 2>/dev/null
 python bench.py --workload e2e --e2e-windows 0 > gpurun_out/$T/bench_e2e_chr21_full.json 2>/dev/null
+( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/sal_prof && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/sal_prof -- python3 $GRAFT_REPO_ROOT/tools/saliency_bench.py > $GRAFT_REPO_ROOT/gpurun_out/$T/saliency.log 2>&1; f=$(find /tmp/sal_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && { echo "# rocprofv3 --kernel-trace --stats -- python3 tools/saliency_bench.py (adjacency saliency of a chr21-size and a chr1-size chromosome, 6 calls each)"; cat "$f"; } > $GRAFT_REPO_ROOT/gpurun_out/$T/saliency_kernel_stats.csv )
 bash tools/profile_round.sh $T genome
 bash tools/profile_round.sh $T genome_hic --hic-like
 bash tools/profile_round.sh $T chr21 --workload chr21
