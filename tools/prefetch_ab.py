@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of GCNStage.prefetch_input_aggregation (tuning tool): trains the synthetic genome for a few epochs in both orders,
-checks parameters bit for bit, and times epochs of each order alternately.  Needs tools/micro/prefetch_agg.patch applied
+checks parameters bit for bit, and times epochs of each order alternately.  Needs profiles/patches/prefetch_agg.patch applied
 (the switch was measured neutral and is not in the product: profiles/r05_prefetch_agg_experiment.txt)."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
