@@ -9,7 +9,7 @@ from tools.kbench import timeit
 
 def main():
     dev = torch.device("cuda"); lib = _lib.load()
-    n, d, S, C = int(os.environ.get("KS_N", 5776)), 128, 2, 103
+    n, d, S, C = int(os.environ.get("KS_N", 5776)), int(os.environ.get("KS_D", 128)), 2, 103
     x = torch.randn(S, n, d, device=dev)
     bn_w = torch.rand(d, device=dev) + 0.5; bn_b = torch.randn(d, device=dev) * 0.1
     rm = torch.zeros(d, device=dev); rv = torch.ones(d, device=dev); nbt = torch.zeros(1, dtype=torch.int64, device=dev)
