@@ -1893,6 +1893,53 @@ __device__ __forceinline__ void reduce_slab(int slab, int P, int D, const float*
   }
 }
 
+// The same second stage for FEW partial records (d = 256: 64 records of 263 KB): one workgroup finishes 256 elements instead
+// of 64 -- a wave-row of float4 covers them, wave w sums records [w P / 8, (w + 1) P / 8) with all of its loads in flight, the
+// eight waves' sums are added in wave order.  At d = 256 the 64-element form meant 1 033 rider workgroups of 16 KB each at the
+// tail of k_bwd_sliced (round 6: 259 of 64 KB).  Deterministic: fixed order, no atomics.
+#ifndef REDUCE_WIDE_MAX_P
+#define REDUCE_WIDE_MAX_P 64   // (0: the 64-element form at every record count: A/B)
+#endif
+template <int NT>
+__device__ __forceinline__ void reduce_slab_wide(int wg, int P, int D, const float* __restrict__ part,
+                                                 float* __restrict__ dW, float* __restrict__ db, float* __restrict__ dwg,
+                                                 float* __restrict__ dcg, int accumulate, const SgdFuse& sg) {
+  constexpr int NW = NT / 64;
+  const int PSTRIDE = D * D + 2 * D + 4;
+  const int total = D * D + 2 * D + 1;
+  __shared__ __attribute__((aligned(16))) float redw[NW][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int e0 = wg * 256 + lane * 4;   // PSTRIDE is a multiple of 4 and the row is padded to it
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  if (e0 < PSTRIDE) {
+    const int per = (P + NW - 1) / NW;
+    const int p0 = wave * per, p1 = min(P, p0 + per);
+    for (int p = p0; p < p1; p += 8) {
+      f32x4 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = *(const f32x4*)(part + (size_t)min(p + u, p1 - 1) * PSTRIDE + e0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (p + u < p1) a += t[u];
+    }
+  }
+  *(f32x4*)&redw[wave][lane * 4] = a;
+  __syncthreads();
+  const int e = wg * 256 + (int)threadIdx.x;
+  if (threadIdx.x < 256 && e < total) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += redw[w][threadIdx.x];
+    float* dst;
+    if (e < D * D) dst = dW + e;
+    else if (e < D * D + D) dst = db + (e - D * D);
+    else if (e < D * D + 2 * D) dst = dwg + (e - D * D - D);
+    else dst = dcg;
+    *dst = accumulate ? (*dst + s) : s;
+    if (sg.param) sgd_apply(sg, (int)(dst - sg.grad), s);   // this element's gradient is final: step it right here
+  }
+}
+
 // Extra workgroups of a launch that carries the optimizer step (cgcn_sgd_fuse): every arena element whose gradient an
 // EARLIER launch finished, i.e. all but this layer's own dW / db / dwg / dcg (the reduce slabs step those as they finish).
 __device__ __forceinline__ void sgd_other_elements(const SgdFuse& sg, int block, int D, const float* dW, const float* db,
@@ -2216,8 +2263,9 @@ __device__ __forceinline__ void bwd_riders(int extra, int n, int P, const float*
                                            float* __restrict__ db, float* __restrict__ dwg, float* __restrict__ dcg,
                                            int accumulate, const SgdFuse& sg, int reduce_slabs, const HeadApply& hp,
                                            int head_slabs, void* scratch = nullptr) {
-  if (extra < reduce_slabs) {
-    reduce_slab<512>(extra, P, D, part, dW, db, dwg, dcg, accumulate, sg);
+  if (extra < reduce_slabs) {   // (the host counts wide slabs when P <= REDUCE_WIDE_MAX_P: layer_bwd_impl)
+    if (P <= REDUCE_WIDE_MAX_P) reduce_slab_wide<512>(extra, P, D, part, dW, db, dwg, dcg, accumulate, sg);
+    else reduce_slab<512>(extra, P, D, part, dW, db, dwg, dcg, accumulate, sg);
     return;
   }
   extra -= reduce_slabs;
@@ -3040,6 +3088,8 @@ static int layer_bwd_impl(cgcn_stream_t stream, int n, int S, int d, const int32
       rs_stream = (hipStream_t)aux_stream;
   }
   const int slabs = (total + 63) / 64;
+  // (riding in a gather launch, few partial records are finished 256 elements per workgroup: reduce_slab_wide)
+  const int rslabs = P <= REDUCE_WIDE_MAX_P ? (total + 255) / 256 : slabs;
   // default: the sum rides at the end of the gather launch; no gather when the caller does not want dX
   const bool fuse_reduce = (rs_stream == st) && n > 0 && dX != nullptr;
   if (!fuse_reduce) {
@@ -3059,9 +3109,9 @@ static int layer_bwd_impl(cgcn_stream_t stream, int n, int S, int d, const int32
   if (band_graph(aux_t, val_t)) {   // band operator (symmetric): the sliding-window stream with the same riders
     const int bblocks = S * ((n + BAND_R - 1) / BAND_R);
 #define CALLB(S_, D_)                                                                                                 \
-  hipLaunchKernelGGL((k_bwd_band<S_, D_, BAND_R>), dim3(bblocks + (fuse_reduce ? slabs : 0) + head_slabs_g + sgd_blocks), dim3(512), 0, st, \
+  hipLaunchKernelGGL((k_bwd_band<S_, D_, BAND_R>), dim3(bblocks + (fuse_reduce ? rslabs : 0) + head_slabs_g + sgd_blocks), dim3(512), 0, st, \
                      n, dHs, dXn, gate, dX, ks, th, rng_state, in_stream_id, bblocks, P, part, dW, db, dwg, dcg, accumulate, sg, \
-                     fuse_reduce ? slabs : 0, hp, head_slabs_g)
+                     fuse_reduce ? rslabs : 0, hp, head_slabs_g)
     if (S == 1 && d == 128) CALLB(1, 128);
     else if (S == 2 && d == 128) CALLB(2, 128);
     else if (S == 1 && d == 256) CALLB(1, 256);
@@ -3070,9 +3120,9 @@ static int layer_bwd_impl(cgcn_stream_t stream, int n, int S, int d, const int32
   } else if (bandplus_graph(aux_t, val_t)) {   // 'both': the unit-entry CSR + the band window from LDS (BP)
     const SlicedCsr c = sliced_csr(aux_t, rowptr_t, col_t, val_t, n);
 #define CALLBP(S_, D_, IT_, COL_)                                                                                    \
-  hipLaunchKernelGGL((k_bwd_sliced<S_, D_, false, IT_, true>), dim3(blocks + (fuse_reduce ? slabs : 0) + head_slabs_g + sgd_blocks), dim3(512), 0, \
+  hipLaunchKernelGGL((k_bwd_sliced<S_, D_, false, IT_, true>), dim3(blocks + (fuse_reduce ? rslabs : 0) + head_slabs_g + sgd_blocks), dim3(512), 0, \
                      st, n, c.rowptr, COL_, nullptr, dHs, dXn, gate, dX, ks, th, rng_state, in_stream_id, blocks, P,  \
-                     part, dW, db, dwg, dcg, accumulate, sg, fuse_reduce ? slabs : 0, c.order, hp, head_slabs_g)
+                     part, dW, db, dwg, dcg, accumulate, sg, fuse_reduce ? rslabs : 0, c.order, hp, head_slabs_g)
 #define CALLBP16(S_, D_) CALLBP(S_, D_, uint16_t, c.col16)
 #define CALLBP32(S_, D_) CALLBP(S_, D_, int, c.col)
     if (c.col16) { if (S == 1 && d == 128) CALLBP16(1, 128); else if (S == 2 && d == 128) CALLBP16(2, 128); else if (S == 1 && d == 256) CALLBP16(1, 256); else CALLBP16(2, 256); }
@@ -3082,9 +3132,9 @@ static int layer_bwd_impl(cgcn_stream_t stream, int n, int S, int d, const int32
 #undef CALLBP
   } else if (const uint16_t* col16_t = use_col16(aux_t, val_t, n)) {
 #define CALL16(S_, D_)                                                                                               \
-  hipLaunchKernelGGL((k_bwd_sliced<S_, D_, false, uint16_t>), dim3(blocks + (fuse_reduce ? slabs : 0) + head_slabs_g + sgd_blocks), dim3(512), 0, \
+  hipLaunchKernelGGL((k_bwd_sliced<S_, D_, false, uint16_t>), dim3(blocks + (fuse_reduce ? rslabs : 0) + head_slabs_g + sgd_blocks), dim3(512), 0, \
                      st, n, rowptr_t, col16_t, val_t, dHs, dXn, gate, dX, ks, th, rng_state, in_stream_id, blocks, P, \
-                     part, dW, db, dwg, dcg, accumulate, sg, fuse_reduce ? slabs : 0, row_order(aux_t), hp, head_slabs_g)
+                     part, dW, db, dwg, dcg, accumulate, sg, fuse_reduce ? rslabs : 0, row_order(aux_t), hp, head_slabs_g)
     if (S == 1 && d == 128) CALL16(1, 128);
     else if (S == 2 && d == 128) CALL16(2, 128);
     else if (S == 1 && d == 256) CALL16(1, 256);
@@ -3092,9 +3142,9 @@ static int layer_bwd_impl(cgcn_stream_t stream, int n, int S, int d, const int32
 #undef CALL16
   } else {
 #define CALL(S_, D_, V_)                                                                                             \
-  hipLaunchKernelGGL((k_bwd_sliced<S_, D_, V_, int>), dim3(blocks + (fuse_reduce ? slabs : 0) + head_slabs_g + sgd_blocks), dim3(512), 0, \
+  hipLaunchKernelGGL((k_bwd_sliced<S_, D_, V_, int>), dim3(blocks + (fuse_reduce ? rslabs : 0) + head_slabs_g + sgd_blocks), dim3(512), 0, \
                      st, n, rowptr_t, col_t, val_t, dHs, dXn, gate, dX, ks, th, rng_state, in_stream_id, blocks, P,  \
-                     part, dW, db, dwg, dcg, accumulate, sg, fuse_reduce ? slabs : 0, row_order(aux_t), hp, head_slabs_g)
+                     part, dW, db, dwg, dcg, accumulate, sg, fuse_reduce ? rslabs : 0, row_order(aux_t), hp, head_slabs_g)
     DISPATCH_SDV(S, d, val_t != nullptr, CALL);
 #undef CALL
   }
