@@ -1858,7 +1858,7 @@ static int head_train_impl(cgcn_stream_t stream, int n, int S, int d, int C, con
   if (!X || !bn_w || !bn_b || !Wout || !bout || !target || !probs || !loss || !workspace || !run_mean || !run_var ||
       !save_mean || !save_invstd || n < 2)
     return CGCN_ERR_BAD_ARG;
-  // accumulate mode (cgcn_layer_fwd_colstats_tiles reported rows = -1): the buffer holds integer totals, not records
+  // accumulate mode (cgcn_layer_fwd_colstats_plan reported rows = -1): the buffer holds integer totals, not records
   const size_t acc_tile_bytes = (size_t)S * d * 2 * sizeof(float);
   const bool stat_acc = col_stats && col_stats_rows == -1;
   if (stat_acc && ((size_t)col_stats_tiles * acc_tile_bytes < stat_acc_words(S, d) * 8 || ((uintptr_t)col_stats & 7)))

@@ -735,7 +735,7 @@ __global__ __launch_bounds__(512, DENSE_WAVES_PER_SIMD) void k_layer_dense(int n
   // Tile walk.  Without column statistics: tiles b, b + G, b + 2G, ... (G = grid).  With them: the CONTIGUOUS tiles
   // [b * stat_chunk, (b + 1) * stat_chunk), whose statistics are merged on chip (Chan) into ONE record per workgroup --
   // a record then covers stat_chunk * R consecutive nodes, which is all the head's finalize kernel needs to know
-  // (cgcn_layer_fwd_colstats_tiles), and there are <= 512 of them instead of one per 16 / S nodes.
+  // (cgcn_layer_fwd_colstats_plan), and there are <= 512 of them instead of one per 16 / S nodes.
   const int tfirst = colstats ? (int)blockIdx.x * stat_chunk : (int)blockIdx.x;
   const int tstep = colstats ? 1 : (int)gridDim.x;
   const int tend = colstats ? min(ntiles, tfirst + stat_chunk) : ntiles;

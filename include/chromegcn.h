@@ -348,7 +348,7 @@ int cgcn_head_logits(cgcn_stream_t stream, int n, int S, int d, int C, const flo
  * set: that call finishes every head gradient.  (cgcn_head_bwd with dpred == NULL and dX == NULL is accepted and
  * launches nothing.)  d loss / d pred never touches memory.
  * col_stats (may be NULL): the colstats output of the cgcn_layer_fwd call that produced X, with its tile count and
- * rows per tile (cgcn_layer_fwd_colstats_tiles); the head then skips its own first pass over X.
+ * rows per tile (cgcn_layer_fwd_colstats_plan; rows = -1: accumulate mode, the integer totals); the head then skips its own first pass over X.
  */
 int cgcn_head_train(cgcn_stream_t stream, int n, int S, int d, int C, const float *X, const float *bn_w,
                     const float *bn_b, float *run_mean, float *run_var, long long *num_batches_tracked,
