@@ -51,6 +51,7 @@ _SIGNATURES = {
 }
 ABI_VERSION = 24
 COLSTATS_RECORDS, COLSTATS_ACCUMULATE = 0, 1   # include/chromegcn.h: CGCN_COLSTATS_*
+COLSTATS_ROWS_ACCUMULATE, COLSTATS_ROWS_ZERO_ONLY, COLSTATS_ROWS_ACCUMULATE_ZEROED = -1, -2, -3   # CGCN_COLSTATS_ROWS_*
 _lib = None
 
 

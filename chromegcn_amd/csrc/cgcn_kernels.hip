@@ -494,8 +494,12 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512, FWD_WAVES_PE
                                                      float* __restrict__ Zout, float* __restrict__ Hout,
                                                      float* __restrict__ gate, float keep_scale, uint32_t thresh,
                                                      const unsigned long long* __restrict__ rng_state,
-                                                     uint32_t stream_id, float* __restrict__ colstats) {
+                                                     uint32_t stream_id, float* __restrict__ colstats, int stat_acc,
+                                                     unsigned long long* __restrict__ zero_words, int zero_count) {
   using G = Geo<S, D>;
+  // (statistics totals of a LATER launch of the step -- cgcn_layer_fwd's colstats_rows = -2 -- zeroed here like k_aggregate_sliced does)
+  if (zero_words && (int)blockIdx.x < min((int)gridDim.x, 8))
+    for (int i = (int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x; i < zero_count; i += min((int)gridDim.x, 8) * (int)blockDim.x) zero_words[i] = 0ull;
   constexpr int ROWS = 16 * MB;      // MFMA rows in the tile
   constexpr int R = ROWS / S;        // nodes in the tile
   constexpr int CBW = (D == 128) ? CBW128 : 2;  // 16-wide output column blocks per wave
@@ -633,7 +637,23 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512, FWD_WAVES_PE
   }
   // ---- optional: first stage of the classifier head's BatchNorm statistics (k_head_colstats' job) while the tile
   // is still on chip: per (strand, column) the exact two-pass (mean, M2) of relu(Xn) over this tile's nodes
-  if (colstats) {
+  if (colstats && stat_acc) {
+    // accumulate mode (cgcn_common.hpp, STAT_ACC_*; totals zeroed by an EARLIER launch of the step): this tile's sum x and
+    // sum x^2 per (strand, column), the squares in double, straight into the slot of this workgroup's XCD
+    __syncthreads();
+    const int cnt = min(R, n - node0);
+    for (int idx = threadIdx.x; idx < S * D; idx += blockDim.x) {
+      const int s = idx / D, c = idx % D;
+      double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr) {
+        const double v = rr < cnt ? (double)T[(s * R + rr) * LD + c] : 0.0;
+        s1 += v;
+        s2 += v * v;
+      }
+      stat_acc_add((unsigned long long*)colstats, S, D, (int)blockIdx.x & (STAT_ACC_SLOTS - 1), s, c, s1, s2);
+    }
+  } else if (colstats) {
     __syncthreads();
     const int cnt = min(R, n - node0);
     const float inv = 1.f / (float)cnt;
@@ -678,7 +698,9 @@ __global__ __launch_bounds__(512, DENSE_WAVES_PER_SIMD) void k_layer_dense(int n
                                                     float keep_scale, uint32_t thresh,
                                                     const unsigned long long* __restrict__ rng_state,
                                                     uint32_t stream_id, float* __restrict__ colstats, int stat_chunk,
-                                                    int stat_acc) {
+                                                    int stat_acc, unsigned long long* __restrict__ zero_words, int zero_count) {
+  if (zero_words && (int)blockIdx.x < min((int)gridDim.x, 8))   // (totals of a LATER launch of the step: colstats_rows = -2)
+    for (int i = (int)blockIdx.x * 512 + (int)threadIdx.x; i < zero_count; i += min((int)gridDim.x, 8) * 512) zero_words[i] = 0ull;
   constexpr int ROWS = 16 * MB;      // MFMA rows in the tile
   constexpr int R = ROWS / S;        // nodes in the tile
   static_assert(D == 128, "d = 256 has its own kernel (k_layer_dense256)");
@@ -910,7 +932,9 @@ __global__ __launch_bounds__(1024) void k_layer_dense256(int n, int ntiles, cons
                                                           float keep_scale, uint32_t thresh,
                                                           const unsigned long long* __restrict__ rng_state,
                                                           uint32_t stream_id, float* __restrict__ colstats, int stat_chunk,
-                                                          int stat_acc) {
+                                                          int stat_acc, unsigned long long* __restrict__ zero_words, int zero_count) {
+  if (zero_words && (int)blockIdx.x < min((int)gridDim.x, 8))   // (totals of a LATER launch of the step: colstats_rows = -2)
+    for (int i = (int)blockIdx.x * 1024 + (int)threadIdx.x; i < zero_count; i += min((int)gridDim.x, 8) * 1024) zero_words[i] = 0ull;
   constexpr int D = 256, ROWS = 16, R = ROWS / S, LD = D + 4, KCH = 64, TILE = ROWS * LD;
   // one W staging round (64 rows); afterwards the A tile T, the tanh tile Zt and the relu(Xn) tile St of the statistics
   __shared__ __attribute__((aligned(16))) float smem[KCH * LD];
@@ -2868,7 +2892,7 @@ int cgcn_debug_layer_fwd_route(int n, int S, int d, const cgcn_graph_aux* aux, i
   const int rc = check_shape(n, S, d);
   if (rc) return rc;
   if (band_graph(aux, nullptr)) return 2;
-  const bool need_dense = colstats_rows == -1 || colstats_rows > 16 * DENSE_MB / S;   // see cgcn_layer_fwd
+  const bool need_dense = colstats_rows == CGCN_COLSTATS_ROWS_ACCUMULATE || colstats_rows > 16 * DENSE_MB / S;   // see cgcn_layer_fwd
   return (fwd_split_shape(n, S, d) || hub_graph(aux) || (aux && aux->bp_rowptr && aux->bp_col) || need_dense) ? 1 : 0;
 }
 
@@ -2894,11 +2918,16 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   // Column statistics as the caller planned them (cgcn_layer_fwd_colstats_plan): -1 = accumulate mode, else the nodes per
   // record.  One record per 16 / S-node tile is what the fused kernel writes; merged records (k_layer_dense's contiguous
   // tile chunks) and the integer totals come from the row-local kernel, i.e. need the two-launch route: H or H_in.
+  //   -1 accumulate, THIS call zeroes the totals (its aggregation launch does: two-launch route);
+  //   -2 no statistics from this call: its first launch zeroes the totals in `colstats` for a LATER call of the step;
+  //   -3 accumulate into totals an earlier call zeroed (-2): any route, the fused kernel included.
   const int tn0 = 16 * DENSE_MB / S;
-  const bool acc = colstats && colstats_rows == -1;
+  const bool zero_only = colstats && colstats_rows == CGCN_COLSTATS_ROWS_ZERO_ONLY;
+  const bool acc_pre = colstats && colstats_rows == CGCN_COLSTATS_ROWS_ACCUMULATE_ZEROED;
+  const bool acc = colstats && (colstats_rows == CGCN_COLSTATS_ROWS_ACCUMULATE || acc_pre);
   int chunk = 1;
   if (colstats) {
-    if (acc) {
+    if (acc || zero_only) {
       if (n < 2 || ((uintptr_t)colstats & 7)) return CGCN_ERR_BAD_ARG;
       chunk = acc_chunk(n, S, d);
     } else {
@@ -2906,21 +2935,27 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
       chunk = colstats_rows / tn0;
     }
   }
-  const bool need_dense = colstats && (acc || chunk != 1);
+  unsigned long long* zw = zero_only ? (unsigned long long*)colstats : nullptr;   // zeroed by this call's FIRST launch
+  const int zc = zero_only ? (int)stat_acc_words(S, d) : 0;
+  if (zero_only) colstats = nullptr;                                              // ... which produces no statistics
+  const bool need_dense = colstats && ((acc && !acc_pre) || (!acc && chunk != 1));
   const bool split = !H_in && H && (fwd_split_shape(n, S, d) || hub_graph(aux) || band || bandplus_graph(aux, val) || need_dense);
-  bool acc_zeroed = false;
+  if (!split && !H_in) chunk = 1;   // (the fused kernel: one tile per workgroup; accumulate mode has no records to count)
+  bool acc_zeroed = acc_pre;
   if (need_dense && !split && !H_in) return CGCN_ERR_BAD_ARG;
   if (split) {
     const int gblocks = (S * d / 32) * ((n + 63) / 64);
+    // (the aggregation launch zeroes: this call's own totals, or a later call's)
+    unsigned long long* zq = zw ? zw : ((acc && !acc_pre) ? (unsigned long long*)colstats : nullptr);
+    const int zn = zq ? (int)stat_acc_words(S, d) : 0;
     if (band) {
-      launch_band_aggregate(st, n, S, d, row_scale, X, H, acc ? (unsigned long long*)colstats : nullptr, acc ? (int)stat_acc_words(S, d) : 0);
-      acc_zeroed = acc;
+      launch_band_aggregate(st, n, S, d, row_scale, X, H, zq, zn);
     } else {
       const SlicedCsr c = sliced_csr(aux, rowptr, col, val, n);
-      launch_aggregate_sliced(st, gblocks, n, S, d, c.rowptr, c.col, c.col16, c.val, row_scale, X, H, c.order, c.bp,
-                              acc ? (unsigned long long*)colstats : nullptr, acc ? (int)stat_acc_words(S, d) : 0);
-      acc_zeroed = acc;
+      launch_aggregate_sliced(st, gblocks, n, S, d, c.rowptr, c.col, c.col16, c.val, row_scale, X, H, c.order, c.bp, zq, zn);
     }
+    acc_zeroed = acc;
+    zw = nullptr;
     if ((rc = launch_status())) return rc;
     H_in = H;
   }
@@ -2933,14 +2968,14 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
     const int grid = colstats ? (ntiles + chunk - 1) / chunk : (ntiles < dense_max_blocks(d) ? ntiles : dense_max_blocks(d));
     if (d == 256) {   // one 16-wave workgroup per CU (k_layer_dense256)
       if (S == 1) hipLaunchKernelGGL((k_layer_dense256<1>), dim3(grid), dim3(1024), 0, st, n, ntiles, H_in, X, W, b, wg, cg, Xn, Z, gate,
-                                     ks, th, rng_state, stream_id, colstats, chunk, acc ? 1 : 0);
+                                     ks, th, rng_state, stream_id, colstats, chunk, acc ? 1 : 0, zw, zc);
       else hipLaunchKernelGGL((k_layer_dense256<2>), dim3(grid), dim3(1024), 0, st, n, ntiles, H_in, X, W, b, wg, cg, Xn, Z, gate,
-                              ks, th, rng_state, stream_id, colstats, chunk, acc ? 1 : 0);
+                              ks, th, rng_state, stream_id, colstats, chunk, acc ? 1 : 0, zw, zc);
       return launch_status();
     }
 #define CALL(S_) \
     hipLaunchKernelGGL((k_layer_dense<S_, 128, MB>), dim3(grid), dim3(512), 0, st, n, ntiles, H_in, X, W, b, wg, cg, Xn, Z, gate, \
-                       ks, th, rng_state, stream_id, colstats, chunk, acc ? 1 : 0)
+                       ks, th, rng_state, stream_id, colstats, chunk, acc ? 1 : 0, zw, zc)
     if (S == 1) CALL(1); else CALL(2);
 #undef CALL
     return launch_status();
@@ -2951,7 +2986,7 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   const bool deep = pick_deep(n, S, d);
 #define FWD(S_, D_, MB_, V_, DP_)                                                                                     \
   hipLaunchKernelGGL((k_layer_fwd<S_, D_, MB_, V_, DP_>), dim3(blocks), blk, 0, st, n, rowptr, col, val, row_scale,    \
-                     X, W, b, wg, cg, Xn, Z, H, gate, ks, th, rng_state, stream_id, colstats)
+                     X, W, b, wg, cg, Xn, Z, H, gate, ks, th, rng_state, stream_id, colstats, acc ? 1 : 0, zw, zc)
 #define CALL(S_, D_, V_)                                                                                              \
   do {                                                                                                                \
     const dim3 blk((D_ == 128 && CBW128 == 2) ? 256 : 512);                                                           \

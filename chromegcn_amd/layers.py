@@ -123,11 +123,12 @@ class ChromeGCN(nn.Module):
         return None if any(g is None for g in grads) else grads
 
     # -- the gated stack on a [S, n, d] block -------------------------------------------------
-    def _gated_stack(self, x, graph, rng, upto=None, h1_cache=None):
+    def _gated_stack(self, x, graph, rng, upto=None, h1_cache=None, zero_stat=None):
         gates = []
         L = self.n_layers
         p = float(self.dropout) if (self.training and rng is not None) else 0.0
-        for k in range(1, (L if upto is None else upto) + 1):
+        last = L if upto is None else upto
+        for k in range(1, last + 1):
             gc = getattr(self, "GC%d" % k)
             wk = getattr(self, "W%d" % k)
             # F.dropout between layers (ChromeModels.py:42) runs inside the kernels: layer k drops its own
@@ -135,7 +136,8 @@ class ChromeGCN(nn.Module):
             x, g = ops.gated_layer(x, gc.weight, gc.bias, wk.weight, wk.bias, graph,
                                    dropout_out=p if k < L else 0.0, dropout_in=p if k > 1 else 0.0,
                                    rng_state=rng, layer_id=k, grad_sink=self._sink(gc.weight, gc.bias, wk.weight, wk.bias),
-                                   h_cache=h1_cache if k == 1 else None)
+                                   h_cache=h1_cache if k == 1 else None,
+                                   zero_stat=zero_stat if k == last else None)   # (the next layer's statistics totals)
             gates.append(g)
         return x, gates
 
@@ -186,12 +188,15 @@ class ChromeGCN(nn.Module):
         graph = as_graph(adj, x_fr.device, n=x_fr.shape[1])
         rng = self._step_rng()
         L = self.n_layers
-        x, gates = self._gated_stack(x_fr, graph, rng, upto=L - 1, h1_cache=h1_cache)
+        # accumulate mode with a layer in front of the last one: that layer's first launch zeroes the totals, so the last
+        # layer needs no aggregation launch of its own to do it and keeps the one-launch forward on small tables
+        stat_buf = ops.stat_buffer(x_fr) if (stat_acc and self.training and L > 1 and torch.is_grad_enabled()) else None
+        x, gates = self._gated_stack(x_fr, graph, rng, upto=L - 1, h1_cache=h1_cache, zero_stat=stat_buf)
         p = float(self.dropout) if (self.training and rng is not None) else 0.0
         gc, wk, bn, out = getattr(self, "GC%d" % L), getattr(self, "W%d" % L), self.batch_norm, self.out
         loss, probs, g = ops.last_layer_head_loss(
             x, gc, wk, bn, out, graph, target, self.training, p, p if L > 1 else 0.0, rng, L,
             layer_sink=self._sink(gc.weight, gc.bias, wk.weight, wk.bias),
             head_sink=self._sink(bn.weight, bn.bias, out.weight, out.bias), h_cache=h1_cache if L == 1 else None,
-            out_slots=out_slots, stat_acc=stat_acc)
+            out_slots=out_slots, stat_acc=stat_acc, stat_buf=stat_buf)
         return loss, probs, gates + [g]

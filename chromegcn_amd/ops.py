@@ -163,7 +163,7 @@ class GatedLayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gate_w, gate_b, graph: ChromGraph, dropout_out, dropout_in, rng_state,
-                layer_id, grad_sink, h_cache):
+                layer_id, grad_sink, h_cache, zero_stat=None):
         _check_feat(x, graph)
         for t, nm in ((weight, "weight"), (bias, "bias"), (gate_w, "gate weight"), (gate_b, "gate bias")):
             _require_cuda(t, nm)
@@ -187,7 +187,9 @@ class GatedLayerFn(torch.autograd.Function):
                                       _lib.ptr(graph.val), _lib.ptr(graph.row_scale), x.data_ptr(), weight.data_ptr(),
                                       bias.data_ptr(), wg.data_ptr(), cg.data_ptr(), xn.data_ptr(), _lib.ptr(z),
                                       _lib.ptr(h), gate.data_ptr(), float(dropout_out),
-                                      _lib.ptr(rng_state) if dropout_out > 0 else None, int(layer_id), _lib.ptr(h_in), None, 0,
+                                      _lib.ptr(rng_state) if dropout_out > 0 else None, int(layer_id), _lib.ptr(h_in),
+                                      # zero_stat: the NEXT (last) layer's statistics totals, zeroed by this call's first launch
+                                      _lib.ptr(zero_stat), _lib.COLSTATS_ROWS_ZERO_ONLY if zero_stat is not None else 0,
                                       G.aux_ptr(graph.col)),
                    "cgcn_layer_fwd")
         h = _store_h_cache(h_cache, h_in, h)
@@ -208,7 +210,7 @@ class GatedLayerFn(torch.autograd.Function):
         g = ctx.graph
         S, n, d = x.shape
         if dxn is None and dgate is None:
-            return (None,) * 12
+            return (None,) * 13
         dxn = torch.zeros_like(x) if dxn is None else _dense(dxn)
         dgate = None if dgate is None else dgate.contiguous()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None  # None: skip the gather over Ahat^T
@@ -238,16 +240,18 @@ class GatedLayerFn(torch.autograd.Function):
         if _saliency_tap is not None:
             _saliency_tap.append((x, dhs, g))
         if ctx.sink is not None:
-            return (dx, None, None, None, None) + (None,) * 7
-        return (dx, dw, db, dwg.view(ctx.gate_w_shape), dcg.view(ctx.gate_b_shape)) + (None,) * 7
+            return (dx, None, None, None, None) + (None,) * 8
+        return (dx, dw, db, dwg.view(ctx.gate_w_shape), dcg.view(ctx.gate_b_shape)) + (None,) * 8
 
 
 def gated_layer(x, weight, bias, gate_w, gate_b, graph, dropout_out=0.0, dropout_in=0.0, rng_state=None,
-                layer_id=0, grad_sink=None, h_cache=None):
+                layer_id=0, grad_sink=None, h_cache=None, zero_stat=None):
     """One gated layer -> (X', gate).  Plain callers (ChromeGCN.forward, tests) go through the registered operator
     torch.ops.chromegcn.gated_layer; the engine's extras (gradient sinks, cached aggregation, the saliency tap) need
-    the autograd node below."""
-    if grad_sink is None and h_cache is None and _saliency_tap is None:
+    the autograd node below.
+    zero_stat: the statistics-totals buffer of the LAST layer's call (stat_buffer), zeroed by this call's first launch so
+    that the last layer may accumulate into it on any route (cgcn_layer_fwd, colstats_rows = -2 / -3)."""
+    if grad_sink is None and h_cache is None and _saliency_tap is None and zero_stat is None:
         _check_feat(x, graph)
         from . import torch_ops  # noqa: F401
         xn, gate, _z, _h = torch.ops.chromegcn.gated_layer(
@@ -255,7 +259,18 @@ def gated_layer(x, weight, bias, gate_w, gate_b, graph, dropout_out=0.0, dropout
             graph.col_t, graph.val_t, float(dropout_out), float(dropout_in), rng_state, int(layer_id))
         return xn, gate
     return GatedLayerFn.apply(x, weight, bias, gate_w, gate_b, graph, float(dropout_out), float(dropout_in),
-                              rng_state, int(layer_id), grad_sink, h_cache)
+                              rng_state, int(layer_id), grad_sink, h_cache, zero_stat)
+
+
+def stat_buffer(x):
+    """The accumulate-mode statistics buffer for features x [S, n, d] (include/chromegcn.h, cgcn_layer_fwd_colstats_plan with
+    CGCN_COLSTATS_ACCUMULATE), or None when the shape has none (n < 2).  Uninitialised: a launch of the step zeroes it."""
+    S, n, d = x.shape
+    rows = ctypes.c_int(0)
+    tiles = _lib.load().cgcn_layer_fwd_colstats_plan(n, S, d, _lib.COLSTATS_ACCUMULATE, ctypes.byref(rows))
+    if tiles <= 0 or rows.value != -1:
+        return None
+    return torch.empty((tiles, S, d, 2), device=x.device, dtype=torch.float32)
 
 
 class HeadLossFn(torch.autograd.Function):
@@ -344,7 +359,7 @@ class LastLayerHeadLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, gate_w, gate_b, bn_w, bn_b, w_out, b_out, graph, target, run_mean, run_var, nbt,
                 momentum, eps, training, dropout_p, dropout_in, rng_state, layer_id, layer_sink, head_sink, h_cache,
-                out_slots=None, stat_acc=False):
+                out_slots=None, stat_acc=False, stat_buf=None):
         _check_feat(x, graph)
         for t, nm in ((weight, "weight"), (bias, "bias"), (gate_w, "gate weight"), (gate_b, "gate bias"),
                       (bn_w, "bn weight"), (bn_b, "bn bias"), (w_out, "out.weight"), (b_out, "out.bias"), (target, "target")):
@@ -373,16 +388,23 @@ class LastLayerHeadLossFn(torch.autograd.Function):
             # stat_acc: the caller vouches for the range of the fixed-point totals (include/chromegcn.h,
             # cgcn_layer_fwd_colstats_plan; GCNStage does, per chromosome) -> accumulate mode: no finalize / finish launches;
             # otherwise per-workgroup records.  Accumulate mode needs the two-launch route, i.e. an H buffer of this call.
+            # stat_buf: totals an EARLIER launch of this step has zeroed (the previous layer's forward: gated_layer(zero_stat=...));
+            # this layer then accumulates on whatever route its table size gives it -- the fused kernel for small tables.
             rows = ctypes.c_int(0)
-            mode = _lib.COLSTATS_ACCUMULATE if (stat_acc and (h is not None or h_in is not None)) else _lib.COLSTATS_RECORDS
-            cs_tiles = lib.cgcn_layer_fwd_colstats_plan(n, S, d, mode, ctypes.byref(rows))
-            cs_rows = rows.value
-            colstats = torch.empty((cs_tiles, S, d, 2), device=x.device, dtype=torch.float32)
+            fwd_rows = None
+            if stat_acc and stat_buf is not None:
+                colstats, cs_tiles, cs_rows = stat_buf, stat_buf.shape[0], -1
+                fwd_rows = _lib.COLSTATS_ROWS_ACCUMULATE_ZEROED
+            else:
+                mode = _lib.COLSTATS_ACCUMULATE if (stat_acc and (h is not None or h_in is not None)) else _lib.COLSTATS_RECORDS
+                cs_tiles = lib.cgcn_layer_fwd_colstats_plan(n, S, d, mode, ctypes.byref(rows))
+                cs_rows = rows.value
+                colstats = torch.empty((cs_tiles, S, d, 2), device=x.device, dtype=torch.float32)
         _lib.check(lib.cgcn_layer_fwd(_lib.stream_ptr(), n, S, d, _lib.ptr(graph.rowptr), _lib.ptr(graph.col),
                                       _lib.ptr(graph.val), _lib.ptr(graph.row_scale), x.data_ptr(), weight.data_ptr(),
                                       bias.data_ptr(), wg.data_ptr(), cg.data_ptr(), xn.data_ptr(), _lib.ptr(z),
                                       _lib.ptr(h), gate.data_ptr(), 0.0, None, int(layer_id), _lib.ptr(h_in), _lib.ptr(colstats),
-                                      cs_rows, G.aux_ptr(graph.col)), "cgcn_layer_fwd")
+                                      cs_rows if (not need_bwd or fwd_rows is None) else fwd_rows, G.aux_ptr(graph.col)), "cgcn_layer_fwd")
         h = _store_h_cache(h_cache, h_in, h)
         ws_bytes = lib.cgcn_head_workspace_bytes(n, S, d, C)
         if ws_bytes == 0:
@@ -449,7 +471,7 @@ class LastLayerHeadLossFn(torch.autograd.Function):
             dw, db, dwg, dcg = torch.empty_like(weight), torch.empty(d, **f32), torch.empty(d, **f32), torch.empty(1, **f32)
         hws_bytes = hws.numel()
         if dloss is None:
-            return (None,) * 26
+            return (None,) * 27
         dloss = dloss.contiguous().view(1)
         # dym, bnc and the partials are already in the workspace cgcn_head_train filled (for d loss = 1); every head
         # gradient is finished inside cgcn_layer_bwd (cgcn_head_grad.dloss / dbn_w / dbn_b), so no head launch here
@@ -477,18 +499,20 @@ class LastLayerHeadLossFn(torch.autograd.Function):
             _sgd_fuse["done"] = True
         gl = (None,) * 4 if ctx.layer_sink is not None else (dw, db, dwg.view(ctx.shapes[0]), dcg.view(ctx.shapes[1]))
         gh = (None,) * 4 if ctx.head_sink is not None else (dbn_w, dbn_b, dw_out, db_out)
-        return (dx,) + gl + gh + (None,) * 17
+        return (dx,) + gl + gh + (None,) * 18
 
 
 def last_layer_head_loss(x, gc, wk, bn, out, graph, target, training, dropout_p, dropout_in, rng_state, layer_id,
-                         layer_sink=None, head_sink=None, h_cache=None, out_slots=None, stat_acc=False):
+                         layer_sink=None, head_sink=None, h_cache=None, out_slots=None, stat_acc=False, stat_buf=None):
     """stat_acc: accumulate mode of the head's BatchNorm sums (fixed-point integer totals, two launches fewer per step).  Its
     range is finite (sum relu(x)^2 < 2.1e9 per column) and outside it the loss is NaN, so it is the caller's statement about
-    its inputs: False (records, any magnitude) unless the caller has bounded them -- finetune.GCNStage does per chromosome."""
+    its inputs: False (records, any magnitude) unless the caller has bounded them -- finetune.GCNStage does per chromosome.
+    stat_buf (with stat_acc): stat_buffer(x) that an earlier launch of this step zeroes (gated_layer(zero_stat=stat_buf) of the
+    layer before): the last layer then keeps the route its table size gives it (small tables: the one-launch forward)."""
     return LastLayerHeadLossFn.apply(x, gc.weight, gc.bias, wk.weight, wk.bias, bn.weight, bn.bias, out.weight, out.bias,
                                      graph, target, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum,
                                      bn.eps, bool(training), float(dropout_p), float(dropout_in), rng_state, int(layer_id),
-                                     layer_sink, head_sink, h_cache, out_slots, bool(stat_acc))
+                                     layer_sink, head_sink, h_cache, out_slots, bool(stat_acc), stat_buf)
 
 
 def head_loss(x, bn: torch.nn.BatchNorm1d, out: torch.nn.Linear, target, training, dropout_p, rng_state, grad_sink=None,

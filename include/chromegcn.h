@@ -143,8 +143,14 @@ int cgcn_spmm(cgcn_stream_t stream, int n_rows, int n_cols, int S, int d,
  *   colstats_rows > 0 (RECORDS): per tile of colstats_rows nodes and (strand, column) the mean and the sum of squared
  *     deviations.  colstats_rows must be a multiple of 16 / S; more than 16 / S nodes per record (merged records) are
  *     produced by the two-launch route only and need H or H_in (CGCN_ERR_BAD_ARG otherwise).
- *   colstats_rows = -1 (ACCUMULATE): the buffer holds 64-bit fixed-point integer totals (see the plan); two-launch route
- *     only (its aggregation launch zeroes them): needs H or H_in, n >= 2, an 8-byte aligned buffer.
+ *   colstats_rows = -1 (CGCN_COLSTATS_ROWS_ACCUMULATE): the buffer holds 64-bit fixed-point integer totals (see the plan);
+ *     this call zeroes them in its aggregation launch, so it takes the two-launch route: needs H or H_in, n >= 2, an 8-byte
+ *     aligned buffer.
+ *   colstats_rows = -2 (CGCN_COLSTATS_ROWS_ZERO_ONLY): this call produces NO statistics; its first launch zeroes the totals
+ *     in `colstats` for a LATER call of the same step (the previous layer's forward prepares the last layer's buffer) ...
+ *   colstats_rows = -3 (CGCN_COLSTATS_ROWS_ACCUMULATE_ZEROED): ... which then accumulates into them on ANY route, the fused
+ *     kernel included (tables below the two-launch size keep their one-launch forward).  Hand the buffer to cgcn_head_train
+ *     with col_stats_rows = -1 either way.
  * The mode is an argument of the call (ABI v24): nothing about it is read from process state.
  */
 int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d,
@@ -154,9 +160,13 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d,
                    float dropout_p, const unsigned long long *rng_state, unsigned int stream_id,
                    const float *H_in, float *colstats, int colstats_rows, const cgcn_graph_aux *aux);
 
-/* Column-statistics modes of cgcn_layer_fwd / cgcn_head_train. */
+/* Column-statistics modes of cgcn_layer_fwd / cgcn_head_train (cgcn_layer_fwd_colstats_plan's `mode`) ... */
 #define CGCN_COLSTATS_RECORDS 0
 #define CGCN_COLSTATS_ACCUMULATE 1
+/* ... and the special values of colstats_rows (above). */
+#define CGCN_COLSTATS_ROWS_ACCUMULATE (-1)
+#define CGCN_COLSTATS_ROWS_ZERO_ONLY (-2)
+#define CGCN_COLSTATS_ROWS_ACCUMULATE_ZEROED (-3)
 
 /* What to allocate for the column statistics of cgcn_layer_fwd(n, S, d) in `mode`: returns the number of tiles ([S][d][2]
  * floats each; 0 = unsupported shape or mode), *rows_per_tile = the value to pass as colstats_rows / col_stats_rows.

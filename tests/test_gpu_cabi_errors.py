@@ -2,6 +2,7 @@
 launching on bad input, names it through cgcn_strerror, and treats empty inputs as a no-op."""
 import ctypes
 
+import numpy as np
 import pytest
 import torch
 
@@ -128,7 +129,7 @@ def test_colstats_on_a_split_size_table_needs_an_aggregation_buffer(env, mode):
                                   P(env["b"]), P(env["wg"]), P(env["cg"]), P(y), P(z), hptr, P(gate), 0.0, None, 0, None, P(cs),
                                   rows.value if r is None else r, None)
     assert call(None) == BAD_ARG
-    assert call(P(h), 0) == BAD_ARG and call(P(h), 3) == BAD_ARG and call(P(h), -2) == BAD_ARG   # not a plan's value
+    assert call(P(h), 0) == BAD_ARG and call(P(h), 3) == BAD_ARG and call(P(h), -4) == BAD_ARG   # not a plan's value
     for split_bytes in (-1, 0, 1 << 40):        # the threshold moved between plan and call: same records, no overrun
         lib.cgcn_debug_set_fwd_split_bytes(split_bytes)
         try:
@@ -140,6 +141,66 @@ def test_colstats_on_a_split_size_table_needs_an_aggregation_buffer(env, mode):
             assert not bool((cs[:S * d * 2] == 7.0).all())                 # ... and something inside them
         finally:
             lib.cgcn_debug_set_fwd_split_bytes(-1)
+
+
+def test_zero_only_and_prezeroed_accumulate_modes(env):
+    """colstats_rows = -2: the call produces no statistics and its first launch zeroes the totals for a LATER call;
+    colstats_rows = -3: accumulate into such totals on ANY route -- here the fused one-launch forward of a small table, without an
+    H buffer -- and the decoded totals are the sums of relu(Xn) (and equal the two-launch route's, which zeroes for itself: -1)."""
+    lib = env["lib"]
+    P = _lib.ptr
+    n, S, d = 3001, 2, 128                       # 3 MB table: the fused route
+    rows = ctypes.c_int(0)
+    tiles = lib.cgcn_layer_fwd_colstats_plan(n, S, d, _lib.COLSTATS_ACCUMULATE, ctypes.byref(rows))
+    assert rows.value == -1
+    g = G.upload(G.normalize_graph("hic", synth.contact_graph(n, 9000, 5), n), DEV)
+    x = torch.randn(S, n, d, device=DEV)
+    y, z, h = (torch.empty_like(x) for _ in range(3))
+    gate = torch.empty(S, n, device=DEV)
+    words = 8 * S * d * 2 * 2 + 6                # forward block + backward block (cgcn_common.hpp)
+    def fresh():
+        return torch.full((tiles * S * d * 2 + 1024,), float("nan"), device=DEV)
+    def call(cs, r, hptr=None, hin=None, xin=x):
+        return lib.cgcn_layer_fwd(_lib.stream_ptr(), n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(xin), P(env["W"]),
+                                  P(env["b"]), P(env["wg"]), P(env["cg"]), P(y), P(z), hptr, P(gate), 0.0, None, 0, hin, P(cs), r, None)
+    def decode(cs):
+        t = cs[:8 * S * d * 2 * 2].view(torch.int64).view(8, S, d, 2).sum(0).double() / 2.0 ** 32
+        return t[..., 0], t[..., 1]
+    r = torch.relu
+    for zero_route in ("fused", "two_launch", "h_in"):
+        cs = fresh()
+        if zero_route == "fused":
+            assert call(cs, _lib.COLSTATS_ROWS_ZERO_ONLY) == OK
+        elif zero_route == "two_launch":
+            lib.cgcn_debug_set_fwd_split_bytes(0)
+            try:
+                assert call(cs, _lib.COLSTATS_ROWS_ZERO_ONLY, hptr=P(h)) == OK
+            finally:
+                lib.cgcn_debug_set_fwd_split_bytes(-1)
+        else:
+            hin = torch.randn_like(x)
+            assert call(cs, _lib.COLSTATS_ROWS_ZERO_ONLY, hin=P(hin)) == OK
+        torch.cuda.synchronize()
+        assert bool((cs[:words * 2].view(torch.int32) == 0).all()), zero_route     # zeroed: both blocks and the header words
+        assert bool(torch.isnan(cs[words * 2:]).all())                                # ... and nothing behind them
+        assert bool(torch.isfinite(y).all())
+    # accumulate into the zeroed totals on the fused route (no H): sums of relu(Xn) over the nodes
+    assert call(cs, _lib.COLSTATS_ROWS_ACCUMULATE_ZEROED) == OK
+    torch.cuda.synchronize()
+    s1, s2 = decode(cs)
+    want1, want2 = r(y).double().sum(1), (r(y).double() ** 2).sum(1)
+    np.testing.assert_allclose(s1.cpu().numpy(), want1.cpu().numpy(), rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(s2.cpu().numpy(), want2.cpu().numpy(), rtol=1e-6, atol=1e-5)
+    assert bool(torch.isnan(cs[words * 2:]).all())
+    # the two-launch route in its own accumulate mode (-1: zeroes for itself) arrives at the same totals
+    cs2 = fresh()
+    assert call(cs2, _lib.COLSTATS_ROWS_ACCUMULATE) == BAD_ARG           # needs an H buffer
+    assert call(cs2, _lib.COLSTATS_ROWS_ACCUMULATE, hptr=P(h)) == OK
+    torch.cuda.synchronize()
+    t1, t2 = decode(cs2)
+    np.testing.assert_allclose(t1.cpu().numpy(), s1.cpu().numpy(), rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(t2.cpu().numpy(), s2.cpu().numpy(), rtol=1e-6, atol=1e-5)
+    assert call(cs2, -4) == BAD_ARG
 
 
 def test_fused_sgd_rejects_input_dropout_with_an_input_gradient(env):
