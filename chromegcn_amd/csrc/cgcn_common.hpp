@@ -179,8 +179,11 @@ __device__ __forceinline__ void bacc_get(const unsigned long long* __restrict__ 
   c1 = (float)(ldexp((double)tb, -fb) * invn);
   if (h[BACC_FLAG] != 0ull) c0 = c1 = __builtin_nanf("");
 }
-__device__ __forceinline__ void stat_acc_add(unsigned long long* acc, int S, int D, int slot, int s, int c, double sum1, double sum2) {
-  const double sc = (double)(1ll << STAT_ACC_FBITS), lim = 4194304.0;   // 2^22
+// lim: what one adder may contribute so that the total of ALL adders stays below 2^31 -- 2^22 for the <= 512 workgroups of the
+// row-local kernels; the one-launch forward has a workgroup per 16 / S-node tile and passes 2^31 / its grid
+__device__ __forceinline__ void stat_acc_add(unsigned long long* acc, int S, int D, int slot, int s, int c, double sum1, double sum2,
+                                             double lim = 4194304.0) {
+  const double sc = (double)(1ll << STAT_ACC_FBITS);
   unsigned long long* w = acc + ((size_t)(slot * S + s) * D + c) * 2;
   if (!(__builtin_fabs(sum1) < lim) || !(sum2 < lim)) {
     atomicOr(acc + (size_t)STAT_ACC_SLOTS * S * D * 2, 1ull);

@@ -651,7 +651,8 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512, FWD_WAVES_PE
         s1 += v;
         s2 += v * v;
       }
-      stat_acc_add((unsigned long long*)colstats, S, D, (int)blockIdx.x & (STAT_ACC_SLOTS - 1), s, c, s1, s2);
+      stat_acc_add((unsigned long long*)colstats, S, D, (int)blockIdx.x & (STAT_ACC_SLOTS - 1), s, c, s1, s2,
+                   2147483648.0 / (double)gridDim.x);   // (loud, not wrapped, whatever the number of tiles)
     }
   } else if (colstats) {
     __syncthreads();
