@@ -1212,6 +1212,9 @@ __global__ __launch_bounds__(512, HF_LOWREG ? 4 : 1) void k_head_fused(int n, in
 // accumulators -- lives in the SAME 40 registers).  LDS: W_out 72 KB + two Yt + two Pt tiles 73 KB.
 // Same partial records, label passes and results as k_head_fused.
 // ------------------------------------------------------------------------------------------
+#if (defined(HRSX_NOBACC) || defined(HRSX_NOSTAGE) || defined(HRSX_NOTICKET)) && !defined(CGCN_EXPERIMENT_BUILD)
+#error "HRSX_* are decomposition switches (garbage results): build a variant with -DCGCN_EXPERIMENT_BUILD (tools/mkvariant.py), never the shipped library"
+#endif
 #ifndef HEAD_RS
 #define HEAD_RS 1   // 0: the 8-wave k_head_fused at d = 128 as well (A/B builds)
 #endif
@@ -1298,7 +1301,9 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
   // period 1, read by both roles right behind the "Wl complete" barrier)
   float* const stash = Pt[1];
   static_assert(TR * LDP >= 6 * D, "the stash fits a P tile");
+#ifndef HRSX_NOSTAGE   // (decomposition build)
   if (sa.acc) head_stat_stage<D>(sa, n, S, stash, 1024);
+#endif
   // The two roles run SEPARATE loops (the register allocator then sees each role's state on its own path) that execute
   // the same number of workgroup barriers: one before and one after the loop, three per period.
   // In every role phase the lane-derived indices are re-derived from an opaque copy of the lane id: addresses kept live
@@ -1458,7 +1463,9 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
       for (int w = 0; w < 8; ++w) t += lsum[w];
       const float tl = first ? t : loss_part[blockIdx.x] + t;   // the label passes' shares add up
       loss_part[blockIdx.x] = tl;
+#ifndef HRSX_NOTICKET   // (decomposition build)
       if (sa.acc && last) head_loss_ticket(sa, S, D, tl, inv_count);   // (the Q team's integer adds: before the barrier above)
+#endif
     }
   } else {
     // =============================================================== Q: grad team, one tile behind
@@ -1625,7 +1632,9 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
             int fa, fb;
             head_bacc_points(wmax, 16, keep_scale, n, fa, fb);
             unsigned long long* bb = bacc_base(sa.acc, S, D);
+#ifndef HRSX_NOBACC   // (decomposition build: profiles/r06_stat_acc_experiment.txt item 5)
             bacc_add(bb, S, D, (int)blockIdx.x & (STAT_ACC_SLOTS - 1), s, own * 16 + r, a, b, fa, fb);
+#endif
             if (blockIdx.x == 0 && s == 0 && own == 0 && r == 0)
               bb[(size_t)STAT_ACC_SLOTS * S * D * 2 + BACC_EXP] = ((unsigned long long)(unsigned)(fb + 1024) << 32) | (unsigned long long)(unsigned)(fa + 1024);
           }
