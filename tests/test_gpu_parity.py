@@ -271,10 +271,18 @@ def test_model_train_steps_against_reference_golden(golden, batched, split_forwa
 def test_deeper_wider_model_against_oracle():
     """config 4 shape family: d = 256, 4 layers -- beyond the reference (its ctor caps at 2 layers);
     oracle = the restatement rule 'repeat ChromeModels.py:42-46'."""
+    _deeper_wider_case(5)
+
+
+def _deeper_wider_case(seed):
     n, d, L, c = 300, 256, 4, 11
     a = O.random_symmetric_graph(n, 2000, 9)
+    # (every parameter from a seeded stream: the gate weights and the classifier keep their constructor values, which used
+    # to come from whatever state the tests before had left the global generator in -- and with them the size of the gate-bias
+    # gradients, single scalars that are sums of cancelling per-row terms)
+    torch.manual_seed(seed)
     orc = O.GatedGCNOracle(d, c, 0.0, L)
-    g_ = torch.Generator().manual_seed(5)
+    g_ = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         for k, p in orc.named_parameters():
             if "GC" in k and "weight" in k:
@@ -289,8 +297,13 @@ def test_deeper_wider_model_against_oracle():
     g = C.process_graph("hic", {"c": a}, n, "c", device=DEV)
     orc.train(); m.train()
     xo = x.clone().requires_grad_(True)
-    lo = F.binary_cross_entropy_with_logits((orc(xo[0], adj_cpu)[1] + orc(xo[1], adj_cpu)[1]) / 2, tgt)
-    lo.backward()
+    threads = torch.get_num_threads()
+    torch.set_num_threads(8)   # (the host oracle's fp32 sums depend on the thread count: tests/test_gpu_fullsize_oracle.py)
+    try:
+        lo = F.binary_cross_entropy_with_logits((orc(xo[0], adj_cpu)[1] + orc(xo[1], adj_cpu)[1]) / 2, tgt)
+        lo.backward()
+    finally:
+        torch.set_num_threads(threads)
     xg = x.to(DEV).requires_grad_(True)
     p, gates = m.forward_strands(xg, g)
     lg = F.binary_cross_entropy_with_logits((p[0] + p[1]) / 2, tgt.to(DEV))
@@ -298,9 +311,19 @@ def test_deeper_wider_model_against_oracle():
     assert len(gates) == 4 and abs(lo.item() - lg.item()) < 1e-4
     np.testing.assert_allclose(xg.grad.cpu().numpy(), xo.grad.numpy(), atol=1e-4 * xo.grad.abs().max().item(), rtol=1e-4)
     po = dict(orc.named_parameters())
+    # scale-relative 1e-4 per tensor; a gate-bias gradient is ONE number -- the sum of n x S signed per-row terms that cancel to a
+    # fraction of a percent of their absolute sum (tests/test_gpu_fullsize_oracle.py) -- so its scale is the largest gate-bias
+    # gradient of the model, not its own (possibly accidentally tiny) value: two fp32 summation orders of the same terms differ
+    # by 1e-4 of a scalar that happens to come out 5x smaller than its siblings, and did (one box, round 6)
+    kind_scale = {}
+    for k, p_ in po.items():
+        kind = k.split(".")[0].rstrip("0123456789") + "." + k.split(".", 1)[1]
+        kind_scale[kind] = max(kind_scale.get(kind, 0.0), float(p_.grad.abs().max()))
     for k, pp in m.named_parameters():
         ref = po[k].grad.numpy()
-        np.testing.assert_allclose(pp.grad.cpu().numpy(), ref, atol=1e-4 * float(np.abs(ref).max()), rtol=1e-4, err_msg=k)
+        kind = k.split(".")[0].rstrip("0123456789") + "." + k.split(".", 1)[1]
+        scale = kind_scale[kind] if ref.size == 1 else float(np.abs(ref).max())
+        np.testing.assert_allclose(pp.grad.cpu().numpy(), ref, atol=1e-4 * scale, rtol=1e-4, err_msg=k)
 
 
 def test_cpu_inputs_fail_loudly():
