@@ -24,6 +24,8 @@ _SIGNATURES = {
     "cgcn_layer_fwd": (_c_int, [_c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 13 + [_c_float, _c_vp, _c_uint, _c_vp, _c_vp, _c_int, _c_vp]),
     "cgcn_layer_fwd_colstats_plan": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_vp]),
     "cgcn_debug_set_fwd_split_bytes": (None, [ctypes.c_longlong]),
+    "cgcn_debug_set_products": (None, [ctypes.c_int]),
+    "cgcn_debug_get_products": (ctypes.c_int, []),
     "cgcn_debug_layer_fwd_route": (_c_int, [_c_int, _c_int, _c_int, _c_vp, _c_int]),
     "cgcn_debug_layer_bwd_route": (_c_int, [_c_int, _c_int, _c_int]),
     "cgcn_layer_bwd_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
@@ -49,7 +51,7 @@ _SIGNATURES = {
     "cgcn_multilabel_metrics_nonneg": (_c_int, [_c_vp, ctypes.c_longlong, _c_int, _c_vp, _c_vp, _c_float, _c_vp, _c_vp, _c_vp, _c_sz]),
     "cgcn_sgd_step": (_c_int, [_c_vp, ctypes.c_longlong, _c_vp, _c_vp, _c_vp, _c_float, _c_float, _c_float, _c_int, _c_float, _c_vp]),
 }
-ABI_VERSION = 24
+ABI_VERSION = 25
 COLSTATS_RECORDS, COLSTATS_ACCUMULATE = 0, 1   # include/chromegcn.h: CGCN_COLSTATS_*
 COLSTATS_ROWS_ACCUMULATE, COLSTATS_ROWS_ZERO_ONLY, COLSTATS_ROWS_ACCUMULATE_ZEROED = -1, -2, -3   # CGCN_COLSTATS_ROWS_*
 _lib = None

@@ -15,6 +15,59 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #endif
 
 // ------------------------------------------------------------------------------------------
+// fp32 products on the bf16 matrix cores ("split products", round 6; profiles/r06_bf16x6_probe.txt).
+// On gfx950 v_mfma_f32_16x16x4_f32 runs at the fp32 VECTOR rate (64 flop/clk/SIMD) and keeps the SIMD's vector ALUs busy;
+// v_mfma_f32_16x16x32_bf16 is 16 times faster and leaves half of its issue slots to vector work.  A float has 24
+// significant bits = three bf16 numbers of 8:  x = h + m + l EXACTLY (cut by truncation: h = the float's upper 16 bits, m the
+// upper 16 bits of x - h, l = x - h - m, which has <= 8 significant bits left), so
+//     a b = ah bh + (ah bm + am bh) + (ah bl + am bm + al bh) + [am bl + al bm + al bl  <= 2^-23 |a b|, dropped]
+// is six bf16 MFMAs whose partial products are exact and whose sums are kept in three fp32 accumulators by magnitude
+// (big / mid / small, added once at the end).  Measured against float64 (K = 256, 524 288 dot products, in units of
+// 2^-24 sum |a_k b_k|): fp32 MFMA chain rms 0.43 / worst 4.0, this form rms 0.15 / worst 1.6 -- the chain rounds 64
+// times, this form 8 times per accumulator.  Same fp32 range (bf16 has the fp32 exponent): no scaling, Inf / NaN propagate.
+// ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float sp_hi(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
+// the upper halves of two floats as a bf16 pair (x0 in the low half)
+__device__ __forceinline__ uint32_t sp_pack(float x0, float x1) {
+  return __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+}
+// four consecutive floats -> 4 bf16 of each level (8 bytes per level)
+__device__ __forceinline__ void sp_split4(const f32x4 x, u32x2& h, u32x2& m, u32x2& l) {
+  const float r0 = x[0] - sp_hi(x[0]), r1 = x[1] - sp_hi(x[1]), r2 = x[2] - sp_hi(x[2]), r3 = x[3] - sp_hi(x[3]);
+  const float s0 = r0 - sp_hi(r0), s1 = r1 - sp_hi(r1), s2 = r2 - sp_hi(r2), s3 = r3 - sp_hi(r3);
+  h = (u32x2){sp_pack(x[0], x[1]), sp_pack(x[2], x[3])};
+  m = (u32x2){sp_pack(r0, r1), sp_pack(r2, r3)};
+  l = (u32x2){sp_pack(s0, s1), sp_pack(s2, s3)};
+}
+// eight consecutive K values -> one MFMA operand of each level
+__device__ __forceinline__ void sp_split8(const float (&x)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+  u32x2 h0, m0, l0, h1, m1, l1;
+  sp_split4((f32x4){x[0], x[1], x[2], x[3]}, h0, m0, l0);
+  sp_split4((f32x4){x[4], x[5], x[6], x[7]}, h1, m1, l1);
+  h = __builtin_bit_cast(bf16x8, (u32x4){h0[0], h0[1], h1[0], h1[1]});
+  m = __builtin_bit_cast(bf16x8, (u32x4){m0[0], m0[1], m1[0], m1[1]});
+  l = __builtin_bit_cast(bf16x8, (u32x4){l0[0], l0[1], l1[0], l1[1]});
+}
+struct SpAcc {   // the three accumulators of one 16 x 16 output block
+  f32x4 big, mid, small;
+  __device__ __forceinline__ void zero() { big = mid = small = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  // one K-step of 32: the six partial products, ordered so that no MFMA follows one into the same accumulator
+  __device__ __forceinline__ void step(const bf16x8 ah, const bf16x8 am, const bf16x8 al, const bf16x8 bh, const bf16x8 bm,
+                                       const bf16x8 bl) {
+    small = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, small, 0, 0, 0);
+    mid = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, mid, 0, 0, 0);
+    big = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, big, 0, 0, 0);
+    small = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, small, 0, 0, 0);
+    mid = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, mid, 0, 0, 0);
+    small = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, small, 0, 0, 0);
+  }
+  __device__ __forceinline__ f32x4 sum() const { return big + (mid + small); }
+};
+
+// ------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int rl_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }

@@ -690,7 +690,7 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512, FWD_WAVES_PE
 #ifndef DENSE_WAVES_PER_SIMD
 #define DENSE_WAVES_PER_SIMD 4
 #endif
-template <int S, int D, int MB>
+template <int S, int D, int MB, int PROD>
 __global__ __launch_bounds__(512, DENSE_WAVES_PER_SIMD) void k_layer_dense(int n, int ntiles, const float* __restrict__ Hin,
                                                     const float* __restrict__ X, const float* __restrict__ W,
                                                     const float* __restrict__ bias, const float* __restrict__ wg,
@@ -713,12 +713,30 @@ __global__ __launch_bounds__(512, DENSE_WAVES_PER_SIMD) void k_layer_dense(int n
   constexpr bool PRE = true;         // W fragments resident in registers
   static_assert(D / (16 * CBW) == NW && ROWS % NW == 0, "geometry");
   __shared__ __attribute__((aligned(16))) float T[ROWS * LD];
+  // PROD == 1 (split products, cgcn_common.hpp): the A operand lives in its own tile as three bf16 levels -- level v, row m
+  // at Tb[(v ROWS + m) LDB ..]; 272-byte rows: the 16-byte operand reads of 16 rows tile the 64 banks -- so T only ever
+  // holds the tanh tile and two of the four barriers of a tile go (nobody reads T as an operand, nobody rewrites it early)
+  constexpr int LDB = D + 8;
+  __shared__ __attribute__((aligned(16))) uint16_t Tb[PROD ? 3 * ROWS * LDB : 8];
+  static_assert(PROD == 0 || (D == 128 && MB == 1 && DENSE_HALF_WAVE_ROWS), "split products: the half-wave-row form");
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   KT_STAMP(8);
-  float bw[CBW][D / 4];
-  if (PRE) load_wfrag<D, CBW, false>(W, wave, lane, bw);
+  float bw[PROD ? 1 : CBW][PROD ? 1 : D / 4];
+  bf16x8 wh[PROD ? D / 32 : 1], wm[PROD ? D / 32 : 1], wl[PROD ? D / 32 : 1];
+  if constexpr (PROD != 0) {   // B operand of K-step s: W[32 s + 8 q + u][16 wave + r], u < 8, as three levels
+    const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < D / 32; ++s) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = W[(size_t)(32 * s + 8 * q + u) * D + wave * 16 + r];
+      sp_split8(v, wh[s], wm[s], wl[s]);
+    }
+  } else {
+    if (PRE) load_wfrag<D, CBW, false>(W, wave, lane, bw);
+  }
   float bjv[CBW], wgl[EPL];
 #pragma unroll
   for (int cb = 0; cb < CBW; ++cb) bjv[cb] = bias[wave * (16 * CBW) + cb * 16 + (lane & 15)];
@@ -777,7 +795,15 @@ __global__ __launch_bounds__(512, DENSE_WAVES_PER_SIMD) void k_layer_dense(int n
     const int node0 = tile * R;
     KT_STAMP(10);
     if (HW) {
-      *(f32x4*)&T[hm * LD + l4] = hrow4;
+      if (PROD) {
+        u32x2 h2, m2, l2;
+        sp_split4(hrow4, h2, m2, l2);
+        *(u32x2*)&Tb[(0 * ROWS + hm) * LDB + l4] = h2;
+        *(u32x2*)&Tb[(1 * ROWS + hm) * LDB + l4] = m2;
+        *(u32x2*)&Tb[(2 * ROWS + hm) * LDB + l4] = l2;
+      } else {
+        *(f32x4*)&T[hm * LD + l4] = hrow4;
+      }
       xres4 = xnext4;
       if (tile + tstep < tend) {
         load_rows4(hrow4, Hin, tile + tstep);
@@ -799,8 +825,22 @@ __global__ __launch_bounds__(512, DENSE_WAVES_PER_SIMD) void k_layer_dense(int n
     KT_STAMP(11);
     // ---- U = H W
     f32x4 acc[MB][CBW];
-    tile_mfma<MB, D, CBW, LD, false, PRE>(T, W, bw, wave, lane, acc);
-    __syncthreads();  // every wave is done reading T as the A operand
+    if constexpr (PROD != 0) {
+      const int r = lane & 15, q = lane >> 4;
+      SpAcc sa;
+      sa.zero();
+#pragma unroll
+      for (int s = 0; s < D / 32; ++s) {
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const u32x4*)&Tb[(0 * ROWS + r) * LDB + 32 * s + 8 * q]);
+        const bf16x8 am = __builtin_bit_cast(bf16x8, *(const u32x4*)&Tb[(1 * ROWS + r) * LDB + 32 * s + 8 * q]);
+        const bf16x8 al = __builtin_bit_cast(bf16x8, *(const u32x4*)&Tb[(2 * ROWS + r) * LDB + 32 * s + 8 * q]);
+        sa.step(ah, am, al, wh[s], wm[s], wl[s]);
+      }
+      acc[0][0] = sa.sum();
+    } else {
+      tile_mfma<MB, D, CBW, LD, false, PRE>(T, W, bw, wave, lane, acc);
+      __syncthreads();  // every wave is done reading T as the A operand
+    }
     KT_STAMP(12);
     // ---- Z = tanh(U + b) back into the tile
     {
@@ -889,7 +929,7 @@ __global__ __launch_bounds__(512, DENSE_WAVES_PER_SIMD) void k_layer_dense(int n
         chan_combine(st_cnt, st_mean, st_m2, (float)cnt, mean, m2);
       }
     }
-    __syncthreads();  // T is rewritten by the next tile
+    if (!PROD) __syncthreads();  // T is rewritten by the next tile (PROD: only behind the next tile's first barrier)
   }
   if (colstats && threadIdx.x < S * D && tfirst < tend) {
     if (stat_acc) {   // accumulate mode (cgcn_common.hpp, STAT_ACC_*): this workgroup's sum x and sum x^2, formed in double
@@ -2775,6 +2815,19 @@ static long long fwd_split_default() {   // tuning: CGCN_FWD_SPLIT_BYTES in the 
 }
 static std::atomic<long long> g_fwd_split_bytes{fwd_split_default()};
 void cgcn_debug_set_fwd_split_bytes(long long bytes) { g_fwd_split_bytes.store(bytes < 0 ? fwd_split_default() : bytes); }
+// How the dense products are formed (cgcn_common.hpp, "split products"): six bf16 MFMA partial products of an exact 3-way
+// split (default) or the fp32 MFMA chain of rounds 1-5.  Both are fp32 arithmetic (the split form is the more accurate one);
+// they differ in the last bits, so the choice is process-wide, made once from CGCN_PRODUCTS=fp32|split and movable only by
+// the measurement hook below (bench.py's A/B, the tests that run both forms).
+static int products_default() {
+  const char* e = getenv("CGCN_PRODUCTS");
+  return (e && (e[0] == 'f' || e[0] == '0')) ? CGCN_PRODUCTS_FP32_CHAIN : CGCN_PRODUCTS_SPLIT;
+}
+static std::atomic<int> g_products{products_default()};
+void cgcn_debug_set_products(int mode) {
+  g_products.store((mode == CGCN_PRODUCTS_FP32_CHAIN || mode == CGCN_PRODUCTS_SPLIT) ? mode : products_default());
+}
+int cgcn_debug_get_products(void) { return g_products.load(); }
 
 // 16-bit column indices serve the feature-sliced kernels of implicit-value graphs (HAS_VAL = false) with <= 65 536 columns
 static inline const uint16_t* use_col16(const cgcn_graph_aux* aux, const float* val, int n_cols) {
@@ -2974,10 +3027,12 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
                               ks, th, rng_state, stream_id, colstats, chunk, acc ? 1 : 0, zw, zc);
       return launch_status();
     }
-#define CALL(S_) \
-    hipLaunchKernelGGL((k_layer_dense<S_, 128, MB>), dim3(grid), dim3(512), 0, st, n, ntiles, H_in, X, W, b, wg, cg, Xn, Z, gate, \
+    const bool sp = g_products.load() != CGCN_PRODUCTS_FP32_CHAIN;
+#define CALL(S_, P_) \
+    hipLaunchKernelGGL((k_layer_dense<S_, 128, MB, P_>), dim3(grid), dim3(512), 0, st, n, ntiles, H_in, X, W, b, wg, cg, Xn, Z, gate, \
                        ks, th, rng_state, stream_id, colstats, chunk, acc ? 1 : 0, zw, zc)
-    if (S == 1) CALL(1); else CALL(2);
+    if (S == 1) { if (sp) CALL(1, 1); else CALL(1, 0); }
+    else { if (sp) CALL(2, 1); else CALL(2, 0); }
 #undef CALL
     return launch_status();
   }

@@ -50,7 +50,7 @@ extern "C" {
 #define CGCN_ERR_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after a launch      */
 #define CGCN_ERR_WORKSPACE (-4)   /* workspace too small (see cgcn_*_workspace_bytes)    */
 
-#define CGCN_ABI_VERSION 24
+#define CGCN_ABI_VERSION 25
 
 typedef void *cgcn_stream_t; /* hipStream_t */
 
@@ -187,6 +187,17 @@ int cgcn_layer_fwd_colstats_plan(int n, int S, int d, int mode, int *rows_per_ti
 /* Test / tuning hook: feature-table size in bytes from which cgcn_layer_fwd takes the two-launch route when H is
  * given (0 = always, negative = restore the built-in default).  Process-wide. */
 void cgcn_debug_set_fwd_split_bytes(long long bytes);
+
+/* Measurement hook: how the dense fp32 products of the row-local kernels are formed.  CGCN_PRODUCTS_SPLIT (default): six
+ * bf16 MFMA partial products of an EXACT three-way split of every fp32 operand (x = h + m + l, 8 + 8 + 8 significant
+ * bits), fp32 accumulators -- fp32 arithmetic on the bf16 matrix cores, measured MORE accurate against float64 than the
+ * chain (it rounds 8 times where the chain rounds K / 4 times; profiles/r06_bf16x6_probe.txt).  CGCN_PRODUCTS_FP32_CHAIN:
+ * v_mfma_f32_16x16x4_f32, the form of rounds 1-5.  The two differ in the last bits.  Process-wide; initial value from the
+ * environment (CGCN_PRODUCTS=fp32 | split); any other argument restores that initial value. */
+#define CGCN_PRODUCTS_FP32_CHAIN 0
+#define CGCN_PRODUCTS_SPLIT 1
+void cgcn_debug_set_products(int mode);
+int cgcn_debug_get_products(void);
 
 /* Which kernels a call WOULD launch, so that a profiler prices the kernel that actually runs (bench.py's roofline);
  * nothing is launched, no GPU is needed.

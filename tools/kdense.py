@@ -21,7 +21,9 @@ def main():
             ns = [int(v) for v in a[4:].split(",")]
         if a.startswith("--d="):
             d = int(a[4:])
-    libs = [(a.split("=")[0], _lib.open_library(os.path.join(ROOT, a.split("=")[1]))) for a in args]
+    # name=path[:fp32|:split] -- the suffix sets the products form (cgcn_debug_set_products) for that entry's runs
+    libs = [(a.split("=")[0], _lib.open_library(os.path.join(ROOT, a.split("=")[1].split(":")[0])),
+             {"fp32": 0, "split": 1}.get((a.split("=")[1].split(":") + [""])[1], -1)) for a in args]
     dev = torch.device("cuda")
     S = 2
     P = _lib.ptr; st = _lib.stream_ptr
@@ -36,7 +38,9 @@ def main():
         xn64 = (1 - g64)[..., None] * x.double() + g64[..., None] * z64
         r64 = torch.relu(xn64)
         rng = torch.tensor([1234, 5], dtype=torch.int64, device=dev)
-        for name, lib in libs:
+        for name, lib, products in libs:
+            if hasattr(lib, "cgcn_debug_set_products"):
+                lib.cgcn_debug_set_products(products)
             xn, z = torch.empty_like(x), torch.empty_like(x)
             gate = torch.empty(S, n, device=dev)
             rows = ctypes.c_int(0)
