@@ -66,6 +66,20 @@ struct SpAcc {   // the three accumulators of one 16 x 16 output block
   }
   __device__ __forceinline__ f32x4 sum() const { return big + (mid + small); }
 };
+struct SpAcc2 {   // two accumulators (the leading product | the five others): four registers fewer, the same error to 2^-32
+  f32x4 big, rest;
+  __device__ __forceinline__ void zero() { big = rest = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  __device__ __forceinline__ void step(const bf16x8 ah, const bf16x8 am, const bf16x8 al, const bf16x8 bh, const bf16x8 bm,
+                                       const bf16x8 bl) {
+    rest = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, rest, 0, 0, 0);
+    rest = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, rest, 0, 0, 0);
+    rest = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, rest, 0, 0, 0);
+    big = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, big, 0, 0, 0);
+    rest = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, rest, 0, 0, 0);
+    rest = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, rest, 0, 0, 0);
+  }
+  __device__ __forceinline__ f32x4 sum() const { return big + rest; }
+};
 
 // ------------------------------------------------------------------------------------------
 // small helpers

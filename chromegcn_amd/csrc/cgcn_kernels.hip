@@ -485,8 +485,8 @@ extern "C" int cgcn_debug_kt_stamps(unsigned long long* out) {
 #define KT_STAMP_NW(i, tid, cond)
 #endif
 
-template <int S, int D, int MB, bool HAS_VAL, bool DEEP>
-__global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512, FWD_WAVES_PER_SIMD(S, D)) FWD_OCC void k_layer_fwd(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
+template <int S, int D, int MB, bool HAS_VAL, bool DEEP, int PROD>
+__global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512, PROD ? 4 : FWD_WAVES_PER_SIMD(S, D)) FWD_OCC void k_layer_fwd(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
                                                      const float* __restrict__ val, const float* __restrict__ rs,
                                                      const float* __restrict__ X, const float* __restrict__ W,
                                                      const float* __restrict__ bias, const float* __restrict__ wg,
@@ -510,13 +510,20 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512, FWD_WAVES_PE
   constexpr bool PRE = (D == 128);
   __shared__ __attribute__((aligned(16))) float T[ROWS * LD];
   __shared__ __attribute__((aligned(16))) float LR[NW * S * D];  // hub-row partial sums (gather_tile)
+  // PROD == 1 (split products, cgcn_common.hpp; d = 128): the gathered tile is re-staged as three bf16 levels (k_layer_dense's
+  // Tb) and the product is formed exactly as k_layer_dense forms it -- the same bits on both routes.  The W operands are 48
+  // registers instead of 32: 4 waves per SIMD (this kernel only serves tables below the 8 MiB split threshold).
+  constexpr int LDB = D + 8;
+  __shared__ __attribute__((aligned(16))) uint16_t Tb[PROD ? 3 * ROWS * LDB : 8];
+  static_assert(PROD == 0 || (D == 128 && MB == 1 && CBW == 1 && FWD_HALF_WAVE_ROWS), "split products: d = 128, the half-wave-row form");
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int node0 = xcd_contiguous(blockIdx.x, gridDim.x) * R;
 
   KT_STAMP(8);
-  float bw[CBW][D / 4];  // W fragments: loaded after the gather (below)
+  float bw[PROD ? 1 : CBW][PROD ? 1 : D / 4];  // W fragments: loaded after the gather (below)
+  bf16x8 wh[PROD ? D / 32 : 1], wm[PROD ? D / 32 : 1], wl[PROD ? D / 32 : 1];
 
   unsigned lane_off[G::NV];
 #pragma unroll
@@ -528,7 +535,18 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512, FWD_WAVES_PE
   // W fragments -> registers once the gather's loads are issued: in front of it they delay the first neighbour rows
   // (vector loads return in order) and hold 32 registers through the gather loop; here they land during the barrier
   // and the residual prefetch (measured: -0.3 ... -1.5 % per step, every workload)
-  if (PRE) load_wfrag<D, CBW, false>(W, wave, lane, bw);
+  if constexpr (PROD != 0) {   // B operand of K-step s: W[32 s + 8 q + u][16 wave + r], u < 8, as three levels
+    const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < D / 32; ++s) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = W[(size_t)(32 * s + 8 * q + u) * D + wave * 16 + r];
+      sp_split8(v, wh[s], wm[s], wl[s]);
+    }
+  } else {
+    if (PRE) load_wfrag<D, CBW, false>(W, wave, lane, bw);
+  }
   KT_STAMP(10);
   // prefetch the residual rows this wave will mix in phase 3 (latency hides behind the MFMA phase)
   // D = 128: the row-wise epilogue takes a row per HALF-wave, 16 bytes per lane (see k_layer_dense): the wave's two rows
@@ -564,8 +582,30 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512, FWD_WAVES_PE
   KT_STAMP(11);
   // ---- phase 2
   f32x4 acc[MB][CBW];
-  tile_mfma<MB, D, CBW, LD, false, PRE>(T, W, bw, wave, lane, acc);
-  __syncthreads();  // every wave is done reading T as the A operand
+  if constexpr (PROD != 0) {
+    {   // this half-wave's row of the gathered tile -> the three levels
+      u32x2 h2, m2, l2;
+      sp_split4(*(const f32x4*)&T[hm * LD + l4], h2, m2, l2);
+      *(u32x2*)&Tb[(0 * ROWS + hm) * LDB + l4] = h2;
+      *(u32x2*)&Tb[(1 * ROWS + hm) * LDB + l4] = m2;
+      *(u32x2*)&Tb[(2 * ROWS + hm) * LDB + l4] = l2;
+    }
+    __syncthreads();   // (also: every wave is done reading T, which the tanh tile overwrites)
+    const int r = lane & 15, q = lane >> 4;
+    SpAcc sa;
+    sa.zero();
+#pragma unroll
+    for (int s = 0; s < D / 32; ++s) {
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const u32x4*)&Tb[(0 * ROWS + r) * LDB + 32 * s + 8 * q]);
+      const bf16x8 am = __builtin_bit_cast(bf16x8, *(const u32x4*)&Tb[(1 * ROWS + r) * LDB + 32 * s + 8 * q]);
+      const bf16x8 al = __builtin_bit_cast(bf16x8, *(const u32x4*)&Tb[(2 * ROWS + r) * LDB + 32 * s + 8 * q]);
+      sa.step(ah, am, al, wh[s], wm[s], wl[s]);
+    }
+    acc[0][0] = sa.sum();
+  } else {
+    tile_mfma<MB, D, CBW, LD, false, PRE>(T, W, bw, wave, lane, acc);
+    __syncthreads();  // every wave is done reading T as the A operand
+  }
 
   KT_STAMP(12);
   // ---- phase 3a: Z = tanh(U + b) back into the tile
@@ -1226,7 +1266,36 @@ __device__ __forceinline__ void ring_arrive(unsigned* flag, int lane) {
   if (lane == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // HEAD: the last layer (dL/dXn recomputed from the head's backward state, HeadApply); DROP: ... with the head's dropout
-template <bool HEAD, bool DROP>
+// PROD == 1 (split products, cgcn_common.hpp): both products on the bf16 matrix cores.  The row team splits every H and
+// dU row into its three bf16 levels on the way into the slot (the fp32 tiles are gone: a slot is 2 operands x 3 levels x
+// 4 KB, RING_SLOTS_SP = 6 of them); the matrix team forms
+//   dW  with v_mfma_f32_32x32x16_bf16 -- K = the slot's 16 rows; wave `own` owns H columns [32 (own >> 1), +32) x dU columns
+//        [64 (own & 1), +64): two 32 x 32 accumulators; both operands are K-major reads of row-major tiles, i.e.
+//        ds_read_b64_tr_b16 (the hardware transpose: a 16-lane group fetches 4 rows x 16 columns and every lane receives
+//        one column's 4 rows); the six partial products go into ONE accumulator per block, small terms first --
+//   dHs with v_mfma_f32_16x16x32_bf16 -- dU rows by ds_read_b128, the W^T levels resident (48 registers), three
+//        accumulators (the leading product | the other five: SpAcc2).
+// Level tile image: 16 rows x 256 B, 16-byte chunk c of row m at c ^ sigma(m), sigma(m) = (m & 3) << 2 | tau[m >> 2],
+// tau = {2, 0, 1, 3}: conflict-free for the row team's 8-byte stores, for the transposed reads (the 4 rows of a block
+// differ in sigma >> 2: 16 distinct chunks per 32-lane half) and for the ds_read_b128 row reads (sigma of rows 4..11 is
+// closed under ^ 1: the instruction's lane groups {0-3, 12-15 | 20-27} ... see 16 distinct chunks).
+// 768 matrix-core cycles per slot and wave instead of 2 048: the matrix team, which bounded the fp32 form (39 us alone
+// against the row team's 18 at n = 29 910), no longer does.
+#ifndef RING_SLOTS_SP
+#define RING_SLOTS_SP 6
+#endif
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int ring_sigma(int m) { return ((m & 3) << 2) | ((0xD2 >> ((m >> 2) << 1)) & 3); }
+__device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+}
+__device__ __forceinline__ bf16x8 tr_pair(const unsigned char* p0, const unsigned char* p1) {   // rows 8h..8h+3 | 8h+4..8h+7
+  const s16x4 a = lds_tr16(p0), b = lds_tr16(p1);
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  return __builtin_bit_cast(bf16x8, (s16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]});
+}
+template <bool HEAD, bool DROP, int PROD>
 __global__ __launch_bounds__(RING_THREADS) void k_bwd_rowlocal_ring(int M, int n, const float* __restrict__ dXn,
                                                             const float* __restrict__ Z, const float* __restrict__ X,
                                                             const float* __restrict__ gate, const float* __restrict__ dgate,
@@ -1235,14 +1304,16 @@ __global__ __launch_bounds__(RING_THREADS) void k_bwd_rowlocal_ring(int M, int n
                                                             float* __restrict__ part, HeadApply hp,
                                                             float* __restrict__ dxn_store, int row_blocks, int head_slabs,
                                                             const float* __restrict__ W) {
-  constexpr int D = 128, SR = 16, NSL = RING_SLOTS, PF = HEAD ? RING_PF_HEAD : RING_PF;
+  constexpr int D = 128, SR = 16, NSL = PROD ? RING_SLOTS_SP : RING_SLOTS, PF = HEAD ? RING_PF_HEAD : RING_PF;
+  constexpr int SLOT_F = PROD ? 3 * SR * D / 2 : SR * D;   // floats per slot and operand (PROD: three bf16 level tiles)
+  constexpr int LVB = SR * D * 2;                          // bytes of one level tile
   constexpr int NRW = RING_ROW_WAVES;          // row-team waves (the matrix team always has 8: one per 16 rows of dW)
   constexpr int NT = RING_THREADS;
   constexpr int RT = SR / (2 * NRW);           // row PAIRS (one wave instruction = 2 rows) per row wave per slot
   static_assert(NRW * 2 * RT == SR && (NRW == 4 || NRW == 8), "row-team geometry");
   constexpr int PSTRIDE = D * D + 2 * D + 4;
   constexpr int RS = 2 * D + 4;
-  __shared__ __attribute__((aligned(16))) float Hs[NSL][SR * D];
+  __shared__ __attribute__((aligned(16))) float Hs[NSL][SLOT_F];
   if ((int)blockIdx.x >= row_blocks) {   // extra workgroups: the head's deferred second stage (see k_bwd_rowlocal); they
     const int extra = (int)blockIdx.x - row_blocks;      // stage through the (here unused) ring memory
     const int wslabs = (hp.hf_CP * D + hp.hf_CP) / 64;
@@ -1255,7 +1326,7 @@ __global__ __launch_bounds__(RING_THREADS) void k_bwd_rowlocal_ring(int M, int n
                                     nullptr, hp.hf_accumulate, hp.dloss, &Hs[0][0]);
     return;
   }
-  __shared__ __attribute__((aligned(16))) float Us[NSL][SR * D];
+  __shared__ __attribute__((aligned(16))) float Us[NSL][SLOT_F];
   __shared__ __attribute__((aligned(16))) float Sc[NSL][SR];   // row_scale of the slot's rows (0 past the end)
   __shared__ __attribute__((aligned(16))) float Hc[HEAD ? 9 * D : 4];   // head mode: BatchNorm constants (row team)
   __shared__ __attribute__((aligned(16))) float red[NRW][RS];  // column sums of the row waves
@@ -1420,8 +1491,23 @@ __global__ __launch_bounds__(RING_THREADS) void k_bwd_rowlocal_ring(int M, int n
 #pragma unroll
       for (int t = 0; t < RT; ++t) {   // swizzled chunk positions (see the header)
         const int rowi = row0 + 2 * NRW * t;
-        *(f32x4*)&Hs[slot][rowi * D + ((l ^ ((rowi & 1) << 2)) << 2)] = w.h[t];
-        *(f32x4*)&Us[slot][rowi * D + ((l ^ rowi) << 2)] = du[t];
+        if constexpr (PROD != 0) {
+          const int wo = rowi * 256 + (((l >> 1) ^ ring_sigma(rowi)) << 4) + ((l & 1) << 3);   // bytes inside a level tile
+          u32x2 h2, m2, l2;
+          sp_split4(w.h[t], h2, m2, l2);
+          unsigned char* hb = (unsigned char*)Hs[slot] + wo;
+          *(u32x2*)hb = h2;
+          *(u32x2*)(hb + LVB) = m2;
+          *(u32x2*)(hb + 2 * LVB) = l2;
+          sp_split4(du[t], h2, m2, l2);
+          unsigned char* ub = (unsigned char*)Us[slot] + wo;
+          *(u32x2*)ub = h2;
+          *(u32x2*)(ub + LVB) = m2;
+          *(u32x2*)(ub + 2 * LVB) = l2;
+        } else {
+          *(f32x4*)&Hs[slot][rowi * D + ((l ^ ((rowi & 1) << 2)) << 2)] = w.h[t];
+          *(f32x4*)&Us[slot][rowi * D + ((l ^ rowi) << 2)] = du[t];
+        }
         if (l == 0) Sc[slot][rowi] = w.sc[t];
       }
 #endif
@@ -1470,6 +1556,121 @@ __global__ __launch_bounds__(RING_THREADS) void k_bwd_rowlocal_ring(int M, int n
       for (int w = 0; w < NRW; ++w) sacc += red[w][c];
       P[D * D + c] = sacc;
     }
+  } else if constexpr (PROD != 0) {
+    // =============================================================== matrix team, split products (see the header)
+    const int own = wave - NRW;
+    int lq = lane;
+    asm volatile("" : "+v"(lq));
+    const int r16 = lq & 15, q4 = lq >> 4;
+    // W^T levels of this wave's 16 output columns of dHs: B operand of K-step s = W[16 own + r][32 s + 8 q .. + 7]
+    bf16x8 th[4], tm[4], tl[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      float v[8];
+      const f32x4 v0 = dHs ? *(const f32x4*)&W[(size_t)(16 * own + r16) * D + 32 * s4 + 8 * q4] : (f32x4){0.f, 0.f, 0.f, 0.f};
+      const f32x4 v1 = dHs ? *(const f32x4*)&W[(size_t)(16 * own + r16) * D + 32 * s4 + 8 * q4 + 4] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        v[u] = v0[u];
+        v[4 + u] = v1[u];
+      }
+      sp_split8(v, th[s4], tm[s4], tl[s4]);
+    }
+    f32x16 accW[2];
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) accW[bb][e] = 0.f;
+    __syncthreads();   // flags zeroed (and the row team's staging of the head constants)
+    if (RING_PRIO) __builtin_amdgcn_s_setprio(RING_PRIO);
+    // transposed reads (32x32x16 operands): lane = 32 h + 16 c16 + i; its 16-lane group fetches rows 8 h + 4 rd + (i >> 2),
+    // the 8-byte piece (i & 3) of columns [16 c16, +16) of the wave's block, and receives column 16 c16 + i of those rows
+    const int hh = lq >> 5, c16 = (lq >> 4) & 1, qp = (lq & 15) >> 2, pp = lq & 3;
+    const int hcb = own >> 1, ucb = own & 1;
+    int trH[2], trU[2];
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      const int row = 8 * hh + 4 * rd + qp, sg = ring_sigma(row);
+      trH[rd] = row * 256 + (((4 * hcb + 2 * c16 + (pp >> 1)) ^ sg) << 4) + ((pp & 1) << 3);
+      trU[rd] = row * 256 + (((8 * ucb + 2 * c16 + (pp >> 1)) ^ sg) << 4) + ((pp & 1) << 3);   // block bb: ^ (bb << 6)
+    }
+    // row reads (16x16x32 A operand of dHs): row r16, chunk 4 s + q4
+    const int ua0 = r16 * 256 + ((q4 ^ (ring_sigma(r16) & 3)) << 4), ua_hi = ring_sigma(r16) >> 2;
+    const unsigned dh_lane = (unsigned)(4 * q4 * D + own * 16 + r16);   // this lane's element of a slot's dHs rows
+    bool next_full = false;
+    auto slot_loop = [&](auto DH_) {
+      constexpr bool DH = decltype(DH_)::value;
+      for (int it = 0; it < ns; ++it) {
+        const int slot = it % NSL;
+#ifdef RING_TEST_SLOW_MATRIX
+        ring_test_delay(wave, it);
+#endif
+#ifndef RING_SKIP_MFMA
+        const unsigned char* Hb = (const unsigned char*)Hs[slot];
+        const unsigned char* Ub = (const unsigned char*)Us[slot];
+        if (!(RING_EARLY_FLAG && next_full)) ring_wait(&FULL[slot], (unsigned)NRW * (unsigned)(it / NSL + 1));
+        bf16x8 hf[3], uf[3];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) hf[v] = tr_pair(Hb + v * LVB + trH[0], Hb + v * LVB + trH[1]);
+        SpAcc2 sa;
+        sa.zero();
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+#pragma unroll
+          for (int v = 0; v < 3; ++v) uf[v] = tr_pair(Ub + v * LVB + (trU[0] ^ (bb << 6)), Ub + v * LVB + (trU[1] ^ (bb << 6)));
+          accW[bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[2], uf[0], accW[bb], 0, 0, 0);
+          accW[bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[0], uf[2], accW[bb], 0, 0, 0);
+          accW[bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[1], uf[1], accW[bb], 0, 0, 0);
+          accW[bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[1], uf[0], accW[bb], 0, 0, 0);
+          accW[bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[0], uf[1], accW[bb], 0, 0, 0);
+          accW[bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[0], uf[0], accW[bb], 0, 0, 0);
+          if (DH) {   // two K-steps of the dHs product beside each dW block
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+              const int s4 = 2 * bb + s2;
+              const int o = ua0 + ((s4 ^ ua_hi) << 6);
+              const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const u32x4*)(Ub + o));
+              const bf16x8 am = __builtin_bit_cast(bf16x8, *(const u32x4*)(Ub + LVB + o));
+              const bf16x8 al = __builtin_bit_cast(bf16x8, *(const u32x4*)(Ub + 2 * LVB + o));
+              sa.step(ah, am, al, th[s4], tm[s4], tl[s4]);
+            }
+          }
+        }
+        f32x4 sc_cur = {0.f, 0.f, 0.f, 0.f};
+        if (DH) sc_cur = *(const f32x4*)&Sc[slot][4 * q4];
+        if (RING_EARLY_FLAG) {   // the next slot's flag, looked at once: usually up already -> no poll at the top of the next trip
+          const unsigned nflag = __hip_atomic_load(&FULL[(it + 1) % NSL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          next_full = it + 1 < ns && (int)(__builtin_amdgcn_readfirstlane(nflag) - (unsigned)NRW * (unsigned)((it + 1) / NSL + 1)) >= 0;
+          asm volatile("" ::: "memory");
+        }
+        ring_arrive(&FREE[slot], lane);   // every operand of the slot is in registers
+        if (DH) {
+          const f32x4 hacc = sa.sum();
+          const int m0 = (s_begin + it) * SR + 4 * q4;
+          const unsigned o = (unsigned)((s_begin + it) * SR * D) + dh_lane;
+          if ((s_begin + it) * SR + SR <= M) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dHs[o + e * D] = hacc[e] * sc_cur[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (m0 + e < M) dHs[o + e * D] = hacc[e] * sc_cur[e];
+          }
+        }
+#else
+        ring_wait(&FULL[slot], (unsigned)NRW * (unsigned)(it / NSL + 1));
+        ring_arrive(&FREE[slot], lane);
+#endif
+      }
+    };
+    if (dHs) slot_loop(std::true_type{});
+    else slot_loop(std::false_type{});
+    // ---- this workgroup's dW partial: accW[bb][reg] = dW[32 hcb + (reg & 3) + 8 (reg >> 2) + 4 hh][64 ucb + 32 bb + (lane & 31)]
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        P[(32 * hcb + (e & 3) + 8 * (e >> 2) + 4 * hh) * D + 64 * ucb + 32 * bb + (lq & 31)] = accW[bb][e];
   } else {
     // =============================================================== matrix team
     const int own = wave - NRW;   // 16 rows of dW / 16 columns of dHs
@@ -3040,14 +3241,15 @@ int cgcn_layer_fwd(cgcn_stream_t stream, int n, int S, int d, const int32_t* row
   const int tn = 16 * mb / S;
   const int blocks = (n + tn - 1) / tn;
   const bool deep = pick_deep(n, S, d);
-#define FWD(S_, D_, MB_, V_, DP_)                                                                                     \
-  hipLaunchKernelGGL((k_layer_fwd<S_, D_, MB_, V_, DP_>), dim3(blocks), blk, 0, st, n, rowptr, col, val, row_scale,    \
+  const bool spf = g_products.load() != CGCN_PRODUCTS_FP32_CHAIN;   // (d = 128 only: d = 256 keeps the chain on every route)
+#define FWD(S_, D_, MB_, V_, DP_, P_)                                                                                 \
+  hipLaunchKernelGGL((k_layer_fwd<S_, D_, MB_, V_, DP_, (D_ == 128) ? P_ : 0>), dim3(blocks), blk, 0, st, n, rowptr, col, val, row_scale, \
                      X, W, b, wg, cg, Xn, Z, H, gate, ks, th, rng_state, stream_id, colstats, acc ? 1 : 0, zw, zc)
 #define CALL(S_, D_, V_)                                                                                              \
   do {                                                                                                                \
     const dim3 blk((D_ == 128 && CBW128 == 2) ? 256 : 512);                                                           \
-    if (deep) FWD(S_, D_, 1, V_, true);                                                                               \
-    else FWD(S_, D_, 1, V_, false);                                                                                   \
+    if (deep) { if (spf) FWD(S_, D_, 1, V_, true, 1); else FWD(S_, D_, 1, V_, true, 0); }                             \
+    else { if (spf) FWD(S_, D_, 1, V_, false, 1); else FWD(S_, D_, 1, V_, false, 0); }                                \
   } while (0)
   DISPATCH_SDV(S, d, val != nullptr, CALL);
 #undef CALL
@@ -3156,11 +3358,14 @@ static int layer_bwd_impl(cgcn_stream_t stream, int n, int S, int d, const int32
   if (!(phases & 1)) {
     // profiling only: the partials / dHs / dL/dXn of an earlier full call are still in place
   } else if (d == 128) {
-#define RING(H_, D_) hipLaunchKernelGGL((k_bwd_rowlocal_ring<H_, D_>), dim3(P + head_slabs_rl), dim3(RING_THREADS), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, P, head_slabs_rl, W)
+    const bool spb = g_products.load() != CGCN_PRODUCTS_FP32_CHAIN;
+#define RING_(H_, D_, P_) hipLaunchKernelGGL((k_bwd_rowlocal_ring<H_, D_, P_>), dim3(P + head_slabs_rl), dim3(RING_THREADS), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, P, head_slabs_rl, W)
+#define RING(H_, D_) do { if (spb) RING_(H_, D_, 1); else RING_(H_, D_, 0); } while (0)
     if (!head) RING(false, false);
     else if (hp.thresh) RING(true, true);
     else RING(true, false);
 #undef RING
+#undef RING_
   } else
     hipLaunchKernelGGL((k_bwd_rowlocal256s<32>), dim3(4 * P + head_slabs_rl), dim3(RL256_THREADS), 0, st, M, n, dXn, Z, X, gate, dgate, H, wg, row_scale, dHs, part, hp, dX, 4 * P, head_slabs_rl, W);
   if ((rc = launch_status())) return rc;

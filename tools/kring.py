@@ -19,9 +19,10 @@ def main():
             ns = [int(v) for v in a[4:].split(",")]
     reps = 100
     libs = []
-    for a in args:
+    for a in args:   # name=path[:fp32|:split] -- the suffix sets the products form (cgcn_debug_set_products) for that entry
         name, path = a.split("=")
-        libs.append((name, _lib.open_library(os.path.join(ROOT, path))))
+        path, _, form = path.partition(":")
+        libs.append((name, _lib.open_library(os.path.join(ROOT, path)), {"fp32": 0, "split": 1}.get(form, -1)))
     dev = torch.device("cuda")
     d, S = 128, 2
     P = _lib.ptr; st = _lib.stream_ptr
@@ -33,7 +34,9 @@ def main():
         gate = torch.rand(S, n, device=dev)
         W = torch.randn(d, d, device=dev) / d ** 0.5; wg = torch.randn(d, device=dev) / d ** 0.5
         ref = None
-        for name, lib in libs:
+        for name, lib, products in libs:
+            if hasattr(lib, "cgcn_debug_set_products"):
+                lib.cgcn_debug_set_products(products)
             dx, dhs = torch.zeros_like(x), torch.zeros_like(x)
             dW = torch.zeros_like(W); db = torch.zeros(d, device=dev); dwg = torch.zeros(d, device=dev); dcg = torch.zeros(1, device=dev)
             wsb = lib.cgcn_layer_bwd_workspace_bytes(n, S, d); ws = torch.zeros(wsb, dtype=torch.uint8, device=dev)
