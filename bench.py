@@ -450,7 +450,7 @@ def kernel_costs(n, nnz, S, d, C, P_rl, P_head):
 def time_kernels(stage, name, reps, dropout_p):
     """Average duration (seconds) of every kernel of one chromosome's train step, each launched in isolation `reps`
     times back to back and bracketed by HIP events on the stream the library launches on (torch's current stream):
-    the C ABI runs the forward's two launches as cgcn_spmm (k_aggregate_sliced on tables >= 8 MiB) and cgcn_layer_fwd
+    the C ABI runs the forward's two launches as cgcn_spmm (k_aggregate_sliced on tables >= 6 MiB) and cgcn_layer_fwd
     with H_in (k_layer_dense), the backward's and the head's through the cgcn_debug_*_phases hooks.
     Returns {kernel: (seconds per launch, launches per train step)}."""
     import ctypes

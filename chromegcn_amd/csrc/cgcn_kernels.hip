@@ -512,7 +512,7 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512, PROD ? 4 : F
   __shared__ __attribute__((aligned(16))) float LR[NW * S * D];  // hub-row partial sums (gather_tile)
   // PROD == 1 (split products, cgcn_common.hpp; d = 128): the gathered tile is re-staged as three bf16 levels (k_layer_dense's
   // Tb) and the product is formed exactly as k_layer_dense forms it -- the same bits on both routes.  The W operands are 48
-  // registers instead of 32: 4 waves per SIMD (this kernel only serves tables below the 8 MiB split threshold).
+  // registers instead of 32: 4 waves per SIMD (this kernel only serves tables below the split threshold).
   constexpr int LDB = D + 8;
   __shared__ __attribute__((aligned(16))) uint16_t Tb[PROD ? 3 * ROWS * LDB : 8];
   static_assert(PROD == 0 || (D == 128 && MB == 1 && CBW == 1 && FWD_HALF_WAVE_ROWS), "split products: d = 128, the half-wave-row form");
@@ -2999,9 +2999,13 @@ const char* cgcn_strerror(int code) {
   }
 }
 
-// the split forward (see cgcn_layer_fwd): tables from this size on; workgroups and tile height of k_layer_dense
+// the split forward (see cgcn_layer_fwd): tables from this size on; workgroups and tile height of k_layer_dense.
+// 6 MiB since the split products (rounds 2-6: 8): the fused kernel's W operands grew from 32 to 48 registers (6 instead of 8
+// waves per SIMD under its gather) while the row-local kernel got 17 % faster, and inside a genome epoch -- inputs cold, not
+// the L2-warm loop of a single-chromosome benchmark -- the two launches win from the smallest training chromosome (6.0 MiB)
+// on: epoch 3.97 -> 3.90 ms; a 5.6 MiB table alone still prefers the fused kernel by 1 % (profiles/r06_split_products.txt).
 #ifndef FWD_SPLIT_TABLE_BYTES
-#define FWD_SPLIT_TABLE_BYTES (8u << 20)
+#define FWD_SPLIT_TABLE_BYTES (6u << 20)
 #endif
 #ifndef DENSE_MAX_BLOCKS
 #define DENSE_MAX_BLOCKS (256 * (DENSE_WAVES_PER_SIMD / 2))   // exactly the workgroups resident at once: one round

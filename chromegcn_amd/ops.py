@@ -109,7 +109,7 @@ def _sgd_fuse_arg(layer_id, dx, sink):
 
 
 # feature tables from this size on do not fit the L2s: cgcn_layer_fwd's split route (FWD_SPLIT_TABLE_BYTES in csrc)
-_SPLIT_TABLE_BYTES = 8 << 20
+_SPLIT_TABLE_BYTES = 6 << 20
 
 
 def _resolve_h_cache(h_cache, x, need_bwd):

@@ -40,7 +40,7 @@ def test_route_queries_are_pure_host_logic():
     """cgcn_debug_layer_{fwd,bwd}_route (ABI v19): which kernels a call would launch; nothing is launched, no GPU needed."""
     import ctypes
     lib = _lib.load()
-    # forward: fused below the split threshold (8 MiB of feature table), two launches above, or for a hub-heavy graph
+    # forward: fused below the split threshold (6 MiB of feature table), two launches above, or for a hub-heavy graph
     assert lib.cgcn_debug_layer_fwd_route(5776, 2, 128, None, 0) == 0       # 5.9 MB
     assert lib.cgcn_debug_layer_fwd_route(29910, 2, 128, None, 0) == 1      # 30.6 MB
     assert lib.cgcn_debug_layer_fwd_route(5776, 2, 256, None, 0) == 1       # d = 256, both strands (11.8 MB): the same threshold since round 6

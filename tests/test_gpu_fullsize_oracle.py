@@ -69,6 +69,12 @@ CASES = [   # name, n, pairs, hic_like, adj_type, seed, d, layers, labels
     ("chr21_constant", synth.chrom_nodes("chr21"), 250000, False, "constant", 29, 128, 2, NC),
     ("chr10_constant", synth.chrom_nodes("chr10"), 250000, False, "constant", 30, 128, 2, NC),
     ("k562_constant_d256_L4", synth.chrom_nodes("chr21"), 250000, False, "constant", 31, 256, 4, NC),
+    # every case above runs the dense products in the library's default form (split: six bf16 MFMA partial products of an
+    # exact 3-way operand split, cgcn_common.hpp); these run the fp32 MFMA chain of rounds 1-5 -- the one-launch forward,
+    # the row-local forward and the ring backward each have both forms -- against the same oracle at the same bounds
+    ("chr21_fp32chain", synth.chrom_nodes("chr21"), 250000, False, "hic", 21, 128, 2, NC),
+    ("chr1_fp32chain", synth.chrom_nodes("chr1"), 250000, True, "hic", 1, 128, 2, NC),
+    ("config1_forced_split_fp32chain", 5000, 125000, False, "hic", 0, 128, 2, NC),
 ]
 
 
@@ -91,7 +97,8 @@ def _rel(a, b):
 def test_train_steps_match_oracle_at_full_size(case):
     name, n, pairs, hic_like, adj_type, seed, d, layers, labels = case
     from chromegcn_amd import _lib
-    _lib.load().cgcn_debug_set_fwd_split_bytes(0 if name.endswith("forced_split") else -1)
+    _lib.load().cgcn_debug_set_fwd_split_bytes(0 if "forced_split" in name else -1)
+    _lib.load().cgcn_debug_set_products(0 if name.endswith("_fp32chain") else -1)
     # The host oracle's fp32 sums depend on torch's thread count (another test module pins it to 1 at import, i.e. for a
     # whole `pytest tests` session but not for this file alone: sequential sums over a hub's 10^4 neighbours are 100x less
     # accurate than the chunked ones).  Fix it here, so that the oracle is the same oracle in every session.
@@ -102,6 +109,7 @@ def test_train_steps_match_oracle_at_full_size(case):
     finally:
         torch.set_num_threads(threads)
         _lib.load().cgcn_debug_set_fwd_split_bytes(-1)
+        _lib.load().cgcn_debug_set_products(-1)
 
 
 def _train_steps_case(name, n, pairs, hic_like, adj_type, seed, d, layers, labels):

@@ -1,0 +1,149 @@
+"""The two forms of the dense fp32 products (include/chromegcn.h, cgcn_debug_set_products; chromegcn_amd/csrc/cgcn_common.hpp):
+  split (default)  six bf16 MFMA partial products of an EXACT three-way split of every fp32 operand, fp32 accumulators;
+  fp32 chain       v_mfma_f32_16x16x4_f32, the form of rounds 1-5.
+Both are fp32 arithmetic.  What is asserted here, through the C ABI on random inputs, against a float64 restatement of the
+same formulas (models/SubLayers.py:43-50 + models/ChromeModels.py:37-40 forward; SURVEY App. A backward):
+  * the split form's error is NOT LARGER than the chain's (it rounds K / 32 times per accumulator where the chain rounds
+    K / 4 times) -- the claim that makes it legitimate as the default;
+  * both stay within 1e-5 of float64 in scale-relative terms (the north star's tolerance is 1e-4);
+  * the hook restores the process default, the forms are bit-reproducible, and they do differ (the hook does something).
+The full-size oracle cases of tests/test_gpu_fullsize_oracle.py run in the default (split) form; its `*_fp32chain` cases run
+the chain form of every kernel that has both."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from chromegcn_amd import _lib, graph as G, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+FORMS = {"fp32_chain": 0, "split": 1}
+
+
+def _rel(a, t):
+    return float((a.double() - t).abs().max() / t.abs().max().clamp_min(1e-300))
+
+
+def _rms(a, t):   # relative root-mean-square error: what the forms are ranked by (a maximum over 10^4 ... 10^6 elements is a noisy statistic)
+    return float(((a.double() - t) ** 2).mean().sqrt() / (t ** 2).mean().sqrt().clamp_min(1e-300))
+
+
+@pytest.fixture
+def lib():
+    h = _lib.load()
+    default = h.cgcn_debug_get_products()
+    yield h
+    h.cgcn_debug_set_products(-1)
+    assert h.cgcn_debug_get_products() == default
+    h.cgcn_debug_set_fwd_split_bytes(-1)
+
+
+def test_default_form_is_split_and_hook_round_trips(lib):
+    import os
+    if os.environ.get("CGCN_PRODUCTS", "").startswith(("f", "0")):
+        pytest.skip("CGCN_PRODUCTS selects the chain form in this session")
+    assert lib.cgcn_debug_get_products() == FORMS["split"]
+    lib.cgcn_debug_set_products(FORMS["fp32_chain"])
+    assert lib.cgcn_debug_get_products() == FORMS["fp32_chain"]
+    lib.cgcn_debug_set_products(12345)   # anything else: back to the process default
+    assert lib.cgcn_debug_get_products() == FORMS["split"]
+
+
+@pytest.mark.parametrize("route", ["row_local", "fused"])
+@pytest.mark.parametrize("n", [333, 5776])
+def test_forward_split_not_less_accurate_than_chain(lib, route, n):
+    """cgcn_layer_fwd at d = 128: the row-local kernel on a given H (k_layer_dense) and the one-launch kernel (k_layer_fwd)."""
+    S, d = 2, 128
+    P, st = _lib.ptr, _lib.stream_ptr
+    torch.manual_seed(n)
+    g = G.upload(G.normalize_graph("hic", synth.contact_graph(n, 20 * n, 3), n), torch.device(DEV))
+    x = torch.randn(S, n, d, device=DEV)
+    W = torch.randn(d, d, device=DEV) / d ** 0.5
+    b = torch.randn(d, device=DEV) * 0.1
+    wg = torch.randn(d, device=DEV) / d ** 0.5
+    cg = torch.randn(1, device=DEV) * 0.1
+    A = torch.sparse_csr_tensor(g.rowptr.long(), g.col.long(), torch.ones(g.col.numel(), dtype=torch.float64, device=DEV), size=(n, n))
+    h64 = torch.stack([g.row_scale.double()[:, None] * (A @ x[s].double()) for s in range(S)])
+    h = h64.float()
+    hin = h if route == "row_local" else None
+    z64 = torch.tanh((h.double() if route == "row_local" else h64) @ W.double() + b.double())
+    g64 = torch.sigmoid(z64 @ wg.double() + cg.double())
+    xn64 = (1 - g64)[..., None] * x.double() + g64[..., None] * z64
+    out, err = {}, {}
+    lib.cgcn_debug_set_fwd_split_bytes(1 << 40 if route == "fused" else 0)
+    for form, mode in FORMS.items():
+        lib.cgcn_debug_set_products(mode)
+        xn, z, gate = torch.empty_like(x), torch.empty_like(x), torch.empty(S, n, device=DEV)
+        for rep in range(2):
+            _lib.check(lib.cgcn_layer_fwd(st(), n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(W), P(b), P(wg), P(cg),
+                                          P(xn), P(z), None, P(gate), 0.0, None, 1, None if hin is None else P(hin), None, 0,
+                                          G.aux_ptr(g.col)), "layer_fwd")
+            torch.cuda.synchronize()
+            if rep == 0:
+                first = (xn.clone(), z.clone(), gate.clone())
+        assert all(torch.equal(a, c) for a, c in zip(first, (xn, z, gate))), "bit-reproducible"
+        out[form] = first
+        err[form] = {"Z": _rel(z, z64), "Xn": _rel(xn, xn64), "gate": _rel(gate, g64), "Z_rms": _rms(z, z64)}
+    print(route, n, err)
+    assert not torch.equal(out["split"][1], out["fp32_chain"][1]), "the two forms differ in the last bits"
+    for k in ("Z", "Xn", "gate"):
+        assert err["split"][k] < 1e-5 and err["fp32_chain"][k] < 1e-5
+    # the aggregation's own fp32 rounding is common to both forms on the fused route; on the row-local route (H given) the
+    # product is the only difference: there the split form must be at least as accurate as the chain
+    slack = 1.1 if route == "row_local" else 1.25
+    assert err["split"]["Z_rms"] <= slack * err["fp32_chain"]["Z_rms"], err
+    assert err["split"]["Z"] <= 2 * err["fp32_chain"]["Z"] + 2e-8, err
+
+
+@pytest.mark.parametrize("n", [100, 5776, 16264])
+def test_backward_split_not_less_accurate_than_chain(lib, n):
+    """The row-local backward launch at d = 128 (k_bwd_rowlocal_ring): dW = H^T dU and dHs = diag(1/deg) dU W^T, both forms,
+    against float64; column sums and the row math are common to both forms (bitwise equal)."""
+    S, d = 2, 128
+    P, st = _lib.ptr, _lib.stream_ptr
+    torch.manual_seed(1000 + n)
+    g = G.upload(G.normalize_graph("hic", synth.contact_graph(n, min(250000, 20 * n), 7), n), torch.device(DEV))
+    x, z, h, dxn = (torch.randn(S, n, d, device=DEV) for _ in range(4))
+    z = torch.tanh(z)
+    gate = torch.rand(S, n, device=DEV)
+    W = torch.randn(d, d, device=DEV) / d ** 0.5
+    wg = torch.randn(d, device=DEV) / d ** 0.5
+    # float64 restatement: dg = sum_e gup (z - x); gamma = g (1 - g) dg; dz = g gup + gamma wg; dU = dz (1 - z^2)
+    z6, x6, h6, u6, g6 = z.double(), x.double(), h.double(), dxn.double(), gate.double()
+    dg = (u6 * (z6 - x6)).sum(-1)
+    gamma = g6 * (1 - g6) * dg
+    du = (g6[..., None] * u6 + gamma[..., None] * wg.double()) * (1 - z6 * z6)
+    dW64 = sum(h6[s].T @ du[s] for s in range(S))
+    dHs64 = g.row_scale.double()[None, :, None] * (du @ W.double().T)
+    out, err = {}, {}
+    for form, mode in FORMS.items():
+        lib.cgcn_debug_set_products(mode)
+        dx, dhs = torch.zeros_like(x), torch.zeros_like(x)
+        dW = torch.zeros_like(W); db = torch.zeros(d, device=DEV); dwg = torch.zeros(d, device=DEV); dcg = torch.zeros(1, device=DEV)
+        wsb = lib.cgcn_layer_bwd_workspace_bytes(n, S, d)
+        ws = torch.zeros(wsb, dtype=torch.uint8, device=DEV)
+        for rep in range(2):
+            rc = lib.cgcn_debug_layer_bwd_phases(st(), n, S, d, P(g.rowptr), P(g.col), None, P(g.row_scale), P(x), P(z), P(h), P(gate), P(W), P(wg),
+                                                 P(dxn), None, P(dx), P(dhs), P(dW), P(db), P(dwg), P(dcg), 0, 0.0, None, 0, None, P(ws), wsb, 3,
+                                                 G.aux_ptr(g.col))
+            assert rc == 0
+            torch.cuda.synchronize()
+            if rep == 0:
+                first = {"dHs": dhs.clone(), "dW": dW.clone(), "db": db.clone(), "dwg": dwg.clone(), "dcg": dcg.clone(), "dX": dx.clone()}
+        now = {"dHs": dhs, "dW": dW, "db": db, "dwg": dwg, "dcg": dcg, "dX": dx}
+        assert all(torch.equal(first[k], now[k]) for k in first), "bit-reproducible"
+        out[form] = first
+        err[form] = {"dW": _rel(first["dW"], dW64), "dHs": _rel(first["dHs"], dHs64),
+                     "dW_rms": _rms(first["dW"], dW64), "dHs_rms": _rms(first["dHs"], dHs64)}
+    print(n, err)
+    for k in ("db", "dwg", "dcg"):
+        assert torch.equal(out["split"][k], out["fp32_chain"][k]), k
+    assert not torch.equal(out["split"]["dHs"], out["fp32_chain"]["dHs"])
+    for k in ("dW", "dHs"):
+        assert err["split"][k] < 1e-5 and err["fp32_chain"][k] < 1e-5
+        # (dW: one accumulator per block, small terms first, and a second-stage sum over the workgroups' partials that is
+        # common to both forms -- on a par with the chain; dHs: two accumulators, clearly below it)
+        assert err["split"][k + "_rms"] <= 1.1 * err["fp32_chain"][k + "_rms"], (k, err)
+        assert err["split"][k] <= 2 * err["fp32_chain"][k] + 2e-8, (k, err)

@@ -149,7 +149,7 @@ def test_super_hub_rows_and_skewed_waves(S, d, kind):
     finally:
         lib.cgcn_debug_set_fwd_split_bytes(-1)
     # cgcn_graph_aux::max_row_len routes this graph through the sliced kernels without the debug hook, table size
-    # regardless (6 ... 12 MB here: S = 2, d = 128 is below the 8 MiB threshold): same bits as the forced route
+    # regardless (6 ... 12 MB here: S = 2, d = 128 can be below the split threshold): same bits as the forced route
     assert G.max_row_len(g.col) == int(deg.max())
     y2 = torch.empty_like(x)
     _lib.check(lib.cgcn_spmm(_lib.stream_ptr(), n, n, S, d, P(g.rowptr), P(g.col), None if g.val is None else P(g.val),
