@@ -412,6 +412,12 @@ def single_shape(name):
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA = the fp32 vector rate (dense)
+# Split products (chromegcn_amd/csrc/cgcn_common.hpp): one fp32 product = six bf16 MFMA partial products, so the matrix roof of
+# a kernel that runs them is the dense bf16 peak / 6, in fp32-EQUIVALENT flops (the algorithmic 2 m n k; MI355X_MICROARCH.md:
+# ~2.5 PF dense bf16).  The kernels that have the form (d = 128): the row-local forward, the one-launch forward, the ring backward.
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+MATRIX_SPLIT_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 6.0
+SPLIT_KERNELS = ("k_layer_dense", "k_layer_fwd", "k_bwd_rowlocal")
 
 
 def layer_fwd_bytes(n, nnz, S, d):
@@ -917,7 +923,7 @@ def main():
         return out
 
     import chromegcn_amd as C
-    from chromegcn_amd import synth
+    from chromegcn_amd import synth, _lib
     from chromegcn_amd.finetune import GCNStage
 
     genome = args.workload == "genome"
@@ -1094,6 +1100,24 @@ def main():
             extras["generators_note"] = ("same genome shape and train epoch on synth.contact_graph's other generators: hic_like = "
                                          "contact probability ~ 1 / distance, hub = top-K-style heavy-tailed degrees with 8 hubs of "
                                          "2 000 - 10 000 neighbours per chromosome; `value` is the %s generator" % args.generator)
+        # the same step with the dense products as the fp32 MFMA chain of rounds 1-5 (cgcn_debug_set_products): the stage's HIP
+        # graphs fix the kernels at capture, so they are dropped and captured again while the hook holds the chain form
+        if not multi and _lib.load().cgcn_debug_get_products() == 1 and args.d == 128:
+            _lib.load().cgcn_debug_set_products(0)
+            try:
+                stage._drop_graphs()
+                for _ in range(max(warmup, 3)):
+                    step()
+                f_el, _, _ = timed(step, steps)
+                extras["fp32_chain_ms_per_step"] = f_el / steps * 1e3
+                extras["fp32_chain_windows_per_s"] = windows * steps / f_el
+                extras["fp32_chain_note"] = ("the same workload with the dense products on v_mfma_f32_16x16x4_f32 (CGCN_PRODUCTS=fp32: the form "
+                                             "of rounds 1-5; everything else as shipped); `value` is the split form")
+            finally:
+                _lib.load().cgcn_debug_set_products(-1)
+                stage._drop_graphs()
+                for _ in range(2):
+                    step()
         # inference: eval-mode forward of both strands over the same chromosomes
         if genome:
             def ev():
@@ -1150,6 +1174,7 @@ def main():
         # epoch's summed kernel time; roofline_top3 = the three largest, each against both roofs
         reps = 20 if genome else 100
         agg, forms = {}, {}
+        products_split = _lib.load().cgcn_debug_get_products() == 1
         for nm, n, nnz in shapes:
             if nm not in stage.chroms or args.no_roofline:
                 continue
@@ -1181,9 +1206,15 @@ def main():
             us = e["s"] / e["launches"] * 1e6
             gbps, tfl = e["bytes"] / e["s"] / 1e9, e["flops"] / e["s"] / 1e12
             traffic, ttag = stored_traffic(wl_key, k)
-            fh, fm = gbps / HBM_PEAK_GBPS, tfl / MFMA_F32_PEAK_TFLOPS
+            # the matrix roof of THIS kernel in the form it runs: the fp32 MFMA chain's, or -- split products, d = 128 -- the bf16
+            # matrix cores' at six partial products per fp32 product (fp32-equivalent flops either way)
+            split_k = products_split and args.d == 128 and k.split("(")[0].startswith(SPLIT_KERNELS)
+            mpeak = MATRIX_SPLIT_PEAK_TFLOPS if split_k else MFMA_F32_PEAK_TFLOPS
+            fh, fm = gbps / HBM_PEAK_GBPS, tfl / mpeak
             return {"kernel": k, "bound": "hbm" if fh >= fm else "mfma",
-                    "achieved": gbps if fh >= fm else tfl, "peak": HBM_PEAK_GBPS if fh >= fm else MFMA_F32_PEAK_TFLOPS,
+                    "achieved": gbps if fh >= fm else tfl, "peak": HBM_PEAK_GBPS if fh >= fm else mpeak,
+                    "matrix_roof": ("bf16 MFMA dense peak / 6 (split products: six bf16 partial products per fp32 product)" if split_k
+                                    else "fp32 MFMA (v_mfma_f32_16x16x4_f32)"), "matrix_peak_TFLOPs": mpeak,
                     "unit": "GB/s" if fh >= fm else "TFLOP/s", "frac": max(fh, fm), "traffic": traffic,
                     "traffic_source": ("profiles/traffic.json was collected on other library sources than this build: no value"
                                        if ttag == "stale" else None) if traffic is None else
@@ -1191,7 +1222,7 @@ def main():
                                       "beyond-L2 bytes incl. Infinity-Cache hits), not measured in this run" % ttag,
                     "algorithmic_bytes_per_launch": e["bytes"] / e["launches"], "flops_per_launch": e["flops"] / e["launches"],
                     "avg_kernel_us": us, "launches_per_step": e["launches"], "share_of_kernel_time": None,
-                    "hbm_GBps": gbps, "frac_hbm": fh, "mfma_f32_TFLOPs": tfl, "frac_mfma_f32": fm,
+                    "hbm_GBps": gbps, "frac_hbm": fh, "mfma_f32_TFLOPs": tfl, "frac_mfma_f32": tfl / MFMA_F32_PEAK_TFLOPS, "frac_matrix": fm,
                     # gathered neighbour rows (4 nnz S d bytes per launch): served by the L2s / vector L1s, not by HBM -- the
                     # table is cache resident -- so this rate may legitimately exceed the HBM peak
                     "gathered_bytes_per_launch": (e["gather"] / e["launches"]) if e["gather"] else None,
@@ -1257,6 +1288,12 @@ def main():
             "higher_is_better": True, "scaling": "strong" if genome else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": wl, "generator": args.generator,
+                       "products": ("split: every dense fp32 product of the d = 128 row-local kernels (U = H W, dW = H^T dU, dHs = dU W^T) as six "
+                                    "bf16 MFMA partial products of an EXACT three-way split of both fp32 operands (x = h + m + l, 8 + 8 + 8 "
+                                    "significant bits), fp32 accumulators -- fp32 arithmetic on the bf16 matrix cores, measured more accurate "
+                                    "against float64 than the fp32 MFMA chain (tests/test_gpu_products.py, profiles/r06_bf16x6_probe.txt); "
+                                    "the chain's figure: fp32_chain_ms_per_step" if _lib.load().cgcn_debug_get_products() == 1 else
+                                    "fp32 MFMA chain (v_mfma_f32_16x16x4_f32), CGCN_PRODUCTS=fp32"),
                        "hip_graph": not args.no_hip_graph, "epoch_graph": bool(stage.epoch_graph and not args.no_hip_graph and not multi),
                        "parallelism": ("chromosomes sharded over %d rank(s)" % world) if genome else "chromosome-per-rank x%d" % world,
                        "allreduce": stage.allreduce_kind if multi else None,

@@ -163,6 +163,28 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
+// tanh of the gated layer's pre-activation.  CGCN_FAST_TANH (A/B builds; profiles/r05_fast_tanh_experiment.txt, measured again
+// behind the split products in profiles/r06_split_products_ab.txt): the same two branches as the library's tanhf -- a series
+// below 0.25, 1 - 2 / (e^{2|x|} + 1) above -- on the hardware exp2 / rcp without the range reduction around them: 15 instead
+// of 27 vector instructions, |error| <= 1e-7 (<= 6 ulp between 0.25 and 1, <= 1.2 ulp elsewhere; tanhf: <= 1.4 ulp).
+#ifndef CGCN_FAST_TANH
+#define CGCN_FAST_TANH 0
+#endif
+__device__ __forceinline__ float layer_tanh(float x) {
+#if CGCN_FAST_TANH
+  const float a = fabsf(x);
+  const float e = __builtin_amdgcn_exp2f(a * 2.885390081777927f);   // e^(2a)
+  const float r = __builtin_amdgcn_rcpf(e + 1.f);
+  float z = __builtin_fmaf(-2.f, r, 1.f);
+  const float x2 = x * x;
+  const float p = a * (1.f + x2 * (-0.33333333f + x2 * (0.13333333f + x2 * (-0.053968254f + x2 * 0.021869488f))));
+  z = a < 0.25f ? p : z;
+  return copysignf(z, x);
+#else
+  return tanhf(x);
+#endif
+}
+
 __device__ __forceinline__ uint32_t dropout_key(const unsigned long long* rng_state, uint32_t stream_id) {
   const unsigned long long seed = rng_state[0], ctr = rng_state[1];
   uint32_t k = mix32((uint32_t)seed ^ 0x9E3779B9u);

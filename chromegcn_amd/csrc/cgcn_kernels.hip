@@ -621,7 +621,7 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512, PROD ? 4 : F
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) T[(mb * 16 + q * 4 + e) * LD + j] = tanhf(acc[mb][cb][e] + bj);
+        for (int e = 0; e < 4; ++e) T[(mb * 16 + q * 4 + e) * LD + j] = layer_tanh(acc[mb][cb][e] + bj);
     }
   }
   __syncthreads();
@@ -891,7 +891,7 @@ __global__ __launch_bounds__(512, DENSE_WAVES_PER_SIMD) void k_layer_dense(int n
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) T[(mb * 16 + q * 4 + e) * LD + j] = tanhf(acc[mb][cb][e] + bjv[cb]);
+          for (int e = 0; e < 4; ++e) T[(mb * 16 + q * 4 + e) * LD + j] = layer_tanh(acc[mb][cb][e] + bjv[cb]);
       }
     }
     __syncthreads();
@@ -1094,7 +1094,7 @@ __global__ __launch_bounds__(1024) void k_layer_dense256(int n, int ntiles, cons
     KT_STAMP(12);
     // ---- Z = tanh(U + b) -> the tanh tile (its last readers, the row pass of the tile before, are behind the barrier above)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) Zt[(q * 4 + e) * LD + j] = tanhf(acc[e] + bj);
+    for (int e = 0; e < 4; ++e) Zt[(q * 4 + e) * LD + j] = layer_tanh(acc[e] + bj);
     __syncthreads();   // (also: every wave is done reading T)
     KT_STAMP(13);
     // ---- row `wave`: gate, residual mix, dropout, coalesced stores
@@ -3003,7 +3003,7 @@ const char* cgcn_strerror(int code) {
 // 6 MiB since the split products (rounds 2-6: 8): the fused kernel's W operands grew from 32 to 48 registers (6 instead of 8
 // waves per SIMD under its gather) while the row-local kernel got 17 % faster, and inside a genome epoch -- inputs cold, not
 // the L2-warm loop of a single-chromosome benchmark -- the two launches win from the smallest training chromosome (6.0 MiB)
-// on: epoch 3.97 -> 3.90 ms; a 5.6 MiB table alone still prefers the fused kernel by 1 % (profiles/r06_split_products.txt).
+// on: epoch 3.97 -> 3.90 ms; a 5.6 MiB table alone still prefers the fused kernel by 1 % (profiles/r06_split_products_ab.txt).
 #ifndef FWD_SPLIT_TABLE_BYTES
 #define FWD_SPLIT_TABLE_BYTES (6u << 20)
 #endif
