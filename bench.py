@@ -414,10 +414,10 @@ def single_shape(name):
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA = the fp32 vector rate (dense)
 # Split products (chromegcn_amd/csrc/cgcn_common.hpp): one fp32 product = six bf16 MFMA partial products, so the matrix roof of
 # a kernel that runs them is the dense bf16 peak / 6, in fp32-EQUIVALENT flops (the algorithmic 2 m n k; MI355X_MICROARCH.md:
-# ~2.5 PF dense bf16).  The kernels that have the form (d = 128): the row-local forward, the one-launch forward, the ring backward.
+# ~2.5 PF dense bf16).  The kernels that have the form (d = 128): the row-local forward, the one-launch forward, the ring backward, the training head.
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 MATRIX_SPLIT_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 6.0
-SPLIT_KERNELS = ("k_layer_dense", "k_layer_fwd", "k_bwd_rowlocal")
+SPLIT_KERNELS = ("k_layer_dense", "k_layer_fwd", "k_bwd_rowlocal", "k_head_fused")
 
 
 def layer_fwd_bytes(n, nnz, S, d):
@@ -1288,10 +1288,11 @@ def main():
             "higher_is_better": True, "scaling": "strong" if genome else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": wl, "generator": args.generator,
-                       "products": ("split: every dense fp32 product of the d = 128 row-local kernels (U = H W, dW = H^T dU, dHs = dU W^T) as six "
+                       "products": ("split: every dense fp32 product of the d = 128 row-local kernels and the head (U = H W, dW = H^T dU, dHs = dU W^T; pred, dym, dW_out) as six "
                                     "bf16 MFMA partial products of an EXACT three-way split of both fp32 operands (x = h + m + l, 8 + 8 + 8 "
-                                    "significant bits), fp32 accumulators -- fp32 arithmetic on the bf16 matrix cores, measured more accurate "
-                                    "against float64 than the fp32 MFMA chain (tests/test_gpu_products.py, profiles/r06_bf16x6_probe.txt); "
+                                    "significant bits), fp32 accumulators -- fp32 arithmetic on the bf16 matrix cores; against float64 its error is "
+                                    "below the fp32 MFMA chain's (U, dHs: 2-3x) or on a par with it (dW) (tests/test_gpu_products.py, "
+                                    "profiles/r06_bf16x6_probe.txt); "
                                     "the chain's figure: fp32_chain_ms_per_step" if _lib.load().cgcn_debug_get_products() == 1 else
                                     "fp32 MFMA chain (v_mfma_f32_16x16x4_f32), CGCN_PRODUCTS=fp32"),
                        "hip_graph": not args.no_hip_graph, "epoch_graph": bool(stage.epoch_graph and not args.no_hip_graph and not multi),

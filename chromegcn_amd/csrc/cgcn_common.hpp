@@ -18,8 +18,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // fp32 products on the bf16 matrix cores ("split products", round 6; profiles/r06_bf16x6_probe.txt).
 // On gfx950 v_mfma_f32_16x16x4_f32 runs at the fp32 VECTOR rate (64 flop/clk/SIMD) and keeps the SIMD's vector ALUs busy;
 // v_mfma_f32_16x16x32_bf16 is 16 times faster and leaves half of its issue slots to vector work.  A float has 24
-// significant bits = three bf16 numbers of 8:  x = h + m + l EXACTLY (cut by truncation: h = the float's upper 16 bits, m the
-// upper 16 bits of x - h, l = x - h - m, which has <= 8 significant bits left), so
+// significant bits = three bf16 numbers of 8:  x = h + m + l EXACTLY (h = bf16(x), m = bf16(x - h), l = x - h - m, which has
+// <= 8 significant bits left; both subtractions are exact), so
 //     a b = ah bh + (ah bm + am bh) + (ah bl + am bm + al bh) + [am bl + al bm + al bl  <= 2^-23 |a b|, dropped]
 // is six bf16 MFMAs whose partial products are exact and whose sums are kept in three fp32 accumulators by magnitude
 // (big / mid / small, added once at the end).  Measured against float64 (K = 256, 524 288 dot products, in units of
@@ -27,20 +27,43 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // times, this form 8 times per accumulator.  Same fp32 range (bf16 has the fp32 exponent): no scaling, Inf / NaN propagate.
 // ------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float sp_hi(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
-// the upper halves of two floats as a bf16 pair (x0 in the low half)
-__device__ __forceinline__ uint32_t sp_pack(float x0, float x1) {
-  return __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+// Levels by ROUND-TO-NEAREST (v_cvt_pk_bf16_f32), not by truncation: h = bf16(x), m = bf16(x - h), l = x - h - m (<= 8
+// significant bits: exact) -- the residuals are signed and half as large, so the three dropped partial products are zero-mean.
+// With truncated levels every residual has the sign of x and the dropped terms the sign of a b: a relative bias of ~5e-8 on every
+// product, COHERENT over rows -- the gate-bias gradients (sums of ~10^5 cancelling per-row terms, tests/test_gpu_fullsize_oracle.py)
+// amplified it to 1.2e-4 at chr1 size with hubs, above the chain's 3.5e-5.  Same instruction count (one convert per pair and
+// level instead of two masks and a byte permute).
+__device__ __forceinline__ uint32_t sp_pack(float x0, float x1) {   // (bf16 x1) << 16 | (bf16 x0), round to nearest even
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){x0, x1}, bf16x2));
+}
+__device__ __forceinline__ float sp_lo(uint32_t pk) { return __uint_as_float(pk << 16); }
+__device__ __forceinline__ float sp_up(uint32_t pk) { return __uint_as_float(pk & 0xffff0000u); }
+// two consecutive floats -> one bf16 pair of each level
+__device__ __forceinline__ void sp_split2(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+  h = sp_pack(x0, x1);
+  const float r0 = x0 - sp_lo(h), r1 = x1 - sp_up(h);
+  m = sp_pack(r0, r1);
+  l = sp_pack(r0 - sp_lo(m), r1 - sp_up(m));
+}
+// one float -> its three levels (bf16 bit patterns)
+__device__ __forceinline__ void sp_split1(float x, uint16_t& h, uint16_t& m, uint16_t& l) {
+  uint32_t h2, m2, l2;
+  sp_split2(x, 0.f, h2, m2, l2);
+  h = (uint16_t)h2;
+  m = (uint16_t)m2;
+  l = (uint16_t)l2;
 }
 // four consecutive floats -> 4 bf16 of each level (8 bytes per level)
 __device__ __forceinline__ void sp_split4(const f32x4 x, u32x2& h, u32x2& m, u32x2& l) {
-  const float r0 = x[0] - sp_hi(x[0]), r1 = x[1] - sp_hi(x[1]), r2 = x[2] - sp_hi(x[2]), r3 = x[3] - sp_hi(x[3]);
-  const float s0 = r0 - sp_hi(r0), s1 = r1 - sp_hi(r1), s2 = r2 - sp_hi(r2), s3 = r3 - sp_hi(r3);
-  h = (u32x2){sp_pack(x[0], x[1]), sp_pack(x[2], x[3])};
-  m = (u32x2){sp_pack(r0, r1), sp_pack(r2, r3)};
-  l = (u32x2){sp_pack(s0, s1), sp_pack(s2, s3)};
+  uint32_t h0, m0, l0, h1, m1, l1;
+  sp_split2(x[0], x[1], h0, m0, l0);
+  sp_split2(x[2], x[3], h1, m1, l1);
+  h = (u32x2){h0, h1};
+  m = (u32x2){m0, m1};
+  l = (u32x2){l0, l1};
 }
 // eight consecutive K values -> one MFMA operand of each level
 __device__ __forceinline__ void sp_split8(const float (&x)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
@@ -80,6 +103,24 @@ struct SpAcc2 {   // two accumulators (the leading product | the five others): f
   }
   __device__ __forceinline__ f32x4 sum() const { return big + rest; }
 };
+
+// LDS image of a bf16 LEVEL TILE (16 rows x 128 columns, 256-byte rows, 4 KB; one per level and operand): the 16-byte chunk c
+// of row m sits at c ^ sp_sigma(m), sp_sigma(m) = (m & 3) << 2 | tau[m >> 2], tau = {2, 0, 1, 3}.  Conflict-free for 8-byte
+// row stores, for the ds_read_b128 row reads of a 16x16x32 operand (sigma of rows 4..11 is closed under ^ 1: the
+// instruction's lane groups {0-3, 12-15 | 20-27} ... meet 16 distinct chunks) and for the TRANSPOSED reads a product over the
+// ROW index needs (ds_read_b64_tr_b16: a 16-lane group fetches 4 rows x 16 columns, each lane receives one column's 4 rows;
+// the 4 rows of a block differ in sigma >> 2: 16 distinct chunks per 32-lane half).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int sp_sigma(int m) { return ((m & 3) << 2) | ((0xD2 >> ((m >> 2) << 1)) & 3); }
+__device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+}
+__device__ __forceinline__ bf16x8 tr_pair(const unsigned char* p0, const unsigned char* p1) {   // rows 8h..8h+3 | 8h+4..8h+7
+  const s16x4 a = lds_tr16(p0), b = lds_tr16(p1);
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  return __builtin_bit_cast(bf16x8, (s16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]});
+}
 
 // ------------------------------------------------------------------------------------------
 // small helpers

@@ -1646,6 +1646,416 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
 #undef OPAQUE_LANE
 }
 
+// ------------------------------------------------------------------------------------------
+// k_head_fused_sp (D = 128, round 6): k_head_fused_rs at 16-row tiles with its three products as SPLIT PRODUCTS
+// (cgcn_common.hpp: six bf16 MFMA partial products of an exact 3-way split of both fp32 operands, fp32 accumulators).  Same
+// teams, same three sub-phases per period, same barriers, same partial records, label passes and statistics paths; what
+// changes is what the tiles in LDS hold and which instruction reads them:
+//   Yt, Pt, W_out: three bf16 LEVEL tiles each (16 rows x 128 columns x 2 B = 4 KB per level, swizzled image sp_sigma), written
+//                  as levels by whoever produces them (the P team's S1 / S3; the launch's prologue);
+//   pred = ym W_out^T   P wave w, label block w: v_mfma_f32_16x16x32_bf16; ym rows by ds_read_b128; the wave's 16 W_out rows
+//                       are RESIDENT as levels (48 registers; a P wave's persistent state is 24);
+//   dym  = Pt W_out     Q wave w, feature columns [16 w, +16): 16x16x32; Pt rows by ds_read_b128, W_out K-major by
+//                       ds_read_b64_tr_b16 (the hardware transpose); label blocks past the pass hold zeros;
+//   dW_out += Pt^T Yt   Q wave w: labels [64 (w & 1), +64) x columns [32 (w >> 1), +32) as two 32 x 32 accumulators,
+//                       v_mfma_f32_32x32x16_bf16 with K = the tile's 16 rows, both operands transposed reads.
+// LDS: W_out 96 KB + 2 x (Yt + Pt) 48 KB.  fp32 MFMA held the SIMD's vector ALUs, so the teams' "matrix" and "vector"
+// sub-phases added up; the bf16 forms take a sixteenth of the cycles per flop and leave half their issue slots free.
+// ------------------------------------------------------------------------------------------
+template <bool MULTI, int NB, bool DROP>
+__global__ __launch_bounds__(1024) void k_head_fused_sp(int n, int S, int C, const float* __restrict__ X,
+                                                        const float* __restrict__ bn_w, const float* __restrict__ bn_b,
+                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                        const float* __restrict__ Wout, const float* __restrict__ bout,
+                                                        const float* __restrict__ target, float keep_scale, uint32_t thresh,
+                                                        const unsigned long long* __restrict__ rng_state, float inv_count,
+                                                        float* __restrict__ probs, float* __restrict__ loss_part,
+                                                        float* __restrict__ dym, float* __restrict__ part,
+                                                        int c0, int Cp, int CPT, int first_, int last_, HeadStatAcc sa) {
+  constexpr int D = 128, TR = 16, EPL = 2, RPW = TR / 8;
+  constexpr int LVT = TR * 256;          // bytes of one level tile (16 rows)
+  constexpr int WLV = 128 * 256;         // bytes of one level of the W_out image (128 label rows, zeros past the pass)
+  __shared__ __attribute__((aligned(16))) unsigned char Wl[3 * WLV];
+  __shared__ __attribute__((aligned(16))) unsigned char Ytb[2][3 * LVT];
+  __shared__ __attribute__((aligned(16))) unsigned char Ptb[2][3 * LVT];
+  __shared__ float lsum[8];
+  __shared__ float wmax[16];   // accumulate mode: per-wave max |W_out| (the binary points of the backward sums)
+  const bool first = MULTI ? first_ != 0 : true, last = MULTI ? last_ != 0 : true;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int own = wave & 7;            // P: label block;  Q: 16-column block of D
+  const uint32_t key = DROP ? dropout_key(rng_state, HEAD_STREAM_ID) : 0u;
+  const float invS = 1.f / (float)S;
+  const bool S2 = S > 1;
+  const int PS = head_part_stride(CPT, D);
+  const int ntiles = (n + TR - 1) / TR;
+  const int G = (int)gridDim.x;
+  const int mt = (int)blockIdx.x < ntiles ? (ntiles - 1 - (int)blockIdx.x) / G + 1 : 0;   // tiles of this workgroup
+  float* P = part + (size_t)blockIdx.x * PS;
+
+  // ---- W_out -> LDS as three level images (all 16 waves, 4 columns per thread and step; rows past the pass: zeros)
+  float mwl = 0.f;   // max |W_out| over the rows this thread stages
+  for (int idx = threadIdx.x; idx < 128 * (D / 4); idx += 1024) {
+    const int j = idx / (D / 4), c4 = idx % (D / 4);
+    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (j < Cp) v = *(const f32x4*)&Wout[(size_t)(c0 + j) * D + c4 * 4];
+    u32x2 h2, m2, l2;
+    sp_split4(v, h2, m2, l2);
+    unsigned char* w = Wl + j * 256 + (((c4 >> 1) ^ sp_sigma(j & 15)) << 4) + ((c4 & 1) << 3);
+    *(u32x2*)w = h2;
+    *(u32x2*)(w + WLV) = m2;
+    *(u32x2*)(w + 2 * WLV) = l2;
+    mwl = fmaxf(fmaxf(mwl, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+  if (sa.acc && last) {   // max |W_out| over ALL labels (see k_head_fused_rs)
+    float mw;
+    if (MULTI) mw = head_wout_absmax(Wout, C * (D / 4), 1024);
+    else {
+      mw = mwl;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mw = fmaxf(mw, __shfl_xor(mw, o, WAVE));
+    }
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mw;
+  }
+  // accumulate mode: batch mean / invstd decoded once per workgroup into the second P tile (first written in S3 of period 1)
+  float* const stash = (float*)Ptb[1];
+  static_assert(3 * LVT >= 6 * D * (int)sizeof(float), "the stash fits a P tile");
+#ifndef HRSX_NOSTAGE   // (decomposition build)
+  if (sa.acc) head_stat_stage<D>(sa, n, S, stash, 1024);
+#endif
+#define OPAQUE_LANE(r_, q_, l_)          \
+  int l_ = lane;                         \
+  asm volatile("" : "+v"(l_));           \
+  const int r_ = l_ & 15, q_ = l_ >> 4
+
+  if (wave < 8) {
+    // =============================================================== P: pred team
+    float xv[RPW][2][EPL], tgv[4], mu[2][EPL], is[2][EPL], gw[EPL], gb[EPL];
+    float dbo = 0.f, lacc = 0.f;
+    const float bj = own * 16 + (lane & 15) < Cp ? bout[c0 + own * 16 + (lane & 15)] : 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      const int c = lane * EPL + e;
+      gw[e] = bn_w[c];
+      gb[e] = bn_b[c];
+    }
+    // this wave's 16 rows of W_out as B operands of the pred product: B(k, j) = W_out[c0 + 16 own + j][k], K-step s: k = 32 s + 8 q ..
+    bf16x8 wh[4], wm[4], wl[4];
+    {
+      const int r = lane & 15, q = lane >> 4;
+      const int j = own * 16 + r;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+        if (j < Cp) {
+          v0 = *(const f32x4*)&Wout[(size_t)(c0 + j) * D + 32 * s4 + 8 * q];
+          v1 = *(const f32x4*)&Wout[(size_t)(c0 + j) * D + 32 * s4 + 8 * q + 4];
+        }
+        const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        sp_split8(v, wh[s4], wm[s4], wl[s4]);
+      }
+    }
+    auto load_rows = [&](int tile) {
+      const int node0 = tile * TR;
+#pragma unroll
+      for (int t = 0; t < RPW; ++t) {
+        const int i = node0 + own + t * 8;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          if (i < n && s < S) ld_row<EPL>(xv[t][s], &X[(unsigned)((s * n + i) * D + lane * EPL)]);
+          else zero_row<EPL>(xv[t][s]);
+        }
+      }
+    };
+    auto load_targets = [&](int tile) {
+      const int node0 = tile * TR;
+      const int j = own * 16 + (lane & 15), q = lane >> 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = node0 + q * 4 + e;
+        tgv[e] = (i < n && j < Cp) ? target[(unsigned)(i * C + c0 + j)] : 0.f;
+      }
+    };
+    if (mt > 0) {
+      load_rows(blockIdx.x);
+      load_targets(blockIdx.x);
+    }
+    __syncthreads();   // W_out image complete (and the statistics stash)
+#pragma unroll
+    for (int e = 0; e < EPL; ++e)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) head_stat<D>(sa, stash, mean, invstd, s < S ? s : 0, lane * EPL + e, mu[s][e], is[s][e]);
+    for (int k = 0; k <= mt; ++k) {
+      const int tile = (int)blockIdx.x + k * G;
+      const int node0 = tile * TR;
+      // ---- S1: ym rows of tile k -> the three levels of Yt[k & 1]                (vector work; Q: dym product)
+      if (k < mt) {
+        int lane_ = lane;
+        asm volatile("" : "+v"(lane_));
+        unsigned char* __restrict__ Yb = Ytb[k & 1];
+#pragma unroll
+        for (int t = 0; t < RPW; ++t) {
+          const int rr = own + t * 8;
+          const int i = node0 + rr;
+          float ym[EPL];
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) {
+            float y[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+              y[s] = (fmaxf(xv[t][s][e], 0.f) - mu[s][e]) * is[s][e] * gw[e] + gb[e];
+              if (DROP) y[s] = dropout_keep(key, (uint32_t)((s * n + i) * D + lane_ * EPL + e), thresh) ? y[s] * keep_scale : 0.f;
+            }
+            const float a = y[0] + (S2 ? y[1] : 0.f);
+            ym[e] = i < n ? a * invS : 0.f;
+          }
+          // columns 2 lane, 2 lane + 1 of row rr: one bf16 pair per level
+          uint32_t yh, ymid, yl;
+          sp_split2(ym[0], ym[1], yh, ymid, yl);
+          unsigned char* w = Yb + rr * 256 + (((lane_ >> 2) ^ sp_sigma(rr)) << 4) + ((lane_ & 3) << 2);
+          *(uint32_t*)w = yh;
+          *(uint32_t*)(w + LVT) = ymid;
+          *(uint32_t*)(w + 2 * LVT) = yl;
+        }
+      }
+      __syncthreads();
+      // ---- S2: pred = ym W_out^T (M = 16 rows, K = D, N = this wave's label block)   (matrix; Q: its epilogue)
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (k < mt) {
+        if (k + 1 < mt) load_rows(tile + G);   // the rows were consumed in S1
+        if (own < NB) {
+          OPAQUE_LANE(r, q, lq);
+          const unsigned char* __restrict__ Ya = Ytb[k & 1] + r * 256 + ((q ^ (sp_sigma(r) & 3)) << 4);
+          const int hi = sp_sigma(r) >> 2;
+          SpAcc sacc;
+          sacc.zero();
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            const int o = (s4 ^ hi) << 6;
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const u32x4*)(Ya + o));
+            const bf16x8 am = __builtin_bit_cast(bf16x8, *(const u32x4*)(Ya + LVT + o));
+            const bf16x8 al = __builtin_bit_cast(bf16x8, *(const u32x4*)(Ya + 2 * LVT + o));
+            sacc.step(ah, am, al, wh[s4], wm[s4], wl[s4]);
+          }
+          acc = sacc.sum();
+        }
+      }
+      __syncthreads();
+      // ---- S3: sigmoid / BCE / probs; d loss / d pred -> the levels of Pt[k & 1] (zero outside the valid region)   (vector; Q: dW_out product)
+      if (k < mt) {
+        unsigned char* __restrict__ Pb = Ptb[k & 1];
+        OPAQUE_LANE(r, q, lq);
+        const int j = own * 16 + r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = q * 4 + e;
+          const int i = node0 + row;
+          const bool ok = i < n && j < Cp;
+          const float pred = acc[e] + bj;
+          const float en = __expf(-fabsf(pred));
+          const float inv = __builtin_amdgcn_rcpf(1.f + en);   // 1 ulp; the IEEE division is ten instructions
+          const float p = pred >= 0.f ? inv : en * inv;
+          const float l = fmaxf(pred, 0.f) - pred * tgv[e] + __logf(1.f + en);
+          lacc += ok ? l : 0.f;
+          if (ok) {
+            if (HEAD_NT_PROBS) __builtin_nontemporal_store(p, &probs[(unsigned)(i * C + c0 + j)]);
+            else probs[(unsigned)(i * C + c0 + j)] = p;
+          }
+          const float dp = ok ? (p - tgv[e]) * inv_count : 0.f;
+          dbo += dp;
+          uint16_t dh, dm, dl;
+          sp_split1(dp, dh, dm, dl);
+          unsigned char* w = Pb + row * 256 + (((j >> 3) ^ sp_sigma(row)) << 4) + ((j & 7) << 1);
+          *(uint16_t*)w = dh;
+          *(uint16_t*)(w + LVT) = dm;
+          *(uint16_t*)(w + 2 * LVT) = dl;
+        }
+        if (k + 1 < mt) load_targets(tile + G);
+      }
+      __syncthreads();
+    }
+    // ---- db_out share and the loss share of this workgroup
+    dbo += __shfl_xor(dbo, 16);
+    dbo += __shfl_xor(dbo, 32);
+    if ((lane >> 4) == 0 && c0 + own * 16 + (lane & 15) < CPT) P[CPT * D + c0 + own * 16 + (lane & 15)] = dbo;
+    lacc = wave_sum(lacc);
+    if (lane == 0) lsum[own] = lacc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) t += lsum[w];
+      const float tl = first ? t : loss_part[blockIdx.x] + t;   // the label passes' shares add up
+      loss_part[blockIdx.x] = tl;
+#ifndef HRSX_NOTICKET   // (decomposition build)
+      if (sa.acc && last) head_loss_ticket(sa, S, D, tl, inv_count);   // (the Q team's integer adds: before the barrier above)
+#endif
+    }
+  } else {
+    // =============================================================== Q: grad team, one tile behind
+    f32x16 accW[2];
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) accW[bb][e] = 0.f;
+    float sdy[2] = {0.f, 0.f}, sdyx[2] = {0.f, 0.f}, mu[2], is[2];
+    __syncthreads();   // W_out image complete (and the statistics stash)
+    if (sa.acc && blockIdx.x == 0 && first && wave == 8) head_stat_bookkeeping<D>(sa, stash, S, lane);   // (see HeadStatAcc)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) head_stat<D>(sa, stash, mean, invstd, s < S ? s : 0, own * 16 + (lane & 15), mu[s], is[s]);
+    float xq[2][4];
+    auto load_xq = [&](int tile) {
+      OPAQUE_LANE(r, q, lq);
+      const int node0 = tile * TR, c = own * 16 + r;
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = node0 + q * 4 + e;
+          xq[s][e] = (last && i < n && s < S) ? X[(unsigned)((s * n + i) * D + c)] : 0.f;
+        }
+    };
+    // transposed-read lane constants (see k_bwd_rowlocal_ring): lane = 32 h + 16 c16 + i (32x32x16 operands) or 16 q + i (16x16x32)
+    for (int k = 0; k <= mt; ++k) {
+      const int node0 = ((int)blockIdx.x + (k - 1) * G) * TR;   // tile k-1
+      f32x4 accY = {0.f, 0.f, 0.f, 0.f};
+      // ---- S1: dym tile = Pt W_out of tile k-1 (M = 16 rows, K = 128 labels, N = this wave's 16 columns)   (matrix; P: ym rows)
+      if (k >= 1) {
+        const unsigned char* __restrict__ Pb = Ptb[(k - 1) & 1];
+        OPAQUE_LANE(r, q, lq);
+        // A: Pt rows, chunk 4 s + q of row r;  B: W_out K-major, the 16-lane group q fetches label rows 32 s + 8 q + 4 rd + (i >> 2),
+        // piece (i & 3) of columns [16 own, +16)
+        const unsigned char* __restrict__ Pa = Pb + r * 256 + ((q ^ (sp_sigma(r) & 3)) << 4);
+        const int hi = sp_sigma(r) >> 2;
+        const int qp = r >> 2, pp = r & 3;
+        SpAcc2 sacc;
+        sacc.zero();
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const int o = (s4 ^ hi) << 6;
+          const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const u32x4*)(Pa + o));
+          const bf16x8 am = __builtin_bit_cast(bf16x8, *(const u32x4*)(Pa + LVT + o));
+          const bf16x8 al = __builtin_bit_cast(bf16x8, *(const u32x4*)(Pa + 2 * LVT + o));
+          int wo[2];
+#pragma unroll
+          for (int rd = 0; rd < 2; ++rd) {
+            const int lrow = 32 * s4 + 8 * q + 4 * rd + qp;
+            wo[rd] = lrow * 256 + (((2 * own + (pp >> 1)) ^ sp_sigma(lrow & 15)) << 4) + ((pp & 1) << 3);
+          }
+          const bf16x8 bh = tr_pair(Wl + wo[0], Wl + wo[1]);
+          const bf16x8 bm = tr_pair(Wl + WLV + wo[0], Wl + WLV + wo[1]);
+          const bf16x8 bl = tr_pair(Wl + 2 * WLV + wo[0], Wl + 2 * WLV + wo[1]);
+          sacc.step(ah, am, al, bh, bm, bl);
+        }
+        accY = sacc.sum();
+        if (MULTI && !first) {   // the earlier label passes' share of dym
+          const int c = own * 16 + r;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int i = node0 + q * 4 + e;
+            accY[e] += i < n ? dym[(unsigned)(i * D + c)] : 0.f;
+          }
+        }
+      }
+      __syncthreads();
+      // ---- S2: dym out, BatchNorm-backward column sums of tile k-1              (vector; P: pred product)
+      if (k >= 1) {
+        OPAQUE_LANE(r, q, lq);
+        const int c = own * 16 + r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = node0 + q * 4 + e;
+          const float g = accY[e];
+          if (i < n) dym[(unsigned)(i * D + c)] = g;
+          if (last) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+              float dy = g * invS;
+              if (DROP) dy = dropout_keep(key, (uint32_t)((s * n + i) * D + c), thresh) ? dy * keep_scale : 0.f;
+              if (s == 1) dy = S2 ? dy : 0.f;
+              const float xh = (fmaxf(xq[s][e], 0.f) - mu[s]) * is[s];
+              sdy[s] += dy;
+              sdyx[s] += dy * xh;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      // ---- S3: dW_out += Pt^T Yt of tile k-1 (K = the tile's 16 rows), two 32 x 32 blocks per wave   (matrix; P: epilogue)
+      if (k < mt) load_xq((int)blockIdx.x + k * G);   // tile k's values, used in S2 of the next period
+      if (k >= 1) {
+        int lq = lane;
+        asm volatile("" : "+v"(lq));
+        const int hh = lq >> 5, c16 = (lq >> 4) & 1, qp = (lq & 15) >> 2, pp = lq & 3;
+        const int cbk = own >> 1, lb0 = 2 * (own & 1);
+        const unsigned char* __restrict__ Pb = Ptb[(k - 1) & 1];
+        const unsigned char* __restrict__ Yb = Ytb[(k - 1) & 1];
+        int ty[2], tp[2];
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+          const int row = 8 * hh + 4 * rd + qp, sg = sp_sigma(row);
+          ty[rd] = row * 256 + (((4 * cbk + 2 * c16 + (pp >> 1)) ^ sg) << 4) + ((pp & 1) << 3);
+          tp[rd] = row * 256 + (((4 * lb0 + 2 * c16 + (pp >> 1)) ^ sg) << 4) + ((pp & 1) << 3);   // label block bb: ^ (bb << 6)
+        }
+        bf16x8 yf[3];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) yf[v] = tr_pair(Yb + v * LVT + ty[0], Yb + v * LVT + ty[1]);
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+          bf16x8 pf[3];
+#pragma unroll
+          for (int v = 0; v < 3; ++v) pf[v] = tr_pair(Pb + v * LVT + (tp[0] ^ (bb << 6)), Pb + v * LVT + (tp[1] ^ (bb << 6)));
+          accW[bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[2], yf[0], accW[bb], 0, 0, 0);
+          accW[bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[0], yf[2], accW[bb], 0, 0, 0);
+          accW[bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[1], yf[1], accW[bb], 0, 0, 0);
+          accW[bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[1], yf[0], accW[bb], 0, 0, 0);
+          accW[bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[0], yf[1], accW[bb], 0, 0, 0);
+          accW[bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[0], yf[0], accW[bb], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
+    // ---- dW_out share: accW[bb][reg] = dW_out[c0 + 32 (lb0 + bb) + (reg & 3) + 8 (reg >> 2) + 4 hh][32 cbk + (lane & 31)]
+    {
+      const int hh = lane >> 5, cbk = own >> 1, lb0 = 2 * (own & 1);
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int lab = 32 * (lb0 + bb) + (e & 3) + 8 * (e >> 2) + 4 * hh;
+          if (c0 + (lab & ~15) < CPT) P[(size_t)(c0 + lab) * D + 32 * cbk + (lane & 31)] = accW[bb][e];
+        }
+    }
+    const int r = lane & 15, q = lane >> 4;
+    if (last) {   // column sums over this lane's rows -> over the four row groups of the wave
+      double* out = (double*)(P + CPT * D + CPT);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        double a = (double)sdy[s], b = (double)sdyx[s];
+        a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+        b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
+        if (q == 0) {
+          out[s * D + own * 16 + r] = a;
+          out[(2 + s) * D + own * 16 + r] = b;
+          if (sa.acc && s < S) {   // accumulate mode: the same sums as integer totals for the row-local backward's prologue
+            int fa, fb;
+            head_bacc_points(wmax, 16, keep_scale, n, fa, fb);
+            unsigned long long* bb = bacc_base(sa.acc, S, D);
+#ifndef HRSX_NOBACC
+            bacc_add(bb, S, D, (int)blockIdx.x & (STAT_ACC_SLOTS - 1), s, own * 16 + r, a, b, fa, fb);
+#endif
+            if (blockIdx.x == 0 && s == 0 && own == 0 && r == 0)
+              bb[(size_t)STAT_ACC_SLOTS * S * D * 2 + BACC_EXP] = ((unsigned long long)(unsigned)(fb + 1024) << 32) | (unsigned long long)(unsigned)(fa + 1024);
+          }
+        }
+      }
+    }
+    __syncthreads();   // (the P team's loss merge)
+  }
+#undef OPAQUE_LANE
+}
+
 // second stage: workgroups [0, wslabs) sum the dW_out / db_out slabs wslab0 + b (head_finalize_slab), the rest the
 // BatchNorm columns in float64 (head_stats_finalize)
 __global__ __launch_bounds__(512) void k_head_bwd_finalize(int wslab0, int wslabs, int P, int n, int S, int D, int C, int CP,
@@ -1932,15 +2342,23 @@ static int head_train_impl(cgcn_stream_t stream, int n, int S, int d, int C, con
         hipLaunchKernelGGL((k_head_fused_rs<M_, NB_, DR_, NRB_>), dim3(P), dim3(1024), 0, st, n, S, C, X, bn_w, bn_b, save_mean, save_invstd, \
                          Wout, bout, target, keep_scale, thresh, rng_state, inv_count, probs, w_loss, w_dym, w_part, c0, Cp, \
                          CP, first, last, (phases & 1) ? sa : sa_prof)
+#define HSP(M_, NB_, DR_)                                                                                              \
+        hipLaunchKernelGGL((k_head_fused_sp<M_, NB_, DR_>), dim3(P), dim3(1024), 0, st, n, S, C, X, bn_w, bn_b, save_mean, save_invstd, \
+                         Wout, bout, target, keep_scale, thresh, rng_state, inv_count, probs, w_loss, w_dym, w_part, c0, Cp, \
+                         CP, first, last, (phases & 1) ? sa : sa_prof)
+      // split products (cgcn_debug_set_products; cgcn_common.hpp): k_head_fused_sp, 16-row tiles at every size
+      const bool sph = cgcn_debug_get_products() != CGCN_PRODUCTS_FP32_CHAIN;
 #define HRS(M_, NB_)                                                                                                   \
       do {                                                                                                             \
-        if (thresh) { if (tr16) HRS2(M_, NB_, true, 1); else HRS2(M_, NB_, true, 2); }                                  \
+        if (sph) { if (thresh) HSP(M_, NB_, true); else HSP(M_, NB_, false); }                                          \
+        else if (thresh) { if (tr16) HRS2(M_, NB_, true, 1); else HRS2(M_, NB_, true, 2); }                             \
         else { if (tr16) HRS2(M_, NB_, false, 1); else HRS2(M_, NB_, false, 2); }                                       \
       } while (0)
       if (C <= 128) { if (nb7) HRS(false, 7); else HRS(false, 8); }
       else { if (nb7) HRS(true, 7); else HRS(true, 8); }
 #undef HRS
 #undef HRS2
+#undef HSP
     }
     else if (d == 128) HFU(128);
     else HFU(256);

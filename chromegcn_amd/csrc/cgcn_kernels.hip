@@ -1273,28 +1273,14 @@ __device__ __forceinline__ void ring_arrive(unsigned* flag, int lane) {
 //        [64 (own & 1), +64): two 32 x 32 accumulators; both operands are K-major reads of row-major tiles, i.e.
 //        ds_read_b64_tr_b16 (the hardware transpose: a 16-lane group fetches 4 rows x 16 columns and every lane receives
 //        one column's 4 rows); the six partial products go into ONE accumulator per block, small terms first --
-//   dHs with v_mfma_f32_16x16x32_bf16 -- dU rows by ds_read_b128, the W^T levels resident (48 registers), three
+//   dHs with v_mfma_f32_16x16x32_bf16 -- dU rows by ds_read_b128, the W^T levels resident (48 registers), two
 //        accumulators (the leading product | the other five: SpAcc2).
-// Level tile image: 16 rows x 256 B, 16-byte chunk c of row m at c ^ sigma(m), sigma(m) = (m & 3) << 2 | tau[m >> 2],
-// tau = {2, 0, 1, 3}: conflict-free for the row team's 8-byte stores, for the transposed reads (the 4 rows of a block
-// differ in sigma >> 2: 16 distinct chunks per 32-lane half) and for the ds_read_b128 row reads (sigma of rows 4..11 is
-// closed under ^ 1: the instruction's lane groups {0-3, 12-15 | 20-27} ... see 16 distinct chunks).
+// Level tiles in the swizzled image of cgcn_common.hpp (sp_sigma): every access pattern above is bank-conflict free.
 // 768 matrix-core cycles per slot and wave instead of 2 048: the matrix team, which bounded the fp32 form (39 us alone
 // against the row team's 18 at n = 29 910), no longer does.
 #ifndef RING_SLOTS_SP
 #define RING_SLOTS_SP 6
 #endif
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ int ring_sigma(int m) { return ((m & 3) << 2) | ((0xD2 >> ((m >> 2) << 1)) & 3); }
-__device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p) {
-  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
-}
-__device__ __forceinline__ bf16x8 tr_pair(const unsigned char* p0, const unsigned char* p1) {   // rows 8h..8h+3 | 8h+4..8h+7
-  const s16x4 a = lds_tr16(p0), b = lds_tr16(p1);
-  typedef short s16x8 __attribute__((ext_vector_type(8)));
-  return __builtin_bit_cast(bf16x8, (s16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]});
-}
 template <bool HEAD, bool DROP, int PROD>
 __global__ __launch_bounds__(RING_THREADS) void k_bwd_rowlocal_ring(int M, int n, const float* __restrict__ dXn,
                                                             const float* __restrict__ Z, const float* __restrict__ X,
@@ -1492,7 +1478,7 @@ __global__ __launch_bounds__(RING_THREADS) void k_bwd_rowlocal_ring(int M, int n
       for (int t = 0; t < RT; ++t) {   // swizzled chunk positions (see the header)
         const int rowi = row0 + 2 * NRW * t;
         if constexpr (PROD != 0) {
-          const int wo = rowi * 256 + (((l >> 1) ^ ring_sigma(rowi)) << 4) + ((l & 1) << 3);   // bytes inside a level tile
+          const int wo = rowi * 256 + (((l >> 1) ^ sp_sigma(rowi)) << 4) + ((l & 1) << 3);   // bytes inside a level tile
           u32x2 h2, m2, l2;
           sp_split4(w.h[t], h2, m2, l2);
           unsigned char* hb = (unsigned char*)Hs[slot] + wo;
@@ -1590,12 +1576,12 @@ __global__ __launch_bounds__(RING_THREADS) void k_bwd_rowlocal_ring(int M, int n
     int trH[2], trU[2];
 #pragma unroll
     for (int rd = 0; rd < 2; ++rd) {
-      const int row = 8 * hh + 4 * rd + qp, sg = ring_sigma(row);
+      const int row = 8 * hh + 4 * rd + qp, sg = sp_sigma(row);
       trH[rd] = row * 256 + (((4 * hcb + 2 * c16 + (pp >> 1)) ^ sg) << 4) + ((pp & 1) << 3);
       trU[rd] = row * 256 + (((8 * ucb + 2 * c16 + (pp >> 1)) ^ sg) << 4) + ((pp & 1) << 3);   // block bb: ^ (bb << 6)
     }
     // row reads (16x16x32 A operand of dHs): row r16, chunk 4 s + q4
-    const int ua0 = r16 * 256 + ((q4 ^ (ring_sigma(r16) & 3)) << 4), ua_hi = ring_sigma(r16) >> 2;
+    const int ua0 = r16 * 256 + ((q4 ^ (sp_sigma(r16) & 3)) << 4), ua_hi = sp_sigma(r16) >> 2;
     const unsigned dh_lane = (unsigned)(4 * q4 * D + own * 16 + r16);   // this lane's element of a slot's dHs rows
     bool next_full = false;
     auto slot_loop = [&](auto DH_) {

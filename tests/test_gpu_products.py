@@ -3,8 +3,10 @@
   fp32 chain       v_mfma_f32_16x16x4_f32, the form of rounds 1-5.
 Both are fp32 arithmetic.  What is asserted here, through the C ABI on random inputs, against a float64 restatement of the
 same formulas (models/SubLayers.py:43-50 + models/ChromeModels.py:37-40 forward; SURVEY App. A backward):
-  * the split form's error is NOT LARGER than the chain's (it rounds K / 32 times per accumulator where the chain rounds
-    K / 4 times) -- the claim that makes it legitimate as the default;
+  * the split form's error is NOT LARGER than the chain's where it keeps the leading partial product in an accumulator of
+    its own (U = H W, dHs = dU W^T: it rounds K / 32 times where the chain rounds K / 4 times; measured 2-3 times smaller)
+    and ON A PAR with it where register pressure leaves one accumulator (dW = H^T dU: within 1.3 x in rms, both ~2e-7) --
+    the claim that makes it legitimate as the default;
   * both stay within 1e-5 of float64 in scale-relative terms (the north star's tolerance is 1e-4);
   * the hook restores the process default, the forms are bit-reproducible, and they do differ (the hook does something).
 The full-size oracle cases of tests/test_gpu_fullsize_oracle.py run in the default (split) form; its `*_fp32chain` cases run
@@ -143,7 +145,9 @@ def test_backward_split_not_less_accurate_than_chain(lib, n):
     assert not torch.equal(out["split"]["dHs"], out["fp32_chain"]["dHs"])
     for k in ("dW", "dHs"):
         assert err["split"][k] < 1e-5 and err["fp32_chain"][k] < 1e-5
-        # (dW: one accumulator per block, small terms first, and a second-stage sum over the workgroups' partials that is
-        # common to both forms -- on a par with the chain; dHs: two accumulators, clearly below it)
-        assert err["split"][k + "_rms"] <= 1.1 * err["fp32_chain"][k + "_rms"], (k, err)
+        # dHs: two accumulators (8 roundings of the leading sum per row where the chain has 32): clearly below the chain.
+        # dW: ONE 32 x 32 accumulator per block takes all six partial products (the ring kernel has no registers for a
+        # second one): six roundings of the running sum per 16 rows where the chain has four -- on a par with the chain
+        # (measured +14 % rms at 1.6e-7 ... 2.6e-7 of max |dW|; the second-stage sum over the workgroups is common to both)
+        assert err["split"][k + "_rms"] <= (1.3 if k == "dW" else 1.0) * err["fp32_chain"][k + "_rms"], (k, err)
         assert err["split"][k] <= 2 * err["fp32_chain"][k] + 2e-8, (k, err)
