@@ -21,7 +21,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 $B
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/fetch" -- python3 $BP --steps 3 --warmup 1 > "$O/fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/write" -- python3 $BP --steps 3 --warmup 1 > "$O/write.log" 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d "$O/sq" -- python3 $BP --steps 3 --warmup 1 > "$O/sq.log" 2>&1
-rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES --kernel-trace --output-format csv -d "$O/mfma" -- python3 $BP --steps 3 --warmup 1 > "$O/mfma.log" 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES --kernel-trace --output-format csv -d "$O/mfma" -- python3 $BP --steps 3 --warmup 1 > "$O/mfma.log" 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d "$O/l2" -- python3 $BP --steps 3 --warmup 1 > "$O/l2.log" 2>&1
 python3 "$R/tools/summarize_profiles.py" "$O" "$TAG" "$WL" "$*"
 # the raw per-dispatch CSVs are tens of MB per pass; gpurun merges at most 64 MiB back: keep the summaries and logs only

@@ -91,7 +91,7 @@ def main():
                     continue
                 o.write("%s,%d,%.1f,%s\n" % (k, len(durs[k]), sum(durs[k]) / len(durs[k]), ",".join("%d" % (sum(vals[k][c]) / max(1, len(vals[k][c]))) for c in names)))
     vals, durs = counters(os.path.join(root, "mfma"))
-    names = ["SQ_BUSY_CU_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_WAVE_CYCLES"]
+    names = ["SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_WAVE_CYCLES"]
     if vals:
         with open(os.path.join(out, f"{tag}_{wl}_pmc_mfma.csv"), "w") as o:
             o.write("# rocprofv3 --pmc " + " ".join(names) + " --kernel-trace -- %s --steps 3 --warmup 1 ; mean per launch.\n" % cmd)
