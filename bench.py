@@ -1100,24 +1100,25 @@ def main():
             extras["generators_note"] = ("same genome shape and train epoch on synth.contact_graph's other generators: hic_like = "
                                          "contact probability ~ 1 / distance, hub = top-K-style heavy-tailed degrees with 8 hubs of "
                                          "2 000 - 10 000 neighbours per chromosome; `value` is the %s generator" % args.generator)
-        # the same step with the dense products as the fp32 MFMA chain of rounds 1-5 (cgcn_debug_set_products): the stage's HIP
-        # graphs fix the kernels at capture, so they are dropped and captured again while the hook holds the chain form
+        # the same workload with the dense products as the fp32 MFMA chain of rounds 1-5: a child process of this script with
+        # CGCN_PRODUCTS=fp32 in its environment -- the same measurement protocol from a fresh process, like `value` itself
+        # (timed inside this process behind the other extras, the chain form read 4.69 ms where a fresh process reads 4.23-4.30)
         if not multi and _lib.load().cgcn_debug_get_products() == 1 and args.d == 128:
-            _lib.load().cgcn_debug_set_products(0)
+            import subprocess
             try:
-                stage._drop_graphs()
-                for _ in range(max(warmup, 3)):
-                    step()
-                f_el, _, _ = timed(step, steps)
-                extras["fp32_chain_ms_per_step"] = f_el / steps * 1e3
-                extras["fp32_chain_windows_per_s"] = windows * steps / f_el
-                extras["fp32_chain_note"] = ("the same workload with the dense products on v_mfma_f32_16x16x4_f32 (CGCN_PRODUCTS=fp32: the form "
-                                             "of rounds 1-5; everything else as shipped); `value` is the split form")
-            finally:
-                _lib.load().cgcn_debug_set_products(-1)
-                stage._drop_graphs()
-                for _ in range(2):
-                    step()
+                cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-extras", "--no-roofline", "--no-cpu-baseline",
+                                     "--steps", str(steps), "--warmup", str(warmup)] + _carried_args(),
+                                    env=dict(os.environ, CGCN_PRODUCTS="fp32"), capture_output=True, text=True, timeout=600)
+                cl = [l for l in cp.stdout.splitlines() if l.startswith("{")]
+                cj = json.loads(cl[-1])
+                assert cj["config"]["products"].startswith("fp32 MFMA chain")
+                extras["fp32_chain_ms_per_step"] = cj["ms_per_step"]
+                extras["fp32_chain_windows_per_s"] = cj["value"]
+                extras["fp32_chain_note"] = ("the same workload, steps and warm-up in a child process with CGCN_PRODUCTS=fp32: the dense products on "
+                                             "v_mfma_f32_16x16x4_f32 (the form of rounds 1-5; everything else as shipped); `value` is the split form")
+            except Exception as e:  # pragma: no cover
+                extras["fp32_chain_ms_per_step"] = None
+                extras["fp32_chain_error"] = str(e)[:300]
         # inference: eval-mode forward of both strands over the same chromosomes
         if genome:
             def ev():

@@ -511,10 +511,10 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512, PROD ? 4 : F
   __shared__ __attribute__((aligned(16))) float T[ROWS * LD];
   __shared__ __attribute__((aligned(16))) float LR[NW * S * D];  // hub-row partial sums (gather_tile)
   // PROD == 1 (split products, cgcn_common.hpp; d = 128): the gathered tile is re-staged as three bf16 levels (k_layer_dense's
-  // Tb) and the product is formed exactly as k_layer_dense forms it -- the same bits on both routes.  The W operands are 48
+  // Tb, the same image) and the product is formed exactly as k_layer_dense forms it -- the same bits on both routes.  The W operands are 48
   // registers instead of 32: 4 waves per SIMD (this kernel only serves tables below the split threshold).
-  constexpr int LDB = D + 8;
-  __shared__ __attribute__((aligned(16))) uint16_t Tb[PROD ? 3 * ROWS * LDB : 8];
+  constexpr int LVT = ROWS * 256;   // bytes of one level tile (swizzled image of cgcn_common.hpp, sp_sigma)
+  __shared__ __attribute__((aligned(16))) unsigned char Tb[PROD ? 3 * LVT : 16];
   static_assert(PROD == 0 || (D == 128 && MB == 1 && CBW == 1 && FWD_HALF_WAVE_ROWS), "split products: d = 128, the half-wave-row form");
 
   const int lane = threadIdx.x & 63;
@@ -586,19 +586,23 @@ __global__ __launch_bounds__((D == 128 && CBW128 == 2) ? 256 : 512, PROD ? 4 : F
     {   // this half-wave's row of the gathered tile -> the three levels
       u32x2 h2, m2, l2;
       sp_split4(*(const f32x4*)&T[hm * LD + l4], h2, m2, l2);
-      *(u32x2*)&Tb[(0 * ROWS + hm) * LDB + l4] = h2;
-      *(u32x2*)&Tb[(1 * ROWS + hm) * LDB + l4] = m2;
-      *(u32x2*)&Tb[(2 * ROWS + hm) * LDB + l4] = l2;
+      unsigned char* w = Tb + hm * 256 + ((((lane & 31) >> 1) ^ sp_sigma(hm)) << 4) + ((lane & 1) << 3);
+      *(u32x2*)w = h2;
+      *(u32x2*)(w + LVT) = m2;
+      *(u32x2*)(w + 2 * LVT) = l2;
     }
     __syncthreads();   // (also: every wave is done reading T, which the tanh tile overwrites)
     const int r = lane & 15, q = lane >> 4;
+    const unsigned char* __restrict__ Ta = Tb + r * 256 + ((q ^ (sp_sigma(r) & 3)) << 4);
+    const int hi = sp_sigma(r) >> 2;
     SpAcc sa;
     sa.zero();
 #pragma unroll
     for (int s = 0; s < D / 32; ++s) {
-      const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const u32x4*)&Tb[(0 * ROWS + r) * LDB + 32 * s + 8 * q]);
-      const bf16x8 am = __builtin_bit_cast(bf16x8, *(const u32x4*)&Tb[(1 * ROWS + r) * LDB + 32 * s + 8 * q]);
-      const bf16x8 al = __builtin_bit_cast(bf16x8, *(const u32x4*)&Tb[(2 * ROWS + r) * LDB + 32 * s + 8 * q]);
+      const int o = (s ^ hi) << 6;
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const u32x4*)(Ta + o));
+      const bf16x8 am = __builtin_bit_cast(bf16x8, *(const u32x4*)(Ta + LVT + o));
+      const bf16x8 al = __builtin_bit_cast(bf16x8, *(const u32x4*)(Ta + 2 * LVT + o));
       sa.step(ah, am, al, wh[s], wm[s], wl[s]);
     }
     acc[0][0] = sa.sum();
@@ -753,11 +757,12 @@ __global__ __launch_bounds__(512, DENSE_WAVES_PER_SIMD) void k_layer_dense(int n
   constexpr bool PRE = true;         // W fragments resident in registers
   static_assert(D / (16 * CBW) == NW && ROWS % NW == 0, "geometry");
   __shared__ __attribute__((aligned(16))) float T[ROWS * LD];
-  // PROD == 1 (split products, cgcn_common.hpp): the A operand lives in its own tile as three bf16 levels -- level v, row m
-  // at Tb[(v ROWS + m) LDB ..]; 272-byte rows: the 16-byte operand reads of 16 rows tile the 64 banks -- so T only ever
-  // holds the tanh tile and two of the four barriers of a tile go (nobody reads T as an operand, nobody rewrites it early)
-  constexpr int LDB = D + 8;
-  __shared__ __attribute__((aligned(16))) uint16_t Tb[PROD ? 3 * ROWS * LDB : 8];
+  // PROD == 1 (split products, cgcn_common.hpp): the A operand lives in its own tile as three bf16 levels (the swizzled level-tile
+  // image sp_sigma: padded 272-byte rows cost 2 800 bank-conflict cycles per CU and launch on the ds_read_b128 operand reads,
+  // whose lane groups are not the contiguous sixteen) -- so T only ever holds the tanh tile and two of the four barriers of a
+  // tile go (nobody reads T as an operand, nobody rewrites it early)
+  constexpr int LVT = ROWS * 256;
+  __shared__ __attribute__((aligned(16))) unsigned char Tb[PROD ? 3 * LVT : 16];
   static_assert(PROD == 0 || (D == 128 && MB == 1 && DENSE_HALF_WAVE_ROWS), "split products: the half-wave-row form");
 
   const int lane = threadIdx.x & 63;
@@ -838,9 +843,10 @@ __global__ __launch_bounds__(512, DENSE_WAVES_PER_SIMD) void k_layer_dense(int n
       if (PROD) {
         u32x2 h2, m2, l2;
         sp_split4(hrow4, h2, m2, l2);
-        *(u32x2*)&Tb[(0 * ROWS + hm) * LDB + l4] = h2;
-        *(u32x2*)&Tb[(1 * ROWS + hm) * LDB + l4] = m2;
-        *(u32x2*)&Tb[(2 * ROWS + hm) * LDB + l4] = l2;
+        unsigned char* w = Tb + hm * 256 + ((((lane & 31) >> 1) ^ sp_sigma(hm)) << 4) + ((lane & 1) << 3);
+        *(u32x2*)w = h2;
+        *(u32x2*)(w + LVT) = m2;
+        *(u32x2*)(w + 2 * LVT) = l2;
       } else {
         *(f32x4*)&T[hm * LD + l4] = hrow4;
       }
@@ -867,13 +873,16 @@ __global__ __launch_bounds__(512, DENSE_WAVES_PER_SIMD) void k_layer_dense(int n
     f32x4 acc[MB][CBW];
     if constexpr (PROD != 0) {
       const int r = lane & 15, q = lane >> 4;
+      const unsigned char* __restrict__ Ta = Tb + r * 256 + ((q ^ (sp_sigma(r) & 3)) << 4);
+      const int hi = sp_sigma(r) >> 2;
       SpAcc sa;
       sa.zero();
 #pragma unroll
       for (int s = 0; s < D / 32; ++s) {
-        const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const u32x4*)&Tb[(0 * ROWS + r) * LDB + 32 * s + 8 * q]);
-        const bf16x8 am = __builtin_bit_cast(bf16x8, *(const u32x4*)&Tb[(1 * ROWS + r) * LDB + 32 * s + 8 * q]);
-        const bf16x8 al = __builtin_bit_cast(bf16x8, *(const u32x4*)&Tb[(2 * ROWS + r) * LDB + 32 * s + 8 * q]);
+        const int o = (s ^ hi) << 6;
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const u32x4*)(Ta + o));
+        const bf16x8 am = __builtin_bit_cast(bf16x8, *(const u32x4*)(Ta + LVT + o));
+        const bf16x8 al = __builtin_bit_cast(bf16x8, *(const u32x4*)(Ta + 2 * LVT + o));
         sa.step(ah, am, al, wh[s], wm[s], wl[s]);
       }
       acc[0][0] = sa.sum();
