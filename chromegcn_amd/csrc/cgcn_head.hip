@@ -23,6 +23,8 @@
 //   k_head_bn_finalize     on the per-tile statistics the last cgcn_layer_fwd emitted (colstats)
 //   k_head_fused<D,CBMAX>  k_head_fwd + the tile-local half of k_head_bwd in one pass: d loss / d pred lives only
 //                          in LDS; leaves dym and the per-workgroup partial sums in the workspace
+//   (d = 128: k_head_fused_rs, two wave teams one tile apart, or -- the default -- k_head_fused_sp, the same with its three
+//   products as split products on the bf16 matrix cores: cgcn_common.hpp)
 //   k_head_train_finish    loss sum + BatchNorm-backward column means; every parameter sum of the head is then
 //                          finished by extra workgroups of the layer backward (head_finalize_slab, cgcn_common.hpp)
 #include "cgcn_common.hpp"

@@ -7,10 +7,13 @@
 // Kernel inventory (DESIGN.md has the roofline for each):
 //   k_spmm<S,D>             unfused aggregation  Y = diag(rs) Ahat X, whole-row gather  (tables that fit the L2s)
 //   k_aggregate_sliced<S,D> the same aggregation, feature-sliced: one 128-byte column slice per XCD (large tables)
-//   k_layer_fwd<S,D>        fused layer forward: gather -> LDS tile -> fp32 MFMA (x W) -> bias/tanh/gate/mix epilogue
+//   k_layer_fwd<S,D>        fused layer forward: gather -> LDS tile -> MFMA (x W) -> bias/tanh/gate/mix epilogue
 //   k_layer_dense<S,D>      the row-local half of the layer forward on an H that is in memory (after k_aggregate_sliced)
-//   k_bwd_rowlocal_ring     (d = 128) per-row gate/tanh derivative by a row team, H^T dU and dHs = diag(rs) dU W^T on fp32 MFMA by a
+//   k_bwd_rowlocal_ring     (d = 128) per-row gate/tanh derivative by a row team, H^T dU and dHs = diag(rs) dU W^T on MFMA by a
 //                           matrix team, the teams meeting through a flag-synchronised ring of LDS slots (no per-tile barrier)
+//   The dense fp32 products of the d = 128 kernels come in two forms (template parameter PROD; cgcn_common.hpp):
+//   split products (default) -- six v_mfma_f32_*_bf16 partial products of an exact 3-way split of both fp32 operands, fp32
+//   accumulators -- or the fp32 MFMA chain v_mfma_f32_16x16x4_f32 (rounds 1-5; CGCN_PRODUCTS=fp32); d = 256 runs the chain.
 //   k_bwd_rowlocal256s      the same work at d = 256: column-slab workgroups, both products per 32-row tile
 //   k_reduce_partials       deterministic second stage of the column / dW sums
 //   k_bwd_sliced<S,D>       dX = mask ((1-g) dXn + Ahat^T dHs): feature-sliced gather + element-wise epilogue
