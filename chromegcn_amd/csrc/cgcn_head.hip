@@ -1664,6 +1664,13 @@ __global__ __launch_bounds__(1024) void k_head_fused_rs(int n, int S, int C, con
 // LDS: W_out 96 KB + 2 x (Yt + Pt) 48 KB.  fp32 MFMA held the SIMD's vector ALUs, so the teams' "matrix" and "vector"
 // sub-phases added up; the bf16 forms take a sixteenth of the cycles per flop and leave half their issue slots free.
 // ------------------------------------------------------------------------------------------
+// Barriers per period: TWO.  k_head_fused_rs has three, so that in every sub-phase one team is on the matrix pipe and the other
+// on the vector pipe (fp32 MFMA holds the vector ALUs); with the bf16 forms that alternation buys nothing, and the data only asks
+// for: P's ym rows complete before P's pred product (B1), and the period's tiles complete before the next period reuses their
+// buffers (B2).  P: S1 | B1 | S2 S3 | B2;  Q (one tile behind): S1 S2 | B1 | S3 | B2.  (HEADSP_BARRIERS = 3: A/B builds.)
+#ifndef HEADSP_BARRIERS
+#define HEADSP_BARRIERS 2
+#endif
 template <bool MULTI, int NB, bool DROP>
 __global__ __launch_bounds__(1024) void k_head_fused_sp(int n, int S, int C, const float* __restrict__ X,
                                                         const float* __restrict__ bn_w, const float* __restrict__ bn_b,
@@ -1843,7 +1850,9 @@ __global__ __launch_bounds__(1024) void k_head_fused_sp(int n, int S, int C, con
           acc = sacc.sum();
         }
       }
+#if HEADSP_BARRIERS == 3
       __syncthreads();
+#endif
       // ---- S3: sigmoid / BCE / probs; d loss / d pred -> the levels of Pt[k & 1] (zero outside the valid region)   (vector; Q: dW_out product)
       if (k < mt) {
         unsigned char* __restrict__ Pb = Ptb[k & 1];
@@ -1960,7 +1969,9 @@ __global__ __launch_bounds__(1024) void k_head_fused_sp(int n, int S, int C, con
           }
         }
       }
+#if HEADSP_BARRIERS == 3
       __syncthreads();
+#endif
       // ---- S2: dym out, BatchNorm-backward column sums of tile k-1              (vector; P: pred product)
       if (k >= 1) {
         OPAQUE_LANE(r, q, lq);
